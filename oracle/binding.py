@@ -1,0 +1,169 @@
+"""ctypes binding of oracle/liboracle.so (the C restatement).
+
+TEST INFRASTRUCTURE ONLY -- see the header of ligero_oracle.c.  Field elements are
+numpy uint64 arrays of shape (..., 4): Montgomery form, little-endian limbs.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_sz = ctypes.c_size_t
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "ligero_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.orc_fr_mul.argtypes = [_vp, _vp, _vp]
+        L.orc_fr_add.argtypes = [_vp, _vp, _vp]
+        L.orc_fr_sub.argtypes = [_vp, _vp, _vp]
+        L.orc_fr_to_mont.argtypes = [_vp, _vp, _sz]
+        L.orc_fr_from_mont.argtypes = [_vp, _vp, _sz]
+        L.orc_domain_generator.argtypes = [_u32, _vp]
+        L.orc_fft.argtypes = [_u32, _vp]
+        L.orc_ifft.argtypes = [_u32, _vp]
+        L.orc_reed_solomon_interpolate.argtypes = [_u32, _vp, _u32, _vp]
+        L.orc_reed_solomon_evaluate.argtypes = [_u32, _vp, _u32, _vp]
+        L.orc_blake2s256.argtypes = [_vp, _sz, _vp]
+        L.orc_sha256.argtypes = [_vp, _sz, _vp]
+        L.orc_col_hash.argtypes = [_vp, _u32, _vp]
+        L.orc_merkle_tree.argtypes = [_u32, _vp, _vp]
+        L.orc_encode_commit.argtypes = [_u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]
+        L.orc_open_columns.argtypes = [_u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]
+        L.orc_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+# ---- element conversion helpers (python ints <-> limb arrays) ----
+def ints_to_limbs(vals) -> np.ndarray:
+    out = np.empty((len(vals), 4), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        out[i, 0] = v & mask
+        out[i, 1] = (v >> 64) & mask
+        out[i, 2] = (v >> 128) & mask
+        out[i, 3] = (v >> 192) & mask
+    return out
+
+
+def limbs_to_ints(a: np.ndarray):
+    a = np.ascontiguousarray(a).reshape(-1, 4)
+    return [int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) | (int(r[3]) << 192) for r in a]
+
+
+def to_mont(canon: np.ndarray) -> np.ndarray:
+    canon = np.ascontiguousarray(canon, dtype=np.uint64)
+    out = np.empty_like(canon)
+    lib().orc_fr_to_mont(_p(canon), _p(out), canon.size // 4)
+    return out
+
+
+def from_mont(mont: np.ndarray) -> np.ndarray:
+    mont = np.ascontiguousarray(mont, dtype=np.uint64)
+    out = np.empty_like(mont)
+    lib().orc_fr_from_mont(_p(mont), _p(out), mont.size // 4)
+    return out
+
+
+def fft(a: np.ndarray) -> np.ndarray:
+    a = np.array(a, dtype=np.uint64, copy=True).reshape(-1, 4)
+    assert lib().orc_fft(a.shape[0], _p(a)) == 0
+    return a
+
+
+def ifft(a: np.ndarray) -> np.ndarray:
+    a = np.array(a, dtype=np.uint64, copy=True).reshape(-1, 4)
+    assert lib().orc_ifft(a.shape[0], _p(a)) == 0
+    return a
+
+
+def reed_solomon_interpolate(msg: np.ndarray, k: int) -> np.ndarray:
+    msg = np.ascontiguousarray(msg, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty((k, 4), dtype=np.uint64)
+    assert lib().orc_reed_solomon_interpolate(k, _p(msg), msg.shape[0], _p(out)) == 0
+    return out
+
+
+def reed_solomon_evaluate(coeffs: np.ndarray, n: int) -> np.ndarray:
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty((n, 4), dtype=np.uint64)
+    assert lib().orc_reed_solomon_evaluate(n, _p(coeffs), coeffs.shape[0], _p(out)) == 0
+    return out
+
+
+def blake2s256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    lib().orc_blake2s256(ctypes.cast(ctypes.c_char_p(data), _vp), len(data), ctypes.cast(out, _vp))
+    return out.raw
+
+
+def sha256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    lib().orc_sha256(ctypes.cast(ctypes.c_char_p(data), _vp), len(data), ctypes.cast(out, _vp))
+    return out.raw
+
+
+def col_hash(col_mont: np.ndarray) -> bytes:
+    col = np.ascontiguousarray(col_mont, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty(32, dtype=np.uint8)
+    lib().orc_col_hash(_p(col), col.shape[0], _p(out))
+    return out.tobytes()
+
+
+def merkle_tree(leaves: np.ndarray) -> np.ndarray:
+    leaves = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+    n = leaves.shape[0]
+    nodes = np.empty((n - 1, 32), dtype=np.uint8)
+    assert lib().orc_merkle_tree(n, _p(leaves), _p(nodes)) == 0
+    return nodes
+
+
+def encode_commit(preenc: np.ndarray, k: int, n: int, threads: int = 1, want_u: bool = True):
+    """preenc: (rows, k, 4) uint64 Montgomery.  Returns dict(coeffs, u, leaves, nodes, root)."""
+    preenc = np.ascontiguousarray(preenc, dtype=np.uint64).reshape(-1, k, 4)
+    rows = preenc.shape[0]
+    coeffs = np.empty((rows, k, 4), dtype=np.uint64)
+    u = np.empty((rows, n, 4), dtype=np.uint64) if want_u else None
+    leaves = np.empty((n, 32), dtype=np.uint8)
+    nodes = np.empty((n - 1, 32), dtype=np.uint8)
+    root = np.empty(32, dtype=np.uint8)
+    rc = lib().orc_encode_commit(rows, k, n, _p(preenc), _p(coeffs), _p(u), _p(leaves), _p(nodes), _p(root), threads)
+    assert rc == 0, rc
+    return dict(coeffs=coeffs, u=u, leaves=leaves, nodes=nodes, root=root.tobytes())
+
+
+def open_columns(u: np.ndarray, leaves: np.ndarray, nodes: np.ndarray, idx):
+    rows, n = u.shape[0], u.shape[1]
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    t = idx.shape[0]
+    plen = int(n).bit_length() - 2
+    cols = np.empty((t, rows, 4), dtype=np.uint64)
+    sib = np.empty((t, 32), dtype=np.uint8)
+    paths = np.empty((t, plen, 32), dtype=np.uint8)
+    rc = lib().orc_open_columns(rows, n, _p(u), _p(leaves), _p(nodes), _p(idx), t, _p(cols), _p(sib), _p(paths))
+    assert rc == 0, rc
+    return cols, sib, paths

@@ -1,0 +1,471 @@
+/*
+ * CPU restatement (plain C) of the Ligero encode-and-commit hot path of
+ * NP-Eng/ligero: src/ligero/mod.rs:521-551 (+ openings 935-955, RS helpers
+ * 998-1012), src/matrices/mod.rs:163-171, src/ligero/types.rs:15-46.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library, and only as the checker
+ * or as the timed CPU baseline -- never as part of the product path.
+ *
+ * PARITY UNPINNED: the Rust reference cannot be built in this environment and
+ * its tests hold no golden bytes for this path.  The arithmetic lives in
+ * third-party crates that are not under /root/reference (ark-ff / ark-poly /
+ * ark-serialize / ark-crypto-primitives 0.5.0-alpha, ark-poly-commit @
+ * HungryCatsStudio/poly-commit release-0.5, blake2 0.10); their published
+ * algorithms are restated here.  This file is cross-checked against the
+ * independent Python big-int model (oracle/model.py), hashlib and RFC 7693 /
+ * FIPS 180-4 vectors by tests/test_oracle.py.
+ *
+ * All field elements crossing this API are BN254 Fr in Montgomery form,
+ * 4 x u64 little-endian limbs (the in-memory layout of ark_ff::Fp).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fr_t;
+
+/* ---- BN254 Fr constants (ark_bn254::Fr; SURVEY Appendix A1, recomputed in model.py) ---- */
+static const fr_t FR_P   = {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+static const fr_t FR_R   = {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}};
+static const fr_t FR_R2  = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+static const uint64_t FR_INV = 0xc2e1f593efffffffULL;
+/* 5^((r-1)/2^28) in canonical form */
+static const fr_t FR_TWO_ADIC_ROOT_CANON = {{0x9bd61b6e725b19f0ULL, 0x402d111e41112ed4ULL, 0x00e0a7eb8ef62abcULL, 0x2a3c09f0a58a7e85ULL}};
+#define FR_TWO_ADICITY 28
+
+static inline int fr_geq(const fr_t *a, const fr_t *b) {
+    for (int i = 3; i >= 0; i--) {
+        if (a->l[i] > b->l[i]) return 1;
+        if (a->l[i] < b->l[i]) return 0;
+    }
+    return 1;
+}
+static inline void fr_sub_raw(fr_t *r, const fr_t *a, const fr_t *b) {
+    u128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a->l[i] - b->l[i] - borrow;
+        r->l[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+}
+static inline void fr_add(fr_t *r, const fr_t *a, const fr_t *b) {
+    u128 c = 0;
+    fr_t t;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a->l[i] + b->l[i];
+        t.l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (c || fr_geq(&t, &FR_P)) fr_sub_raw(&t, &t, &FR_P);
+    *r = t;
+}
+static inline void fr_sub(fr_t *r, const fr_t *a, const fr_t *b) {
+    fr_t t;
+    if (fr_geq(a, b)) {
+        fr_sub_raw(&t, a, b);
+    } else {
+        fr_t u;
+        fr_sub_raw(&u, &FR_P, b);
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)a->l[i] + u.l[i];
+            t.l[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    *r = t;
+}
+/* Montgomery product a*b*R^-1 mod p (CIOS, as ark-ff MontBackend::mul_assign computes) */
+static inline void fr_mul(fr_t *r, const fr_t *a, const fr_t *b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a->l[j] * b->l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * FR_INV;
+        c = (u128)m * FR_P.l[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * FR_P.l[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    fr_t o = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || fr_geq(&o, &FR_P)) fr_sub_raw(&o, &o, &FR_P);
+    *r = o;
+}
+static inline void fr_to_mont(fr_t *r, const fr_t *a) { fr_mul(r, a, &FR_R2); }
+static inline void fr_from_mont(fr_t *r, const fr_t *a) {
+    fr_t one = {{1, 0, 0, 0}};
+    fr_mul(r, a, &one);
+}
+static void fr_pow_u64(fr_t *r, const fr_t *base, uint64_t e) {
+    fr_t acc = FR_R, b = *base;
+    while (e) {
+        if (e & 1) fr_mul(&acc, &acc, &b);
+        fr_mul(&b, &b, &b);
+        e >>= 1;
+    }
+    *r = acc;
+}
+/* a^(p-2) */
+static void fr_inverse(fr_t *r, const fr_t *a) {
+    fr_t e = FR_P, acc = FR_R, b = *a;
+    e.l[0] -= 2;
+    for (int i = 0; i < 4; i++) {
+        uint64_t w = e.l[i];
+        for (int j = 0; j < 64; j++) {
+            if (w & 1) fr_mul(&acc, &acc, &b);
+            fr_mul(&b, &b, &b);
+            w >>= 1;
+        }
+    }
+    *r = acc;
+}
+
+/* ---- exported scalar helpers (used by tests to pin the arithmetic) ---- */
+void orc_fr_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) { fr_mul((fr_t *)out, (const fr_t *)a, (const fr_t *)b); }
+void orc_fr_add(const uint64_t *a, const uint64_t *b, uint64_t *out) { fr_add((fr_t *)out, (const fr_t *)a, (const fr_t *)b); }
+void orc_fr_sub(const uint64_t *a, const uint64_t *b, uint64_t *out) { fr_sub((fr_t *)out, (const fr_t *)a, (const fr_t *)b); }
+void orc_fr_to_mont(const uint64_t *in, uint64_t *out, size_t count) {
+    for (size_t i = 0; i < count; i++) fr_to_mont((fr_t *)out + i, (const fr_t *)in + i);
+}
+void orc_fr_from_mont(const uint64_t *in, uint64_t *out, size_t count) {
+    for (size_t i = 0; i < count; i++) fr_from_mont((fr_t *)out + i, (const fr_t *)in + i);
+}
+
+/* ---- radix-2 domain (GeneralEvaluationDomain::new, call sites mod.rs:204-212) ---- */
+static int log2_exact(uint32_t n) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while ((1u << l) < n) l++;
+    return l;
+}
+static void domain_group_gen(fr_t *g, uint32_t size) {
+    fr_t root;
+    fr_to_mont(&root, &FR_TWO_ADIC_ROOT_CANON);
+    fr_pow_u64(g, &root, 1ULL << (FR_TWO_ADICITY - log2_exact(size)));
+}
+void orc_domain_generator(uint32_t size, uint64_t *out) { domain_group_gen((fr_t *)out, size); }
+
+static void bitrev_permute(fr_t *a, uint32_t n) {
+    uint32_t j = 0;
+    for (uint32_t i = 1; i < n; i++) {
+        uint32_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j |= bit;
+        if (i < j) { fr_t t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+}
+/* powers w^0 .. w^(n/2-1): upstream recomputes them on every fft call (roots_of_unity) */
+static fr_t *root_powers(const fr_t *w, uint32_t n) {
+    uint32_t h = n / 2 ? n / 2 : 1;
+    fr_t *r = (fr_t *)malloc(sizeof(fr_t) * h);
+    r[0] = FR_R;
+    for (uint32_t i = 1; i < h; i++) fr_mul(&r[i], &r[i - 1], w);
+    return r;
+}
+/* forward: DIF butterflies (upstream io_helper) then bit reversal => natural order out */
+static void fft_in_place(fr_t *a, uint32_t n, const fr_t *w) {
+    fr_t *roots = root_powers(w, n);
+    for (uint32_t gap = n / 2; gap >= 1; gap >>= 1) {
+        uint32_t step = (n / 2) / gap;
+        for (uint32_t start = 0; start < n; start += 2 * gap) {
+            for (uint32_t i = 0; i < gap; i++) {
+                fr_t *lo = &a[start + i], *hi = &a[start + i + gap], d;
+                fr_sub(&d, lo, hi);
+                fr_add(lo, lo, hi);
+                fr_mul(hi, &d, &roots[i * step]);
+            }
+        }
+    }
+    free(roots);
+    bitrev_permute(a, n);
+}
+/* inverse: bit reversal then DIT butterflies (upstream oi_helper) then * size_inv */
+static void ifft_in_place(fr_t *a, uint32_t n, const fr_t *w) {
+    fr_t winv, ninv, nn = {{n, 0, 0, 0}};
+    fr_inverse(&winv, w);
+    fr_to_mont(&nn, &nn);
+    fr_inverse(&ninv, &nn);
+    fr_t *roots = root_powers(&winv, n);
+    bitrev_permute(a, n);
+    for (uint32_t gap = 1; gap < n; gap <<= 1) {
+        uint32_t step = (n / 2) / gap;
+        for (uint32_t start = 0; start < n; start += 2 * gap) {
+            for (uint32_t i = 0; i < gap; i++) {
+                fr_t *lo = &a[start + i], *hi = &a[start + i + gap], t;
+                fr_mul(&t, hi, &roots[i * step]);
+                fr_sub(hi, lo, &t);
+                fr_add(lo, lo, &t);
+            }
+        }
+    }
+    free(roots);
+    for (uint32_t i = 0; i < n; i++) fr_mul(&a[i], &a[i], &ninv);
+}
+int orc_fft(uint32_t size, uint64_t *inout) {
+    if (log2_exact(size) < 0 || log2_exact(size) > FR_TWO_ADICITY) return -1;
+    fr_t g;
+    domain_group_gen(&g, size);
+    fft_in_place((fr_t *)inout, size, &g);
+    return 0;
+}
+int orc_ifft(uint32_t size, uint64_t *inout) {
+    if (log2_exact(size) < 0 || log2_exact(size) > FR_TWO_ADICITY) return -1;
+    fr_t g;
+    domain_group_gen(&g, size);
+    ifft_in_place((fr_t *)inout, size, &g);
+    return 0;
+}
+
+/* reed_solomon_interpolate, mod.rs:998-1002: resize to k, small_domain.ifft */
+int orc_reed_solomon_interpolate(uint32_t k, const uint64_t *msg, uint32_t msg_len, uint64_t *coeffs_out) {
+    if (msg_len > k) return -1;
+    memset(coeffs_out, 0, sizeof(fr_t) * k);
+    memcpy(coeffs_out, msg, sizeof(fr_t) * msg_len);
+    return orc_ifft(k, coeffs_out);
+}
+/* reed_solomon_evaluate, mod.rs:1004-1008: resize to n, large_domain.fft (full size-n FFT on 7/8 zeros) */
+int orc_reed_solomon_evaluate(uint32_t n, const uint64_t *coeffs, uint32_t len, uint64_t *out) {
+    if (len > n) return -1;
+    memset(out, 0, sizeof(fr_t) * n);
+    memcpy(out, coeffs, sizeof(fr_t) * len);
+    return orc_fft(n, out);
+}
+
+/* ---- Blake2s-256 (RFC 7693), unkeyed; blake2 0.10 Blake2s256 (types.rs:10,18) ---- */
+static const uint32_t B2S_IV[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
+static const uint8_t B2S_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+typedef struct { uint32_t h[8]; uint64_t t; uint8_t buf[64]; size_t buflen; } b2s_t;
+static inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void b2s_compress(b2s_t *s, const uint8_t *block, int last) {
+    uint32_t m[16], v[16];
+    for (int i = 0; i < 16; i++) m[i] = (uint32_t)block[4 * i] | ((uint32_t)block[4 * i + 1] << 8) | ((uint32_t)block[4 * i + 2] << 16) | ((uint32_t)block[4 * i + 3] << 24);
+    for (int i = 0; i < 8; i++) { v[i] = s->h[i]; v[i + 8] = B2S_IV[i]; }
+    v[12] ^= (uint32_t)s->t;
+    v[13] ^= (uint32_t)(s->t >> 32);
+    if (last) v[14] = ~v[14];
+#define B2S_G(a, b, c, d, x, y) \
+    v[a] += v[b] + (x); v[d] = rotr32(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = rotr32(v[b] ^ v[c], 12); \
+    v[a] += v[b] + (y); v[d] = rotr32(v[d] ^ v[a], 8);  v[c] += v[d]; v[b] = rotr32(v[b] ^ v[c], 7);
+    for (int r = 0; r < 10; r++) {
+        const uint8_t *sg = B2S_SIGMA[r];
+        B2S_G(0, 4, 8, 12, m[sg[0]], m[sg[1]]) B2S_G(1, 5, 9, 13, m[sg[2]], m[sg[3]])
+        B2S_G(2, 6, 10, 14, m[sg[4]], m[sg[5]]) B2S_G(3, 7, 11, 15, m[sg[6]], m[sg[7]])
+        B2S_G(0, 5, 10, 15, m[sg[8]], m[sg[9]]) B2S_G(1, 6, 11, 12, m[sg[10]], m[sg[11]])
+        B2S_G(2, 7, 8, 13, m[sg[12]], m[sg[13]]) B2S_G(3, 4, 9, 14, m[sg[14]], m[sg[15]])
+    }
+#undef B2S_G
+    for (int i = 0; i < 8; i++) s->h[i] ^= v[i] ^ v[i + 8];
+}
+static void b2s_init(b2s_t *s) {
+    memcpy(s->h, B2S_IV, sizeof(B2S_IV));
+    s->h[0] ^= 0x01010020u; /* digest_length = 32, key_length = 0, fanout = depth = 1 */
+    s->t = 0;
+    s->buflen = 0;
+}
+static void b2s_update(b2s_t *s, const uint8_t *in, size_t len) {
+    while (len) {
+        if (s->buflen == 64) { /* buffer full and more input follows: not the last block */
+            s->t += 64;
+            b2s_compress(s, s->buf, 0);
+            s->buflen = 0;
+        }
+        size_t take = 64 - s->buflen;
+        if (take > len) take = len;
+        memcpy(s->buf + s->buflen, in, take);
+        s->buflen += take;
+        in += take;
+        len -= take;
+    }
+}
+static void b2s_final(b2s_t *s, uint8_t out[32]) {
+    s->t += s->buflen;
+    memset(s->buf + s->buflen, 0, 64 - s->buflen);
+    b2s_compress(s, s->buf, 1);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)s->h[i]; out[4 * i + 1] = (uint8_t)(s->h[i] >> 8); out[4 * i + 2] = (uint8_t)(s->h[i] >> 16); out[4 * i + 3] = (uint8_t)(s->h[i] >> 24); }
+}
+void orc_blake2s256(const uint8_t *data, size_t len, uint8_t out[32]) {
+    b2s_t s;
+    b2s_init(&s);
+    b2s_update(&s, data, len);
+    b2s_final(&s, out);
+}
+
+/* ---- SHA-256 (FIPS 180-4); ark-crypto-primitives crh::sha256::Sha256 (types.rs:2,26) ---- */
+static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static void sha256_block(uint32_t h[8], const uint8_t *p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25), ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + SHA_K[i] + w[i];
+        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+void orc_sha256(const uint8_t *data, size_t len, uint8_t out[32]) {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    size_t full = len / 64;
+    for (size_t i = 0; i < full; i++) sha256_block(h, data + 64 * i);
+    uint8_t tail[128];
+    size_t rem = len - 64 * full;
+    memset(tail, 0, sizeof(tail));
+    memcpy(tail, data + 64 * full, rem);
+    tail[rem] = 0x80;
+    size_t tl = (rem + 9 <= 64) ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_block(h, tail);
+    if (tl == 128) sha256_block(h, tail + 64);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+
+/* ---- column hash: FieldToBytesColHasher<F, Blake2s256>::evaluate (mod.rs:536-542, types.rs:18) ----
+ * Blake2s-256( LE64(len) || canonical-LE32(col[0]) || ... ), elements leave Montgomery form. */
+void orc_col_hash(const uint64_t *col_mont, uint32_t len, uint8_t out[32]) {
+    b2s_t s;
+    b2s_init(&s);
+    uint8_t pre[8];
+    uint64_t l64 = len;
+    for (int i = 0; i < 8; i++) pre[i] = (uint8_t)(l64 >> (8 * i));
+    b2s_update(&s, pre, 8);
+    for (uint32_t i = 0; i < len; i++) {
+        fr_t c;
+        uint8_t bytes[32];
+        fr_from_mont(&c, (const fr_t *)col_mont + i);
+        for (int j = 0; j < 4; j++)
+            for (int b = 0; b < 8; b++) bytes[8 * j + b] = (uint8_t)(c.l[j] >> (8 * b));
+        b2s_update(&s, bytes, 32);
+    }
+    b2s_final(&s, out);
+}
+
+/* ---- Merkle tree: create_merkle_tree (mod.rs:544-549) with TestMerkleTreeParams ----
+ * n leaf digests (32 B each, identity leaf hash) -> n-1 inner nodes, heap order, root = node 0.
+ * Bottom inner level hashes LE64(32)||L||LE64(32)||R (ByteDigestConverter), upper levels L||R. */
+int orc_merkle_tree(uint32_t n, const uint8_t *leaves, uint8_t *nodes) {
+    if (n < 2 || (n & (n - 1))) return -1;
+    uint32_t base = n / 2 - 1;
+    for (uint32_t i = 0; i < n / 2; i++) {
+        uint8_t msg[80];
+        memset(msg, 0, sizeof(msg));
+        msg[0] = 32;
+        memcpy(msg + 8, leaves + 64 * (size_t)i, 32);
+        msg[40] = 32;
+        memcpy(msg + 48, leaves + 64 * (size_t)i + 32, 32);
+        orc_sha256(msg, 80, nodes + 32 * (size_t)(base + i));
+    }
+    for (uint32_t i = base; i-- > 0;) {
+        uint8_t msg[64];
+        memcpy(msg, nodes + 32 * (size_t)(2 * i + 1), 32);
+        memcpy(msg + 32, nodes + 32 * (size_t)(2 * i + 2), 32);
+        orc_sha256(msg, 64, nodes + 32 * (size_t)i);
+    }
+    return 0;
+}
+
+/* ---- the hot path, mod.rs:521-551 ----
+ * preenc: rows x k, row-major.  Outputs (any may be NULL except root): coeffs rows x k,
+ * u rows x n (row-major, Montgomery), leaves n x 32, nodes (n-1) x 32, root 32.
+ * threads <= 1: the reference's shape -- serial row loop (521-533), explicit transpose
+ * (matrices/mod.rs:163-167), serial column hashing (536-542; the crate defines no
+ * `parallel` feature so cfg_into_iter! is serial).  threads > 1: same arithmetic with the
+ * row / column loops spread over OpenMP threads (reported separately as an all-cores variant). */
+int orc_encode_commit(uint32_t rows, uint32_t k, uint32_t n, const uint64_t *preenc, uint64_t *coeffs_out,
+                      uint64_t *u_out, uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out, int threads) {
+    if (log2_exact(k) < 0 || log2_exact(n) < 0 || n < k || n < 2 || rows == 0) return -1;
+    fr_t *coeffs = coeffs_out ? (fr_t *)coeffs_out : (fr_t *)malloc(sizeof(fr_t) * (size_t)rows * k);
+    fr_t *u = u_out ? (fr_t *)u_out : (fr_t *)malloc(sizeof(fr_t) * (size_t)rows * n);
+    uint8_t *leaves = leaves_out ? leaves_out : (uint8_t *)malloc((size_t)n * 32);
+    uint8_t *nodes = nodes_out ? nodes_out : (uint8_t *)malloc((size_t)(n - 1) * 32);
+    if (!coeffs || !u || !leaves || !nodes) return -2;
+    (void)threads;
+#pragma omp parallel for schedule(static) if (threads > 1) num_threads(threads > 1 ? threads : 1)
+    for (long i = 0; i < (long)rows; i++) {
+        orc_reed_solomon_interpolate(k, preenc + 4 * (size_t)i * k, k, (uint64_t *)(coeffs + (size_t)i * k));
+        orc_reed_solomon_evaluate(n, (const uint64_t *)(coeffs + (size_t)i * k), k, (uint64_t *)(u + (size_t)i * n));
+    }
+#pragma omp parallel if (threads > 1) num_threads(threads > 1 ? threads : 1)
+    {
+        fr_t *col = (fr_t *)malloc(sizeof(fr_t) * rows);
+#pragma omp for schedule(static)
+        for (long j = 0; j < (long)n; j++) {
+            for (uint32_t i = 0; i < rows; i++) col[i] = u[(size_t)i * n + j]; /* DenseMatrix::columns */
+            orc_col_hash((const uint64_t *)col, rows, leaves + 32 * (size_t)j);
+        }
+        free(col);
+    }
+    orc_merkle_tree(n, leaves, nodes);
+    memcpy(root_out, nodes, 32);
+    if (!coeffs_out) free(coeffs);
+    if (!u_out) free(u);
+    if (!leaves_out) free(leaves);
+    if (!nodes_out) free(nodes);
+    return 0;
+}
+
+/* ---- open_columns, mod.rs:944-952 (indices come from the host-side Fiat-Shamir PRNG) ----
+ * cols_out: t x rows (Montgomery); sib_out: t x 32 (leaf_sibling_hash);
+ * paths_out: t x (log2 n - 1) x 32, root-side first (MerkleTree::generate_proof). */
+int orc_open_columns(uint32_t rows, uint32_t n, const uint64_t *u, const uint8_t *leaves, const uint8_t *nodes,
+                     const uint32_t *idx, uint32_t t, uint64_t *cols_out, uint8_t *sib_out, uint8_t *paths_out) {
+    int logn = log2_exact(n);
+    if (logn < 1) return -1;
+    uint32_t plen = (uint32_t)logn - 1;
+    for (uint32_t c = 0; c < t; c++) {
+        uint32_t j = idx[c];
+        if (j >= n) return -1;
+        for (uint32_t i = 0; i < rows; i++) memcpy(cols_out + 4 * ((size_t)c * rows + i), u + 4 * ((size_t)i * n + j), 32);
+        memcpy(sib_out + 32 * (size_t)c, leaves + 32 * (size_t)(j ^ 1), 32);
+        uint32_t cur = (n / 2 - 1) + (j >> 1), pos = plen;
+        while (cur != 0) {
+            uint32_t s = (cur & 1) ? cur + 1 : cur - 1;
+            pos--;
+            memcpy(paths_out + 32 * ((size_t)c * plen + pos), nodes + 32 * (size_t)s, 32);
+            cur = (cur - 1) >> 1;
+        }
+    }
+    return 0;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
