@@ -1,0 +1,137 @@
+/*
+ * ligero_hip.h -- C ABI of the MI355X (gfx950) Ligero encode-and-commit hot path.
+ *
+ * Drop-in boundary for NP-Eng/ligero `LigeroCircuit::prove_inner`, lines
+ * src/ligero/mod.rs:521-551 (Reed-Solomon row encoding, Blake2s column hashing, SHA-256
+ * Merkle commitment) and `open_columns`, src/ligero/mod.rs:935-955.  The reference has no
+ * FFI seam of its own (its only extension point is the hash bundle `LigeroMTParams`,
+ * mod.rs:31-47); these entry points are what a Rust `extern "C"` block replacing those
+ * lines would bind -- INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - Field elements are BN254 Fr, 4 x u64 little-endian limbs in MONTGOMERY form: the
+ *     in-memory representation of `ark_bn254::Fr` (`ark_ff::Fp<MontBackend<_,4>,4>`), so a
+ *     `&[Fr]` can be passed as `*const u64` without conversion.
+ *   - Matrices are row-major and contiguous (the reference's `DenseMatrix` is `Vec<Vec<F>>`,
+ *     src/matrices/mod.rs:128-131: the caller flattens rows).
+ *   - Digests are 32 raw bytes.
+ *   - The caller owns every host pointer; the library owns all device memory.
+ *   - Every function returns LG_OK (0) or a negative lg_status; nothing unwinds.  (The
+ *     reference panics instead: mod.rs:205-209, 539, 549.)
+ *   - A context is used from one host thread at a time; contexts are independent (one per
+ *     HIP stream), so several can run concurrently on one GPU or on different GPUs.
+ *   - There is no CPU fallback: without a usable HIP device every call fails with
+ *     LG_ERR_HIP / LG_ERR_NO_DEVICE.
+ */
+#ifndef LIGERO_HIP_H
+#define LIGERO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lg_ctx lg_ctx;
+
+typedef enum lg_status {
+    LG_OK = 0,
+    LG_ERR_BAD_ARG = -1,    /* null pointer, index out of range, ... */
+    LG_ERR_BAD_DIMS = -2,   /* k, n not powers of two, n != 8k, k < 2, k > 2^25, rows == 0 */
+    LG_ERR_NO_DEVICE = -3,  /* device ordinal not present */
+    LG_ERR_HIP = -4,        /* a HIP runtime call failed; see lg_last_error() */
+    LG_ERR_OOM = -5,        /* device or host allocation failed */
+    LG_ERR_STATE = -6,      /* call order violated (e.g. open_columns before a commitment) */
+    LG_ERR_UNSUPPORTED = -7 /* shape not supported by this build */
+} lg_status;
+
+/* Human-readable text for a status code (static storage). */
+const char* lg_status_string(int status);
+/* Text of the most recent HIP failure seen by this context (static/ctx storage). */
+const char* lg_last_error(const lg_ctx* ctx);
+/* ABI version of this header: bumped on any incompatible change. */
+uint32_t lg_abi_version(void);
+#define LG_ABI_VERSION 1u
+
+/*
+ * Context for `batch` independent commitments of identical shape (batch = 1 for
+ * lg_ctx_create).  rows = 4m, k = message length, n = codeword length = 8k
+ * (LigeroCircuit::new, mod.rs:171-175, 283-285).  Allocates all device buffers and builds
+ * the domain tables (large_domain / small_domain of mod.rs:204-211).
+ */
+int lg_ctx_create(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n);
+int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch);
+void lg_ctx_destroy(lg_ctx* ctx);
+
+/*
+ * The hot path, mod.rs:521-551, for every proof of the batch:
+ *   preenc      batch * rows * k elements  (preenc_u, mod.rs:516)
+ *   coeffs_out  batch * rows * k elements  (u_polynomial_coeffs, mod.rs:521-526); may be NULL
+ *   root_out    batch * 32 bytes           (u_root, mod.rs:551)
+ * The encoded matrix U, the leaf digests and the tree stay resident on the device for
+ * lg_open_columns / lg_read_*.
+ */
+int lg_encode_commit(lg_ctx* ctx, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out);
+
+/* The same in three steps, so that a caller can keep inputs resident in HBM and time the
+ * device work alone: upload (H2D) -- commit (kernels only, asynchronous on the context's
+ * stream) -- sync / read back. */
+int lg_upload_preenc(lg_ctx* ctx, const uint64_t* preenc);
+int lg_commit_resident(lg_ctx* ctx);
+int lg_sync(lg_ctx* ctx);
+int lg_read_root(lg_ctx* ctx, uint8_t* root_out /* batch*32 */);
+int lg_read_coeffs(lg_ctx* ctx, uint64_t* coeffs_out /* batch*rows*k */);
+/* leaf digests = column hashes (mod.rs:536-542), batch * n * 32 bytes: lets a Rust host
+ * rebuild an ark `MerkleTree` if it prefers to own the tree */
+int lg_read_leaves(lg_ctx* ctx, uint8_t* leaves_out);
+/* inner nodes, heap order (root first), batch * (n-1) * 32 bytes */
+int lg_read_nodes(lg_ctx* ctx, uint8_t* nodes_out);
+/* rows [row0, row0+nrows) of the encoded matrix U of one proof, natural column order,
+ * Montgomery form (nrows * n elements): `u.rows` of mod.rs:528-533 */
+int lg_read_codeword_rows(lg_ctx* ctx, uint32_t proof, uint32_t row0, uint32_t nrows, uint64_t* out);
+
+/*
+ * open_columns, mod.rs:944-952 (the index derivation at 941-942 is Fiat-Shamir and stays
+ * on the host).  For each of the t indices (each < n):
+ *   cols_out   t * rows elements      u.column(i)                (src/matrices/mod.rs:169-171)
+ *   sib_out    t * 32 bytes           Path::leaf_sibling_hash
+ *   paths_out  t * (log2 n - 1) * 32  Path::auth_path, root side first
+ * (Path::leaf_index is the index itself.)
+ */
+int lg_open_columns(lg_ctx* ctx, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out,
+                    uint8_t* sib_out, uint8_t* paths_out);
+
+/* Row-level operators, independent of the resident commitment (own scratch):
+ *   reed_solomon_interpolate  mod.rs:998-1002   nrows * k -> nrows * k
+ *   reed_solomon_evaluate     mod.rs:1004-1008  nrows * k -> nrows * n
+ *   reed_solomon              mod.rs:1010-1012  nrows * k -> nrows * n   (verifier, mod.rs:702)
+ * nrows <= batch * rows. */
+int lg_reed_solomon_interpolate(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* coeffs_out);
+int lg_reed_solomon_evaluate(lg_ctx* ctx, const uint64_t* coeffs, uint32_t nrows, uint64_t* codeword_out);
+int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* codeword_out);
+
+/* Shape queries. */
+int lg_ctx_dims(const lg_ctx* ctx, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch);
+
+/*
+ * Per-kernel timing with HIP events on the context's stream (for roofline reports).
+ * While enabled, lg_commit_resident brackets each stage with events (no host sync).
+ * lg_profile_read synchronises and returns, per stage, the mean milliseconds over the
+ * commits issued since lg_profile_enable(ctx, 1) (at most the last 64); *samples_out (may be
+ * NULL) receives how many commits were averaged.
+ */
+typedef enum lg_stage {
+    LG_STAGE_INTERPOLATE = 0, /* rs_interpolate rows: size-k inverse NTT            */
+    LG_STAGE_EVALUATE = 1,    /* rs_evaluate rows: 7 coset NTTs of size k           */
+    LG_STAGE_COLHASH = 2,     /* Blake2s over the n columns                         */
+    LG_STAGE_MERKLE = 3,      /* SHA-256 tree                                       */
+    LG_STAGE_COUNT = 4
+} lg_stage;
+int lg_profile_enable(lg_ctx* ctx, int on);
+int lg_profile_read(lg_ctx* ctx, float ms_out[LG_STAGE_COUNT], uint32_t* samples_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGERO_HIP_H */

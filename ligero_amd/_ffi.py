@@ -1,0 +1,99 @@
+"""ctypes loader for the C ABI in include/ligero_hip.h (ligero_amd/lib/libligero_hip.so).
+
+There is no fallback: if the shared library is missing or fails to load this raises, and
+every compute entry point fails with a negative status when no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libligero_hip.so")
+
+# every symbol include/ligero_hip.h declares (tests check the export list against this)
+SYMBOLS = [
+    "lg_status_string", "lg_last_error", "lg_abi_version",
+    "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_destroy",
+    "lg_encode_commit", "lg_upload_preenc", "lg_commit_resident", "lg_sync",
+    "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
+    "lg_open_columns",
+    "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
+    "lg_ctx_dims", "lg_profile_enable", "lg_profile_read",
+]
+
+LG_OK = 0
+LG_ERR_BAD_ARG = -1
+LG_ERR_BAD_DIMS = -2
+LG_ERR_NO_DEVICE = -3
+LG_ERR_HIP = -4
+LG_ERR_OOM = -5
+LG_ERR_STATE = -6
+LG_ERR_UNSUPPORTED = -7
+LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
+
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_int = ctypes.c_int
+
+_lib = None
+
+
+class LigeroHipError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({detail})")
+
+
+def lib():
+    """Load libligero_hip.so (once).  Raises if it is not built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ligero_amd/csrc`.  ligero_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.lg_status_string.restype = ctypes.c_char_p
+    L.lg_status_string.argtypes = [_int]
+    L.lg_last_error.restype = ctypes.c_char_p
+    L.lg_last_error.argtypes = [_vp]
+    L.lg_abi_version.restype = _u32
+    L.lg_ctx_create.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32]
+    L.lg_ctx_create_batched.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32, _u32]
+    L.lg_ctx_destroy.argtypes = [_vp]
+    L.lg_ctx_destroy.restype = None
+    L.lg_encode_commit.argtypes = [_vp, _vp, _vp, _vp]
+    L.lg_upload_preenc.argtypes = [_vp, _vp]
+    L.lg_commit_resident.argtypes = [_vp]
+    L.lg_sync.argtypes = [_vp]
+    L.lg_read_root.argtypes = [_vp, _vp]
+    L.lg_read_coeffs.argtypes = [_vp, _vp]
+    L.lg_read_leaves.argtypes = [_vp, _vp]
+    L.lg_read_nodes.argtypes = [_vp, _vp]
+    L.lg_read_codeword_rows.argtypes = [_vp, _u32, _u32, _u32, _vp]
+    L.lg_open_columns.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _vp]
+    L.lg_reed_solomon_interpolate.argtypes = [_vp, _vp, _u32, _vp]
+    L.lg_reed_solomon_evaluate.argtypes = [_vp, _vp, _u32, _vp]
+    L.lg_reed_solomon.argtypes = [_vp, _vp, _u32, _vp]
+    L.lg_ctx_dims.argtypes = [_vp, _vp, _vp, _vp, _vp]
+    L.lg_profile_enable.argtypes = [_vp, _int]
+    L.lg_profile_read.argtypes = [_vp, _vp, _vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("lg_abi_version",):
+            fn.restype = _int
+    _lib = L
+    return L
+
+
+def check(status: int, what: str, ctx=None):
+    if status != LG_OK:
+        L = lib()
+        detail = L.lg_status_string(status).decode()
+        if ctx is not None:
+            extra = L.lg_last_error(ctx).decode()
+            if extra:
+                detail += "; " + extra
+        raise LigeroHipError(status, what, detail)

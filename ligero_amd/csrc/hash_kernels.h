@@ -1,0 +1,232 @@
+// Column hashing (Blake2s-256) and Merkle tree (SHA-256) kernels for gfx950.
+//
+// Replaces, from NP-Eng/ligero:
+//   * u.columns() + H::evaluate per column        src/ligero/mod.rs:536-542, src/matrices/mod.rs:163-167
+//     with H = FieldToBytesColHasher<F, Blake2s256> (src/ligero/types.rs:18): digest_j =
+//     Blake2s-256( LE64(rows) || canonicalLE32(U[0][j]) || ... || canonicalLE32(U[rows-1][j]) )
+//   * create_merkle_tree + root                   src/ligero/mod.rs:544-551
+//     with TestMerkleTreeParams (types.rs:6-8,25-26): identity leaf hash; bottom inner level
+//     SHA-256( LE64(32)||L || LE64(32)||R ); upper levels SHA-256( L || R ); heap order.
+//
+// There is no transpose: the codeword matrix is stored as 8 coset planes [s][row][q]
+// (column j = 8q + s) holding canonical integers, so lanes = adjacent q read adjacent
+// 32-byte elements of one row -- coalesced row-major streaming.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lg {
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+// ---------------------------------------------------------------- Blake2s
+__device__ __forceinline__ constexpr uint32_t b2s_iv(int i) {
+    constexpr uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+    return IV[i];
+}
+__device__ __forceinline__ constexpr int b2s_sigma(int r, int i) {
+    constexpr uint8_t S[10][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+    return S[r][i];
+}
+
+#define LG_B2S_G(a, b, c, d, x, y)        \
+    a += b + (x); d = rotr32(d ^ a, 16);  \
+    c += d;       b = rotr32(b ^ c, 12);  \
+    a += b + (y); d = rotr32(d ^ a, 8);   \
+    c += d;       b = rotr32(b ^ c, 7);
+
+// one compression; t = byte counter after this block (fits 64 bits, high word passed separately)
+__device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t t_lo, uint32_t t_hi, bool last) {
+    uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+    uint32_t v8 = b2s_iv(0), v9 = b2s_iv(1), v10 = b2s_iv(2), v11 = b2s_iv(3);
+    uint32_t v12 = b2s_iv(4) ^ t_lo, v13 = b2s_iv(5) ^ t_hi, v14 = last ? ~b2s_iv(6) : b2s_iv(6), v15 = b2s_iv(7);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        LG_B2S_G(v0, v4, v8, v12, m[b2s_sigma(r, 0)], m[b2s_sigma(r, 1)])
+        LG_B2S_G(v1, v5, v9, v13, m[b2s_sigma(r, 2)], m[b2s_sigma(r, 3)])
+        LG_B2S_G(v2, v6, v10, v14, m[b2s_sigma(r, 4)], m[b2s_sigma(r, 5)])
+        LG_B2S_G(v3, v7, v11, v15, m[b2s_sigma(r, 6)], m[b2s_sigma(r, 7)])
+        LG_B2S_G(v0, v5, v10, v15, m[b2s_sigma(r, 8)], m[b2s_sigma(r, 9)])
+        LG_B2S_G(v1, v6, v11, v12, m[b2s_sigma(r, 10)], m[b2s_sigma(r, 11)])
+        LG_B2S_G(v2, v7, v8, v13, m[b2s_sigma(r, 12)], m[b2s_sigma(r, 13)])
+        LG_B2S_G(v3, v4, v9, v14, m[b2s_sigma(r, 14)], m[b2s_sigma(r, 15)])
+    }
+    h[0] ^= v0 ^ v8;  h[1] ^= v1 ^ v9;  h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
+    h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+}
+
+struct ColHashArgs {
+    const uint4* u;         // coset planes [8][total_rows][k], canonical integers, 2 x uint4 per element
+    uint8_t* leaves;        // [batch][n][32]
+    uint32_t rows;          // rows per proof (4m)
+    uint32_t k;             // elements per plane row
+    uint32_t batch;         // proofs
+    uint32_t ncos;          // cosets hashed by this launch
+    uint32_t cosets[8];     // their ids (0..7)
+    uint64_t plane_stride;  // in elements
+};
+
+// One lane per column.  Thread id -> (proof b, coset s, q) with q fastest, so a wave reads
+// 64 adjacent elements (2 KiB contiguous) of one row per step.
+__global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)a.batch * a.ncos * a.k;
+    if (gid >= total) return;
+    const uint32_t q = (uint32_t)(gid % a.k);
+    const uint32_t sc = (uint32_t)((gid / a.k) % a.ncos);
+    const uint32_t b = (uint32_t)(gid / ((uint64_t)a.k * a.ncos));
+    const uint32_t s = a.cosets[sc];
+    // element (row i) = p[i * 2k], p[i * 2k + 1]
+    const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + (uint64_t)b * a.rows * a.k + q);
+    const uint64_t step = 2 * (uint64_t)a.k;
+
+    uint32_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = b2s_iv(i);
+    h[0] ^= 0x01010020u;
+    uint32_t m[16];
+    m[0] = a.rows;  // LE64(rows): serialize_compressed length prefix of Vec<F>
+    m[1] = 0;
+    uint64_t t = 0;
+    const uint32_t pairs = a.rows >> 1;
+    uint4 a0, a1, b0, b1;
+    if (pairs) { a0 = p[0]; a1 = p[1]; b0 = p[step]; b1 = p[step + 1]; }
+    for (uint32_t i = 0; i < pairs; i++) {
+        m[2] = a0.x; m[3] = a0.y; m[4] = a0.z; m[5] = a0.w; m[6] = a1.x; m[7] = a1.y; m[8] = a1.z; m[9] = a1.w;
+        m[10] = b0.x; m[11] = b0.y; m[12] = b0.z; m[13] = b0.w; m[14] = b1.x; m[15] = b1.y;
+        const uint32_t c0 = b1.z, c1 = b1.w;
+        p += 2 * step;
+        if (i + 1 < pairs) { a0 = p[0]; a1 = p[1]; b0 = p[step]; b1 = p[step + 1]; }  // prefetch next pair
+        t += 64;
+        b2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), false);
+        m[0] = c0;
+        m[1] = c1;
+    }
+#pragma unroll
+    for (int i = 2; i < 16; i++) m[i] = 0;
+    if (a.rows & 1) {
+        a0 = p[0]; a1 = p[1];
+        m[2] = a0.x; m[3] = a0.y; m[4] = a0.z; m[5] = a0.w; m[6] = a1.x; m[7] = a1.y; m[8] = a1.z; m[9] = a1.w;
+        t += 40;
+    } else {
+        t += 8;
+    }
+    b2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), true);
+    uint4* out = reinterpret_cast<uint4*>(a.leaves + 32 * ((uint64_t)b * a.k * 8 + 8 * (uint64_t)q + s));
+    out[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    out[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// ---------------------------------------------------------------- SHA-256
+__device__ __forceinline__ constexpr uint32_t sha_k(int i) {
+    constexpr uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    return K[i];
+}
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// one SHA-256 block; w[] holds the 16 big-endian message words and is clobbered
+__device__ __forceinline__ void sha256_block(uint32_t (&st)[8], uint32_t (&w)[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = h + S1 + ch + sha_k(i) + w[i & 15];
+        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+__device__ __forceinline__ void sha256_init(uint32_t (&st)[8]) {
+    st[0] = 0x6a09e667u; st[1] = 0xbb67ae85u; st[2] = 0x3c6ef372u; st[3] = 0xa54ff53au;
+    st[4] = 0x510e527fu; st[5] = 0x9b05688cu; st[6] = 0x1f83d9abu; st[7] = 0x5be0cd19u;
+}
+
+// parent = SHA-256 over two 32-byte children (LEAF: each child prefixed by LE64(32))
+template <bool LEAF>
+__device__ __forceinline__ void sha256_two_to_one(const uint4* left, const uint4* right, uint4* out) {
+    uint4 l0 = left[0], l1 = left[1], r0 = right[0], r1 = right[1];
+    uint32_t L[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    uint32_t st[8], w[16];
+    sha256_init(st);
+    if constexpr (LEAF) {
+        // 80-byte message: 20 00 00 00 00 00 00 00 | L | 20 00 .. | R
+        w[0] = 0x20000000u; w[1] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[2 + i] = bswap32(L[i]);
+        w[10] = 0x20000000u; w[11] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[12 + i] = bswap32(R[i]);
+        sha256_block(st, w);
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = bswap32(R[4 + i]);
+        w[4] = 0x80000000u;
+#pragma unroll
+        for (int i = 5; i < 15; i++) w[i] = 0;
+        w[15] = 80 * 8;
+        sha256_block(st, w);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { w[i] = bswap32(L[i]); w[8 + i] = bswap32(R[i]); }
+        sha256_block(st, w);
+        w[0] = 0x80000000u;
+#pragma unroll
+        for (int i = 1; i < 15; i++) w[i] = 0;
+        w[15] = 64 * 8;
+        sha256_block(st, w);
+    }
+    out[0] = make_uint4(bswap32(st[0]), bswap32(st[1]), bswap32(st[2]), bswap32(st[3]));
+    out[1] = make_uint4(bswap32(st[4]), bswap32(st[5]), bswap32(st[6]), bswap32(st[7]));
+}
+
+struct MerkleArgs {
+    const uint8_t* leaves;  // [batch][n][32]
+    uint8_t* nodes;         // [batch][n-1][32], heap order, root at 0
+    uint32_t n;             // leaves per tree (power of two >= 2)
+    uint32_t batch;
+    uint32_t level_nodes;   // nodes in the level being produced
+};
+
+// produces one tree level for every tree of the batch; LEAF: children are the leaf digests
+template <bool LEAF>
+__global__ void __launch_bounds__(256) merkle_level_kernel(const MerkleArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)a.batch * a.level_nodes) return;
+    const uint32_t i = (uint32_t)(gid % a.level_nodes);
+    const uint32_t b = (uint32_t)(gid / a.level_nodes);
+    uint8_t* tree = a.nodes + 32 * (uint64_t)b * (a.n - 1);
+    const uint32_t idx = a.level_nodes - 1 + i;  // heap index of the produced node
+    const uint4* l;
+    const uint4* r;
+    if constexpr (LEAF) {
+        const uint8_t* lv = a.leaves + 32 * ((uint64_t)b * a.n + 2 * (uint64_t)i);
+        l = reinterpret_cast<const uint4*>(lv);
+        r = reinterpret_cast<const uint4*>(lv + 32);
+    } else {
+        l = reinterpret_cast<const uint4*>(tree + 32 * (uint64_t)(2 * idx + 1));
+        r = reinterpret_cast<const uint4*>(tree + 32 * (uint64_t)(2 * idx + 2));
+    }
+    sha256_two_to_one<LEAF>(l, r, reinterpret_cast<uint4*>(tree + 32 * (uint64_t)idx));
+}
+
+}  // namespace lg

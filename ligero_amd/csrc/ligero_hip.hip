@@ -1,0 +1,556 @@
+// C ABI implementation (include/ligero_hip.h) of the MI355X Ligero encode-and-commit path.
+// Host side: context, device buffers, domain tables, kernel launches on one HIP stream.
+// gfx950 only; there is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ligero_hip.h"
+#include "fr_gfx950.h"
+#include "hash_kernels.h"
+#include "host_fr.h"
+#include "ntt_kernels.h"
+#include "ntt_launch.h"
+
+using lg::fr;
+
+// ----------------------------------------------------------------------------- context
+struct lg_ctx {
+    int device = 0;
+    uint32_t rows = 0, k = 0, n = 0, batch = 1;
+    int logk = 0, logn = 0;
+    uint64_t total_rows = 0;  // batch * rows
+    hipStream_t stream = nullptr;
+    // resident commitment
+    fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
+    fr* d_coeffs = nullptr;   // [total_rows][k]  Montgomery
+    fr* d_u = nullptr;        // [8][total_rows][k] canonical integers; plane 0 = message
+    uint8_t* d_leaves = nullptr;  // [batch][n][32]
+    uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
+    // domain tables
+    fr* d_tw_fwd = nullptr;    // omega_k^e, e < k, Montgomery
+    fr* d_tw_inv = nullptr;    // omega_k^-e
+    fr* d_coset_tw = nullptr;  // omega_n^e, e < n, canonical integers
+    fr w8_fwd[3], w8_inv[3], scale_kinv, r2;
+    // scratch for row operators / openings (grown on demand)
+    fr* d_scratch_a = nullptr; size_t scratch_a_elems = 0;  // inputs / coefficients
+    fr* d_scratch_b = nullptr; size_t scratch_b_elems = 0;  // planes / outputs
+    fr* d_scratch_c = nullptr; size_t scratch_c_elems = 0;  // natural-order output
+    uint32_t* d_idx = nullptr; size_t idx_cap = 0;
+    uint8_t* d_path_out = nullptr; size_t path_cap = 0;
+    bool committed = false;
+    bool profiling = false;
+    static constexpr int kProfRing = 64;                 // commits remembered by the profiler
+    hipEvent_t ev[kProfRing][LG_STAGE_COUNT + 1] = {};
+    bool ev_valid = false;
+    uint64_t prof_commits = 0;                            // commits recorded since lg_profile_enable(1)
+    char err[256] = {0};
+};
+
+static int fail_hip(lg_ctx* c, hipError_t e, const char* what) {
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+    return (e == hipErrorOutOfMemory) ? LG_ERR_OOM : LG_ERR_HIP;
+}
+#define LG_HIP(c, call)                                   \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return fail_hip(c, e_, #call); \
+    } while (0)
+
+static fr to_dev(const lg_host::Fr& a) {
+    fr r;
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)a.l[i];
+        r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
+    }
+    return r;
+}
+static int ilog2_exact(uint32_t x) {
+    if (x == 0 || (x & (x - 1))) return -1;
+    int l = 0;
+    while ((1u << l) < x) l++;
+    return l;
+}
+
+// ----------------------------------------------------------------------------- small kernels
+namespace lg {
+
+struct GatherArgs {
+    const fr* u;             // coset planes, canonical
+    const uint8_t* leaves;   // [n][32] of the proof
+    const uint8_t* nodes;    // [n-1][32] of the proof
+    const uint32_t* idx;     // [t]
+    fr* cols;                // [t][rows] Montgomery
+    uint8_t* sib;            // [t][32]
+    uint8_t* paths;          // [t][logn-1][32]
+    fr r2;
+    uint64_t plane_stride;
+    uint64_t row_base;       // proof * rows
+    uint32_t rows, k, n, logn, t;
+};
+
+// u.column(i) for the opened indices (src/matrices/mod.rs:169-171) + generate_proof pieces
+__global__ void __launch_bounds__(256) gather_columns_kernel(const GatherArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t ncol_elems = (uint64_t)a.t * a.rows;
+    if (gid < ncol_elems) {
+        const uint32_t c = (uint32_t)(gid / a.rows), i = (uint32_t)(gid % a.rows);
+        const uint32_t j = a.idx[c];
+        const uint32_t s = j & 7, q = j >> 3;
+        fr x = fr_load(a.u + (uint64_t)s * a.plane_stride + (a.row_base + i) * a.k + q);
+        fr y, z;
+        fr_mul_lazy(y, x, a.r2);
+        fr_reduce(z, y);
+        fr_store(a.cols + gid, z);
+        return;
+    }
+    const uint64_t h = gid - ncol_elems;
+    const uint32_t plen = a.logn - 1;
+    if (h >= (uint64_t)a.t * (plen + 1)) return;
+    const uint32_t c = (uint32_t)(h / (plen + 1)), lvl = (uint32_t)(h % (plen + 1));
+    const uint32_t j = a.idx[c];
+    const uint4* src;
+    uint4* dst;
+    if (lvl == plen) {  // leaf sibling
+        src = reinterpret_cast<const uint4*>(a.leaves + 32 * (uint64_t)(j ^ 1));
+        dst = reinterpret_cast<uint4*>(a.sib + 32 * (uint64_t)c);
+    } else {  // auth_path[lvl], root side first: sibling of the ancestor at depth lvl+1
+        const uint32_t depth = lvl + 1;
+        const uint32_t anc = j >> (a.logn - depth);
+        const uint32_t node = ((1u << depth) - 1) + (anc ^ 1);
+        src = reinterpret_cast<const uint4*>(a.nodes + 32 * (uint64_t)node);
+        dst = reinterpret_cast<uint4*>(a.paths + 32 * ((uint64_t)c * plen + lvl));
+    }
+    dst[0] = src[0];
+    dst[1] = src[1];
+}
+
+// coset planes (canonical) -> natural column order rows (Montgomery): out[i][8q+s]
+__global__ void __launch_bounds__(256) planes_to_rows_kernel(const fr* u, uint64_t plane_stride, uint64_t row_base,
+                                                            uint32_t nrows, uint32_t k, fr r2, fr* out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)nrows * k * 8;
+    if (gid >= total) return;
+    const uint32_t q = (uint32_t)(gid % k);
+    const uint32_t s = (uint32_t)((gid / k) & 7);
+    const uint64_t i = gid / ((uint64_t)k * 8);
+    fr x = fr_load(u + (uint64_t)s * plane_stride + (row_base + i) * k + q);
+    fr y, z;
+    fr_mul_lazy(y, x, r2);
+    fr_reduce(z, y);
+    fr_store(out + i * (uint64_t)k * 8 + 8 * (uint64_t)q + s, z);
+}
+
+}  // namespace lg
+
+// ----------------------------------------------------------------------------- launches
+static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon_out, uint32_t row0, uint32_t rows) {
+    lg::NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.canon_out = canon_out;
+    a.tw = c->d_tw_inv; a.coset_tw = nullptr;
+    for (int i = 0; i < 3; i++) a.w8[i] = c->w8_inv[i];
+    a.scale = c->scale_kinv;
+    a.rows = rows; a.row0 = row0; a.ncos = 0;
+    a.plane_stride = 0;
+    return a;
+}
+static lg::NttArgs eval_args(const lg_ctx* c, const fr* coeffs, fr* planes, uint64_t plane_stride, uint32_t row0, uint32_t rows,
+                             uint32_t first_coset) {
+    lg::NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = coeffs; a.out = planes; a.canon_out = nullptr;
+    a.tw = c->d_tw_fwd; a.coset_tw = c->d_coset_tw;
+    for (int i = 0; i < 3; i++) a.w8[i] = c->w8_fwd[i];
+    a.scale = c->scale_kinv;
+    a.rows = rows; a.row0 = row0;
+    a.ncos = 8 - first_coset;
+    for (uint32_t s = first_coset; s < 8; s++) a.cosets[s - first_coset] = s;
+    a.plane_stride = plane_stride;
+    return a;
+}
+
+static int grow(lg_ctx* c, fr** p, size_t* cap, size_t need) {
+    if (*cap >= need) return LG_OK;
+    if (*p) LG_HIP(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(p), need * sizeof(fr)));
+    *cap = need;
+    return LG_OK;
+}
+
+// ----------------------------------------------------------------------------- ABI
+extern "C" {
+
+const char* lg_status_string(int s) {
+    switch (s) {
+        case LG_OK: return "ok";
+        case LG_ERR_BAD_ARG: return "bad argument";
+        case LG_ERR_BAD_DIMS: return "bad dimensions";
+        case LG_ERR_NO_DEVICE: return "no such HIP device";
+        case LG_ERR_HIP: return "HIP runtime error";
+        case LG_ERR_OOM: return "out of memory";
+        case LG_ERR_STATE: return "invalid call order";
+        case LG_ERR_UNSUPPORTED: return "unsupported shape";
+        default: return "unknown status";
+    }
+}
+const char* lg_last_error(const lg_ctx* c) { return c ? c->err : ""; }
+uint32_t lg_abi_version(void) { return LG_ABI_VERSION; }
+
+void lg_ctx_destroy(lg_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw,
+                    c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    if (c->ev_valid)
+        for (auto& set : c->ev)
+            for (auto& e : set) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+    if (!out) return LG_ERR_BAD_ARG;
+    *out = nullptr;
+    const int logk = ilog2_exact(k), logn = ilog2_exact(n);
+    if (rows == 0 || batch == 0 || logk < 1 || logn < 0 || n != 8 * (uint64_t)k || logn > lg_host::kTwoAdicity) return LG_ERR_BAD_DIMS;
+    if (logk > lg::kMaxLdsLogK) return LG_ERR_UNSUPPORTED;
+    if ((uint64_t)rows * batch > 0xffffffffull / 8) return LG_ERR_BAD_DIMS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LG_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return LG_ERR_NO_DEVICE;
+    lg_ctx* c = new (std::nothrow) lg_ctx();
+    if (!c) return LG_ERR_OOM;
+    c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
+    c->total_rows = (uint64_t)rows * batch;
+    int rc = LG_OK;
+    auto body = [&]() -> int {
+        LG_HIP(c, hipSetDevice(device));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        const size_t mat = (size_t)c->total_rows * k;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coeffs), mat * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u), 8 * mat * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_fwd), (size_t)k * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_inv), (size_t)k * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), (size_t)n * sizeof(fr)));
+        // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
+        using namespace lg_host;
+        const Fr wn = domain_generator(logn);
+        const Fr wk = domain_generator(logk);
+        const Fr wk_inv = inverse(wk);
+        std::vector<fr> tf(k), ti(k), ct(n);
+        Fr a = kOneMont, b = kOneMont;
+        for (uint32_t e = 0; e < k; e++) {
+            tf[e] = to_dev(a);
+            ti[e] = to_dev(b);
+            a = mul(a, wk);
+            b = mul(b, wk_inv);
+        }
+        a = kOneMont;
+        for (uint32_t e = 0; e < n; e++) {
+            ct[e] = to_dev(from_mont(a));
+            a = mul(a, wn);
+        }
+        LG_HIP(c, hipMemcpy(c->d_tw_fwd, tf.data(), tf.size() * sizeof(fr), hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_tw_inv, ti.data(), ti.size() * sizeof(fr), hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size() * sizeof(fr), hipMemcpyHostToDevice));
+        const Fr w8 = domain_generator(3), w8i = inverse(w8);
+        Fr p = w8, pi = w8i;
+        for (int i = 0; i < 3; i++) {
+            c->w8_fwd[i] = to_dev(p);
+            c->w8_inv[i] = to_dev(pi);
+            p = mul(p, w8);
+            pi = mul(pi, w8i);
+        }
+        Fr kk = {{k, 0, 0, 0}};
+        c->scale_kinv = to_dev(inverse(to_mont(kk)));
+        c->r2 = to_dev(kR2);
+        return LG_OK;
+    };
+    rc = body();
+    if (rc != LG_OK) {
+        lg_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LG_OK;
+}
+
+int lg_ctx_create(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n) {
+    return lg_ctx_create_batched(out, device, rows, k, n, 1);
+}
+
+int lg_ctx_dims(const lg_ctx* c, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (rows) *rows = c->rows;
+    if (k) *k = c->k;
+    if (n) *n = c->n;
+    if (batch) *batch = c->batch;
+    return LG_OK;
+}
+
+int lg_upload_preenc(lg_ctx* c, const uint64_t* preenc) {
+    if (!c || !preenc) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipMemcpyAsync(c->d_preenc, preenc, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    return LG_OK;
+}
+
+int lg_profile_enable(lg_ctx* c, int on) {
+    if (!c) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    if (on && !c->ev_valid) {
+        for (auto& set : c->ev)
+            for (auto& e : set) LG_HIP(c, hipEventCreate(&e));
+        c->ev_valid = true;
+    }
+    c->profiling = on != 0;
+    c->prof_commits = 0;
+    return LG_OK;
+}
+
+int lg_commit_resident(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint64_t plane = c->total_rows * c->k;
+    const bool prof = c->profiling && c->ev_valid;
+    hipEvent_t* ev = c->ev[c->prof_commits % lg_ctx::kProfRing];
+    if (prof) LG_HIP(c, hipEventRecord(ev[0], c->stream));
+    // rows -> coefficients (mod.rs:521-526); also emits the canonical message = coset plane 0
+    {
+        lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, 0, (uint32_t)c->total_rows);
+        LG_HIP(c, lg::launch_ntt(c->logk, false, c->stream, a));
+    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[1], c->stream));
+    // coefficients -> cosets 1..7 of the order-n domain (mod.rs:528-533)
+    {
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, 0, (uint32_t)c->total_rows, 1);
+        LG_HIP(c, lg::launch_ntt(c->logk, true, c->stream, a));
+    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[2], c->stream));
+    // column hashes (mod.rs:536-542)
+    {
+        lg::ColHashArgs h;
+        memset(&h, 0, sizeof(h));
+        h.u = reinterpret_cast<const uint4*>(c->d_u);
+        h.leaves = c->d_leaves;
+        h.rows = c->rows; h.k = c->k; h.batch = c->batch; h.ncos = 8;
+        for (uint32_t s = 0; s < 8; s++) h.cosets[s] = s;
+        h.plane_stride = plane;
+        const uint64_t threads = (uint64_t)c->batch * c->n;
+        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, h);
+        LG_HIP(c, hipGetLastError());
+    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[3], c->stream));
+    // Merkle tree (mod.rs:544-551)
+    {
+        lg::MerkleArgs m;
+        m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.batch = c->batch;
+        for (uint32_t lvl = c->n / 2; lvl >= 1; lvl >>= 1) {
+            m.level_nodes = lvl;
+            const uint64_t threads = (uint64_t)c->batch * lvl;
+            const dim3 grid((uint32_t)((threads + 255) / 256));
+            if (lvl == c->n / 2)
+                hipLaunchKernelGGL(lg::merkle_level_kernel<true>, grid, dim3(256), 0, c->stream, m);
+            else
+                hipLaunchKernelGGL(lg::merkle_level_kernel<false>, grid, dim3(256), 0, c->stream, m);
+        }
+        LG_HIP(c, hipGetLastError());
+    }
+    if (prof) {
+        LG_HIP(c, hipEventRecord(ev[4], c->stream));
+        c->prof_commits++;
+    }
+    c->committed = true;
+    return LG_OK;
+}
+
+int lg_profile_read(lg_ctx* c, float ms_out[LG_STAGE_COUNT], uint32_t* samples_out) {
+    if (!c || !ms_out) return LG_ERR_BAD_ARG;
+    if (!c->ev_valid || !c->profiling || c->prof_commits == 0) return LG_ERR_STATE;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint64_t have = c->prof_commits < lg_ctx::kProfRing ? c->prof_commits : lg_ctx::kProfRing;
+    double acc[LG_STAGE_COUNT] = {0, 0, 0, 0};
+    for (uint64_t s = 0; s < have; s++) {
+        hipEvent_t* ev = c->ev[(c->prof_commits - 1 - s) % lg_ctx::kProfRing];
+        LG_HIP(c, hipEventSynchronize(ev[LG_STAGE_COUNT]));
+        for (int i = 0; i < LG_STAGE_COUNT; i++) {
+            float ms = 0;
+            LG_HIP(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (int i = 0; i < LG_STAGE_COUNT; i++) ms_out[i] = (float)(acc[i] / (double)have);
+    if (samples_out) *samples_out = (uint32_t)have;
+    return LG_OK;
+}
+
+int lg_sync(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipStreamSynchronize(c->stream));
+    return LG_OK;
+}
+
+static int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes) {
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    LG_HIP(c, hipStreamSynchronize(c->stream));
+    return LG_OK;
+}
+
+int lg_read_root(lg_ctx* c, uint8_t* root_out) {
+    if (!c || !root_out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipMemcpy2DAsync(root_out, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, c->batch, hipMemcpyDeviceToHost, c->stream));
+    LG_HIP(c, hipStreamSynchronize(c->stream));
+    return LG_OK;
+}
+int lg_read_coeffs(lg_ctx* c, uint64_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    return read_back(c, out, c->d_coeffs, (size_t)c->total_rows * c->k * sizeof(fr));
+}
+int lg_read_leaves(lg_ctx* c, uint8_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    return read_back(c, out, c->d_leaves, (size_t)c->batch * c->n * 32);
+}
+int lg_read_nodes(lg_ctx* c, uint8_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    return read_back(c, out, c->d_nodes, (size_t)c->batch * (c->n - 1) * 32);
+}
+
+int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out) {
+    if (!c || !preenc || !root_out) return LG_ERR_BAD_ARG;
+    int rc = lg_upload_preenc(c, preenc);
+    if (rc != LG_OK) return rc;
+    rc = lg_commit_resident(c);
+    if (rc != LG_OK) return rc;
+    if (coeffs_out) {
+        rc = lg_read_coeffs(c, coeffs_out);
+        if (rc != LG_OK) return rc;
+    }
+    return lg_read_root(c, root_out);
+}
+
+int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nrows, uint64_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    if (proof >= c->batch || (uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
+    if (nrows == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    const size_t elems = (size_t)nrows * c->n;
+    int rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, elems);
+    if (rc != LG_OK) return rc;
+    const uint64_t threads = elems;
+    hipLaunchKernelGGL(lg::planes_to_rows_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_u,
+                       c->total_rows * c->k, (uint64_t)proof * c->rows + row0, nrows, c->k, c->r2, c->d_scratch_c);
+    LG_HIP(c, hipGetLastError());
+    return read_back(c, out, c->d_scratch_c, elems * sizeof(fr));
+}
+
+int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
+    if (!c || !idx || !cols_out || !sib_out || (!paths_out && c->logn > 1)) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    if (proof >= c->batch) return LG_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < t; i++)
+        if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
+    if (t == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint32_t plen = (uint32_t)c->logn - 1;
+    if (c->idx_cap < t) {
+        if (c->d_idx) LG_HIP(c, hipFree(c->d_idx));
+        c->d_idx = nullptr; c->idx_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_idx), (size_t)t * sizeof(uint32_t)));
+        c->idx_cap = t;
+    }
+    const size_t path_bytes = (size_t)t * (plen + 1) * 32;
+    if (c->path_cap < path_bytes) {
+        if (c->d_path_out) LG_HIP(c, hipFree(c->d_path_out));
+        c->d_path_out = nullptr; c->path_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_path_out), path_bytes));
+        c->path_cap = path_bytes;
+    }
+    int rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, (size_t)t * c->rows);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->d_idx, idx, (size_t)t * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    lg::GatherArgs g;
+    memset(&g, 0, sizeof(g));
+    g.u = c->d_u;
+    g.leaves = c->d_leaves + (size_t)proof * c->n * 32;
+    g.nodes = c->d_nodes + (size_t)proof * (c->n - 1) * 32;
+    g.idx = c->d_idx;
+    g.cols = c->d_scratch_c;
+    g.sib = c->d_path_out;
+    g.paths = c->d_path_out + (size_t)t * 32;
+    g.r2 = c->r2;
+    g.plane_stride = c->total_rows * c->k;
+    g.row_base = (uint64_t)proof * c->rows;
+    g.rows = c->rows; g.k = c->k; g.n = c->n; g.logn = (uint32_t)c->logn; g.t = t;
+    const uint64_t threads = (uint64_t)t * c->rows + (uint64_t)t * (plen + 1);
+    hipLaunchKernelGGL(lg::gather_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, g);
+    LG_HIP(c, hipGetLastError());
+    LG_HIP(c, hipMemcpyAsync(cols_out, c->d_scratch_c, (size_t)t * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->stream));
+    LG_HIP(c, hipMemcpyAsync(sib_out, g.sib, (size_t)t * 32, hipMemcpyDeviceToHost, c->stream));
+    if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, g.paths, (size_t)t * plen * 32, hipMemcpyDeviceToHost, c->stream));
+    LG_HIP(c, hipStreamSynchronize(c->stream));
+    return LG_OK;
+}
+
+// row operators on scratch buffers: a = input rows / coefficients, b = coset planes, c = natural-order output
+static int rs_common(lg_ctx* c, const uint64_t* in, uint32_t nrows, uint64_t* out, bool do_interp, bool do_eval) {
+    if (!c || !in || !out) return LG_ERR_BAD_ARG;
+    if (nrows == 0) return LG_OK;
+    if ((uint64_t)nrows > c->total_rows) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    const size_t mat = (size_t)nrows * c->k;
+    int rc = grow(c, &c->d_scratch_a, &c->scratch_a_elems, 2 * mat);
+    if (rc != LG_OK) return rc;
+    fr* d_in = c->d_scratch_a;
+    fr* d_co = c->d_scratch_a + mat;
+    LG_HIP(c, hipMemcpyAsync(d_in, in, mat * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    const fr* coeffs = d_in;
+    if (do_interp) {
+        lg::NttArgs a = interp_args(c, d_in, d_co, nullptr, 0, nrows);
+        LG_HIP(c, lg::launch_ntt(c->logk, false, c->stream, a));
+        coeffs = d_co;
+    }
+    if (!do_eval) return read_back(c, out, coeffs, mat * sizeof(fr));
+    rc = grow(c, &c->d_scratch_b, &c->scratch_b_elems, 8 * mat);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, 8 * mat);
+    if (rc != LG_OK) return rc;
+    lg::NttArgs a = eval_args(c, coeffs, c->d_scratch_b, mat, 0, nrows, 0);
+    LG_HIP(c, lg::launch_ntt(c->logk, true, c->stream, a));
+    const uint64_t threads = 8 * (uint64_t)mat;
+    hipLaunchKernelGGL(lg::planes_to_rows_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_scratch_b,
+                       (uint64_t)mat, (uint64_t)0, nrows, c->k, c->r2, c->d_scratch_c);
+    LG_HIP(c, hipGetLastError());
+    return read_back(c, out, c->d_scratch_c, 8 * mat * sizeof(fr));
+}
+int lg_reed_solomon_interpolate(lg_ctx* c, const uint64_t* msg, uint32_t nrows, uint64_t* coeffs_out) {
+    return rs_common(c, msg, nrows, coeffs_out, true, false);
+}
+int lg_reed_solomon_evaluate(lg_ctx* c, const uint64_t* coeffs, uint32_t nrows, uint64_t* codeword_out) {
+    return rs_common(c, coeffs, nrows, codeword_out, false, true);
+}
+int lg_reed_solomon(lg_ctx* c, const uint64_t* msg, uint32_t nrows, uint64_t* codeword_out) {
+    return rs_common(c, msg, nrows, codeword_out, true, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// One translation unit per transform size (compiled with -DLG_LOGK=<log2 k>) so the size
+// instantiations of the row-NTT kernel build in parallel.
+#include <hip/hip_runtime.h>
+
+#include "ntt_kernels.h"
+#include "ntt_launch.h"
+
+#ifndef LG_LOGK
+#error "compile with -DLG_LOGK=<log2 k>"
+#endif
+
+namespace lg {
+
+template <int LOGK, bool EVAL>
+static hipError_t launch_t(hipStream_t st, const NttArgs& a) {
+    using Plan = NttPlan<LOGK>;
+    static bool attr_set = false;
+    auto kern = ntt_rows_kernel<LOGK, EVAL>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Plan::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint64_t work = EVAL ? (uint64_t)a.rows * a.ncos : a.rows;
+    if (work == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Plan::kWgThreads), Plan::kLdsBytes, st, a);
+    return hipGetLastError();
+}
+
+#define LG_CAT2(a, b) a##b
+#define LG_CAT(a, b) LG_CAT2(a, b)
+hipError_t LG_CAT(launch_ntt_logk_, LG_LOGK)(bool evaluate, hipStream_t st, const NttArgs& a) {
+    return evaluate ? launch_t<LG_LOGK, true>(st, a) : launch_t<LG_LOGK, false>(st, a);
+}
+
+}  // namespace lg

@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Names and argument meaning follow `impl LigeroCircuit` in NP-Eng/ligero
+(src/ligero/mod.rs): `reed_solomon_interpolate` (998-1002), `reed_solomon_evaluate`
+(1004-1008), `reed_solomon` (1010-1012), `open_columns` (935-955, with the Fiat-Shamir index
+derivation left to the caller), plus `encode_commit` for the block mod.rs:521-551.  All
+arithmetic happens on the GPU behind the C ABI (include/ligero_hip.h); this module only
+marshals numpy buffers.
+
+Field elements are numpy ``uint64`` arrays of shape (..., 4): BN254 Fr, little-endian limbs,
+Montgomery form -- the in-memory layout of ``ark_bn254::Fr``.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+
+_vp = ctypes.c_void_p
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+# ---- dimensions: LigeroCircuit::compute_dimensions / reed_solomon_parameters (mod.rs:275-294)
+def compute_dimensions(sol_vec_length: int) -> Tuple[int, int]:
+    """mod.rs:275-279: m = ceil(sqrt(len)), k = m.next_power_of_two()."""
+    m = math.ceil(math.sqrt(float(sol_vec_length)))
+    k = 1
+    while k < m:
+        k <<= 1
+    return m, k
+
+
+def calculate_t(sec_param: int, distance: Tuple[int, int], codeword_len: int, field_bits: int = 254) -> int:
+    """ark-poly-commit linear_codes::utils::calculate_t (called at mod.rs:287-292), f64 arithmetic."""
+    residual = codeword_len / 2.0 ** field_bits
+    rhs = math.log2(2.0 ** (-sec_param) - residual)
+    if not math.isfinite(rhs):
+        raise ValueError("field too small for the requested security level")
+    denom = math.log2(1.0 - 0.5 * distance[0] / distance[1])
+    t = math.ceil((rhs - 1.0) / denom)
+    return t if t < codeword_len else codeword_len
+
+
+def reed_solomon_parameters(m: int, k: int, lam: int) -> Tuple[int, int]:
+    """mod.rs:283-294: n = 8k (rho^-1 = 8 hard-coded), t = calculate_t(lambda, (n-k+1, n), n)."""
+    n = 8 * k
+    return n, calculate_t(lam, (n - k + 1, n), n)
+
+
+class LigeroCommitter:
+    """Device-resident encode-and-commit state for `batch` proofs of one shape.
+
+    rows = 4m (the row blocks [X; Y; Z; W] of preenc_u, mod.rs:516), k = message length,
+    n = 8k.  Mirrors the fields `m, k, n` + `large_domain`/`small_domain` of `LigeroCircuit`
+    (mod.rs:80-90) as far as the hot path needs them.
+    """
+
+    def __init__(self, rows: int, k: int, n: Optional[int] = None, batch: int = 1, device: int = 0):
+        n = 8 * k if n is None else n
+        self._L = _ffi.lib()
+        self._ctx = _vp()
+        self.rows, self.k, self.n, self.batch, self.device = rows, k, n, batch, device
+        st = self._L.lg_ctx_create_batched(ctypes.byref(self._ctx), device, rows, k, n, batch)
+        if st != _ffi.LG_OK:
+            self._ctx = None
+            _ffi.check(st, f"lg_ctx_create_batched(rows={rows}, k={k}, n={n}, batch={batch})")
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.lg_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, st, what):
+        _ffi.check(st, what, self._ctx)
+
+    def _mat(self, a, cols, what) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        if a.size % (cols * 4) != 0:
+            raise ValueError(f"{what}: size {a.size} is not a multiple of {cols} elements")
+        return a.reshape(-1, cols, 4)
+
+    # -- the hot path, mod.rs:521-551
+    def encode_commit(self, preenc_u, want_coeffs: bool = True):
+        """preenc_u: (batch*rows, k, 4).  Returns (u_polynomial_coeffs or None, u_root bytes
+        [batch*32]).  U, the leaf digests and the tree stay on the device."""
+        pre = self._mat(preenc_u, self.k, "preenc_u")
+        if pre.shape[0] != self.batch * self.rows:
+            raise ValueError(f"preenc_u has {pre.shape[0]} rows, expected {self.batch * self.rows}")
+        coeffs = np.empty_like(pre) if want_coeffs else None
+        root = np.empty(32 * self.batch, dtype=np.uint8)
+        self._chk(self._L.lg_encode_commit(self._ctx, _ptr(pre), _ptr(coeffs), _ptr(root)), "lg_encode_commit")
+        return coeffs, root.tobytes()
+
+    def upload(self, preenc_u):
+        pre = self._mat(preenc_u, self.k, "preenc_u")
+        if pre.shape[0] != self.batch * self.rows:
+            raise ValueError(f"preenc_u has {pre.shape[0]} rows, expected {self.batch * self.rows}")
+        self._chk(self._L.lg_upload_preenc(self._ctx, _ptr(pre)), "lg_upload_preenc")
+        self.sync()
+
+    def commit_resident(self):
+        self._chk(self._L.lg_commit_resident(self._ctx), "lg_commit_resident")
+
+    def sync(self):
+        self._chk(self._L.lg_sync(self._ctx), "lg_sync")
+
+    def root(self) -> bytes:
+        """u_tree.root() (mod.rs:551) for every proof of the batch, concatenated."""
+        out = np.empty(32 * self.batch, dtype=np.uint8)
+        self._chk(self._L.lg_read_root(self._ctx, _ptr(out)), "lg_read_root")
+        return out.tobytes()
+
+    def coeffs(self) -> np.ndarray:
+        out = np.empty((self.batch * self.rows, self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_read_coeffs(self._ctx, _ptr(out)), "lg_read_coeffs")
+        return out
+
+    def leaves(self) -> np.ndarray:
+        out = np.empty((self.batch, self.n, 32), dtype=np.uint8)
+        self._chk(self._L.lg_read_leaves(self._ctx, _ptr(out)), "lg_read_leaves")
+        return out
+
+    def nodes(self) -> np.ndarray:
+        out = np.empty((self.batch, self.n - 1, 32), dtype=np.uint8)
+        self._chk(self._L.lg_read_nodes(self._ctx, _ptr(out)), "lg_read_nodes")
+        return out
+
+    def codeword_rows(self, row0: int = 0, nrows: Optional[int] = None, proof: int = 0) -> np.ndarray:
+        """Rows of the encoded matrix U (mod.rs:528-533), natural column order, Montgomery."""
+        nrows = self.rows - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.n, 4), dtype=np.uint64)
+        self._chk(self._L.lg_read_codeword_rows(self._ctx, proof, row0, nrows, _ptr(out)), "lg_read_codeword_rows")
+        return out
+
+    # -- open_columns, mod.rs:944-952
+    def open_columns(self, indices: Sequence[int], proof: int = 0):
+        """Returns (columns (t, rows, 4), leaf_sibling_hash (t, 32), auth_path (t, log2 n - 1, 32)
+        root side first).  `indices` come from the host-side Fiat-Shamir PRNG (mod.rs:941-942)."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        t = idx.shape[0]
+        plen = self.n.bit_length() - 2
+        cols = np.empty((t, self.rows, 4), dtype=np.uint64)
+        sib = np.empty((t, 32), dtype=np.uint8)
+        paths = np.empty((t, plen, 32), dtype=np.uint8)
+        self._chk(self._L.lg_open_columns(self._ctx, proof, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns")
+        return cols, sib, paths
+
+    # -- row operators, mod.rs:998-1012
+    def reed_solomon_interpolate(self, msg) -> np.ndarray:
+        m = self._mat(msg, self.k, "msg")
+        out = np.empty_like(m)
+        self._chk(self._L.lg_reed_solomon_interpolate(self._ctx, _ptr(m), m.shape[0], _ptr(out)), "lg_reed_solomon_interpolate")
+        return out
+
+    def reed_solomon_evaluate(self, coeffs) -> np.ndarray:
+        c = self._mat(coeffs, self.k, "coeffs")
+        out = np.empty((c.shape[0], self.n, 4), dtype=np.uint64)
+        self._chk(self._L.lg_reed_solomon_evaluate(self._ctx, _ptr(c), c.shape[0], _ptr(out)), "lg_reed_solomon_evaluate")
+        return out
+
+    def reed_solomon(self, msg) -> np.ndarray:
+        m = self._mat(msg, self.k, "msg")
+        out = np.empty((m.shape[0], self.n, 4), dtype=np.uint64)
+        self._chk(self._L.lg_reed_solomon(self._ctx, _ptr(m), m.shape[0], _ptr(out)), "lg_reed_solomon")
+        return out
+
+    # -- per-stage timing (HIP events on the context's stream)
+    def profile(self, on: bool = True):
+        self._chk(self._L.lg_profile_enable(self._ctx, 1 if on else 0), "lg_profile_enable")
+
+    def stage_ms(self):
+        """mean ms per stage over the commits since profile(True) (at most the last 64)"""
+        out = (ctypes.c_float * 4)()
+        n = ctypes.c_uint32(0)
+        self._chk(self._L.lg_profile_read(self._ctx, ctypes.cast(out, _vp), ctypes.cast(ctypes.byref(n), _vp)), "lg_profile_read")
+        d = dict(zip(_ffi.LG_STAGE_NAMES, [float(x) for x in out]))
+        d["samples"] = int(n.value)
+        return d

@@ -1,0 +1,79 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def vectors():
+    return json.load(open(os.path.join(GOLDEN, "vectors.json")))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The C restatement (oracle/liboracle.so) -- the checker, never the product."""
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def model():
+    from oracle import model as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def poseidon_case(model):
+    w = model.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))
+    m, k, n, t, pre, circ, outs = model.preenc_from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"), w)
+    return dict(m=m, k=k, n=n, t=t, preenc=pre, circ=circ, outputs=outs)
+
+
+@pytest.fixture(scope="session")
+def cube_case(model):
+    m, k, n, t, pre, circ, outs = model.preenc_from_r1cs(os.path.join(GOLDEN, "cube.r1cs"), [1, 3, 9])
+    return dict(m=m, k=k, n=n, t=t, preenc=pre, circ=circ, outputs=outs)
+
+
+def mont_matrix(oracle, rows_of_ints, k):
+    """list of rows of python ints (canonical) -> (rows, k, 4) uint64 Montgomery"""
+    flat = [v for r in rows_of_ints for v in r]
+    return oracle.to_mont(oracle.ints_to_limbs(flat)).reshape(-1, k, 4)
+
+
+def random_mont(seed, count):
+    """seeded uniform elements, returned directly in Montgomery form (any value < p is a valid
+    Montgomery representative, so no conversion is needed)"""
+    from oracle import model as m
+    rng = np.random.default_rng(seed)
+    out = np.empty((count, 4), dtype=np.uint64)
+    filled = 0
+    p_limbs = [(m.P >> (64 * i)) & (2**64 - 1) for i in range(4)]
+    while filled < count:
+        cand = rng.integers(0, 2**64, size=(count - filled, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64((1 << 62) - 1)
+        # accept if < p (compare top limb first; ties are astronomically unlikely but handled)
+        ok = np.zeros(cand.shape[0], dtype=bool)
+        undecided = np.ones(cand.shape[0], dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt = cand[:, i] < np.uint64(p_limbs[i])
+            gt = cand[:, i] > np.uint64(p_limbs[i])
+            ok |= undecided & lt
+            undecided &= ~(lt | gt)
+        good = cand[ok]
+        out[filled:filled + good.shape[0]] = good
+        filled += good.shape[0]
+    return out

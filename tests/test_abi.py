@@ -1,0 +1,94 @@
+"""CPU tests of the C-ABI boundary: the shared library loads, exports every symbol the header
+declares, and fails loudly (no fallback) when there is no GPU.  No compute is launched."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ligero_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_match_binding():
+    from ligero_amd import _ffi
+    assert sorted(_ffi.SYMBOLS) == _declared_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from ligero_amd import _ffi
+    L = _ffi.lib()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (lg_[a-z0-9_]+)", out))
+    for name in _declared_symbols():
+        assert name in exported, name
+        assert getattr(L, name) is not None
+    assert L.lg_abi_version() == 1
+
+
+def test_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C with no torch / C++ types"""
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HEADER])
+
+
+def test_status_strings():
+    from ligero_amd import _ffi
+    L = _ffi.lib()
+    for code in range(0, -8, -1):
+        assert L.lg_status_string(code)
+    assert L.lg_status_string(0) == b"ok"
+
+
+def test_argument_errors_need_no_gpu():
+    from ligero_amd import _ffi
+    L = _ffi.lib()
+    ctx = ctypes.c_void_p()
+    assert L.lg_ctx_create(None, 0, 16, 4, 32) == _ffi.LG_ERR_BAD_ARG
+    assert L.lg_ctx_create(ctypes.byref(ctx), 0, 16, 6, 48) == _ffi.LG_ERR_BAD_DIMS      # k not a power of two
+    assert L.lg_ctx_create(ctypes.byref(ctx), 0, 16, 4, 16) == _ffi.LG_ERR_BAD_DIMS      # n != 8k
+    assert L.lg_ctx_create(ctypes.byref(ctx), 0, 0, 4, 32) == _ffi.LG_ERR_BAD_DIMS       # rows == 0
+    assert L.lg_ctx_create(ctypes.byref(ctx), 0, 16, 1, 8) == _ffi.LG_ERR_BAD_DIMS       # k < 2
+    assert L.lg_encode_commit(None, None, None, None) == _ffi.LG_ERR_BAD_ARG
+    assert L.lg_open_columns(None, 0, None, 0, None, None, None) == _ffi.LG_ERR_BAD_ARG
+    assert L.lg_sync(None) == _ffi.LG_ERR_BAD_ARG
+    L.lg_ctx_destroy(None)
+
+
+def test_no_fallback_without_gpu():
+    """without a HIP device context creation must fail -- the product has no CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on CPU boxes")
+    import ligero_amd
+    with pytest.raises(ligero_amd.LigeroHipError) as e:
+        ligero_amd.LigeroCommitter(16, 4)
+    assert e.value.status in (-3, -4)
+
+
+def test_product_never_imports_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(ROOT, "ligero_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for line in txt.splitlines():
+                    s = line.strip()
+                    if s.startswith(("#include", "import ", "from ")):
+                        assert "oracle" not in s, (f, s)
+
+
+def test_host_dimension_helpers(vectors):
+    import ligero_amd
+    assert ligero_amd.compute_dimensions(7274) == (86, 128)
+    assert ligero_amd.compute_dimensions(15) == (4, 4)
+    for k, t in vectors["calculate_t"].items():
+        assert ligero_amd.reed_solomon_parameters(int(k), int(k), 128) == (8 * int(k), t)
