@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ligero_hip.h"
+#include "fr29_gfx950.h"
 #include "fr_gfx950.h"
 #include "hash_kernels.h"
 #include "host_fr.h"
@@ -31,11 +32,12 @@ struct lg_ctx {
     fr* d_u = nullptr;        // [8][total_rows][k] canonical integers; plane 0 = message
     uint8_t* d_leaves = nullptr;  // [batch][n][32]
     uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
-    // domain tables
-    fr* d_tw_fwd = nullptr;    // omega_k^e, e < k, Montgomery
-    fr* d_tw_inv = nullptr;    // omega_k^-e
-    fr* d_coset_tw = nullptr;  // omega_n^e, e < n, canonical integers
-    fr w8_fwd[3], w8_inv[3], scale_kinv, r2;
+    // domain tables: 29-bit limbs, value * 2^261 mod p, three planes each (limbs 0-3 | 4-7 | 8)
+    uint8_t* d_tw_fwd = nullptr;    // omega_k^e, e < k
+    uint8_t* d_tw_inv = nullptr;    // omega_k^-e
+    uint8_t* d_coset_tw = nullptr;  // omega_n^e, e < n
+    lg::f29 w8_fwd[3], w8_inv[3], one29, scale29;
+    fr r2;
     // scratch for row operators / openings (grown on demand)
     fr* d_scratch_a = nullptr; size_t scratch_a_elems = 0;  // inputs / coefficients
     fr* d_scratch_b = nullptr; size_t scratch_b_elems = 0;  // planes / outputs
@@ -60,6 +62,35 @@ static int fail_hip(lg_ctx* c, hipError_t e, const char* what) {
         hipError_t e_ = (call);                           \
         if (e_ != hipSuccess) return fail_hip(c, e_, #call); \
     } while (0)
+
+// Montgomery-form (2^256) host element -> 29-bit limbs of value * 2^261 mod p
+static lg::f29 to_f29(const lg_host::Fr& a_mont) {
+    static const lg_host::Fr m32 = lg_host::to_mont(lg_host::Fr{{32, 0, 0, 0}});
+    const lg_host::Fr t = lg_host::mul(a_mont, m32);  // raw limbs now read (a * 2^5) * 2^256 = a * 2^261 mod p
+    lg::f29 r;
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t x = t.l[w] >> sh;
+        if (sh > 35 && w < 3) x |= t.l[w + 1] << (64 - sh);
+        r.v[i] = (i < 8) ? (uint32_t)(x & 0x1fffffffu) : (uint32_t)x;
+    }
+    return r;
+}
+// three-plane table image of `count` constants
+static void fill_planes(std::vector<uint8_t>& img, size_t count, size_t e, const lg::f29& v) {
+    uint32_t* lo = reinterpret_cast<uint32_t*>(img.data());
+    uint32_t* mid = lo + 4 * count;
+    uint32_t* hi = mid + 4 * count;
+    for (int i = 0; i < 4; i++) { lo[4 * e + i] = v.v[i]; mid[4 * e + i] = v.v[4 + i]; }
+    hi[e] = v.v[8];
+}
+static lg::Tw29 planes_of(const uint8_t* base, size_t count) {
+    lg::Tw29 t;
+    t.lo = reinterpret_cast<const uint4*>(base);
+    t.mid = reinterpret_cast<const uint4*>(base + 16 * count);
+    t.hi = reinterpret_cast<const uint32_t*>(base + 32 * count);
+    return t;
+}
 
 static fr to_dev(const lg_host::Fr& a) {
     fr r;
@@ -152,9 +183,11 @@ static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon
     lg::NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.canon_out = canon_out;
-    a.tw = c->d_tw_inv; a.coset_tw = nullptr;
+    a.tw = planes_of(c->d_tw_inv, c->k);
+    a.coset_tw = planes_of(c->d_coset_tw, c->n);
     for (int i = 0; i < 3; i++) a.w8[i] = c->w8_inv[i];
-    a.scale = c->scale_kinv;
+    a.one = c->one29;
+    a.scale = c->scale29;
     a.rows = rows; a.row0 = row0; a.ncos = 0;
     a.plane_stride = 0;
     return a;
@@ -164,9 +197,11 @@ static lg::NttArgs eval_args(const lg_ctx* c, const fr* coeffs, fr* planes, uint
     lg::NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = coeffs; a.out = planes; a.canon_out = nullptr;
-    a.tw = c->d_tw_fwd; a.coset_tw = c->d_coset_tw;
+    a.tw = planes_of(c->d_tw_fwd, c->k);
+    a.coset_tw = planes_of(c->d_coset_tw, c->n);
     for (int i = 0; i < 3; i++) a.w8[i] = c->w8_fwd[i];
-    a.scale = c->scale_kinv;
+    a.one = c->one29;
+    a.scale = c->scale29;
     a.rows = rows; a.row0 = row0;
     a.ncos = 8 - first_coset;
     for (uint32_t s = first_coset; s < 8; s++) a.cosets[s - first_coset] = s;
@@ -242,40 +277,41 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u), 8 * mat * sizeof(fr)));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_fwd), (size_t)k * sizeof(fr)));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_inv), (size_t)k * sizeof(fr)));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), (size_t)n * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_fwd), (size_t)k * 36));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_inv), (size_t)k * 36));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), (size_t)n * 36));
         // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
         using namespace lg_host;
         const Fr wn = domain_generator(logn);
         const Fr wk = domain_generator(logk);
         const Fr wk_inv = inverse(wk);
-        std::vector<fr> tf(k), ti(k), ct(n);
+        std::vector<uint8_t> tf((size_t)k * 36), ti((size_t)k * 36), ct((size_t)n * 36);
         Fr a = kOneMont, b = kOneMont;
         for (uint32_t e = 0; e < k; e++) {
-            tf[e] = to_dev(a);
-            ti[e] = to_dev(b);
+            fill_planes(tf, k, e, to_f29(a));
+            fill_planes(ti, k, e, to_f29(b));
             a = mul(a, wk);
             b = mul(b, wk_inv);
         }
         a = kOneMont;
         for (uint32_t e = 0; e < n; e++) {
-            ct[e] = to_dev(from_mont(a));
+            fill_planes(ct, n, e, to_f29(a));
             a = mul(a, wn);
         }
-        LG_HIP(c, hipMemcpy(c->d_tw_fwd, tf.data(), tf.size() * sizeof(fr), hipMemcpyHostToDevice));
-        LG_HIP(c, hipMemcpy(c->d_tw_inv, ti.data(), ti.size() * sizeof(fr), hipMemcpyHostToDevice));
-        LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size() * sizeof(fr), hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_tw_fwd, tf.data(), tf.size(), hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_tw_inv, ti.data(), ti.size(), hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size(), hipMemcpyHostToDevice));
         const Fr w8 = domain_generator(3), w8i = inverse(w8);
         Fr p = w8, pi = w8i;
         for (int i = 0; i < 3; i++) {
-            c->w8_fwd[i] = to_dev(p);
-            c->w8_inv[i] = to_dev(pi);
+            c->w8_fwd[i] = to_f29(p);
+            c->w8_inv[i] = to_f29(pi);
             p = mul(p, w8);
             pi = mul(pi, w8i);
         }
         Fr kk = {{k, 0, 0, 0}};
-        c->scale_kinv = to_dev(inverse(to_mont(kk)));
+        c->one29 = to_f29(kOneMont);
+        c->scale29 = to_f29(inverse(to_mont(kk)));
         c->r2 = to_dev(kR2);
         return LG_OK;
     };

@@ -5,31 +5,34 @@
 // Replaces LigeroCircuit::reed_solomon_interpolate / reed_solomon_evaluate
 // (src/ligero/mod.rs:998-1008) as driven by the row loops at mod.rs:521-533.
 //
-// Each NTT lives entirely in LDS (two 16-byte planes per element so that ds_read_b128 /
-// ds_write_b128 of lane-contiguous elements are conflict free), butterflies are radix-8
-// (radix-2/4 for the remainder pass) in registers, decimation in frequency, in place; the
-// digit-reversed result is read back permuted so that global stores are coalesced.
+// Each NTT lives entirely in LDS (9 dwords per element in three planes: limbs 0-3, 4-7, 8),
+// butterflies are radix-8 (radix-2/4 for the remainder pass) in registers over 29-bit
+// unsaturated limbs (fr29_gfx950.h), decimation in frequency, in place; the digit-reversed
+// result is read back permuted so that global stores are coalesced.  Every output of every
+// pass goes through one Montgomery product (a twiddle, or the constant one for output 0), which
+// is what keeps limbs and values bounded without any carry chain in the butterflies.
 #pragma once
 #include <type_traits>
 
-#include "fr_gfx950.h"
+#include "fr29_gfx950.h"
 
 namespace lg {
 
-constexpr int kMaxLdsLogK = 12;  // 4096 elements * 32 B = 128 KiB (+ padding) fits the 160 KiB LDS
+constexpr int kMaxLdsLogK = 12;  // 4096 elements * 36 B = 144 KiB of the 160 KiB LDS
 
 struct NttArgs {
-    const fr* in;        // interpolate: message rows [rows][k]; evaluate: coefficient rows [rows][k]
+    const fr* in;        // interpolate: message rows [rows][k]; evaluate: coefficient rows [rows][k]  (ABI words)
     fr* out;             // interpolate: coefficient rows; evaluate: base of the coset planes [8][rows][k]
     fr* canon_out;       // interpolate only: canonical (non-Montgomery) copy of the message = coset plane 0 (may be null)
-    const fr* tw;        // w^e, e < k, Montgomery form; w = omega_k^-1 (interpolate) or omega_k (evaluate)
-    const fr* coset_tw;  // evaluate only: omega_n^e, e < n, canonical integers (pre-scale leaves Montgomery form)
-    fr w8[3];            // w_8^1, w_8^2 (= w_4), w_8^3 for this direction, Montgomery form
-    fr scale;            // interpolate only: 1/k, Montgomery form
+    Tw29 tw;             // w^e * 2^261, e < k; w = omega_k^-1 (interpolate) or omega_k (evaluate)
+    Tw29 coset_tw;       // evaluate only: omega_n^e * 2^261, e < n (pre-scale of coefficient d for coset s: e = s d)
+    f29 w8[3];           // w_8^1, w_8^2 (= w_4), w_8^3 of this direction, * 2^261
+    f29 one;             // 2^261 mod p: the multiplier that only normalises (output 0 of each butterfly)
+    f29 scale;           // interpolate only: 2^261 / k
     uint32_t rows;       // rows handled by this launch
     uint32_t row0;       // first row (offset into in/out)
     uint32_t ncos;       // evaluate only: number of cosets in `cosets`
-    uint32_t cosets[8];  // evaluate only: coset ids (1..7)
+    uint32_t cosets[8];  // evaluate only: coset ids (0..7)
     uint64_t plane_stride;  // elements between coset planes (= total_rows * k)
 };
 
@@ -43,76 +46,81 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ int lds_slot(int pos) { return pos + (pos >> 4); }
-__host__ __device__ constexpr int lds_slots(int k) { return k + (k >> 4); }
+// LDS index swizzle (bank-conflict avoidance for the strided passes): a bijection on [0, K)
+// for every power-of-two K
+__device__ __forceinline__ int lds_swz(int pos) { return pos ^ ((pos >> 4) & 15); }
 
 struct LdsRow {
-    uint4* lo;
-    uint4* hi;
-    __device__ __forceinline__ fr get(int pos) const {
-        int s = lds_slot(pos);
-        uint4 a = lo[s], b = hi[s];
-        fr r;
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    uint4* a;     // limbs 0-3
+    uint4* b;     // limbs 4-7
+    uint32_t* c;  // limb 8
+    __device__ __forceinline__ f29 get(int pos) const {
+        const int s = lds_swz(pos);
+        const uint4 x = a[s], y = b[s];
+        f29 r;
+        r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
+        r.v[4] = y.x; r.v[5] = y.y; r.v[6] = y.z; r.v[7] = y.w;
+        r.v[8] = c[s];
         return r;
     }
-    __device__ __forceinline__ void put(int pos, const fr& x) const {
-        int s = lds_slot(pos);
-        lo[s] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-        hi[s] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    __device__ __forceinline__ void put(int pos, const f29& x) const {
+        const int s = lds_swz(pos);
+        a[s] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        b[s] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+        c[s] = x.v[8];
     }
 };
 
-// (a, b) <- (a + b, a - b), lazy
-__device__ __forceinline__ void bfly(fr& a, fr& b) {
-    fr s, d;
-    fr_add_lazy(s, a, b);
-    fr_sub_lazy(d, a, b);
-    a = s;
-    b = d;
-}
-
-// In-register size-2^LOGR DFT, decimation in frequency.  On return y[m] = sum_q e[q] w_R^(q m)
-// (natural order m).  w8[] holds w_8^1..3 of the transform direction.
+// In-register size-2^LOGR DFT, decimation in frequency, on N inputs (limbs < 2^29, value < 2p).
+// On return y[m] = sum_q e[q] w_R^(q m) in natural order m, as lazy values with limbs
+// <= 5 * 2^29 and value < 24p (tests/test_limb_bounds.py replays these networks with interval
+// arithmetic).  w8[] holds w_8^1..3 of the transform direction (* 2^261).
 template <int LOGR>
-__device__ __forceinline__ void dft_regs(fr (&e)[1 << LOGR], const fr (&w8)[3]);
+__device__ __forceinline__ void dft_regs(f29 (&e)[1 << LOGR], const f29 (&w8)[3]);
 
 template <>
-__device__ __forceinline__ void dft_regs<1>(fr (&e)[2], const fr (&)[3]) {
-    bfly(e[0], e[1]);
+__device__ __forceinline__ void dft_regs<1>(f29 (&e)[2], const f29 (&)[3]) {
+    bfly29<4, 29>(e[0], e[1]);
 }
 template <>
-__device__ __forceinline__ void dft_regs<2>(fr (&e)[4], const fr (&w8)[3]) {
-    bfly(e[0], e[2]);
-    bfly(e[1], e[3]);
-    fr_mul_lazy(e[3], e[3], w8[1]);
-    bfly(e[0], e[1]);  // y0, y2
-    bfly(e[2], e[3]);  // y1, y3
-    fr t = e[1];
+__device__ __forceinline__ void dft_regs<2>(f29 (&e)[4], const f29 (&w8)[3]) {
+    bfly29<4, 29>(e[0], e[2]);
+    bfly29<4, 29>(e[1], e[3]);
+    mul29(e[3], e[3], w8[1]);
+    bfly29<8, 30>(e[0], e[1]);  // y0, y2
+    bfly29<4, 29>(e[2], e[3]);  // y1, y3
+    const f29 t = e[1];
     e[1] = e[2];
     e[2] = t;
 }
 template <>
-__device__ __forceinline__ void dft_regs<3>(fr (&e)[8], const fr (&w8)[3]) {
-    bfly(e[0], e[4]);
-    bfly(e[1], e[5]);
-    bfly(e[2], e[6]);
-    bfly(e[3], e[7]);
-    fr_mul_lazy(e[5], e[5], w8[0]);
-    fr_mul_lazy(e[6], e[6], w8[1]);
-    fr_mul_lazy(e[7], e[7], w8[2]);
-    // two size-4 DFTs: e[0..3] -> even outputs, e[4..7] -> odd outputs
-    static_for<0, 2>([&](auto hc) {
-        constexpr int h = 4 * decltype(hc)::value;
-        bfly(e[h + 0], e[h + 2]);
-        bfly(e[h + 1], e[h + 3]);
-        fr_mul_lazy(e[h + 3], e[h + 3], w8[1]);
-        bfly(e[h + 0], e[h + 1]);  // z0, z2
-        bfly(e[h + 2], e[h + 3]);  // z1, z3
-    });
+__device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3]) {
+    bfly29<4, 29>(e[0], e[4]);
+    bfly29<4, 29>(e[1], e[5]);
+    bfly29<4, 29>(e[2], e[6]);
+    bfly29<4, 29>(e[3], e[7]);
+    mul29(e[5], e[5], w8[0]);
+    mul29(e[6], e[6], w8[1]);
+    mul29(e[7], e[7], w8[2]);
+    // even outputs: size-4 DFT of the sums e[0..3] (limbs <= 2B, value < 4p)
+    bfly29<8, 30>(e[0], e[2]);
+    bfly29<8, 30>(e[1], e[3]);
+    mul29(e[3], e[3], w8[1]);
+    norm29(e[0]);
+    norm29(e[1]);
+    norm29(e[2]);
+    bfly29<16, 30>(e[0], e[1]);  // y0, y4
+    bfly29<4, 29>(e[2], e[3]);   // y2, y6
+    // odd outputs: size-4 DFT of (e[4] lazy, e[5..7] products)
+    bfly29<4, 29>(e[4], e[6]);
+    bfly29<4, 29>(e[5], e[7]);
+    mul29(e[7], e[7], w8[1]);
+    norm29(e[4]);
+    norm29(e[6]);
+    bfly29<8, 30>(e[4], e[5]);  // y1, y5
+    bfly29<4, 29>(e[6], e[7]);  // y3, y7
     // registers now hold (y0, y4, y2, y6, y1, y5, y3, y7)
-    fr y1 = e[4], y2 = e[2], y3 = e[6], y4 = e[1], y5 = e[5], y6 = e[3];
+    const f29 y1 = e[4], y2 = e[2], y3 = e[6], y4 = e[1], y5 = e[5], y6 = e[3];
     e[1] = y1; e[2] = y2; e[3] = y3; e[4] = y4; e[5] = y5; e[6] = y6;
 }
 
@@ -124,7 +132,7 @@ struct NttPlan {
     static constexpr int kThreadsPerNtt = (LOGK <= 3) ? 1 : (1 << (LOGK - 3));
     static constexpr int kWgThreads = (kThreadsPerNtt > 256) ? kThreadsPerNtt : 256;
     static constexpr int kNttsPerWg = kWgThreads / kThreadsPerNtt;
-    static constexpr int kLdsBytes = kNttsPerWg * lds_slots(1 << LOGK) * 32;
+    static constexpr int kLdsBytes = kNttsPerWg * (1 << LOGK) * 36;
 };
 
 // digit reversal of the in-place DIF with the plan above: natural output index j -> LDS position
@@ -144,18 +152,19 @@ __device__ __forceinline__ int dif_position(int j) {
     return pos;
 }
 
-// One DIF pass over an LDS-resident row.  LOGS = log2 of the current sub-transform size.
 // Launch-invariant operands, copied out of the kernel argument block once so that they stay
-// in scalar registers (taking references into the by-value argument struct would force a
-// private-memory copy of it).
+// in scalar registers.
 struct NttConsts {
-    const fr* tw;
-    fr w8[3];
+    Tw29 tw;
+    f29 w8[3];
+    f29 one;
+    f29 last;  // multiplier applied to every output of the last pass (interpolate: 2^261 / k)
 };
 
+// One DIF pass over an LDS-resident row.  LOGS = log2 of the current sub-transform size.
 template <int LOGK, int LOGS, int LOGR, bool FIRST, bool EVALUATE>
 __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, const NttConsts& a,
-                                         const fr* __restrict__ gin, const fr* __restrict__ pre_tw, uint32_t coset,
+                                         const fr* __restrict__ gin, const Tw29& pre_tw, uint32_t coset,
                                          fr* __restrict__ canon_out) {
     constexpr int K = 1 << LOGK;
     constexpr int R = 1 << LOGR;
@@ -167,20 +176,20 @@ __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, 
         const int blk = u >> LOGSUB;
         const int i0 = u & (SUB - 1);
         const int base = (blk << LOGS) + i0;
-        fr e[R];
+        f29 e[R];
         if constexpr (FIRST) {
             static_for<0, R>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 const int d = base + (q << LOGSUB);
-                e[q] = fr_load(gin + d);
+                e[q] = unpack29(fr_load(gin + d));
                 if constexpr (EVALUATE) {
-                    fr w = fr_load(pre_tw + (size_t)coset * d);
-                    fr_mul_lazy(e[q], e[q], w);
+                    const f29 w = tw29_load(pre_tw, (size_t)coset * d);
+                    mul29(e[q], e[q], w);
                 } else {
                     if (canon_out != nullptr) {
-                        fr c;
-                        fr_from_mont(c, e[q]);
-                        fr_store(canon_out + d, c);
+                        f29 c;
+                        mul29_small(c, e[q], 32u);  // x * 2^256 * 32 * 2^-261 = x
+                        fr_store(canon_out + d, pack29_reduced(c));
                     }
                 }
             });
@@ -192,10 +201,19 @@ __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, 
         }
         dft_regs<LOGR>(e, a.w8);
         if constexpr (LOGSUB > 0) {
+            mul29(e[0], e[0], a.one);
             static_for<1, R>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                fr w = fr_load(a.tw + ((size_t)(i0 * m) << (LOGK - LOGS)));
-                fr_mul_lazy(e[m], e[m], w);
+                const f29 w = tw29_load(a.tw, (size_t)(i0 * m) << (LOGK - LOGS));
+                mul29(e[m], e[m], w);
+            });
+        } else {
+            static_for<0, R>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (EVALUATE)
+                    mul29_small(e[m], e[m], 32u);  // leave Montgomery form: the codeword is stored canonical
+                else
+                    mul29(e[m], e[m], a.last);
             });
         }
         static_for<0, R>([&](auto mc) {
@@ -209,7 +227,7 @@ template <int LOGK, int LOGS, bool EVALUATE>
 __device__ __forceinline__ void dif_rest(const LdsRow& row, int t, bool active, const NttConsts& a) {
     if constexpr (LOGS > 0) {
         __syncthreads();
-        dif_pass<LOGK, LOGS, 3, false, EVALUATE>(row, t, active, a, nullptr, nullptr, 0, nullptr);
+        dif_pass<LOGK, LOGS, 3, false, EVALUATE>(row, t, active, a, nullptr, a.tw, 0, nullptr);
         dif_rest<LOGK, LOGS - 3, EVALUATE>(row, t, active, a);
     }
 }
@@ -236,30 +254,24 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
     }
     const size_t row_off = (size_t)(a.row0 + r) * K;
     LdsRow row;
-    row.lo = reinterpret_cast<uint4*>(smem) + (size_t)slot * 2 * lds_slots(K);
-    row.hi = row.lo + lds_slots(K);
+    row.a = reinterpret_cast<uint4*>(smem) + (size_t)slot * K;
+    row.b = reinterpret_cast<uint4*>(smem) + (size_t)Plan::kNttsPerWg * K + (size_t)slot * K;
+    row.c = reinterpret_cast<uint32_t*>(smem + (size_t)Plan::kNttsPerWg * K * 32) + (size_t)slot * K;
 
     NttConsts cs;
     cs.tw = a.tw;
     cs.w8[0] = a.w8[0];
     cs.w8[1] = a.w8[1];
     cs.w8[2] = a.w8[2];
+    cs.one = a.one;
+    cs.last = a.scale;
     fr* canon = (!EVALUATE && a.canon_out != nullptr) ? a.canon_out + row_off : nullptr;
     dif_pass<LOGK, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, t, active, cs, a.in + row_off, a.coset_tw, coset, canon);
     dif_rest<LOGK, LOGK - Plan::kFirstLogR, EVALUATE>(row, t, active, cs);
     __syncthreads();
     if (!active) return;
     fr* gout = EVALUATE ? a.out + (size_t)coset * a.plane_stride + row_off : a.out + row_off;
-    for (int j = t; j < K; j += Plan::kThreadsPerNtt) {
-        fr x = row.get(dif_position<LOGK>(j));
-        if constexpr (!EVALUATE) {
-            const fr scale = a.scale;
-            fr_mul_lazy(x, x, scale);
-        }
-        fr y;
-        fr_reduce(y, x);
-        fr_store(gout + j, y);
-    }
+    for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(dif_position<LOGK>(j))));
 }
 
 }  // namespace lg
