@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "fr29_gfx950.h"
+#include "lds_swizzle_table.h"
 
 namespace lg {
 
@@ -46,16 +47,24 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// LDS index swizzle (bank-conflict avoidance for the strided passes): a bijection on [0, K)
-// for every power-of-two K
-__device__ __forceinline__ int lds_swz(int pos) { return pos ^ ((pos >> 4) & 15); }
+// LDS index swizzle: element `pos` of NTT slot `slot` lives at sigma(slot * K + pos) in each of
+// the three planes.  sigma XORs a 5-bit constant into the low index bits for every set upper
+// bit (table found by tools/lds_swizzle.py so that every pass and the digit-reversed read-back
+// are bank-conflict free or nearly so).  It is GF(2)-linear: sigma(a ^ b) = sigma(a) ^ sigma(b).
+template <int LOGK>
+__host__ __device__ __forceinline__ constexpr int lds_swz(int i) {
+    int x = i;
+    for (int j = 5; j < 24; j++)
+        if (kLdsSwz[LOGK][j] != 0) x ^= (0 - ((i >> j) & 1)) & kLdsSwz[LOGK][j];
+    return x;
+}
 
-struct LdsRow {
+struct LdsPlanes {
     uint4* a;     // limbs 0-3
     uint4* b;     // limbs 4-7
     uint32_t* c;  // limb 8
-    __device__ __forceinline__ f29 get(int pos) const {
-        const int s = lds_swz(pos);
+    // s = swizzled index
+    __device__ __forceinline__ f29 get(int s) const {
         const uint4 x = a[s], y = b[s];
         f29 r;
         r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
@@ -63,8 +72,7 @@ struct LdsRow {
         r.v[8] = c[s];
         return r;
     }
-    __device__ __forceinline__ void put(int pos, const f29& x) const {
-        const int s = lds_swz(pos);
+    __device__ __forceinline__ void put(int s, const f29& x) const {
         a[s] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
         b[s] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
         c[s] = x.v[8];
@@ -163,7 +171,7 @@ struct NttConsts {
 
 // One DIF pass over an LDS-resident row.  LOGS = log2 of the current sub-transform size.
 template <int LOGK, int LOGS, int LOGR, bool FIRST, bool EVALUATE>
-__device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, const NttConsts& a,
+__device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, int t, bool active, const NttConsts& a,
                                          const fr* __restrict__ gin, const Tw29& pre_tw, uint32_t coset,
                                          fr* __restrict__ canon_out) {
     constexpr int K = 1 << LOGK;
@@ -176,15 +184,38 @@ __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, 
         const int blk = u >> LOGSUB;
         const int i0 = u & (SUB - 1);
         const int base = (blk << LOGS) + i0;
+        const int sbase = lds_swz<LOGK>(slot_base + base);  // element q of this butterfly: sbase ^ sigma(q << LOGSUB)
         f29 e[R];
+        // external twiddles first: their global-load latency hides under the LDS reads and the
+        // in-register DFT (5 Montgomery products)
+        f29 w[R];
+        if constexpr (LOGSUB > 0) {
+            static_for<1, R>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+#ifdef LG_ABL_NO_TW  // ablation builds only (tools/ntt_bench.hip)
+                w[m] = a.one;
+#else
+                w[m] = tw29_load(a.tw, (size_t)(i0 * m) << (LOGK - LOGS));
+#endif
+            });
+        }
         if constexpr (FIRST) {
+            fr raw[R];
+            static_for<0, R>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                raw[q] = fr_load(gin + base + (q << LOGSUB));
+            });
             static_for<0, R>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 const int d = base + (q << LOGSUB);
-                e[q] = unpack29(fr_load(gin + d));
+                e[q] = unpack29(raw[q]);
                 if constexpr (EVALUATE) {
-                    const f29 w = tw29_load(pre_tw, (size_t)coset * d);
-                    mul29(e[q], e[q], w);
+#ifdef LG_ABL_NO_PRE
+                    const f29 pw = a.one;
+#else
+                    const f29 pw = tw29_load(pre_tw, (size_t)coset * d);
+#endif
+                    mul29(e[q], e[q], pw);
                 } else {
                     if (canon_out != nullptr) {
                         f29 c;
@@ -196,7 +227,12 @@ __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, 
         } else {
             static_for<0, R>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                e[q] = row.get(base + (q << LOGSUB));
+#ifdef LG_ABL_NO_LDS
+                e[q] = a.one;
+                e[q].v[0] += base + q;
+#else
+                e[q] = row.get(sbase ^ lds_swz<LOGK>(q << LOGSUB));
+#endif
             });
         }
         dft_regs<LOGR>(e, a.w8);
@@ -204,8 +240,7 @@ __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, 
             mul29(e[0], e[0], a.one);
             static_for<1, R>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                const f29 w = tw29_load(a.tw, (size_t)(i0 * m) << (LOGK - LOGS));
-                mul29(e[m], e[m], w);
+                mul29(e[m], e[m], w[m]);
             });
         } else {
             static_for<0, R>([&](auto mc) {
@@ -218,17 +253,23 @@ __device__ __forceinline__ void dif_pass(const LdsRow& row, int t, bool active, 
         }
         static_for<0, R>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            row.put(base + (m << LOGSUB), e[m]);
+#ifdef LG_ABL_NO_LDS
+            if (e[m].v[8] == 0xffffffffu) row.put(sbase ^ lds_swz<LOGK>(m << LOGSUB), e[m]);
+#else
+            row.put(sbase ^ lds_swz<LOGK>(m << LOGSUB), e[m]);
+#endif
         });
     }
 }
 
 template <int LOGK, int LOGS, bool EVALUATE>
-__device__ __forceinline__ void dif_rest(const LdsRow& row, int t, bool active, const NttConsts& a) {
+__device__ __forceinline__ void dif_rest(const LdsPlanes& row, int slot_base, int t, bool active, const NttConsts& a) {
     if constexpr (LOGS > 0) {
+#ifndef LG_ABL_NO_BARRIER
         __syncthreads();
-        dif_pass<LOGK, LOGS, 3, false, EVALUATE>(row, t, active, a, nullptr, a.tw, 0, nullptr);
-        dif_rest<LOGK, LOGS - 3, EVALUATE>(row, t, active, a);
+#endif
+        dif_pass<LOGK, LOGS, 3, false, EVALUATE>(row, slot_base, t, active, a, nullptr, a.tw, 0, nullptr);
+        dif_rest<LOGK, LOGS - 3, EVALUATE>(row, slot_base, t, active, a);
     }
 }
 
@@ -253,10 +294,11 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
         }
     }
     const size_t row_off = (size_t)(a.row0 + r) * K;
-    LdsRow row;
-    row.a = reinterpret_cast<uint4*>(smem) + (size_t)slot * K;
-    row.b = reinterpret_cast<uint4*>(smem) + (size_t)Plan::kNttsPerWg * K + (size_t)slot * K;
-    row.c = reinterpret_cast<uint32_t*>(smem + (size_t)Plan::kNttsPerWg * K * 32) + (size_t)slot * K;
+    LdsPlanes row;
+    row.a = reinterpret_cast<uint4*>(smem);
+    row.b = reinterpret_cast<uint4*>(smem) + (size_t)Plan::kNttsPerWg * K;
+    row.c = reinterpret_cast<uint32_t*>(smem + (size_t)Plan::kNttsPerWg * K * 32);
+    const int slot_base = slot * K;
 
     NttConsts cs;
     cs.tw = a.tw;
@@ -266,12 +308,12 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
     cs.one = a.one;
     cs.last = a.scale;
     fr* canon = (!EVALUATE && a.canon_out != nullptr) ? a.canon_out + row_off : nullptr;
-    dif_pass<LOGK, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, t, active, cs, a.in + row_off, a.coset_tw, coset, canon);
-    dif_rest<LOGK, LOGK - Plan::kFirstLogR, EVALUATE>(row, t, active, cs);
+    dif_pass<LOGK, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, slot_base, t, active, cs, a.in + row_off, a.coset_tw, coset, canon);
+    dif_rest<LOGK, LOGK - Plan::kFirstLogR, EVALUATE>(row, slot_base, t, active, cs);
     __syncthreads();
     if (!active) return;
     fr* gout = EVALUATE ? a.out + (size_t)coset * a.plane_stride + row_off : a.out + row_off;
-    for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(dif_position<LOGK>(j))));
+    for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
 }
 
 }  // namespace lg

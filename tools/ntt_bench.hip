@@ -1,0 +1,52 @@
+// Stand-alone timing of the row-NTT kernels (ligero_amd/csrc/ntt_kernels.h) with synthetic
+// tables, for ablation experiments: compile with -DLG_LOGK=<n> and optional -DLG_ABL_* macros.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "ntt_kernels.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+using namespace lg;
+int main(int argc, char** argv) {
+    constexpr int LOGK = LG_LOGK;
+    constexpr int K = 1 << LOGK;
+    const uint32_t rows = argc > 1 ? atoi(argv[1]) : (LOGK >= 10 ? 2509 : 22016);
+    using Plan = NttPlan<LOGK>;
+    fr *in, *out;
+    uint8_t *tw, *ctw;
+    CK(hipMalloc((void**)&in, (size_t)rows * K * 32));
+    CK(hipMalloc((void**)&out, (size_t)8 * rows * K * 32));
+    CK(hipMalloc((void**)&tw, (size_t)K * 36));
+    CK(hipMalloc((void**)&ctw, (size_t)8 * K * 36));
+    CK(hipMemset(in, 0x11, (size_t)rows * K * 32));
+    CK(hipMemset(tw, 0x05, (size_t)K * 36));
+    CK(hipMemset(ctw, 0x03, (size_t)8 * K * 36));
+    NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.canon_out = nullptr;
+    a.tw = Tw29{(const uint4*)tw, (const uint4*)(tw + 16 * K), (const uint32_t*)(tw + 32 * K)};
+    a.coset_tw = Tw29{(const uint4*)ctw, (const uint4*)(ctw + 16 * 8 * K), (const uint32_t*)(ctw + 32 * 8 * K)};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 9; j++) a.w8[i].v[j] = 0x01234567u >> (j & 3);
+    for (int j = 0; j < 9; j++) { a.one.v[j] = 0x00abcdefu; a.scale.v[j] = 0x00123456u; }
+    a.rows = rows; a.row0 = 0; a.ncos = 7;
+    for (int s = 0; s < 7; s++) a.cosets[s] = s + 1;
+    a.plane_stride = (uint64_t)rows * K;
+    auto kern = ntt_rows_kernel<LOGK, true>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Plan::kLdsBytes));
+    const uint64_t work = (uint64_t)rows * 7;
+    const uint32_t grid = (uint32_t)((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int it = 0; it < 5; it++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Plan::kWgThreads), Plan::kLdsBytes, 0, a);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    printf("logk=%d rows=%u evaluate(7 cosets): %.3f ms  (%.1f us per WG-slot on 256 CUs)\n", LOGK, rows, best, best * 1e3 * 256 / grid);
+    return 0;
+}
