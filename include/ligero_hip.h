@@ -115,11 +115,14 @@ int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* 
 int lg_ctx_dims(const lg_ctx* ctx, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch);
 
 /*
- * Per-kernel timing with HIP events on the context's stream (for roofline reports).
- * While enabled, lg_commit_resident brackets each stage with events (no host sync).
- * lg_profile_read synchronises and returns, per stage, the mean milliseconds over the
+ * Per-stage timing with HIP events on the streams the kernels run on (for roofline
+ * reports).  While enabled, lg_commit_resident brackets each stage with events (no host
+ * sync).  lg_profile_read synchronises and returns, per stage, the mean milliseconds over the
  * commits issued since lg_profile_enable(ctx, 1) (at most the last 64); *samples_out (may be
  * NULL) receives how many commits were averaged.
+ * The commit is pipelined: INTERPOLATE and EVALUATE are back-to-back spans on the encode
+ * stream (EVALUATE covers all its chunk launches); COLHASH is the span from the first to the
+ * last column-hash launch on the hash stream and OVERLAPS EVALUATE; MERKLE follows COLHASH.
  */
 typedef enum lg_stage {
     LG_STAGE_INTERPOLATE = 0, /* rs_interpolate rows: size-k inverse NTT            */

@@ -64,37 +64,52 @@ __device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&
 struct ColHashArgs {
     const uint4* u;         // coset planes [8][total_rows][k], canonical integers, 2 x uint4 per element
     uint8_t* leaves;        // [batch][n][32]
+    uint4* state;           // [batch][8][k][3]: chaining value + 8 carried bytes between row chunks
     uint32_t rows;          // rows per proof (4m)
     uint32_t k;             // elements per plane row
-    uint32_t batch;         // proofs
-    uint32_t ncos;          // cosets hashed by this launch
-    uint32_t cosets[8];     // their ids (0..7)
+    uint32_t proof_begin;   // first proof hashed by this launch
+    uint32_t proof_count;   // proofs hashed by this launch
+    uint32_t row_begin;     // rows [row_begin, row_end) of each proof are absorbed; row_begin is even
+    uint32_t row_end;
+    uint32_t first;         // 1: start from the initial state; 0: resume from `state`
+    uint32_t last;          // 1: finalise and write the leaf digest; 0: save `state`
     uint64_t plane_stride;  // in elements
 };
 
 // One lane per column.  Thread id -> (proof b, coset s, q) with q fastest, so a wave reads
-// 64 adjacent elements (2 KiB contiguous) of one row per step.
+// 64 adjacent elements (2 KiB contiguous) of one row per step.  A column can be absorbed in
+// several launches over consecutive row ranges (the commit pipeline hashes a chunk of rows
+// while the next chunk is still being encoded): the chaining value and the 8 bytes that
+// straddle the 64-byte block boundary are parked in `state` in between.
 __global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)a.batch * a.ncos * a.k;
+    const uint64_t total = (uint64_t)a.proof_count * 8 * a.k;
     if (gid >= total) return;
     const uint32_t q = (uint32_t)(gid % a.k);
-    const uint32_t sc = (uint32_t)((gid / a.k) % a.ncos);
-    const uint32_t b = (uint32_t)(gid / ((uint64_t)a.k * a.ncos));
-    const uint32_t s = a.cosets[sc];
+    const uint32_t s = (uint32_t)((gid / a.k) & 7);
+    const uint32_t b = a.proof_begin + (uint32_t)(gid / ((uint64_t)a.k * 8));
     // element (row i) = p[i * 2k], p[i * 2k + 1]
-    const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + (uint64_t)b * a.rows * a.k + q);
+    const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + a.row_begin) * a.k + q);
     const uint64_t step = 2 * (uint64_t)a.k;
+    uint4* st = a.state + 3 * (((uint64_t)b * 8 + s) * a.k + q);
 
     uint32_t h[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) h[i] = b2s_iv(i);
-    h[0] ^= 0x01010020u;
     uint32_t m[16];
-    m[0] = a.rows;  // LE64(rows): serialize_compressed length prefix of Vec<F>
-    m[1] = 0;
-    uint64_t t = 0;
-    const uint32_t pairs = a.rows >> 1;
+    if (a.first) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) h[i] = b2s_iv(i);
+        h[0] ^= 0x01010020u;
+        m[0] = a.rows;  // LE64(rows): serialize_compressed length prefix of Vec<F>
+        m[1] = 0;
+    } else {
+        const uint4 s0 = st[0], s1 = st[1], s2 = st[2];
+        h[0] = s0.x; h[1] = s0.y; h[2] = s0.z; h[3] = s0.w;
+        h[4] = s1.x; h[5] = s1.y; h[6] = s1.z; h[7] = s1.w;
+        m[0] = s2.x; m[1] = s2.y;
+    }
+    uint64_t t = (uint64_t)a.row_begin * 32;  // bytes compressed so far (whole blocks)
+    const uint32_t nrows = a.row_end - a.row_begin;
+    const uint32_t pairs = nrows >> 1;
     uint4 a0, a1, b0, b1;
     if (pairs) { a0 = p[0]; a1 = p[1]; b0 = p[step]; b1 = p[step + 1]; }
     for (uint32_t i = 0; i < pairs; i++) {
@@ -108,9 +123,15 @@ __global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs 
         m[0] = c0;
         m[1] = c1;
     }
+    if (!a.last) {
+        st[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        st[1] = make_uint4(h[4], h[5], h[6], h[7]);
+        st[2] = make_uint4(m[0], m[1], 0, 0);
+        return;
+    }
 #pragma unroll
     for (int i = 2; i < 16; i++) m[i] = 0;
-    if (a.rows & 1) {
+    if (nrows & 1) {
         a0 = p[0]; a1 = p[1];
         m[2] = a0.x; m[3] = a0.y; m[4] = a0.z; m[5] = a0.w; m[6] = a1.x; m[7] = a1.y; m[8] = a1.z; m[9] = a1.w;
         t += 40;

@@ -25,7 +25,13 @@ struct lg_ctx {
     uint32_t rows = 0, k = 0, n = 0, batch = 1;
     int logk = 0, logn = 0;
     uint64_t total_rows = 0;  // batch * rows
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // encode stream; every public call is ordered on it
+    hipStream_t stream_h = nullptr;  // column-hash / Merkle stream of the commit pipeline
+    static constexpr int kMaxChunks = 8;
+    hipEvent_t ev_chunk[kMaxChunks] = {};  // "rows of chunk c are encoded"
+    hipEvent_t ev_done = nullptr;          // "tree of this commit is complete"
+    uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
+    uint32_t force_chunks = 0;             // LG_FORCE_CHUNKS (testing knob): pipeline depth regardless of size
     // resident commitment
     fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
     fr* d_coeffs = nullptr;   // [total_rows][k]  Montgomery
@@ -47,7 +53,7 @@ struct lg_ctx {
     bool committed = false;
     bool profiling = false;
     static constexpr int kProfRing = 64;                 // commits remembered by the profiler
-    hipEvent_t ev[kProfRing][LG_STAGE_COUNT + 1] = {};
+    hipEvent_t ev[kProfRing][6] = {};  // 0 start, 1 interpolate done, 2 evaluate done | hash stream: 3 first hash start, 4 last hash done, 5 tree done
     bool ev_valid = false;
     uint64_t prof_commits = 0;                            // commits recorded since lg_profile_enable(1)
     char err[256] = {0};
@@ -242,13 +248,18 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream_h) hipStreamSynchronize(c->stream_h);
     void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw,
-                    c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out};
+                    c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (c->ev_valid)
         for (auto& set : c->ev)
             for (auto& e : set) hipEventDestroy(e);
+    for (auto& e : c->ev_chunk)
+        if (e) hipEventDestroy(e);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->stream_h) hipStreamDestroy(c->stream_h);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -267,10 +278,15 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     if (!c) return LG_ERR_OOM;
     c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
     c->total_rows = (uint64_t)rows * batch;
+    if (const char* fc = getenv("LG_FORCE_CHUNKS")) c->force_chunks = (uint32_t)atoi(fc);
     int rc = LG_OK;
     auto body = [&]() -> int {
         LG_HIP(c, hipSetDevice(device));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking));
+        for (auto& e : c->ev_chunk) LG_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        LG_HIP(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
         const size_t mat = (size_t)c->total_rows * k;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coeffs), mat * sizeof(fr)));
@@ -357,12 +373,59 @@ int lg_profile_enable(lg_ctx* c, int on) {
     return LG_OK;
 }
 
+// The commit is pipelined over row chunks on two streams: while the encode stream evaluates
+// chunk c+1, the hash stream absorbs chunk c into the per-column Blake2s states.  The column
+// hash is latency bound (one sequential chain per column, only n columns), so it fills issue
+// slots the NTT kernel leaves idle instead of extending the critical path.
+struct Chunk {
+    uint32_t proof_begin, proof_count, row_begin, row_end;
+};
+static int plan_chunks(const lg_ctx* c, Chunk* out) {
+    int n = 0;
+    // a chunk must be big enough (>= 2^25 codeword elements, a few ms of encoding) for the extra
+    // launches and cross-stream waits to pay; small commits run as one chunk
+    const uint64_t elems = c->total_rows * c->n;
+    uint32_t want = c->force_chunks ? c->force_chunks : (uint32_t)(elems >> 25);
+    if (want > (uint32_t)lg_ctx::kMaxChunks) want = lg_ctx::kMaxChunks;
+    if (want <= 1) {
+        out[0] = Chunk{0, c->batch, 0, c->rows};
+        return 1;
+    }
+    if (c->batch >= want && c->batch >= 4) {  // whole proofs per chunk
+        const uint32_t parts = want;
+        for (uint32_t i = 0; i < parts; i++) {
+            const uint32_t b0 = (uint32_t)((uint64_t)c->batch * i / parts), b1 = (uint32_t)((uint64_t)c->batch * (i + 1) / parts);
+            out[n++] = Chunk{b0, b1 - b0, 0, c->rows};
+        }
+        return n;
+    }
+    // row ranges of each proof; boundaries on even rows (a Blake2s block holds two rows)
+    uint32_t parts = want / c->batch;
+    const uint32_t pairs = c->rows / 2;
+    if (parts > pairs) parts = pairs;
+    if (parts < 1) parts = 1;
+    if ((uint64_t)parts * c->batch > (uint64_t)lg_ctx::kMaxChunks) parts = lg_ctx::kMaxChunks / c->batch;
+    if (parts < 1) {  // more proofs than chunk slots: fall back to one chunk
+        out[0] = Chunk{0, c->batch, 0, c->rows};
+        return 1;
+    }
+    for (uint32_t b = 0; b < c->batch; b++)
+        for (uint32_t i = 0; i < parts; i++) {
+            const uint32_t r0 = 2 * (uint32_t)((uint64_t)pairs * i / parts);
+            const uint32_t r1 = (i + 1 == parts) ? c->rows : 2 * (uint32_t)((uint64_t)pairs * (i + 1) / parts);
+            out[n++] = Chunk{b, 1, r0, r1};
+        }
+    return n;
+}
+
 int lg_commit_resident(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
     const uint64_t plane = c->total_rows * c->k;
     const bool prof = c->profiling && c->ev_valid;
     hipEvent_t* ev = c->ev[c->prof_commits % lg_ctx::kProfRing];
+    Chunk chunks[lg_ctx::kMaxChunks];
+    const int nchunks = plan_chunks(c, chunks);
     if (prof) LG_HIP(c, hipEventRecord(ev[0], c->stream));
     // rows -> coefficients (mod.rs:521-526); also emits the canonical message = coset plane 0
     {
@@ -370,26 +433,36 @@ int lg_commit_resident(lg_ctx* c) {
         LG_HIP(c, lg::launch_ntt(c->logk, false, c->stream, a));
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[1], c->stream));
-    // coefficients -> cosets 1..7 of the order-n domain (mod.rs:528-533)
-    {
-        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, 0, (uint32_t)c->total_rows, 1);
+    for (int i = 0; i < nchunks; i++) {
+        const Chunk& ch = chunks[i];
+        // coefficients -> cosets 1..7 of the order-n domain (mod.rs:528-533)
+        const uint32_t row0 = ch.proof_begin * c->rows + ch.row_begin;
+        const uint32_t nrows = (ch.proof_count - 1) * c->rows + (ch.row_end - ch.row_begin);
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, 1);
         LG_HIP(c, lg::launch_ntt(c->logk, true, c->stream, a));
-    }
-    if (prof) LG_HIP(c, hipEventRecord(ev[2], c->stream));
-    // column hashes (mod.rs:536-542)
-    {
+        LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
+        // column hashes (mod.rs:536-542) of the rows just encoded, on the hash stream
+        LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_chunk[i], 0));
+        if (prof && i == 0) LG_HIP(c, hipEventRecord(ev[3], c->stream_h));
         lg::ColHashArgs h;
         memset(&h, 0, sizeof(h));
         h.u = reinterpret_cast<const uint4*>(c->d_u);
         h.leaves = c->d_leaves;
-        h.rows = c->rows; h.k = c->k; h.batch = c->batch; h.ncos = 8;
-        for (uint32_t s = 0; s < 8; s++) h.cosets[s] = s;
+        h.state = c->d_hstate;
+        h.rows = c->rows; h.k = c->k;
+        h.proof_begin = ch.proof_begin; h.proof_count = ch.proof_count;
+        h.row_begin = ch.row_begin; h.row_end = ch.row_end;
+        h.first = ch.row_begin == 0;
+        h.last = ch.row_end == c->rows;
         h.plane_stride = plane;
-        const uint64_t threads = (uint64_t)c->batch * c->n;
-        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, h);
+        const uint64_t threads = (uint64_t)ch.proof_count * c->n;
+        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream_h, h);
         LG_HIP(c, hipGetLastError());
     }
-    if (prof) LG_HIP(c, hipEventRecord(ev[3], c->stream));
+    if (prof) {
+        LG_HIP(c, hipEventRecord(ev[2], c->stream));
+        LG_HIP(c, hipEventRecord(ev[4], c->stream_h));
+    }
     // Merkle tree (mod.rs:544-551)
     {
         lg::MerkleArgs m;
@@ -399,16 +472,19 @@ int lg_commit_resident(lg_ctx* c) {
             const uint64_t threads = (uint64_t)c->batch * lvl;
             const dim3 grid((uint32_t)((threads + 255) / 256));
             if (lvl == c->n / 2)
-                hipLaunchKernelGGL(lg::merkle_level_kernel<true>, grid, dim3(256), 0, c->stream, m);
+                hipLaunchKernelGGL(lg::merkle_level_kernel<true>, grid, dim3(256), 0, c->stream_h, m);
             else
-                hipLaunchKernelGGL(lg::merkle_level_kernel<false>, grid, dim3(256), 0, c->stream, m);
+                hipLaunchKernelGGL(lg::merkle_level_kernel<false>, grid, dim3(256), 0, c->stream_h, m);
         }
         LG_HIP(c, hipGetLastError());
     }
     if (prof) {
-        LG_HIP(c, hipEventRecord(ev[4], c->stream));
+        LG_HIP(c, hipEventRecord(ev[5], c->stream_h));
         c->prof_commits++;
     }
+    // everything issued later on the encode stream (read-backs, the next commit) sees the tree
+    LG_HIP(c, hipEventRecord(c->ev_done, c->stream_h));
+    LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
     c->committed = true;
     return LG_OK;
 }
@@ -419,12 +495,14 @@ int lg_profile_read(lg_ctx* c, float ms_out[LG_STAGE_COUNT], uint32_t* samples_o
     LG_HIP(c, hipSetDevice(c->device));
     const uint64_t have = c->prof_commits < lg_ctx::kProfRing ? c->prof_commits : lg_ctx::kProfRing;
     double acc[LG_STAGE_COUNT] = {0, 0, 0, 0};
+    static const int from[LG_STAGE_COUNT] = {0, 1, 3, 4}, to[LG_STAGE_COUNT] = {1, 2, 4, 5};
     for (uint64_t s = 0; s < have; s++) {
         hipEvent_t* ev = c->ev[(c->prof_commits - 1 - s) % lg_ctx::kProfRing];
-        LG_HIP(c, hipEventSynchronize(ev[LG_STAGE_COUNT]));
+        LG_HIP(c, hipEventSynchronize(ev[5]));
+        LG_HIP(c, hipEventSynchronize(ev[2]));
         for (int i = 0; i < LG_STAGE_COUNT; i++) {
             float ms = 0;
-            LG_HIP(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            LG_HIP(c, hipEventElapsedTime(&ms, ev[from[i]], ev[to[i]]));
             acc[i] += ms;
         }
     }

@@ -107,6 +107,47 @@ def test_poseidon_commit_golden(lg, oracle, model, vectors, poseidon_case):
         assert c.encode_commit(pre, want_coeffs=False)[1] == root
 
 
+@pytest.fixture
+def forced_chunks(monkeypatch):
+    """LG_FORCE_CHUNKS makes small commits take the chunked two-stream pipeline that large ones
+    (>= 2^26 codeword elements) use, so its Blake2s state hand-over is checked against the oracle"""
+    def _set(nchunks):
+        monkeypatch.setenv("LG_FORCE_CHUNKS", str(nchunks))
+    return _set
+
+
+@pytest.mark.parametrize("rows,k,batch,chunks", [(70, 32, 1, 8), (71, 32, 1, 3), (6, 16, 1, 8), (344, 128, 1, 5),
+                                                 (70, 32, 2, 8), (33, 8, 3, 6), (70, 32, 5, 4), (10, 64, 16, 8)])
+def test_chunked_pipeline_matches_oracle(lg, oracle, forced_chunks, rows, k, batch, chunks):
+    forced_chunks(chunks)
+    pre = random_mont(77 + batch + rows, batch * rows * k).reshape(batch * rows, k, 4)
+    with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+        for rep in range(2):                                     # second commit reuses the parked states
+            coeffs, roots = c.encode_commit(pre)
+        leaves, nodes = c.leaves(), c.nodes()
+        for b in range(batch):
+            ref = oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, 8 * k)
+            assert np.array_equal(coeffs[b * rows:(b + 1) * rows], ref["coeffs"])
+            assert np.array_equal(leaves[b], ref["leaves"]) and np.array_equal(nodes[b], ref["nodes"])
+            assert roots[32 * b:32 * b + 32] == ref["root"]
+            assert np.array_equal(c.codeword_rows(proof=b), ref["u"])
+
+
+@pytest.mark.parametrize("batch", [2, 3, 5])
+def test_small_batches_match_oracle(lg, oracle, batch):
+    rows, k = 70, 32
+    pre = random_mont(77 + batch, batch * rows * k).reshape(batch * rows, k, 4)
+    with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+        coeffs, roots = c.encode_commit(pre)
+        leaves, nodes = c.leaves(), c.nodes()
+        for b in range(batch):
+            ref = oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, 8 * k)
+            assert np.array_equal(coeffs[b * rows:(b + 1) * rows], ref["coeffs"])
+            assert np.array_equal(leaves[b], ref["leaves"]) and np.array_equal(nodes[b], ref["nodes"])
+            assert roots[32 * b:32 * b + 32] == ref["root"]
+            assert np.array_equal(c.codeword_rows(proof=b), ref["u"])
+
+
 def test_poseidon_batch64(lg, oracle, model, vectors):
     """BASELINE config 5 shape: 64 independent Poseidon commitments in one batched context"""
     blob = open(os.path.join(GOLDEN, "poseidon_witness_batch64.bin"), "rb").read()
@@ -126,7 +167,8 @@ def test_poseidon_batch64(lg, oracle, model, vectors):
         assert np.array_equal(c.codeword_rows(row0=100, nrows=5, proof=17), ref["u"][100:105])
 
 
-@pytest.mark.parametrize("rows,k", [(1, 2), (3, 2), (5, 8), (7, 16), (12, 32), (9, 64), (33, 256), (4, 1024), (2, 4096)])
+@pytest.mark.parametrize("rows,k", [(1, 2), (3, 2), (5, 8), (7, 16), (12, 32), (9, 64), (33, 256), (4, 1024), (2, 4096),
+                                    (101, 16), (130, 8), (64, 4), (67, 128)])
 def test_ragged_shapes_match_oracle(lg, oracle, rows, k):
     """odd / tiny row counts (the column-hash tail paths) and every radix plan"""
     n = 8 * k
