@@ -38,12 +38,12 @@ typedef struct lg_ctx lg_ctx;
 typedef enum lg_status {
     LG_OK = 0,
     LG_ERR_BAD_ARG = -1,    /* null pointer, index out of range, ... */
-    LG_ERR_BAD_DIMS = -2,   /* k, n not powers of two, n != 8k, k < 2, k > 2^25, rows == 0 */
+    LG_ERR_BAD_DIMS = -2,   /* k, n not powers of two, n != 8k, k < 2, rows == 0 */
     LG_ERR_NO_DEVICE = -3,  /* device ordinal not present */
     LG_ERR_HIP = -4,        /* a HIP runtime call failed; see lg_last_error() */
     LG_ERR_OOM = -5,        /* device or host allocation failed */
     LG_ERR_STATE = -6,      /* call order violated (e.g. open_columns before a commitment) */
-    LG_ERR_UNSUPPORTED = -7 /* shape not supported by this build */
+    LG_ERR_UNSUPPORTED = -7 /* shape not supported by this build (k > 2^14) */
 } lg_status;
 
 /* Human-readable text for a status code (static storage). */

@@ -8,9 +8,9 @@
 //     with TestMerkleTreeParams (types.rs:6-8,25-26): identity leaf hash; bottom inner level
 //     SHA-256( LE64(32)||L || LE64(32)||R ); upper levels SHA-256( L || R ); heap order.
 //
-// There is no transpose: the codeword matrix is stored as 8 coset planes [s][row][q]
-// (column j = 8q + s) holding canonical integers, so lanes = adjacent q read adjacent
-// 32-byte elements of one row -- coalesced row-major streaming.
+// There is no transpose: the codeword matrix is stored as np = 8 O coset planes [s][row][q]
+// (column j = np q + s; O = 1 up to k = 2048) holding canonical integers, so lanes = adjacent q
+// read adjacent 32-byte elements of one row -- coalesced row-major streaming.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,9 +64,10 @@ __device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&
 struct ColHashArgs {
     const uint4* u;         // coset planes [8][total_rows][k], canonical integers, 2 x uint4 per element
     uint8_t* leaves;        // [batch][n][32]
-    uint4* state;           // [batch][8][k][3]: chaining value + 8 carried bytes between row chunks
+    uint4* state;           // [batch][np][k][3]: chaining value + 8 carried bytes between row chunks
     uint32_t rows;          // rows per proof (4m)
-    uint32_t k;             // elements per plane row
+    uint32_t k;             // elements per plane row (ki)
+    uint32_t lognp;         // log2 of the number of planes np (n = np * k)
     uint32_t proof_begin;   // first proof hashed by this launch
     uint32_t proof_count;   // proofs hashed by this launch
     uint32_t row_begin;     // rows [row_begin, row_end) of each proof are absorbed; row_begin is even
@@ -83,15 +84,15 @@ struct ColHashArgs {
 // straddle the 64-byte block boundary are parked in `state` in between.
 __global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)a.proof_count * 8 * a.k;
+    const uint64_t total = ((uint64_t)a.proof_count * a.k) << a.lognp;
     if (gid >= total) return;
     const uint32_t q = (uint32_t)(gid % a.k);
-    const uint32_t s = (uint32_t)((gid / a.k) & 7);
-    const uint32_t b = a.proof_begin + (uint32_t)(gid / ((uint64_t)a.k * 8));
+    const uint32_t s = (uint32_t)((gid / a.k) & ((1u << a.lognp) - 1));
+    const uint32_t b = a.proof_begin + (uint32_t)((gid / a.k) >> a.lognp);
     // element (row i) = p[i * 2k], p[i * 2k + 1]
     const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + a.row_begin) * a.k + q);
     const uint64_t step = 2 * (uint64_t)a.k;
-    uint4* st = a.state + 3 * (((uint64_t)b * 8 + s) * a.k + q);
+    uint4* st = a.state + 3 * ((((uint64_t)b << a.lognp) + s) * a.k + q);
 
     uint32_t h[8];
     uint32_t m[16];
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs 
         t += 8;
     }
     b2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), true);
-    uint4* out = reinterpret_cast<uint4*>(a.leaves + 32 * ((uint64_t)b * a.k * 8 + 8 * (uint64_t)q + s));
+    uint4* out = reinterpret_cast<uint4*>(a.leaves + 32 * ((((uint64_t)b * a.k + q) << a.lognp) + s));
     out[0] = make_uint4(h[0], h[1], h[2], h[3]);
     out[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }

@@ -24,6 +24,10 @@ struct lg_ctx {
     int device = 0;
     uint32_t rows = 0, k = 0, n = 0, batch = 1;
     int logk = 0, logn = 0;
+    // k = O * ki: transforms are done as O-way folded size-ki transforms (ntt_kernels.h); the
+    // codeword lives in 8 O planes of [total_rows][ki], column j = (8 O) q + s <-> plane s, slot q
+    int logki = 0, logo = 0, lognp = 3;
+    uint32_t ki = 0, nplanes = 8;
     uint64_t total_rows = 0;  // batch * rows
     hipStream_t stream = nullptr;    // encode stream; every public call is ordered on it
     hipStream_t stream_h = nullptr;  // column-hash / Merkle stream of the commit pipeline
@@ -35,13 +39,15 @@ struct lg_ctx {
     // resident commitment
     fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
     fr* d_coeffs = nullptr;   // [total_rows][k]  Montgomery
-    fr* d_u = nullptr;        // [8][total_rows][k] canonical integers; plane 0 = message
+    fr* d_u = nullptr;        // [8 O][total_rows][ki] canonical integers; planes 8c hold the message
     uint8_t* d_leaves = nullptr;  // [batch][n][32]
     uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
     // domain tables: 29-bit limbs, value * 2^261 mod p, three planes each (limbs 0-3 | 4-7 | 8)
-    uint8_t* d_tw_fwd = nullptr;    // omega_k^e, e < k
-    uint8_t* d_tw_inv = nullptr;    // omega_k^-e
-    uint8_t* d_coset_tw = nullptr;  // omega_n^e, e < n
+    uint8_t* d_tw_fwd = nullptr;    // butterfly twiddles of the size-ki transform, pass order (lg::pass_tw_offset)
+    uint8_t* d_tw_inv = nullptr;    // same for the inverse transform
+    uint8_t* d_coset_tw = nullptr;  // [plane s < 8 O][d < k] = omega_n^(s d)
+    uint8_t* d_fold_inv = nullptr;  // O > 1: [h < O][d < k] = omega_k^(-h d)
+    uint32_t n_pass_tw = 0;
     lg::f29 w8_fwd[3], w8_inv[3], one29, scale29;
     fr r2;
     // scratch for row operators / openings (grown on demand)
@@ -127,7 +133,8 @@ struct GatherArgs {
     fr r2;
     uint64_t plane_stride;
     uint64_t row_base;       // proof * rows
-    uint32_t rows, k, n, logn, t;
+    uint32_t rows, k, n, logn, t;  // k = plane row length ki
+    uint32_t lognp;                // log2 of the number of planes
 };
 
 // u.column(i) for the opened indices (src/matrices/mod.rs:169-171) + generate_proof pieces
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(256) gather_columns_kernel(const GatherArgs a)
     if (gid < ncol_elems) {
         const uint32_t c = (uint32_t)(gid / a.rows), i = (uint32_t)(gid % a.rows);
         const uint32_t j = a.idx[c];
-        const uint32_t s = j & 7, q = j >> 3;
+        const uint32_t s = j & ((1u << a.lognp) - 1), q = j >> a.lognp;
         fr x = fr_load(a.u + (uint64_t)s * a.plane_stride + (a.row_base + i) * a.k + q);
         fr y, z;
         fr_mul_lazy(y, x, a.r2);
@@ -166,20 +173,35 @@ __global__ void __launch_bounds__(256) gather_columns_kernel(const GatherArgs a)
     dst[1] = src[1];
 }
 
-// coset planes (canonical) -> natural column order rows (Montgomery): out[i][8q+s]
+// planes (canonical) -> natural column order rows (Montgomery): out[i][np q + s]; k = plane row length
 __global__ void __launch_bounds__(256) planes_to_rows_kernel(const fr* u, uint64_t plane_stride, uint64_t row_base,
-                                                            uint32_t nrows, uint32_t k, fr r2, fr* out) {
+                                                            uint32_t nrows, uint32_t k, uint32_t lognp, fr r2, fr* out) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)nrows * k * 8;
+    const uint64_t total = ((uint64_t)nrows * k) << lognp;
     if (gid >= total) return;
     const uint32_t q = (uint32_t)(gid % k);
-    const uint32_t s = (uint32_t)((gid / k) & 7);
-    const uint64_t i = gid / ((uint64_t)k * 8);
+    const uint32_t s = (uint32_t)((gid / k) & ((1u << lognp) - 1));
+    const uint64_t i = (gid / k) >> lognp;
     fr x = fr_load(u + (uint64_t)s * plane_stride + (row_base + i) * k + q);
     fr y, z;
     fr_mul_lazy(y, x, r2);
     fr_reduce(z, y);
-    fr_store(out + i * (uint64_t)k * 8 + 8 * (uint64_t)q + s, z);
+    fr_store(out + ((i * (uint64_t)k) << lognp) + ((uint64_t)q << lognp) + s, z);
+}
+
+// message rows (Montgomery) -> canonical integers in the planes that hold the systematic part of
+// the codeword: message index d = O j + c sits at codeword index 8 d = (8 O) j + 8 c, i.e. plane 8c,
+// slot j.  (With O = 1 the interpolation kernel writes this copy itself.)
+__global__ void __launch_bounds__(256) canon_planes_kernel(const fr* msg, fr* u, uint64_t plane_stride, uint64_t total_rows,
+                                                          uint32_t logk, uint32_t logo) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (total_rows << logk)) return;
+    const uint64_t row = gid >> logk;
+    const uint32_t d = (uint32_t)(gid & ((1u << logk) - 1));
+    const uint32_t c = d & ((1u << logo) - 1), j = d >> logo;
+    fr x = fr_load(msg + gid), y;
+    fr_from_mont(y, x);
+    fr_store(u + (uint64_t)(8 * c) * plane_stride + (row << (logk - logo)) + j, y);
 }
 
 }  // namespace lg
@@ -189,8 +211,8 @@ static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon
     lg::NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.canon_out = canon_out;
-    a.tw = planes_of(c->d_tw_inv, c->k);
-    a.coset_tw = planes_of(c->d_coset_tw, c->n);
+    a.tw = planes_of(c->d_tw_inv, c->n_pass_tw);
+    a.coset_tw = planes_of(c->d_fold_inv, (size_t)c->k << c->logo);
     for (int i = 0; i < 3; i++) a.w8[i] = c->w8_inv[i];
     a.one = c->one29;
     a.scale = c->scale29;
@@ -198,19 +220,22 @@ static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon
     a.plane_stride = 0;
     return a;
 }
+// with_message: also evaluate the planes that coincide with the message (needed when only
+// coefficients are given: lg_reed_solomon_evaluate); the commit path copies the message instead
 static lg::NttArgs eval_args(const lg_ctx* c, const fr* coeffs, fr* planes, uint64_t plane_stride, uint32_t row0, uint32_t rows,
-                             uint32_t first_coset) {
+                             bool with_message) {
     lg::NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = coeffs; a.out = planes; a.canon_out = nullptr;
-    a.tw = planes_of(c->d_tw_fwd, c->k);
-    a.coset_tw = planes_of(c->d_coset_tw, c->n);
+    a.tw = planes_of(c->d_tw_fwd, c->n_pass_tw);
+    a.coset_tw = planes_of(c->d_coset_tw, (size_t)c->k * c->nplanes);
     for (int i = 0; i < 3; i++) a.w8[i] = c->w8_fwd[i];
     a.one = c->one29;
     a.scale = c->scale29;
     a.rows = rows; a.row0 = row0;
-    a.ncos = 8 - first_coset;
-    for (uint32_t s = first_coset; s < 8; s++) a.cosets[s - first_coset] = s;
+    a.ncos = 0;
+    for (uint32_t s = 0; s < c->nplanes; s++)
+        if (with_message || (s & 7) != 0) a.cosets[a.ncos++] = (uint8_t)s;
     a.plane_stride = plane_stride;
     return a;
 }
@@ -249,7 +274,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream_h) hipStreamSynchronize(c->stream_h);
-    void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw,
+    void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv,
                     c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -269,7 +294,7 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     *out = nullptr;
     const int logk = ilog2_exact(k), logn = ilog2_exact(n);
     if (rows == 0 || batch == 0 || logk < 1 || logn < 0 || n != 8 * (uint64_t)k || logn > lg_host::kTwoAdicity) return LG_ERR_BAD_DIMS;
-    if (logk > lg::kMaxLdsLogK) return LG_ERR_UNSUPPORTED;
+    if (logk > 14) return LG_ERR_UNSUPPORTED;
     if ((uint64_t)rows * batch > 0xffffffffull / 8) return LG_ERR_BAD_DIMS;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LG_ERR_NO_DEVICE;
@@ -278,6 +303,15 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     if (!c) return LG_ERR_OOM;
     c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
     c->total_rows = (uint64_t)rows * batch;
+    // LDS-resident transform size: 2048 at most by default (two workgroups per CU), 4096 for k = 2^14
+    c->logki = logk <= 11 ? logk : (logk <= 13 ? 11 : 12);
+    if (const char* ns = getenv("LG_NO_SPLIT")) {
+        if (atoi(ns) && logk == 12) c->logki = 12;  // A/B knob: whole 4096-point rows in LDS
+    }
+    c->logo = logk - c->logki;
+    c->ki = 1u << c->logki;
+    c->nplanes = 8u << c->logo;
+    c->lognp = 3 + c->logo;
     if (const char* fc = getenv("LG_FORCE_CHUNKS")) c->force_chunks = (uint32_t)atoi(fc);
     int rc = LG_OK;
     auto body = [&]() -> int {
@@ -293,30 +327,65 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u), 8 * mat * sizeof(fr)));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_fwd), (size_t)k * 36));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_inv), (size_t)k * 36));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), (size_t)n * 36));
         // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
         using namespace lg_host;
         const Fr wn = domain_generator(logn);
         const Fr wk = domain_generator(logk);
         const Fr wk_inv = inverse(wk);
-        std::vector<uint8_t> tf((size_t)k * 36), ti((size_t)k * 36), ct((size_t)n * 36);
-        Fr a = kOneMont, b = kOneMont;
-        for (uint32_t e = 0; e < k; e++) {
-            fill_planes(tf, k, e, to_f29(a));
-            fill_planes(ti, k, e, to_f29(b));
-            a = mul(a, wk);
-            b = mul(b, wk_inv);
+        std::vector<Fr> pn(n), pki(c->ki), pki_inv(c->ki), pk_inv(k);  // powers of wn, w_ki, w_ki^-1, wk^-1
+        {
+            Fr a = kOneMont;
+            for (uint32_t e = 0; e < n; e++) { pn[e] = a; a = mul(a, wn); }
+            const Fr wki = pow_u64(wk, 1ull << c->logo), wki_inv = pow_u64(wk_inv, 1ull << c->logo);
+            a = kOneMont;
+            Fr b = kOneMont;
+            for (uint32_t e = 0; e < c->ki; e++) { pki[e] = a; pki_inv[e] = b; a = mul(a, wki); b = mul(b, wki_inv); }
+            a = kOneMont;
+            for (uint32_t e = 0; e < k; e++) { pk_inv[e] = a; a = mul(a, wk_inv); }
         }
-        a = kOneMont;
-        for (uint32_t e = 0; e < n; e++) {
-            fill_planes(ct, n, e, to_f29(a));
-            a = mul(a, wn);
+        // butterfly twiddles in pass order
+        c->n_pass_tw = (uint32_t)lg::pass_tw_total(c->logki);
+        {
+            const size_t cnt = c->n_pass_tw ? c->n_pass_tw : 1;
+            std::vector<uint8_t> tf(cnt * 36), ti(cnt * 36);
+            int logs = c->logki, logr = (c->logki < 3) ? c->logki : ((c->logki % 3) ? (c->logki % 3) : 3);
+            while (logs > 0) {
+                const int logsub = logs - logr;
+                if (logsub > 0) {
+                    const size_t off = (size_t)lg::pass_tw_offset(c->logki, logs);
+                    for (uint32_t m = 1; m < (1u << logr); m++)
+                        for (uint32_t i0 = 0; i0 < (1u << logsub); i0++) {
+                            const uint32_t e = (i0 * m) << (c->logki - logs);
+                            fill_planes(tf, cnt, off + ((size_t)(m - 1) << logsub) + i0, to_f29(pki[e]));
+                            fill_planes(ti, cnt, off + ((size_t)(m - 1) << logsub) + i0, to_f29(pki_inv[e]));
+                        }
+                }
+                logs -= logr;
+                logr = 3;
+            }
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_fwd), tf.size()));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tw_inv), ti.size()));
+            LG_HIP(c, hipMemcpy(c->d_tw_fwd, tf.data(), tf.size(), hipMemcpyHostToDevice));
+            LG_HIP(c, hipMemcpy(c->d_tw_inv, ti.data(), ti.size(), hipMemcpyHostToDevice));
         }
-        LG_HIP(c, hipMemcpy(c->d_tw_fwd, tf.data(), tf.size(), hipMemcpyHostToDevice));
-        LG_HIP(c, hipMemcpy(c->d_tw_inv, ti.data(), ti.size(), hipMemcpyHostToDevice));
-        LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size(), hipMemcpyHostToDevice));
+        // pre-scale table [plane][d] = wn^(s d mod n)
+        {
+            const size_t cnt = (size_t)c->nplanes * k;
+            std::vector<uint8_t> ct(cnt * 36);
+            for (uint32_t sp = 0; sp < c->nplanes; sp++)
+                for (uint32_t d = 0; d < k; d++) fill_planes(ct, cnt, (size_t)sp * k + d, to_f29(pn[((uint64_t)sp * d) & (n - 1)]));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), ct.size()));
+            LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size(), hipMemcpyHostToDevice));
+        }
+        // outer-fold factors of the inverse transform [h][d] = wk^(-h d mod k)
+        {
+            const size_t cnt = (size_t)k << c->logo;
+            std::vector<uint8_t> ft(cnt * 36);
+            for (uint32_t h = 0; h < (1u << c->logo); h++)
+                for (uint32_t d = 0; d < k; d++) fill_planes(ft, cnt, (size_t)h * k + d, to_f29(pk_inv[((uint64_t)h * d) & (k - 1)]));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_fold_inv), ft.size()));
+            LG_HIP(c, hipMemcpy(c->d_fold_inv, ft.data(), ft.size(), hipMemcpyHostToDevice));
+        }
         const Fr w8 = domain_generator(3), w8i = inverse(w8);
         Fr p = w8, pi = w8i;
         for (int i = 0; i < 3; i++) {
@@ -421,16 +490,24 @@ static int plan_chunks(const lg_ctx* c, Chunk* out) {
 int lg_commit_resident(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
-    const uint64_t plane = c->total_rows * c->k;
+    const uint64_t plane = c->total_rows * c->ki;
     const bool prof = c->profiling && c->ev_valid;
     hipEvent_t* ev = c->ev[c->prof_commits % lg_ctx::kProfRing];
     Chunk chunks[lg_ctx::kMaxChunks];
     const int nchunks = plan_chunks(c, chunks);
+    // one chunk: nothing to overlap, so everything stays on the encode stream (no cross-stream waits)
+    hipStream_t hs = nchunks > 1 ? c->stream_h : c->stream;
     if (prof) LG_HIP(c, hipEventRecord(ev[0], c->stream));
     // rows -> coefficients (mod.rs:521-526); also emits the canonical message = coset plane 0
     {
-        lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, 0, (uint32_t)c->total_rows);
-        LG_HIP(c, lg::launch_ntt(c->logk, false, c->stream, a));
+        lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->logo == 0 ? c->d_u : nullptr, 0, (uint32_t)c->total_rows);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+        if (c->logo > 0) {
+            const uint64_t threads = c->total_rows << c->logk;
+            hipLaunchKernelGGL(lg::canon_planes_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_preenc, c->d_u,
+                               plane, c->total_rows, (uint32_t)c->logk, (uint32_t)c->logo);
+            LG_HIP(c, hipGetLastError());
+        }
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[1], c->stream));
     for (int i = 0; i < nchunks; i++) {
@@ -438,31 +515,31 @@ int lg_commit_resident(lg_ctx* c) {
         // coefficients -> cosets 1..7 of the order-n domain (mod.rs:528-533)
         const uint32_t row0 = ch.proof_begin * c->rows + ch.row_begin;
         const uint32_t nrows = (ch.proof_count - 1) * c->rows + (ch.row_end - ch.row_begin);
-        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, 1);
-        LG_HIP(c, lg::launch_ntt(c->logk, true, c->stream, a));
-        LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, false);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+        if (prof && i + 1 == nchunks) LG_HIP(c, hipEventRecord(ev[2], c->stream));
         // column hashes (mod.rs:536-542) of the rows just encoded, on the hash stream
-        LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_chunk[i], 0));
-        if (prof && i == 0) LG_HIP(c, hipEventRecord(ev[3], c->stream_h));
+        if (nchunks > 1) {
+            LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_chunk[i], 0));
+        }
+        if (prof && i == 0) LG_HIP(c, hipEventRecord(ev[3], hs));
         lg::ColHashArgs h;
         memset(&h, 0, sizeof(h));
         h.u = reinterpret_cast<const uint4*>(c->d_u);
         h.leaves = c->d_leaves;
         h.state = c->d_hstate;
-        h.rows = c->rows; h.k = c->k;
+        h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
         h.proof_begin = ch.proof_begin; h.proof_count = ch.proof_count;
         h.row_begin = ch.row_begin; h.row_end = ch.row_end;
         h.first = ch.row_begin == 0;
         h.last = ch.row_end == c->rows;
         h.plane_stride = plane;
         const uint64_t threads = (uint64_t)ch.proof_count * c->n;
-        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream_h, h);
+        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
         LG_HIP(c, hipGetLastError());
     }
-    if (prof) {
-        LG_HIP(c, hipEventRecord(ev[2], c->stream));
-        LG_HIP(c, hipEventRecord(ev[4], c->stream_h));
-    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
     // Merkle tree (mod.rs:544-551)
     {
         lg::MerkleArgs m;
@@ -472,19 +549,21 @@ int lg_commit_resident(lg_ctx* c) {
             const uint64_t threads = (uint64_t)c->batch * lvl;
             const dim3 grid((uint32_t)((threads + 255) / 256));
             if (lvl == c->n / 2)
-                hipLaunchKernelGGL(lg::merkle_level_kernel<true>, grid, dim3(256), 0, c->stream_h, m);
+                hipLaunchKernelGGL(lg::merkle_level_kernel<true>, grid, dim3(256), 0, hs, m);
             else
-                hipLaunchKernelGGL(lg::merkle_level_kernel<false>, grid, dim3(256), 0, c->stream_h, m);
+                hipLaunchKernelGGL(lg::merkle_level_kernel<false>, grid, dim3(256), 0, hs, m);
         }
         LG_HIP(c, hipGetLastError());
     }
     if (prof) {
-        LG_HIP(c, hipEventRecord(ev[5], c->stream_h));
+        LG_HIP(c, hipEventRecord(ev[5], hs));
         c->prof_commits++;
     }
     // everything issued later on the encode stream (read-backs, the next commit) sees the tree
-    LG_HIP(c, hipEventRecord(c->ev_done, c->stream_h));
-    LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    if (nchunks > 1) {
+        LG_HIP(c, hipEventRecord(c->ev_done, hs));
+        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    }
     c->committed = true;
     return LG_OK;
 }
@@ -573,7 +652,7 @@ int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nro
     if (rc != LG_OK) return rc;
     const uint64_t threads = elems;
     hipLaunchKernelGGL(lg::planes_to_rows_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_u,
-                       c->total_rows * c->k, (uint64_t)proof * c->rows + row0, nrows, c->k, c->r2, c->d_scratch_c);
+                       c->total_rows * c->ki, (uint64_t)proof * c->rows + row0, nrows, c->ki, (uint32_t)c->lognp, c->r2, c->d_scratch_c);
     LG_HIP(c, hipGetLastError());
     return read_back(c, out, c->d_scratch_c, elems * sizeof(fr));
 }
@@ -613,9 +692,10 @@ int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, 
     g.sib = c->d_path_out;
     g.paths = c->d_path_out + (size_t)t * 32;
     g.r2 = c->r2;
-    g.plane_stride = c->total_rows * c->k;
+    g.plane_stride = c->total_rows * c->ki;
+    g.lognp = (uint32_t)c->lognp;
     g.row_base = (uint64_t)proof * c->rows;
-    g.rows = c->rows; g.k = c->k; g.n = c->n; g.logn = (uint32_t)c->logn; g.t = t;
+    g.rows = c->rows; g.k = c->ki; g.n = c->n; g.logn = (uint32_t)c->logn; g.t = t;
     const uint64_t threads = (uint64_t)t * c->rows + (uint64_t)t * (plen + 1);
     hipLaunchKernelGGL(lg::gather_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, g);
     LG_HIP(c, hipGetLastError());
@@ -641,7 +721,7 @@ static int rs_common(lg_ctx* c, const uint64_t* in, uint32_t nrows, uint64_t* ou
     const fr* coeffs = d_in;
     if (do_interp) {
         lg::NttArgs a = interp_args(c, d_in, d_co, nullptr, 0, nrows);
-        LG_HIP(c, lg::launch_ntt(c->logk, false, c->stream, a));
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
         coeffs = d_co;
     }
     if (!do_eval) return read_back(c, out, coeffs, mat * sizeof(fr));
@@ -649,11 +729,12 @@ static int rs_common(lg_ctx* c, const uint64_t* in, uint32_t nrows, uint64_t* ou
     if (rc != LG_OK) return rc;
     rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, 8 * mat);
     if (rc != LG_OK) return rc;
-    lg::NttArgs a = eval_args(c, coeffs, c->d_scratch_b, mat, 0, nrows, 0);
-    LG_HIP(c, lg::launch_ntt(c->logk, true, c->stream, a));
+    const uint64_t sstride = (uint64_t)nrows * c->ki;
+    lg::NttArgs a = eval_args(c, coeffs, c->d_scratch_b, sstride, 0, nrows, true);
+    LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
     const uint64_t threads = 8 * (uint64_t)mat;
     hipLaunchKernelGGL(lg::planes_to_rows_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_scratch_b,
-                       (uint64_t)mat, (uint64_t)0, nrows, c->k, c->r2, c->d_scratch_c);
+                       sstride, (uint64_t)0, nrows, c->ki, (uint32_t)c->lognp, c->r2, c->d_scratch_c);
     LG_HIP(c, hipGetLastError());
     return read_back(c, out, c->d_scratch_c, 8 * mat * sizeof(fr));
 }

@@ -1,37 +1,49 @@
-// One translation unit per transform size (compiled with -DLG_LOGK=<log2 k>) so the size
-// instantiations of the row-NTT kernel build in parallel.
+// One translation unit per LDS-resident transform size (compiled with -DLG_LOGK=<log2 ki>) so
+// the size instantiations of the row-NTT kernel build in parallel.
 #include <hip/hip_runtime.h>
 
 #include "ntt_kernels.h"
 #include "ntt_launch.h"
 
 #ifndef LG_LOGK
-#error "compile with -DLG_LOGK=<log2 k>"
+#error "compile with -DLG_LOGK=<log2 ki>"
 #endif
 
 namespace lg {
 
-template <int LOGK, bool EVAL>
+template <int LOGK, int LOGO, bool EVAL>
 static hipError_t launch_t(hipStream_t st, const NttArgs& a) {
     using Plan = NttPlan<LOGK>;
     static bool attr_set = false;
-    auto kern = ntt_rows_kernel<LOGK, EVAL>;
+    auto kern = ntt_rows_kernel<LOGK, LOGO, EVAL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Plan::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const uint64_t work = EVAL ? (uint64_t)a.rows * a.ncos : a.rows;
+    const uint64_t work = EVAL ? (uint64_t)a.rows * a.ncos : ((uint64_t)a.rows << LOGO);
     if (work == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Plan::kWgThreads), Plan::kLdsBytes, st, a);
     return hipGetLastError();
 }
 
+template <int LOGO>
+static hipError_t launch_o(bool evaluate, hipStream_t st, const NttArgs& a) {
+    return evaluate ? launch_t<LG_LOGK, LOGO, true>(st, a) : launch_t<LG_LOGK, LOGO, false>(st, a);
+}
+
 #define LG_CAT2(a, b) a##b
 #define LG_CAT(a, b) LG_CAT2(a, b)
-hipError_t LG_CAT(launch_ntt_logk_, LG_LOGK)(bool evaluate, hipStream_t st, const NttArgs& a) {
-    return evaluate ? launch_t<LG_LOGK, true>(st, a) : launch_t<LG_LOGK, false>(st, a);
+hipError_t LG_CAT(launch_ntt_logk_, LG_LOGK)(int logo, bool evaluate, hipStream_t st, const NttArgs& a) {
+    if (logo == 0) return launch_o<0>(evaluate, st, a);
+#if LG_LOGK == 11
+    if (logo == 1) return launch_o<1>(evaluate, st, a);
+    if (logo == 2) return launch_o<2>(evaluate, st, a);
+#elif LG_LOGK == 12
+    if (logo == 2) return launch_o<2>(evaluate, st, a);
+#endif
+    return hipErrorInvalidValue;
 }
 
 }  // namespace lg

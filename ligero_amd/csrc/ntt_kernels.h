@@ -21,20 +21,30 @@ namespace lg {
 
 constexpr int kMaxLdsLogK = 12;  // 4096 elements * 36 B = 144 KiB of the 160 KiB LDS
 
+// Transforms larger than what one workgroup should keep in LDS are split: k = O * ki with an
+// outer radix O = 2^LOGO folded into the load stage.  Output index O j + h of the size-k transform
+// is output j of a size-ki transform of v_h[i] = sum_c x[i + c ki] f^(i + c ki), with f the
+// appropriate root (omega_k^-h for interpolation; omega_n^(s + 8h) for the evaluation of coset
+// s -- i.e. the codeword is produced as 8 O cosets of the order-ki subgroup, "planes").  The sum
+// over c is one dot product with a single Montgomery reduction.  ki = 2048 keeps two workgroups
+// per CU, so one workgroup's load/store phases overlap the other's butterflies.
+
 struct NttArgs {
     const fr* in;        // interpolate: message rows [rows][k]; evaluate: coefficient rows [rows][k]  (ABI words)
-    fr* out;             // interpolate: coefficient rows; evaluate: base of the coset planes [8][rows][k]
-    fr* canon_out;       // interpolate only: canonical (non-Montgomery) copy of the message = coset plane 0 (may be null)
-    Tw29 tw;             // w^e * 2^261, e < k; w = omega_k^-1 (interpolate) or omega_k (evaluate)
-    Tw29 coset_tw;       // evaluate only: omega_n^e * 2^261, e < n (pre-scale of coefficient d for coset s: e = s d)
+    fr* out;             // interpolate: coefficient rows [rows][k]; evaluate: base of the planes [8 O][rows][ki]
+    fr* canon_out;       // interpolate, O = 1 only: canonical (non-Montgomery) copy of the message = plane 0 (may be null)
+    Tw29 tw;             // butterfly twiddles of the size-ki transform in pass order (pass_tw_offset below), * 2^261;
+                         // root = omega_ki^-1 (interpolate) or omega_ki (evaluate)
+    Tw29 coset_tw;       // evaluate: [plane s][d < k] = omega_n^(s d) * 2^261, the pre-scale of coefficient d;
+                         // interpolate with O > 1: [h < O][d < k] = omega_k^(-h d) * 2^261
     f29 w8[3];           // w_8^1, w_8^2 (= w_4), w_8^3 of this direction, * 2^261
     f29 one;             // 2^261 mod p: the multiplier that only normalises (output 0 of each butterfly)
     f29 scale;           // interpolate only: 2^261 / k
     uint32_t rows;       // rows handled by this launch
     uint32_t row0;       // first row (offset into in/out)
-    uint32_t ncos;       // evaluate only: number of cosets in `cosets`
-    uint32_t cosets[8];  // evaluate only: coset ids (0..7)
-    uint64_t plane_stride;  // elements between coset planes (= total_rows * k)
+    uint32_t ncos;       // evaluate only: number of planes in `cosets`
+    uint8_t cosets[32];  // evaluate only: plane ids (0 .. 8 O - 1)
+    uint64_t plane_stride;  // elements between planes (= total_rows * ki)
 };
 
 // compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- expanded in the front end, so
@@ -143,6 +153,24 @@ struct NttPlan {
     static constexpr int kLdsBytes = kNttsPerWg * (1 << LOGK) * 36;
 };
 
+// Twiddles are stored per pass in exactly the order the lanes consume them, so that every
+// twiddle load is one coalesced (or broadcast) request instead of a 64-line gather: the pass
+// with sub-transform size 2^logs and radix R keeps w^((ki / 2^logs) i0 m) at
+// pass_tw_offset(logk, logs) + (m - 1) * sub + i0 for m = 1..R-1, i0 < sub = 2^logs / R.
+__host__ __device__ constexpr int pass_tw_offset(int logk, int logs_target) {
+    int off = 0;
+    int logs = logk;
+    int logr = (logk < 3) ? logk : ((logk % 3) ? (logk % 3) : 3);
+    while (logs > logs_target) {
+        const int logsub = logs - logr;
+        if (logsub > 0) off += ((1 << logr) - 1) << logsub;
+        logs -= logr;
+        logr = 3;
+    }
+    return off;
+}
+__host__ __device__ constexpr int pass_tw_total(int logk) { return pass_tw_offset(logk, 0); }
+
 // digit reversal of the in-place DIF with the plan above: natural output index j -> LDS position
 template <int LOGK>
 __device__ __forceinline__ int dif_position(int j) {
@@ -169,12 +197,30 @@ struct NttConsts {
     f29 last;  // multiplier applied to every output of the last pass (interpolate: 2^261 / k)
 };
 
+// Synchronisation between passes.  When one NTT is owned by at most one wave (k <= 512) no
+// workgroup barrier is needed: a wave's LDS operations execute in order, so it is enough to
+// stop the compiler from moving reads above the writes; the waves of a workgroup then run
+// their NTTs independently and cover each other's memory stalls.
+template <int LOGK>
+__device__ __forceinline__ void ntt_sync() {
+    if constexpr (NttPlan<LOGK>::kThreadsPerNtt <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
 // One DIF pass over an LDS-resident row.  LOGS = log2 of the current sub-transform size.
-template <int LOGK, int LOGS, int LOGR, bool FIRST, bool EVALUATE>
+// LOGK = log2 of the LDS-resident transform size ki, LOGO = log2 of the outer radix; `sel` is the
+// plane id (evaluate) or the outer output index h (interpolate).
+template <int LOGK, int LOGO, int LOGS, int LOGR, bool FIRST, bool EVALUATE>
 __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, int t, bool active, const NttConsts& a,
-                                         const fr* __restrict__ gin, const Tw29& pre_tw, uint32_t coset,
+                                         const fr* __restrict__ gin, const Tw29& pre_tw, uint32_t sel,
                                          fr* __restrict__ canon_out) {
     constexpr int K = 1 << LOGK;
+    constexpr int O = 1 << LOGO;
     constexpr int R = 1 << LOGR;
     constexpr int LOGSUB = LOGS - LOGR;
     constexpr int SUB = 1 << LOGSUB;
@@ -195,11 +241,11 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
 #ifdef LG_ABL_NO_TW  // ablation builds only (tools/ntt_bench.hip)
                 w[m] = a.one;
 #else
-                w[m] = tw29_load(a.tw, (size_t)(i0 * m) << (LOGK - LOGS));
+                w[m] = tw29_load(a.tw, (size_t)(pass_tw_offset(LOGK, LOGS) + ((m - 1) << LOGSUB) + i0));
 #endif
             });
         }
-        if constexpr (FIRST) {
+        if constexpr (FIRST && LOGO == 0) {
             fr raw[R];
             static_for<0, R>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -213,7 +259,7 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
 #ifdef LG_ABL_NO_PRE
                     const f29 pw = a.one;
 #else
-                    const f29 pw = tw29_load(pre_tw, (size_t)coset * d);
+                    const f29 pw = tw29_load(pre_tw, ((size_t)sel << LOGK) + d);
 #endif
                     mul29(e[q], e[q], pw);
                 } else {
@@ -223,6 +269,20 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
                         fr_store(canon_out + d, pack29_reduced(c));
                     }
                 }
+            });
+        } else if constexpr (FIRST) {
+            // outer radix folded into the load: e[q] = sum_c x[d + c ki] * f^(d + c ki)
+            static_for<0, R>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int d = base + (q << LOGSUB);
+                f29 x[O], f[O];
+                static_for<0, O>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const uint32_t dd = (uint32_t)d + ((uint32_t)c << LOGK);
+                    x[c] = unpack29(fr_load(gin + dd));
+                    f[c] = tw29_load(pre_tw, ((size_t)sel << (LOGK + LOGO)) + dd);
+                });
+                mul29_dot<O>(e[q], x, f);
             });
         } else {
             static_for<0, R>([&](auto qc) {
@@ -262,38 +322,35 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
     }
 }
 
-template <int LOGK, int LOGS, bool EVALUATE>
+template <int LOGK, int LOGO, int LOGS, bool EVALUATE>
 __device__ __forceinline__ void dif_rest(const LdsPlanes& row, int slot_base, int t, bool active, const NttConsts& a) {
     if constexpr (LOGS > 0) {
 #ifndef LG_ABL_NO_BARRIER
-        __syncthreads();
+        ntt_sync<LOGK>();
 #endif
-        dif_pass<LOGK, LOGS, 3, false, EVALUATE>(row, slot_base, t, active, a, nullptr, a.tw, 0, nullptr);
-        dif_rest<LOGK, LOGS - 3, EVALUATE>(row, slot_base, t, active, a);
+        dif_pass<LOGK, LOGO, LOGS, 3, false, EVALUATE>(row, slot_base, t, active, a, nullptr, a.tw, 0, nullptr);
+        dif_rest<LOGK, LOGO, LOGS - 3, EVALUATE>(row, slot_base, t, active, a);
     }
 }
 
-// grid: ceil(work / kNttsPerWg) workgroups; work = rows (interpolate) or rows * ncos (evaluate)
-template <int LOGK, bool EVALUATE>
+// grid: ceil(work / kNttsPerWg) workgroups; work = rows * O (interpolate) or rows * ncos (evaluate)
+template <int LOGK, int LOGO, bool EVALUATE>
 __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(const NttArgs a) {
     using Plan = NttPlan<LOGK>;
-    constexpr int K = 1 << LOGK;
+    constexpr int K = 1 << LOGK;  // LDS-resident transform size ki; the row length is K << LOGO
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int slot = threadIdx.x / Plan::kThreadsPerNtt;
     const int t = threadIdx.x % Plan::kThreadsPerNtt;
-    const uint32_t total = EVALUATE ? a.rows * a.ncos : a.rows;
+    const uint32_t per_row = EVALUATE ? a.ncos : (1u << LOGO);
+    const uint32_t total = a.rows * per_row;
     const uint32_t w = blockIdx.x * Plan::kNttsPerWg + slot;
     const bool active = w < total;
-    uint32_t r = 0, coset = 0;
+    uint32_t r = 0, sel = 0;
     if (active) {
-        if constexpr (EVALUATE) {
-            r = w / a.ncos;
-            coset = a.cosets[w % a.ncos];
-        } else {
-            r = w;
-        }
+        r = w / per_row;
+        sel = EVALUATE ? (uint32_t)a.cosets[w % per_row] : (w % per_row);
     }
-    const size_t row_off = (size_t)(a.row0 + r) * K;
+    const size_t row_in = (size_t)(a.row0 + r) << (LOGK + LOGO);
     LdsPlanes row;
     row.a = reinterpret_cast<uint4*>(smem);
     row.b = reinterpret_cast<uint4*>(smem) + (size_t)Plan::kNttsPerWg * K;
@@ -307,13 +364,19 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
     cs.w8[2] = a.w8[2];
     cs.one = a.one;
     cs.last = a.scale;
-    fr* canon = (!EVALUATE && a.canon_out != nullptr) ? a.canon_out + row_off : nullptr;
-    dif_pass<LOGK, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, slot_base, t, active, cs, a.in + row_off, a.coset_tw, coset, canon);
-    dif_rest<LOGK, LOGK - Plan::kFirstLogR, EVALUATE>(row, slot_base, t, active, cs);
-    __syncthreads();
+    fr* canon = (!EVALUATE && LOGO == 0 && a.canon_out != nullptr) ? a.canon_out + row_in : nullptr;
+    dif_pass<LOGK, LOGO, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, slot_base, t, active, cs, a.in + row_in, a.coset_tw, sel, canon);
+    dif_rest<LOGK, LOGO, LOGK - Plan::kFirstLogR, EVALUATE>(row, slot_base, t, active, cs);
+    ntt_sync<LOGK>();
     if (!active) return;
-    fr* gout = EVALUATE ? a.out + (size_t)coset * a.plane_stride + row_off : a.out + row_off;
-    for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
+    if constexpr (EVALUATE) {
+        fr* gout = a.out + (size_t)sel * a.plane_stride + ((size_t)(a.row0 + r) << LOGK);
+        for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
+    } else {
+        fr* gout = a.out + row_in + sel;  // coefficient O j + h
+        for (int j = t; j < K; j += Plan::kThreadsPerNtt)
+            fr_store(gout + ((size_t)j << LOGO), pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
+    }
 }
 
 }  // namespace lg

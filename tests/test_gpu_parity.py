@@ -32,7 +32,7 @@ def _edge_rows(oracle, model, k):
     return mont_matrix(oracle, rows, k)
 
 
-@pytest.mark.parametrize("logk", list(range(1, 13)))
+@pytest.mark.parametrize("logk", list(range(1, 15)))
 def test_reed_solomon_rows_match_oracle(lg, oracle, model, logk):
     k = 1 << logk
     n = 8 * k
@@ -107,6 +107,20 @@ def test_poseidon_commit_golden(lg, oracle, model, vectors, poseidon_case):
         assert c.encode_commit(pre, want_coeffs=False)[1] == root
 
 
+def test_unsplit_4096_path_matches_oracle(lg, oracle, monkeypatch):
+    """k = 4096 normally runs as two folded 2048-point transforms; LG_NO_SPLIT=1 keeps the
+    whole row in LDS (the A/B variant) -- both must agree with the oracle"""
+    monkeypatch.setenv("LG_NO_SPLIT", "1")
+    rows, k = 3, 4096
+    pre = random_mont(4096, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k)
+    with lg.LigeroCommitter(rows=rows, k=k) as c:
+        coeffs, root = c.encode_commit(pre)
+        assert np.array_equal(coeffs, ref["coeffs"]) and root == ref["root"]
+        assert np.array_equal(c.codeword_rows(), ref["u"])
+        assert np.array_equal(c.reed_solomon(pre), ref["u"])
+
+
 @pytest.fixture
 def forced_chunks(monkeypatch):
     """LG_FORCE_CHUNKS makes small commits take the chunked two-stream pipeline that large ones
@@ -168,7 +182,7 @@ def test_poseidon_batch64(lg, oracle, model, vectors):
 
 
 @pytest.mark.parametrize("rows,k", [(1, 2), (3, 2), (5, 8), (7, 16), (12, 32), (9, 64), (33, 256), (4, 1024), (2, 4096),
-                                    (101, 16), (130, 8), (64, 4), (67, 128)])
+                                    (101, 16), (130, 8), (64, 4), (67, 128), (3, 8192), (2, 16384)])
 def test_ragged_shapes_match_oracle(lg, oracle, rows, k):
     """odd / tiny row counts (the column-hash tail paths) and every radix plan"""
     n = 8 * k

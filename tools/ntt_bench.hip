@@ -17,22 +17,23 @@ int main(int argc, char** argv) {
     uint8_t *tw, *ctw;
     CK(hipMalloc((void**)&in, (size_t)rows * K * 32));
     CK(hipMalloc((void**)&out, (size_t)8 * rows * K * 32));
-    CK(hipMalloc((void**)&tw, (size_t)K * 36));
+    const size_t ntw = pass_tw_total(LOGK) ? pass_tw_total(LOGK) : 1;
+    CK(hipMalloc((void**)&tw, ntw * 36));
     CK(hipMalloc((void**)&ctw, (size_t)8 * K * 36));
     CK(hipMemset(in, 0x11, (size_t)rows * K * 32));
-    CK(hipMemset(tw, 0x05, (size_t)K * 36));
+    CK(hipMemset(tw, 0x05, ntw * 36));
     CK(hipMemset(ctw, 0x03, (size_t)8 * K * 36));
     NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.canon_out = nullptr;
-    a.tw = Tw29{(const uint4*)tw, (const uint4*)(tw + 16 * K), (const uint32_t*)(tw + 32 * K)};
+    a.tw = Tw29{(const uint4*)tw, (const uint4*)(tw + 16 * ntw), (const uint32_t*)(tw + 32 * ntw)};
     a.coset_tw = Tw29{(const uint4*)ctw, (const uint4*)(ctw + 16 * 8 * K), (const uint32_t*)(ctw + 32 * 8 * K)};
     for (int i = 0; i < 3; i++) for (int j = 0; j < 9; j++) a.w8[i].v[j] = 0x01234567u >> (j & 3);
     for (int j = 0; j < 9; j++) { a.one.v[j] = 0x00abcdefu; a.scale.v[j] = 0x00123456u; }
     a.rows = rows; a.row0 = 0; a.ncos = 7;
     for (int s = 0; s < 7; s++) a.cosets[s] = s + 1;
     a.plane_stride = (uint64_t)rows * K;
-    auto kern = ntt_rows_kernel<LOGK, true>;
+    auto kern = ntt_rows_kernel<LOGK, 0, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Plan::kLdsBytes));
     const uint64_t work = (uint64_t)rows * 7;
     const uint32_t grid = (uint32_t)((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg);
