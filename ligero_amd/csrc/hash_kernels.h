@@ -225,30 +225,63 @@ struct MerkleArgs {
     const uint8_t* leaves;  // [batch][n][32]
     uint8_t* nodes;         // [batch][n-1][32], heap order, root at 0
     uint32_t n;             // leaves per tree (power of two >= 2)
+    uint32_t logn;
     uint32_t batch;
-    uint32_t level_nodes;   // nodes in the level being produced
+    uint32_t in_depth;      // depth of the input level (logn: the leaves; otherwise an inner level already in `nodes`)
+    uint32_t chunks;        // workgroups per tree = max(1, 2^in_depth / 512)
 };
 
-// produces one tree level for every tree of the batch; LEAF: children are the leaf digests
+// Each workgroup takes 512 consecutive nodes of the input level (all of it when the level is
+// smaller) and reduces them as far as they go -- up to nine levels -- through LDS, writing every
+// produced node to its heap slot.  A 2^15-leaf tree is two launches instead of fifteen.
 template <bool LEAF>
-__global__ void __launch_bounds__(256) merkle_level_kernel(const MerkleArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)a.batch * a.level_nodes) return;
-    const uint32_t i = (uint32_t)(gid % a.level_nodes);
-    const uint32_t b = (uint32_t)(gid / a.level_nodes);
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(const MerkleArgs a) {
+    __shared__ uint4 buf[2][256][2];
+    const uint32_t b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+    if (b >= a.batch) return;
     uint8_t* tree = a.nodes + 32 * (uint64_t)b * (a.n - 1);
-    const uint32_t idx = a.level_nodes - 1 + i;  // heap index of the produced node
-    const uint4* l;
-    const uint4* r;
-    if constexpr (LEAF) {
-        const uint8_t* lv = a.leaves + 32 * ((uint64_t)b * a.n + 2 * (uint64_t)i);
-        l = reinterpret_cast<const uint4*>(lv);
-        r = reinterpret_cast<const uint4*>(lv + 32);
-    } else {
-        l = reinterpret_cast<const uint4*>(tree + 32 * (uint64_t)(2 * idx + 1));
-        r = reinterpret_cast<const uint4*>(tree + 32 * (uint64_t)(2 * idx + 2));
+    const uint32_t in_count = (a.in_depth >= 9) ? 512u : (1u << a.in_depth);  // inputs handled by this workgroup
+    uint32_t depth = a.in_depth - 1;                                         // depth of the level being produced
+    uint32_t count = in_count >> 1;                                          // nodes this workgroup produces at `depth`
+    const uint32_t t = threadIdx.x;
+    // first level: children come from global memory
+    if (t < count) {
+        const uint32_t i = chunk * count + t;  // index within the level
+        const uint4 *l, *r;
+        if constexpr (LEAF) {
+            const uint8_t* lv = a.leaves + 32 * ((uint64_t)b * a.n + 2 * (uint64_t)i);
+            l = reinterpret_cast<const uint4*>(lv);
+            r = reinterpret_cast<const uint4*>(lv + 32);
+        } else {
+            const uint32_t child = (1u << a.in_depth) - 1 + 2 * i;
+            l = reinterpret_cast<const uint4*>(tree + 32 * (uint64_t)child);
+            r = reinterpret_cast<const uint4*>(tree + 32 * (uint64_t)(child + 1));
+        }
+        uint4 out[2];
+        sha256_two_to_one<LEAF>(l, r, out);
+        uint4* dst = reinterpret_cast<uint4*>(tree + 32 * (uint64_t)((1u << depth) - 1 + i));
+        dst[0] = out[0];
+        dst[1] = out[1];
+        buf[0][t][0] = out[0];
+        buf[0][t][1] = out[1];
     }
-    sha256_two_to_one<LEAF>(l, r, reinterpret_cast<uint4*>(tree + 32 * (uint64_t)idx));
+    int cur = 0;
+    while (count > 1) {
+        __syncthreads();
+        count >>= 1;
+        depth -= 1;
+        if (t < count) {
+            uint4 out[2];
+            sha256_two_to_one<false>(&buf[cur][2 * t][0], &buf[cur][2 * t + 1][0], out);
+            const uint32_t i = chunk * count + t;
+            uint4* dst = reinterpret_cast<uint4*>(tree + 32 * (uint64_t)((1u << depth) - 1 + i));
+            dst[0] = out[0];
+            dst[1] = out[1];
+            buf[cur ^ 1][t][0] = out[0];
+            buf[cur ^ 1][t][1] = out[1];
+        }
+        cur ^= 1;
+    }
 }
 
 }  // namespace lg

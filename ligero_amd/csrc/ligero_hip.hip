@@ -303,11 +303,9 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     if (!c) return LG_ERR_OOM;
     c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
     c->total_rows = (uint64_t)rows * batch;
-    // LDS-resident transform size: 2048 at most by default (two workgroups per CU), 4096 for k = 2^14
-    c->logki = logk <= 11 ? logk : (logk <= 13 ? 11 : 12);
-    if (const char* ns = getenv("LG_NO_SPLIT")) {
-        if (atoi(ns) && logk == 12) c->logki = 12;  // A/B knob: whole 4096-point rows in LDS
-    }
+    // whole rows stay in LDS up to k = 4096 (one workgroup per CU, 188 VGPRs: the column-hash
+    // waves of the commit pipeline still fit beside it); larger k folds an outer radix 2 or 4
+    c->logki = logk <= 12 ? logk : 12;
     c->logo = logk - c->logki;
     c->ki = 1u << c->logki;
     c->nplanes = 8u << c->logo;
@@ -540,18 +538,22 @@ int lg_commit_resident(lg_ctx* c) {
         LG_HIP(c, hipGetLastError());
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
-    // Merkle tree (mod.rs:544-551)
+    // Merkle tree (mod.rs:544-551): nine levels per launch
     {
         lg::MerkleArgs m;
-        m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.batch = c->batch;
-        for (uint32_t lvl = c->n / 2; lvl >= 1; lvl >>= 1) {
-            m.level_nodes = lvl;
-            const uint64_t threads = (uint64_t)c->batch * lvl;
-            const dim3 grid((uint32_t)((threads + 255) / 256));
-            if (lvl == c->n / 2)
-                hipLaunchKernelGGL(lg::merkle_level_kernel<true>, grid, dim3(256), 0, hs, m);
+        m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
+        uint32_t depth = (uint32_t)c->logn;
+        bool leaf = true;
+        while (depth > 0) {
+            m.in_depth = depth;
+            m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
+            const dim3 grid(c->batch * m.chunks);
+            if (leaf)
+                hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, hs, m);
             else
-                hipLaunchKernelGGL(lg::merkle_level_kernel<false>, grid, dim3(256), 0, hs, m);
+                hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, hs, m);
+            leaf = false;
+            depth = depth > 9 ? depth - 9 : 0;
         }
         LG_HIP(c, hipGetLastError());
     }

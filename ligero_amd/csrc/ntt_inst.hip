@@ -37,10 +37,8 @@ static hipError_t launch_o(bool evaluate, hipStream_t st, const NttArgs& a) {
 #define LG_CAT(a, b) LG_CAT2(a, b)
 hipError_t LG_CAT(launch_ntt_logk_, LG_LOGK)(int logo, bool evaluate, hipStream_t st, const NttArgs& a) {
     if (logo == 0) return launch_o<0>(evaluate, st, a);
-#if LG_LOGK == 11
+#if LG_LOGK == 12  // k = 8192, 16384: two / four folded 4096-point transforms
     if (logo == 1) return launch_o<1>(evaluate, st, a);
-    if (logo == 2) return launch_o<2>(evaluate, st, a);
-#elif LG_LOGK == 12
     if (logo == 2) return launch_o<2>(evaluate, st, a);
 #endif
     return hipErrorInvalidValue;

@@ -26,8 +26,10 @@ constexpr int kMaxLdsLogK = 12;  // 4096 elements * 36 B = 144 KiB of the 160 Ki
 // is output j of a size-ki transform of v_h[i] = sum_c x[i + c ki] f^(i + c ki), with f the
 // appropriate root (omega_k^-h for interpolation; omega_n^(s + 8h) for the evaluation of coset
 // s -- i.e. the codeword is produced as 8 O cosets of the order-ki subgroup, "planes").  The sum
-// over c is one dot product with a single Montgomery reduction.  ki = 2048 keeps two workgroups
-// per CU, so one workgroup's load/store phases overlap the other's butterflies.
+// over c is one dot product with a single Montgomery reduction.  (Measured on MI355X: folding
+// k = 4096 into two 2048-point transforms to get two workgroups per CU is not faster than the
+// whole row in LDS, and its higher register count evicts the column-hash waves the commit
+// pipeline runs beside this kernel, so the fold is only used for k > 4096.)
 
 struct NttArgs {
     const fr* in;        // interpolate: message rows [rows][k]; evaluate: coefficient rows [rows][k]  (ABI words)
@@ -226,25 +228,13 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
     constexpr int SUB = 1 << LOGSUB;
     constexpr int T = NttPlan<LOGK>::kThreadsPerNtt;
     if (!active) return;
+#pragma unroll 1
     for (int u = t; u < (K >> LOGR); u += T) {
         const int blk = u >> LOGSUB;
         const int i0 = u & (SUB - 1);
         const int base = (blk << LOGS) + i0;
         const int sbase = lds_swz<LOGK>(slot_base + base);  // element q of this butterfly: sbase ^ sigma(q << LOGSUB)
         f29 e[R];
-        // external twiddles first: their global-load latency hides under the LDS reads and the
-        // in-register DFT (5 Montgomery products)
-        f29 w[R];
-        if constexpr (LOGSUB > 0) {
-            static_for<1, R>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-#ifdef LG_ABL_NO_TW  // ablation builds only (tools/ntt_bench.hip)
-                w[m] = a.one;
-#else
-                w[m] = tw29_load(a.tw, (size_t)(pass_tw_offset(LOGK, LOGS) + ((m - 1) << LOGSUB) + i0));
-#endif
-            });
-        }
         if constexpr (FIRST && LOGO == 0) {
             fr raw[R];
             static_for<0, R>([&](auto qc) {
@@ -300,7 +290,12 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
             mul29(e[0], e[0], a.one);
             static_for<1, R>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                mul29(e[m], e[m], w[m]);
+#ifdef LG_ABL_NO_TW  // ablation builds only (tools/ntt_bench.hip)
+                const f29 w = a.one;
+#else
+                const f29 w = tw29_load(a.tw, (size_t)(pass_tw_offset(LOGK, LOGS) + ((m - 1) << LOGSUB) + i0));
+#endif
+                mul29(e[m], e[m], w);
             });
         } else {
             static_for<0, R>([&](auto mc) {

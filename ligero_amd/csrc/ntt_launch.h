@@ -5,7 +5,7 @@
 #include "ntt_kernels.h"
 
 namespace lg {
-// logki = log2 of the LDS-resident transform size, logo = log2 of the outer radix (0 unless logki >= 11)
+// logki = log2 of the LDS-resident transform size, logo = log2 of the outer radix (0 unless logki == 12)
 #define LG_DECL_NTT(N) hipError_t launch_ntt_logk_##N(int logo, bool evaluate, hipStream_t st, const NttArgs& a);
 LG_DECL_NTT(1) LG_DECL_NTT(2) LG_DECL_NTT(3) LG_DECL_NTT(4) LG_DECL_NTT(5) LG_DECL_NTT(6)
 LG_DECL_NTT(7) LG_DECL_NTT(8) LG_DECL_NTT(9) LG_DECL_NTT(10) LG_DECL_NTT(11) LG_DECL_NTT(12)

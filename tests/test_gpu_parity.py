@@ -107,20 +107,6 @@ def test_poseidon_commit_golden(lg, oracle, model, vectors, poseidon_case):
         assert c.encode_commit(pre, want_coeffs=False)[1] == root
 
 
-def test_unsplit_4096_path_matches_oracle(lg, oracle, monkeypatch):
-    """k = 4096 normally runs as two folded 2048-point transforms; LG_NO_SPLIT=1 keeps the
-    whole row in LDS (the A/B variant) -- both must agree with the oracle"""
-    monkeypatch.setenv("LG_NO_SPLIT", "1")
-    rows, k = 3, 4096
-    pre = random_mont(4096, rows * k).reshape(rows, k, 4)
-    ref = oracle.encode_commit(pre, k, 8 * k)
-    with lg.LigeroCommitter(rows=rows, k=k) as c:
-        coeffs, root = c.encode_commit(pre)
-        assert np.array_equal(coeffs, ref["coeffs"]) and root == ref["root"]
-        assert np.array_equal(c.codeword_rows(), ref["u"])
-        assert np.array_equal(c.reed_solomon(pre), ref["u"])
-
-
 @pytest.fixture
 def forced_chunks(monkeypatch):
     """LG_FORCE_CHUNKS makes small commits take the chunked two-stream pipeline that large ones

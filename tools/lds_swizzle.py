@@ -172,7 +172,7 @@ def main():
     print("// kLdsSwz[logk][j] = 5-bit constant XORed into the LDS index when bit j (j >= 5) of it is set")
     print("#pragma once")
     print("namespace lg {")
-    print("__device__ __host__ constexpr unsigned char kLdsSwz[13][24] = {")
+    print("constexpr unsigned char kLdsSwz[13][24] = {")
     print("    {0},")
     for logk in range(1, 13):
         C, best, ideal = solve(logk)
