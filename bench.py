@@ -150,6 +150,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage = c.stage_ms()
+    launches = c.pipeline_chunks()          # evaluate / column-hash kernel launches per commit
     root = c.root()
 
     if rank == 0:
@@ -158,10 +159,12 @@ def main():
         b_commit, b_eval = algorithmic_bytes(rows, k, n, batch)
         names = ("interpolate", "evaluate", "colhash", "merkle")
         dom = max(names, key=lambda s: stage[s])
+        dom_launches = launches if dom in ("evaluate", "colhash") else 1
         dom_bytes = {"evaluate": b_eval, "interpolate": batch * rows * 96 * k,      # msg in, coeffs out, canonical copy out
-                     "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}[dom]
-        achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9
-        traffic = None
+                     "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}[dom] / dom_launches
+        dom_ms = stage[dom] / dom_launches
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json), if collected
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
@@ -182,8 +185,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
                                                     "colhash": "blake2s_columns_kernel", "merkle": "merkle_level_kernel"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": stage[dom],
-                         "samples": stage["samples"]},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
+                         "launches_per_step": dom_launches, "samples": stage["samples"] * dom_launches},
             "root0": root[:32].hex(),
         }
         if world == 1 and not args.no_cpu_baseline:

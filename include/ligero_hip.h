@@ -113,6 +113,9 @@ int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* 
 
 /* Shape queries. */
 int lg_ctx_dims(const lg_ctx* ctx, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch);
+/* How many row chunks lg_commit_resident pipelines (= launches of the evaluate and column-hash
+ * kernels per commit; 1 for small commits). */
+int lg_ctx_pipeline_chunks(const lg_ctx* ctx, uint32_t* chunks_out);
 
 /*
  * Per-stage timing with HIP events on the streams the kernels run on (for roofline

@@ -19,7 +19,7 @@ SYMBOLS = [
     "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
     "lg_open_columns",
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
-    "lg_ctx_dims", "lg_profile_enable", "lg_profile_read",
+    "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
 
 LG_OK = 0
@@ -78,6 +78,7 @@ def lib():
     L.lg_reed_solomon_evaluate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_ctx_dims.argtypes = [_vp, _vp, _vp, _vp, _vp]
+    L.lg_ctx_pipeline_chunks.argtypes = [_vp, _vp]
     L.lg_profile_enable.argtypes = [_vp, _int]
     L.lg_profile_read.argtypes = [_vp, _vp, _vp]
     for name in SYMBOLS:

@@ -250,6 +250,51 @@ static int grow(lg_ctx* c, fr** p, size_t* cap, size_t need) {
     return LG_OK;
 }
 
+// The commit is pipelined over row chunks on two streams: while the encode stream evaluates
+// chunk c+1, the hash stream absorbs chunk c into the per-column Blake2s states.  The column
+// hash is latency bound (one sequential chain per column, only n columns), so it fills issue
+// slots the NTT kernel leaves idle instead of extending the critical path.
+struct Chunk {
+    uint32_t proof_begin, proof_count, row_begin, row_end;
+};
+static int plan_chunks(const lg_ctx* c, Chunk* out) {
+    int n = 0;
+    // a chunk must be big enough (>= 2^25 codeword elements, a few ms of encoding) for the extra
+    // launches and cross-stream waits to pay; small commits run as one chunk
+    const uint64_t elems = c->total_rows * c->n;
+    uint32_t want = c->force_chunks ? c->force_chunks : (uint32_t)(elems >> 25);
+    if (want > (uint32_t)lg_ctx::kMaxChunks) want = lg_ctx::kMaxChunks;
+    if (want <= 1) {
+        out[0] = Chunk{0, c->batch, 0, c->rows};
+        return 1;
+    }
+    if (c->batch >= want && c->batch >= 4) {  // whole proofs per chunk
+        const uint32_t parts = want;
+        for (uint32_t i = 0; i < parts; i++) {
+            const uint32_t b0 = (uint32_t)((uint64_t)c->batch * i / parts), b1 = (uint32_t)((uint64_t)c->batch * (i + 1) / parts);
+            out[n++] = Chunk{b0, b1 - b0, 0, c->rows};
+        }
+        return n;
+    }
+    // row ranges of each proof; boundaries on even rows (a Blake2s block holds two rows)
+    uint32_t parts = want / c->batch;
+    const uint32_t pairs = c->rows / 2;
+    if (parts > pairs) parts = pairs;
+    if (parts < 1) parts = 1;
+    if ((uint64_t)parts * c->batch > (uint64_t)lg_ctx::kMaxChunks) parts = lg_ctx::kMaxChunks / c->batch;
+    if (parts < 1) {  // more proofs than chunk slots: fall back to one chunk
+        out[0] = Chunk{0, c->batch, 0, c->rows};
+        return 1;
+    }
+    for (uint32_t b = 0; b < c->batch; b++)
+        for (uint32_t i = 0; i < parts; i++) {
+            const uint32_t r0 = 2 * (uint32_t)((uint64_t)pairs * i / parts);
+            const uint32_t r1 = (i + 1 == parts) ? c->rows : 2 * (uint32_t)((uint64_t)pairs * (i + 1) / parts);
+            out[n++] = Chunk{b, 1, r0, r1};
+        }
+    return n;
+}
+
 // ----------------------------------------------------------------------------- ABI
 extern "C" {
 
@@ -420,6 +465,13 @@ int lg_ctx_dims(const lg_ctx* c, uint32_t* rows, uint32_t* k, uint32_t* n, uint3
     return LG_OK;
 }
 
+int lg_ctx_pipeline_chunks(const lg_ctx* c, uint32_t* chunks_out) {
+    if (!c || !chunks_out) return LG_ERR_BAD_ARG;
+    Chunk chunks[lg_ctx::kMaxChunks];
+    *chunks_out = (uint32_t)plan_chunks(c, chunks);
+    return LG_OK;
+}
+
 int lg_upload_preenc(lg_ctx* c, const uint64_t* preenc) {
     if (!c || !preenc) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
@@ -438,51 +490,6 @@ int lg_profile_enable(lg_ctx* c, int on) {
     c->profiling = on != 0;
     c->prof_commits = 0;
     return LG_OK;
-}
-
-// The commit is pipelined over row chunks on two streams: while the encode stream evaluates
-// chunk c+1, the hash stream absorbs chunk c into the per-column Blake2s states.  The column
-// hash is latency bound (one sequential chain per column, only n columns), so it fills issue
-// slots the NTT kernel leaves idle instead of extending the critical path.
-struct Chunk {
-    uint32_t proof_begin, proof_count, row_begin, row_end;
-};
-static int plan_chunks(const lg_ctx* c, Chunk* out) {
-    int n = 0;
-    // a chunk must be big enough (>= 2^25 codeword elements, a few ms of encoding) for the extra
-    // launches and cross-stream waits to pay; small commits run as one chunk
-    const uint64_t elems = c->total_rows * c->n;
-    uint32_t want = c->force_chunks ? c->force_chunks : (uint32_t)(elems >> 25);
-    if (want > (uint32_t)lg_ctx::kMaxChunks) want = lg_ctx::kMaxChunks;
-    if (want <= 1) {
-        out[0] = Chunk{0, c->batch, 0, c->rows};
-        return 1;
-    }
-    if (c->batch >= want && c->batch >= 4) {  // whole proofs per chunk
-        const uint32_t parts = want;
-        for (uint32_t i = 0; i < parts; i++) {
-            const uint32_t b0 = (uint32_t)((uint64_t)c->batch * i / parts), b1 = (uint32_t)((uint64_t)c->batch * (i + 1) / parts);
-            out[n++] = Chunk{b0, b1 - b0, 0, c->rows};
-        }
-        return n;
-    }
-    // row ranges of each proof; boundaries on even rows (a Blake2s block holds two rows)
-    uint32_t parts = want / c->batch;
-    const uint32_t pairs = c->rows / 2;
-    if (parts > pairs) parts = pairs;
-    if (parts < 1) parts = 1;
-    if ((uint64_t)parts * c->batch > (uint64_t)lg_ctx::kMaxChunks) parts = lg_ctx::kMaxChunks / c->batch;
-    if (parts < 1) {  // more proofs than chunk slots: fall back to one chunk
-        out[0] = Chunk{0, c->batch, 0, c->rows};
-        return 1;
-    }
-    for (uint32_t b = 0; b < c->batch; b++)
-        for (uint32_t i = 0; i < parts; i++) {
-            const uint32_t r0 = 2 * (uint32_t)((uint64_t)pairs * i / parts);
-            const uint32_t r1 = (i + 1 == parts) ? c->rows : 2 * (uint32_t)((uint64_t)pairs * (i + 1) / parts);
-            out[n++] = Chunk{b, 1, r0, r1};
-        }
-    return n;
 }
 
 int lg_commit_resident(lg_ctx* c) {

@@ -338,7 +338,17 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
     const int t = threadIdx.x % Plan::kThreadsPerNtt;
     const uint32_t per_row = EVALUATE ? a.ncos : (1u << LOGO);
     const uint32_t total = a.rows * per_row;
-    const uint32_t w = blockIdx.x * Plan::kNttsPerWg + slot;
+    uint32_t w = blockIdx.x * Plan::kNttsPerWg + slot;
+    if constexpr (Plan::kNttsPerWg == 1) {
+        // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+        // share one), each with its own L2.  Give all per_row transforms of a row to blocks that
+        // are congruent mod 8, so the row is fetched into one L2 instead of up to seven.
+        const uint32_t full = (a.rows / 8) * 8 * per_row;  // items of complete groups of 8 rows
+        if (w < full) {
+            const uint32_t x = w & 7, i = w >> 3;              // i-th item of XCD class x
+            w = (8 * (i / per_row) + x) * per_row + (i % per_row);
+        }
+    }
     const bool active = w < total;
     uint32_t r = 0, sel = 0;
     if (active) {

@@ -184,6 +184,12 @@ class LigeroCommitter:
         self._chk(self._L.lg_reed_solomon(self._ctx, _ptr(m), m.shape[0], _ptr(out)), "lg_reed_solomon")
         return out
 
+    def pipeline_chunks(self) -> int:
+        """launches of the evaluate / column-hash kernels per commit (1 for small commits)"""
+        n = ctypes.c_uint32(0)
+        self._chk(self._L.lg_ctx_pipeline_chunks(self._ctx, ctypes.cast(ctypes.byref(n), _vp)), "lg_ctx_pipeline_chunks")
+        return int(n.value)
+
     # -- per-stage timing (HIP events on the context's stream)
     def profile(self, on: bool = True):
         self._chk(self._L.lg_profile_enable(self._ctx, 1 if on else 0), "lg_profile_enable")

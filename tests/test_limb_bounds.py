@@ -1,0 +1,199 @@
+"""CPU test: replays the lazy (carry-free) butterfly networks of ligero_amd/csrc/ntt_kernels.h
+with interval arithmetic and checks every bound ligero_amd/csrc/fr29_gfx950.h relies on:
+
+  * the Bias29<K, L> tables are K*p, with every limb large enough to keep a - b + bias
+    limb-wise non-negative for the subtrahends they are used with;
+  * no limb ever exceeds 32 bits, and every Montgomery-product input has limbs <= 6 * 2^29 and
+    value < 2^261, so the 64-bit column accumulators of mul29 cannot overflow;
+  * mul29 / mul29_dot / mul29_small on random and extreme operands equal the big-int result.
+"""
+import os
+import random
+import re
+
+from conftest import ROOT
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+B = 1 << 29
+M = B - 1
+HDR = open(os.path.join(ROOT, "ligero_amd", "csrc", "fr29_gfx950.h")).read()
+
+
+def limbs29(x):
+    return [(x >> (29 * i)) & M for i in range(8)] + [x >> 232]
+
+
+def value(l):
+    return sum(v << (29 * i) for i, v in enumerate(l))
+
+
+def parse_tables():
+    p29 = [int(x, 16) for x in re.search(r"P\[9\] = \{([^}]*)\}", HDR).group(1).replace("u", "").split(",")]
+    bias = {}
+    for m in re.finditer(r"struct Bias29<(\d+), (\d+)> \{.*?T\[9\] = \{([^}]*)\}", HDR, re.S):
+        bias[(int(m.group(1)), int(m.group(2)))] = [int(x, 16) for x in m.group(3).replace("u", "").split(",")]
+    return p29, bias
+
+
+P29, BIAS = parse_tables()
+
+
+def test_constants():
+    assert value(P29) == P and all(v < B for v in P29[:8])
+    assert int(re.search(r"kPinv29 = (0x[0-9a-f]+)u", HDR).group(1), 16) == (-pow(P, -1, B)) % B
+    assert set(BIAS) == {(4, 29), (8, 30), (16, 30)}
+    for (K, L), t in BIAS.items():
+        assert value(t) == K * P
+        assert all(0 <= v < 2**32 for v in t)
+        assert t[0] >= (1 << L) and all(v >= (1 << L) - (1 << (L - 29)) for v in t[1:8])
+
+
+# ---- interval model: a lazy element is (max limb 0..7, max limb 8, max value in units of p)
+class Lazy:
+    def __init__(self, limb, top, val):
+        self.limb, self.top, self.val = limb, top, val
+
+
+N = lambda: Lazy(M, (2 * P) >> 232, 2)           # product output: limbs < 2^29, value < 2p
+MAX_MUL_LIMB = 6 * B
+
+
+def add(a, b):
+    r = Lazy(a.limb + b.limb, a.top + b.top, a.val + b.val)
+    assert r.limb < 2**32 and r.top < 2**32
+    return r
+
+
+def sub(a, b, K, L):
+    t = BIAS[(K, L)]
+    assert b.limb <= min(t[:8]), f"bias ({K},{L}) does not cover subtrahend limbs {b.limb:#x}"
+    assert b.top <= t[8], "bias top limb too small"
+    assert b.val <= K, "bias value too small: result could go negative"
+    r = Lazy(a.limb + max(t[:8]), a.top + t[8], a.val + K)
+    assert r.limb < 2**32 and r.top < 2**32
+    return r
+
+
+def norm(a):
+    return Lazy(M + (a.limb >> 29), a.top + (a.limb >> 29), a.val)
+
+
+def mul(a):
+    assert a.limb <= MAX_MUL_LIMB, f"mul input limb {a.limb / B:.2f} * 2^29"
+    assert a.val * P < (1 << 261), "mul input value >= 2^261"
+    # column sum: 9 products a_i * b_j (b_j < 2^29) + 9 reduction products + carry
+    assert 8 * a.limb * M + max(a.top, a.limb) * M + 9 * M * M + (1 << 36) < 2**64
+    return N()
+
+
+def bfly(a, b, K, L):
+    return add(a, b), sub(a, b, K, L)
+
+
+def dft8(e):
+    e = list(e)
+    for j in range(4):
+        e[j], e[j + 4] = bfly(e[j], e[j + 4], 4, 29)
+    e[5], e[6], e[7] = mul(e[5]), mul(e[6]), mul(e[7])
+    e[0], e[2] = bfly(e[0], e[2], 8, 30)
+    e[1], e[3] = bfly(e[1], e[3], 8, 30)
+    e[3] = mul(e[3])
+    e[0], e[1], e[2] = norm(e[0]), norm(e[1]), norm(e[2])
+    e[0], e[1] = bfly(e[0], e[1], 16, 30)
+    e[2], e[3] = bfly(e[2], e[3], 4, 29)
+    e[4], e[6] = bfly(e[4], e[6], 4, 29)
+    e[5], e[7] = bfly(e[5], e[7], 4, 29)
+    e[7] = mul(e[7])
+    e[4], e[6] = norm(e[4]), norm(e[6])
+    e[4], e[5] = bfly(e[4], e[5], 8, 30)
+    e[6], e[7] = bfly(e[6], e[7], 4, 29)
+    return e
+
+
+def dft4(e):
+    e = list(e)
+    e[0], e[2] = bfly(e[0], e[2], 4, 29)
+    e[1], e[3] = bfly(e[1], e[3], 4, 29)
+    e[3] = mul(e[3])
+    e[0], e[1] = bfly(e[0], e[1], 8, 30)
+    e[2], e[3] = bfly(e[2], e[3], 4, 29)
+    return e
+
+
+def dft2(e):
+    return list(bfly(e[0], e[1], 4, 29))
+
+
+def test_butterfly_networks_stay_in_range():
+    """every output of a pass is multiplied once (twiddle / one / scale / 32): inputs of the next
+    pass are N again, so checking one pass of each radix with N inputs covers all passes"""
+    for net, r in ((dft8, 8), (dft4, 4), (dft2, 2)):
+        outs = net([N() for _ in range(r)])
+        for o in outs:
+            mul(o)
+
+
+def test_network_source_matches_model():
+    """the model above mirrors dft_regs<3>; if the kernel's sequence of butterflies changes this
+    test must be updated with it"""
+    src = open(os.path.join(ROOT, "ligero_amd", "csrc", "ntt_kernels.h")).read()
+    body = src[src.index("dft_regs<3>(f29 (&e)[8]"):]
+    body = body[:body.index("// registers now hold")]
+    ops = re.findall(r"(bfly29<\d+, \d+>\(e\[\d\], e\[\d\]\)|mul29\(e\[\d\]|norm29\(e\[\d\]\))", body)
+    expect = ["bfly29<4, 29>(e[0], e[4])", "bfly29<4, 29>(e[1], e[5])", "bfly29<4, 29>(e[2], e[6])", "bfly29<4, 29>(e[3], e[7])",
+              "mul29(e[5]", "mul29(e[6]", "mul29(e[7]",
+              "bfly29<8, 30>(e[0], e[2])", "bfly29<8, 30>(e[1], e[3])", "mul29(e[3]", "norm29(e[0])", "norm29(e[1])", "norm29(e[2])",
+              "bfly29<16, 30>(e[0], e[1])", "bfly29<4, 29>(e[2], e[3])",
+              "bfly29<4, 29>(e[4], e[6])", "bfly29<4, 29>(e[5], e[7])", "mul29(e[7]", "norm29(e[4])", "norm29(e[6])",
+              "bfly29<8, 30>(e[4], e[5])", "bfly29<4, 29>(e[6], e[7])"]
+    assert ops == expect
+
+
+# ---- exact model of mul29 (product scanning, 64-bit accumulator) on concrete operands
+def mul29_model(a, b, small=None):
+    acc = 0
+    q = [0] * 9
+    r = [0] * 9
+    pinv = (-pow(P, -1, B)) % B
+    for c in range(9):
+        if small is None:
+            for i in range(c + 1):
+                acc += a[i] * b[c - i]
+        else:
+            acc += a[c] * small
+        for i in range(c):
+            acc += q[i] * P29[c - i]
+        assert acc < 2**64
+        q[c] = ((acc & 0xFFFFFFFF) * pinv) & M
+        acc += q[c] * P29[0]
+        assert acc < 2**64 and acc & M == 0
+        acc >>= 29
+    for c in range(9, 17):
+        if small is None:
+            for i in range(c - 8, 9):
+                acc += a[i] * b[c - i]
+        for i in range(c - 8, 9):
+            acc += q[i] * P29[c - i]
+        assert acc < 2**64
+        r[c - 9] = acc & M
+        acc >>= 29
+    r[8] = acc
+    assert acc < 2**32
+    return r
+
+
+def test_mul29_model_exact():
+    rng = random.Random(1)
+    rinv = pow(1 << 261, -1, P)
+    cases = [(limbs29(rng.randrange(P)), limbs29(rng.randrange(P))) for _ in range(200)]
+    # extreme dirty operand: every low limb at the 6 * 2^29 cap, top limb near the 2^261 value cap
+    dirty = [6 * B] * 8 + [((1 << 261) - value([6 * B] * 8 + [0])) >> 232]
+    assert value(dirty) < (1 << 261)
+    cases += [(dirty, limbs29(P - 1)), (dirty, [M] * 8 + [P >> 232]), (limbs29(P - 1), limbs29(P - 1)), ([0] * 9, limbs29(5))]
+    for a, b in cases:
+        r = mul29_model(a, b)
+        assert value(r) % P == value(a) * value(b) * rinv % P
+        assert all(v < B for v in r[:8]) and value(r) < value(a) * value(b) // (1 << 261) + P + 1
+    for a, _ in cases:
+        r = mul29_model(a, None, small=32)
+        assert value(r) % P == value(a) * 32 * rinv % P
