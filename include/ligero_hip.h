@@ -111,6 +111,27 @@ int lg_reed_solomon_interpolate(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows
 int lg_reed_solomon_evaluate(lg_ctx* ctx, const uint64_t* coeffs, uint32_t nrows, uint64_t* codeword_out);
 int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* codeword_out);
 
+/*
+ * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU
+ * (DESIGN.md section 7).  The exchanges between the stages are the caller's (RCCL all-gather on the
+ * device buffers below); there is no collective inside the library.
+ *   1. lg_stage_interpolate   rows [row0, row0+nrows): upload (preenc_rows may be NULL if the rows
+ *                             are already in LG_BUF_PREENC) and interpolate -> LG_BUF_COEFFS rows
+ *   2. (caller) all-gather LG_BUF_COEFFS rows
+ *   3. lg_stage_evaluate_hash for every plane s in plane_mask (codeword columns j = np q + s, np = 8
+ *                             planes for k <= 4096): evaluate all rows, hash the columns ->
+ *                             LG_BUF_LEAVES entries j
+ *   4. (caller) all-gather the leaf digests
+ *   5. lg_stage_merkle        tree over LG_BUF_LEAVES; afterwards lg_read_root / lg_open_columns
+ *                             (columns of owned planes only) work as after lg_encode_commit
+ */
+int lg_stage_interpolate(lg_ctx* ctx, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows);
+int lg_stage_evaluate_hash(lg_ctx* ctx, uint32_t plane_mask);
+int lg_stage_merkle(lg_ctx* ctx);
+typedef enum lg_buffer { LG_BUF_PREENC = 0, LG_BUF_COEFFS = 1, LG_BUF_LEAVES = 2, LG_BUF_NODES = 3 } lg_buffer;
+/* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers). */
+int lg_device_buffer(lg_ctx* ctx, int which, void** dptr_out, size_t* bytes_out);
+
 /* Shape queries. */
 int lg_ctx_dims(const lg_ctx* ctx, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch);
 /* How many row chunks lg_commit_resident pipelines (= launches of the evaluate and column-hash

@@ -19,6 +19,7 @@ SYMBOLS = [
     "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
     "lg_open_columns",
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
+    "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_merkle", "lg_device_buffer",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
 
@@ -31,6 +32,7 @@ LG_ERR_OOM = -5
 LG_ERR_STATE = -6
 LG_ERR_UNSUPPORTED = -7
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
+LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES = 0, 1, 2, 3
 
 _vp = ctypes.c_void_p
 _u32 = ctypes.c_uint32
@@ -77,6 +79,10 @@ def lib():
     L.lg_reed_solomon_interpolate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon_evaluate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon.argtypes = [_vp, _vp, _u32, _vp]
+    L.lg_stage_interpolate.argtypes = [_vp, _vp, _u32, _u32]
+    L.lg_stage_evaluate_hash.argtypes = [_vp, _u32]
+    L.lg_stage_merkle.argtypes = [_vp]
+    L.lg_device_buffer.argtypes = [_vp, _int, _vp, _vp]
     L.lg_ctx_dims.argtypes = [_vp, _vp, _vp, _vp, _vp]
     L.lg_ctx_pipeline_chunks.argtypes = [_vp, _vp]
     L.lg_profile_enable.argtypes = [_vp, _int]

@@ -72,6 +72,8 @@ struct ColHashArgs {
     uint32_t proof_count;   // proofs hashed by this launch
     uint32_t row_begin;     // rows [row_begin, row_end) of each proof are absorbed; row_begin is even
     uint32_t row_end;
+    uint32_t plane_begin;   // planes [plane_begin, plane_begin + plane_count) are hashed (all of them in a
+    uint32_t plane_count;   // single-GPU commit; the planes a rank owns when a proof is coset-sharded)
     uint32_t first;         // 1: start from the initial state; 0: resume from `state`
     uint32_t last;          // 1: finalise and write the leaf digest; 0: save `state`
     uint64_t plane_stride;  // in elements
@@ -84,11 +86,11 @@ struct ColHashArgs {
 // straddle the 64-byte block boundary are parked in `state` in between.
 __global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = ((uint64_t)a.proof_count * a.k) << a.lognp;
+    const uint64_t total = (uint64_t)a.proof_count * a.plane_count * a.k;
     if (gid >= total) return;
     const uint32_t q = (uint32_t)(gid % a.k);
-    const uint32_t s = (uint32_t)((gid / a.k) & ((1u << a.lognp) - 1));
-    const uint32_t b = a.proof_begin + (uint32_t)((gid / a.k) >> a.lognp);
+    const uint32_t s = a.plane_begin + (uint32_t)((gid / a.k) % a.plane_count);
+    const uint32_t b = a.proof_begin + (uint32_t)((gid / a.k) / a.plane_count);
     // element (row i) = p[i * 2k], p[i * 2k + 1]
     const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + a.row_begin) * a.k + q);
     const uint64_t step = 2 * (uint64_t)a.k;

@@ -539,6 +539,7 @@ int lg_commit_resident(lg_ctx* c) {
         h.row_begin = ch.row_begin; h.row_end = ch.row_end;
         h.first = ch.row_begin == 0;
         h.last = ch.row_end == c->rows;
+        h.plane_begin = 0; h.plane_count = c->nplanes;
         h.plane_stride = plane;
         const uint64_t threads = (uint64_t)ch.proof_count * c->n;
         hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
@@ -712,6 +713,97 @@ int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, 
     LG_HIP(c, hipMemcpyAsync(sib_out, g.sib, (size_t)t * 32, hipMemcpyDeviceToHost, c->stream));
     if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, g.paths, (size_t)t * plen * 32, hipMemcpyDeviceToHost, c->stream));
     LG_HIP(c, hipStreamSynchronize(c->stream));
+    return LG_OK;
+}
+
+// ---- staged commit for one proof sharded over several GPUs ----------------
+// Rank g interpolates its row shard, the host layer all-gathers the coefficient rows (RCCL),
+// then rank g evaluates and hashes the planes it owns for ALL rows, the host layer all-gathers
+// the leaf digests, and every rank builds the (replicated) tree.
+int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->batch != 1) return LG_ERR_STATE;
+    if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
+    if (nrows == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    if (preenc_rows)
+        LG_HIP(c, hipMemcpyAsync(c->d_preenc + (size_t)row0 * c->k, preenc_rows, (size_t)nrows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, nullptr, row0, nrows);
+    LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+    c->committed = false;
+    return LG_OK;
+}
+
+int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->batch != 1) return LG_ERR_STATE;
+    if (c->nplanes < 32 && (plane_mask >> c->nplanes) != 0) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint64_t plane = c->total_rows * c->ki;
+    // every owned plane -- including the ones that coincide with the message -- is produced by
+    // the evaluation kernel from the gathered coefficients, so no second exchange is needed
+    lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, 0, c->rows, true);
+    a.ncos = 0;
+    for (uint32_t s = 0; s < c->nplanes; s++)
+        if (plane_mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
+    if (a.ncos == 0) return LG_OK;
+    LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+    // hash the owned planes: one launch per run of consecutive planes (the kernel takes a plane range)
+    for (uint32_t s = 0; s < c->nplanes;) {
+        if (!(plane_mask & (1u << s))) { s++; continue; }
+        uint32_t e = s;
+        while (e + 1 < c->nplanes && (plane_mask & (1u << (e + 1)))) e++;
+        lg::ColHashArgs h;
+        memset(&h, 0, sizeof(h));
+        h.u = reinterpret_cast<const uint4*>(c->d_u);
+        h.leaves = c->d_leaves;
+        h.state = c->d_hstate;
+        h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
+        h.proof_begin = 0; h.proof_count = 1;
+        h.row_begin = 0; h.row_end = c->rows;
+        h.first = 1; h.last = 1;
+        h.plane_begin = s; h.plane_count = e - s + 1;
+        h.plane_stride = plane;
+        const uint64_t threads = (uint64_t)h.plane_count * c->ki;
+        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, h);
+        LG_HIP(c, hipGetLastError());
+        s = e + 1;
+    }
+    return LG_OK;
+}
+
+int lg_stage_merkle(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    lg::MerkleArgs m;
+    m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
+    uint32_t depth = (uint32_t)c->logn;
+    bool leaf = true;
+    while (depth > 0) {
+        m.in_depth = depth;
+        m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
+        const dim3 grid(c->batch * m.chunks);
+        if (leaf)
+            hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, c->stream, m);
+        else
+            hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, c->stream, m);
+        leaf = false;
+        depth = depth > 9 ? depth - 9 : 0;
+    }
+    LG_HIP(c, hipGetLastError());
+    c->committed = true;
+    return LG_OK;
+}
+
+int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
+    if (!c || !dptr_out || !bytes_out) return LG_ERR_BAD_ARG;
+    switch (which) {
+        case LG_BUF_PREENC: *dptr_out = c->d_preenc; *bytes_out = (size_t)c->total_rows * c->k * sizeof(fr); break;
+        case LG_BUF_COEFFS: *dptr_out = c->d_coeffs; *bytes_out = (size_t)c->total_rows * c->k * sizeof(fr); break;
+        case LG_BUF_LEAVES: *dptr_out = c->d_leaves; *bytes_out = (size_t)c->batch * c->n * 32; break;
+        case LG_BUF_NODES: *dptr_out = c->d_nodes; *bytes_out = (size_t)c->batch * (c->n - 1) * 32; break;
+        default: return LG_ERR_BAD_ARG;
+    }
     return LG_OK;
 }
 

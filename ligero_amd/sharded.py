@@ -1,0 +1,196 @@
+"""Multi-GPU host layer: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  Two modes:
+
+* `ShardedBatchCommitter` -- independent proofs are dealt to ranks; no data-path collective, only
+  the 32-byte roots are gathered.  This is what `bench.py --gpus N` measures (BASELINE configs[4]).
+* `CosetShardedCommitter` -- ONE large proof on G GPUs (BASELINE configs[3]).  A column's Blake2s
+  chain spans all rows, so rows cannot be sharded end to end; instead
+    1. rank g interpolates its row shard                                   (mod.rs:521-526)
+    2. all-gather of the coefficient rows (bulk: 4m*k*32 bytes)            RCCL
+    3. rank g evaluates + hashes the coset planes it owns, for ALL rows    (mod.rs:528-542)
+    4. all-gather of the n 32-byte leaf digests (tiny)                     RCCL
+    5. every rank builds the (replicated) tree                             (mod.rs:544-551)
+  Column j = np*q + s is opened by the owner of plane s.
+
+The device work goes through a *backend* object (`HipStageBackend` wraps the C ABI's staged
+calls and exposes the resident buffers as torch tensors without copies); the CPU tests inject
+an oracle-backed stand-in with the same methods, so the orchestration below is exercised with
+gloo at world_size 2 without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+
+_vp = ctypes.c_void_p
+
+
+def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """contiguous, balanced [begin, end) of `total` items for `rank`"""
+    return (total * rank) // world, (total * (rank + 1)) // world
+
+
+def owned_planes(nplanes: int, world: int, rank: int) -> List[int]:
+    """planes are dealt in contiguous equal runs; nplanes must be divisible by world"""
+    if nplanes % world != 0:
+        raise ValueError(f"{nplanes} coset planes cannot be split evenly over {world} ranks")
+    per = nplanes // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
+class _CudaArray:
+    """minimal __cuda_array_interface__ holder so torch can alias a raw device pointer"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class HipStageBackend:
+    """Staged single-proof commit on this rank's GPU through the C ABI (include/ligero_hip.h:
+    lg_stage_interpolate / lg_stage_evaluate_hash / lg_stage_merkle / lg_device_buffer)."""
+
+    def __init__(self, rows: int, k: int, device: int = 0):
+        from .ligero import LigeroCommitter
+        self.c = LigeroCommitter(rows=rows, k=k, batch=1, device=device)
+        self.rows, self.k, self.n, self.device = rows, k, 8 * k, device
+        self.nplanes = 8 if k <= 4096 else 8 * (k // 4096)
+        self._L = _ffi.lib()
+
+    def _buffer(self, which: int):
+        import torch
+        ptr, size = _vp(), ctypes.c_size_t()
+        _ffi.check(self._L.lg_device_buffer(self.c._ctx, which, ctypes.cast(ctypes.byref(ptr), _vp), ctypes.cast(ctypes.byref(size), _vp)),
+                   "lg_device_buffer", self.c._ctx)
+        return torch.as_tensor(_CudaArray(ptr.value, size.value), device=f"cuda:{self.device}")
+
+    def stage_interpolate(self, preenc_rows: Optional[np.ndarray], row0: int, nrows: int):
+        p = None
+        if preenc_rows is not None:
+            preenc_rows = np.ascontiguousarray(preenc_rows, dtype=np.uint64)
+            assert preenc_rows.size == nrows * self.k * 4
+            p = preenc_rows.ctypes.data_as(_vp)
+        _ffi.check(self._L.lg_stage_interpolate(self.c._ctx, p, row0, nrows), "lg_stage_interpolate", self.c._ctx)
+
+    def stage_evaluate_hash(self, planes: Sequence[int]):
+        mask = 0
+        for s in planes:
+            mask |= 1 << s
+        _ffi.check(self._L.lg_stage_evaluate_hash(self.c._ctx, mask), "lg_stage_evaluate_hash", self.c._ctx)
+
+    def stage_merkle(self):
+        _ffi.check(self._L.lg_stage_merkle(self.c._ctx), "lg_stage_merkle", self.c._ctx)
+
+    def sync(self):
+        self.c.sync()
+
+    def coeffs_bytes(self):
+        """[rows, k*32] uint8 view of the resident coefficient rows"""
+        return self._buffer(_ffi.LG_BUF_COEFFS).view(self.rows, self.k * 32)
+
+    def leaves_bytes(self):
+        """[n, 32] uint8 view of the resident leaf digests"""
+        return self._buffer(_ffi.LG_BUF_LEAVES).view(self.n, 32)
+
+    def root(self) -> bytes:
+        return self.c.root()
+
+    def open_columns(self, indices):
+        return self.c.open_columns(indices)
+
+    def close(self):
+        self.c.close()
+
+
+class CosetShardedCommitter:
+    """One proof over `world` ranks.  `backend` does the device work; `dist` is torch.distributed
+    (already initialised) or None for a single process."""
+
+    def __init__(self, backend, dist=None, group=None):
+        self.be = backend
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.planes = owned_planes(backend.nplanes, self.world, self.rank)
+
+    def row_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
+        return shard_range(self.be.rows, self.world, self.rank if rank is None else rank)
+
+    def commit(self, preenc_rows_local: np.ndarray) -> bytes:
+        """preenc_rows_local: this rank's rows [row_range()) of preenc_u.  Returns u_root."""
+        be, dist = self.be, self.dist
+        r0, r1 = self.row_range()
+        be.stage_interpolate(preenc_rows_local, r0, r1 - r0)
+        be.sync()
+        if self.world > 1:
+            coeffs = be.coeffs_bytes()
+            if be.rows % self.world == 0:   # equal shards: one in-place all-gather
+                dist.all_gather_into_tensor(coeffs, coeffs[r0:r1], group=self.group)
+            else:                           # ragged shards: one broadcast per owner
+                for g in range(self.world):
+                    g0, g1 = self.row_range(g)
+                    if g1 > g0:
+                        dist.broadcast(coeffs[g0:g1], src=g, group=self.group)
+            self._device_sync(coeffs)
+        be.stage_evaluate_hash(self.planes)
+        be.sync()
+        if self.world > 1:
+            import torch
+            np_ = be.nplanes
+            leaves = be.leaves_bytes().view(be.n // np_, np_, 32)          # [q][plane][32]
+            mine = leaves[:, self.planes[0]:self.planes[-1] + 1, :].contiguous()
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            per = np_ // self.world
+            for g in range(self.world):
+                if g != self.rank:
+                    leaves[:, g * per:(g + 1) * per, :] = parts[g]
+            self._device_sync(leaves)
+        be.stage_merkle()
+        be.sync()
+        return be.root()
+
+    @staticmethod
+    def _device_sync(t):
+        if t.is_cuda:
+            import torch
+            torch.cuda.synchronize(t.device)
+
+    def open_columns(self, indices: Sequence[int]):
+        """Each rank opens the columns whose plane it owns; returns {index: (column, sibling, path)}
+        for those (the caller merges ranks with all_gather_object if it needs them in one place)."""
+        np_ = self.be.nplanes
+        mine = [int(j) for j in indices if (int(j) % np_) in self.planes]
+        if not mine:
+            return {}
+        cols, sib, paths = self.be.open_columns(mine)
+        return {j: (cols[i], sib[i], paths[i]) for i, j in enumerate(mine)}
+
+
+class ShardedBatchCommitter:
+    """Independent proofs dealt to ranks (weak scaling, no data-path collective).
+    `make_committer(batch_local)` builds this rank's committer (a `LigeroCommitter` on the GPU)."""
+
+    def __init__(self, make_committer, batch: int, dist=None, group=None):
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.batch = batch
+        self.b0, self.b1 = shard_range(batch, self.world, self.rank)
+        self.c = make_committer(self.b1 - self.b0) if self.b1 > self.b0 else None
+
+    def commit(self, preenc_local) -> bytes:
+        """preenc_local: the rows of proofs [b0, b1).  Returns all `batch` roots, concatenated in
+        proof order, on every rank."""
+        local = b""
+        if self.c is not None:
+            _, local = self.c.encode_commit(preenc_local, want_coeffs=False)
+        if self.world == 1:
+            return local
+        gathered = [None] * self.world
+        self.dist.all_gather_object(gathered, local, group=self.group)   # 32 bytes per proof: control plane only
+        return b"".join(gathered)

@@ -1,0 +1,135 @@
+"""CPU tests of the multi-GPU host layer (ligero_amd/sharded.py) with torch.distributed over
+gloo at world_size 2: the orchestration (row shards, all-gather of coefficient rows, plane
+ownership, all-gather of leaf digests, replicated tree; and proof sharding in throughput mode)
+is the product's; the device work is replaced by an oracle-backed stand-in that implements the
+backend protocol on numpy arrays.  The result must equal the single-process oracle commit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, random_mont
+
+sys.path.insert(0, ROOT)
+
+
+class OracleStageBackend:
+    """test double for ligero_amd.sharded.HipStageBackend (same methods), CPU + oracle"""
+
+    def __init__(self, rows, k):
+        from oracle import binding as orc
+        self.orc = orc
+        self.rows, self.k, self.n, self.nplanes = rows, k, 8 * k, 8
+        self.preenc = np.zeros((rows, k, 4), dtype=np.uint64)
+        self.coeffs = np.zeros((rows, k, 4), dtype=np.uint64)
+        self.leaves = np.zeros((self.n, 32), dtype=np.uint8)
+        self.nodes = None
+        self.u = {}
+
+    def stage_interpolate(self, preenc_rows, row0, nrows):
+        self.preenc[row0:row0 + nrows] = np.asarray(preenc_rows).reshape(nrows, self.k, 4)
+        for r in range(row0, row0 + nrows):
+            self.coeffs[r] = self.orc.reed_solomon_interpolate(self.preenc[r], self.k)
+
+    def stage_evaluate_hash(self, planes):
+        u = np.stack([self.orc.reed_solomon_evaluate(self.coeffs[r], self.n) for r in range(self.rows)])
+        for s in planes:
+            for q in range(self.k):
+                j = 8 * q + s
+                self.leaves[j] = np.frombuffer(self.orc.col_hash(u[:, j]), dtype=np.uint8)
+        self.u = u
+
+    def stage_merkle(self):
+        self.nodes = self.orc.merkle_tree(self.leaves)
+
+    def sync(self):
+        pass
+
+    def coeffs_bytes(self):
+        return torch.from_numpy(self.coeffs.view(np.uint8).reshape(self.rows, self.k * 32))
+
+    def leaves_bytes(self):
+        return torch.from_numpy(self.leaves)
+
+    def root(self):
+        return self.nodes[0].tobytes()
+
+    def open_columns(self, indices):
+        return self.orc.open_columns(self.u, self.leaves, self.nodes, indices)
+
+
+class OracleBatchCommitter:
+    """test double for LigeroCommitter in throughput mode"""
+
+    def __init__(self, rows, k, batch):
+        from oracle import binding as orc
+        self.orc, self.rows, self.k, self.batch = orc, rows, k, batch
+
+    def encode_commit(self, pre, want_coeffs=False):
+        pre = np.asarray(pre).reshape(self.batch, self.rows, self.k, 4)
+        return None, b"".join(self.orc.encode_commit(pre[b], self.k, 8 * self.k, want_u=False)["root"] for b in range(self.batch))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, rows, k, batch, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ligero_amd.sharded import CosetShardedCommitter, ShardedBatchCommitter, shard_range
+        pre = random_mont(4242, rows * k).reshape(rows, k, 4)           # same seed on every rank
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k), dist)
+        r0, r1 = sc.row_range()
+        root = sc.commit(pre[r0:r1])
+        opened = sc.open_columns([0, 1, 9, 8 * k - 1])
+        # throughput mode: `batch` independent proofs dealt to ranks
+        preb = random_mont(777, batch * rows * k).reshape(batch, rows, k, 4)
+        sb = ShardedBatchCommitter(lambda b: OracleBatchCommitter(rows, k, b), batch, dist)
+        roots = sb.commit(preb[sb.b0:sb.b1])
+        out[rank] = (root, sorted(opened), roots, (r0, r1), (sb.b0, sb.b1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,k", [(6, 8), (7, 16)])     # even and ragged row shards
+def test_world2_gloo_matches_single_process(oracle, rows, k):
+    world, batch = 2, 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), rows, k, batch, out), nprocs=world, join=True)
+    pre = random_mont(4242, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    preb = random_mont(777, batch * rows * k).reshape(batch, rows, k, 4)
+    ref_roots = b"".join(oracle.encode_commit(preb[b], k, 8 * k, want_u=False)["root"] for b in range(batch))
+    assert set(out.keys()) == {0, 1}
+    for rank in range(world):
+        root, opened, roots, rr, br = out[rank]
+        assert root == ref["root"]
+        assert roots == ref_roots
+    # plane ownership: rank 0 owns planes 0-3 (columns 0, 1), rank 1 owns 4-7 (column 8k-1 = plane 7)
+    assert out[0][1] == [0, 1, 9] and out[1][1] == [8 * k - 1]
+    assert out[0][3][1] == out[1][3][0] and out[1][3][1] == rows
+
+
+def test_single_process_degenerate(oracle):
+    from ligero_amd.sharded import CosetShardedCommitter, owned_planes, shard_range
+    rows, k = 5, 8
+    pre = random_mont(99, rows * k).reshape(rows, k, 4)
+    sc = CosetShardedCommitter(OracleStageBackend(rows, k), None)
+    assert sc.commit(pre) == oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
+    assert owned_planes(8, 4, 3) == [6, 7] and owned_planes(16, 8, 1) == [2, 3]
+    assert [shard_range(10, 4, r) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    with pytest.raises(ValueError):
+        owned_planes(8, 3, 0)
