@@ -84,7 +84,7 @@ struct ColHashArgs {
 // several launches over consecutive row ranges (the commit pipeline hashes a chunk of rows
 // while the next chunk is still being encoded): the chaining value and the 8 bytes that
 // straddle the 64-byte block boundary are parked in `state` in between.
-__global__ void __launch_bounds__(256) blake2s_columns_kernel(const ColHashArgs a) {
+__global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const ColHashArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = (uint64_t)a.proof_count * a.plane_count * a.k;
     if (gid >= total) return;

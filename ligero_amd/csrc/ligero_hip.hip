@@ -104,6 +104,12 @@ static lg::Tw29 planes_of(const uint8_t* base, size_t count) {
     return t;
 }
 
+// flags of the cross-stream "chunk encoded" / "tree done" events (LG_EVENT_FLAGS overrides, for experiments)
+static unsigned lg_event_flags() {
+    if (const char* f = getenv("LG_EVENT_FLAGS")) return (unsigned)strtoul(f, nullptr, 0);
+    return hipEventDisableTiming;
+}
+
 static fr to_dev(const lg_host::Fr& a) {
     fr r;
     for (int i = 0; i < 4; i++) {
@@ -361,8 +367,8 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         LG_HIP(c, hipSetDevice(device));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking));
-        for (auto& e : c->ev_chunk) LG_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        LG_HIP(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        for (auto& e : c->ev_chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->ev_done, lg_event_flags()));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
         const size_t mat = (size_t)c->total_rows * k;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
