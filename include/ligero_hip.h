@@ -112,6 +112,23 @@ int lg_reed_solomon_evaluate(lg_ctx* ctx, const uint64_t* coeffs, uint32_t nrows
 int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* codeword_out);
 
 /*
+ * The arithmetic of the three sub-proofs on the resident commitment (next rows of the path,
+ * SURVEY.md 8f #1-2).  The challenge vectors come from the caller's Fiat-Shamir transcript.
+ *   lg_interleaved_row_mul        mod.rs:658       preenc_u.row_mul(r)  (src/matrices/mod.rs:138-149);
+ *                                                  r: rows elements, out: k elements
+ *   lg_linear_constraint_poly     mod.rs:723-736   r_a = A.row_mul(r_linear) (rows * k elements, the
+ *                                                  k-chunks of mod.rs:723) -> coefficients of
+ *                                                  sum_i u_polys[i] * ifft(r_a_i), 2k of them (zero padded;
+ *                                                  the reference's DensePolynomial trims trailing zeros)
+ *   lg_quadratic_constraint_poly  mod.rs:842-848   r: m = rows/4 elements -> coefficients of
+ *                                                  sum_i r_i (p_x_i p_y_i - p_z_i), 2k of them
+ * All need a commitment (lg_encode_commit) on this context; k <= 8192.
+ */
+int lg_interleaved_row_mul(lg_ctx* ctx, uint32_t proof, const uint64_t* r, uint64_t* out);
+int lg_linear_constraint_poly(lg_ctx* ctx, uint32_t proof, const uint64_t* r_a, uint64_t* coeffs_out);
+int lg_quadratic_constraint_poly(lg_ctx* ctx, uint32_t proof, const uint64_t* r, uint64_t* coeffs_out);
+
+/*
  * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU
  * (DESIGN.md section 7).  The exchanges between the stages are the caller's (RCCL all-gather on the
  * device buffers below); there is no collective inside the library.

@@ -16,6 +16,7 @@
 #include "host_fr.h"
 #include "ntt_kernels.h"
 #include "ntt_launch.h"
+#include "subproof_kernels.h"
 
 using lg::fr;
 
@@ -35,6 +36,11 @@ struct lg_ctx {
     hipEvent_t ev_chunk[kMaxChunks] = {};  // "rows of chunk c are encoded"
     hipEvent_t ev_done = nullptr;          // "tree of this commit is complete"
     uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
+    lg_ctx* aux2k = nullptr;               // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
+    fr* d_sub_partial = nullptr; size_t sub_partial_elems = 0;  // row-sum partials of the sub-proof polynomials
+    fr* d_sub_q = nullptr;                 // [2k] evaluations / coefficients
+    fr* d_sub_r = nullptr; size_t sub_r_elems = 0;              // challenge vector
+    fr r3;                                 // 2^768 mod p
     uint32_t force_chunks = 0;             // LG_FORCE_CHUNKS (testing knob): pipeline depth regardless of size
     // resident commitment
     fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
@@ -301,6 +307,8 @@ static int plan_chunks(const lg_ctx* c, Chunk* out) {
     return n;
 }
 
+static int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes);
+
 // ----------------------------------------------------------------------------- ABI
 extern "C" {
 
@@ -325,6 +333,11 @@ void lg_ctx_destroy(lg_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream_h) hipStreamSynchronize(c->stream_h);
+    if (c->aux2k) lg_ctx_destroy(c->aux2k);
+    hipSetDevice(c->device);
+    void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r};
+    for (void* b : bufs2)
+        if (b) hipFree(b);
     void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv,
                     c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
@@ -447,6 +460,7 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         c->one29 = to_f29(kOneMont);
         c->scale29 = to_f29(inverse(to_mont(kk)));
         c->r2 = to_dev(kR2);
+        c->r3 = to_dev(mul(kR2, kR2));  // R^2 (*) R^2 = R^4 / R = R^3
         return LG_OK;
     };
     rc = body();
@@ -720,6 +734,146 @@ int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, 
     if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, g.paths, (size_t)t * plen * 32, hipMemcpyDeviceToHost, c->stream));
     LG_HIP(c, hipStreamSynchronize(c->stream));
     return LG_OK;
+}
+
+// ---- sub-proof polynomials on the resident commitment -------------------------
+static int sub_buffers(lg_ctx* c, size_t partial_elems, size_t r_elems) {
+    int rc = grow(c, &c->d_sub_partial, &c->sub_partial_elems, partial_elems);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->d_sub_r, &c->sub_r_elems, r_elems);
+    if (rc != LG_OK) return rc;
+    if (!c->d_sub_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_sub_q), 2 * (size_t)c->k * sizeof(fr)));
+    return LG_OK;
+}
+static uint32_t sub_chunks(uint32_t rows, uint32_t* per_chunk) {
+    uint32_t per = rows / 256;  // at most ~256 partial rows
+    if (per < 32) per = 32;
+    *per_chunk = per;
+    return (rows + per - 1) / per;
+}
+static int sub_finish(lg_ctx* c, uint32_t nchunks, uint32_t cols, const fr& post, fr* out, uint32_t stride, uint32_t off) {
+    hipLaunchKernelGGL(lg::rowsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, c->stream, c->d_sub_partial, nchunks, cols, post, out, stride, off);
+    LG_HIP(c, hipGetLastError());
+    return LG_OK;
+}
+// size-2k inverse NTT of d_sub_q in place-ish (intermediate_domain of mod.rs:212), then copy out
+static int sub_interpolate_2k(lg_ctx* c, uint64_t* coeffs_out) {
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    if (!c->aux2k) {
+        int rc = lg_ctx_create_batched(&c->aux2k, c->device, 1, 2 * c->k, 16 * c->k, 1);
+        if (rc != LG_OK) return rc;
+        LG_HIP(c, hipSetDevice(c->device));
+    }
+    lg_ctx* x = c->aux2k;
+    lg::NttArgs a = interp_args(x, c->d_sub_q, x->d_coeffs, nullptr, 0, 1);
+    LG_HIP(c, lg::launch_ntt(x->logki, x->logo, false, c->stream, a));
+    return read_back(c, coeffs_out, x->d_coeffs, 2 * (size_t)c->k * sizeof(fr));
+}
+
+int lg_interleaved_row_mul(lg_ctx* c, uint32_t proof, const uint64_t* r, uint64_t* out) {
+    if (!c || !r || !out) return LG_ERR_BAD_ARG;
+    if (proof >= c->batch) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    uint32_t per;
+    const uint32_t nch = sub_chunks(c->rows, &per);
+    int rc = sub_buffers(c, (size_t)nch * 2 * c->k, c->rows);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)c->rows * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    lg::RowSumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = c->d_preenc + (size_t)proof * c->rows * c->k; a.a_row = c->k; a.a_col = 1;
+    a.b = nullptr; a.r = c->d_sub_r;
+    a.partial = c->d_sub_partial;
+    a.rows = c->rows; a.cols = c->k; a.rows_per_chunk = per;
+    hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->k + 255) / 256, nch), dim3(256), 0, c->stream, a);
+    LG_HIP(c, hipGetLastError());
+    // Montgomery x Montgomery -> Montgomery already: multiply by one (R) only to normalise
+    lg_host::Fr one = lg_host::kOneMont;
+    rc = sub_finish(c, nch, c->k, to_dev(one), c->d_sub_q, 1, 0);
+    if (rc != LG_OK) return rc;
+    return read_back(c, out, c->d_sub_q, (size_t)c->k * sizeof(fr));
+}
+
+int lg_linear_constraint_poly(lg_ctx* c, uint32_t proof, const uint64_t* r_a, uint64_t* coeffs_out) {
+    if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    if (proof >= c->batch) return LG_ERR_BAD_ARG;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint32_t rows = c->rows, O = 1u << c->logo;
+    const size_t mat = (size_t)rows * c->k;
+    uint32_t per;
+    const uint32_t nch = sub_chunks(rows, &per);
+    int rc = sub_buffers(c, (size_t)nch * 2 * c->k, 1);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->d_scratch_a, &c->scratch_a_elems, 2 * mat);   // r_a rows | their coefficients
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)c->nplanes * rows * c->ki);
+    if (rc != LG_OK) return rc;
+    fr* d_ra = c->d_scratch_a;
+    fr* d_rc = c->d_scratch_a + mat;
+    LG_HIP(c, hipMemcpyAsync(d_ra, r_a, mat * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    // r_polys = small_domain.ifft(row) (mod.rs:726-729), then their values on the odd points of the
+    // size-2k domain = planes s = 4 (mod 8) of their encoding
+    {
+        lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, rows);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+        const uint64_t sstride = (uint64_t)rows * c->ki;
+        lg::NttArgs e = eval_args(c, d_rc, c->d_scratch_b, sstride, 0, rows, true);
+        e.ncos = 0;
+        for (uint32_t s = 4; s < c->nplanes; s += 8) e.cosets[e.ncos++] = (uint8_t)s;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, e));
+    }
+    const uint64_t plane = c->total_rows * c->ki, splane = (uint64_t)rows * c->ki;
+    const uint64_t row_base = (uint64_t)proof * rows;
+    for (uint32_t s = 0; s < c->nplanes; s += 4) {
+        lg::RowSumArgs a;
+        memset(&a, 0, sizeof(a));
+        a.a = c->d_u + (uint64_t)s * plane + row_base * c->ki; a.a_row = c->ki; a.a_col = 1;   // u_i on this plane (canonical)
+        if ((s & 7) == 0) {  // message plane 8c': r_i there = r_a[i][O j + c'] (Montgomery)
+            a.b = d_ra + (s >> 3); a.b_row = c->k; a.b_col = O;
+        } else {             // computed plane (canonical)
+            a.b = c->d_scratch_b + (uint64_t)s * splane; a.b_row = c->ki; a.b_col = 1;
+        }
+        a.partial = c->d_sub_partial;
+        a.rows = rows; a.cols = c->ki; a.rows_per_chunk = per;
+        hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->ki + 255) / 256, nch), dim3(256), 0, c->stream, a);
+        LG_HIP(c, hipGetLastError());
+        // canonical x Montgomery = plain -> x R^2; canonical x canonical = plain / R -> x R^3; point index j = (np/4) q + s/4
+        rc = sub_finish(c, nch, c->ki, (s & 7) == 0 ? c->r2 : c->r3, c->d_sub_q, c->nplanes / 4, s / 4);
+        if (rc != LG_OK) return rc;
+    }
+    return sub_interpolate_2k(c, coeffs_out);
+}
+
+int lg_quadratic_constraint_poly(lg_ctx* c, uint32_t proof, const uint64_t* r, uint64_t* coeffs_out) {
+    if (!c || !r || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (!c->committed) return LG_ERR_STATE;
+    if (proof >= c->batch || (c->rows & 3) != 0) return LG_ERR_BAD_ARG;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint32_t m = c->rows / 4;
+    uint32_t per;
+    const uint32_t nch = sub_chunks(m, &per);
+    int rc = sub_buffers(c, (size_t)nch * 2 * c->k, m);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)m * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    const uint64_t plane = c->total_rows * c->ki;
+    for (uint32_t s = 0; s < c->nplanes; s += 4) {
+        lg::QuadSumArgs a;
+        memset(&a, 0, sizeof(a));
+        a.u = c->d_u + (uint64_t)s * plane;
+        a.r = c->d_sub_r;
+        a.partial = c->d_sub_partial;
+        a.r2 = c->r2;
+        a.row_base = (uint64_t)proof * c->rows;
+        a.m = m; a.ki = c->ki; a.rows_per_chunk = per;
+        hipLaunchKernelGGL(lg::quadsum_kernel, dim3((c->ki + 255) / 256, nch), dim3(256), 0, c->stream, a);
+        LG_HIP(c, hipGetLastError());
+        rc = sub_finish(c, nch, c->ki, c->r2, c->d_sub_q, c->nplanes / 4, s / 4);   // plain -> Montgomery
+        if (rc != LG_OK) return rc;
+    }
+    return sub_interpolate_2k(c, coeffs_out);
 }
 
 // ---- staged commit for one proof sharded over several GPUs ----------------

@@ -184,6 +184,29 @@ class LigeroCommitter:
         self._chk(self._L.lg_reed_solomon(self._ctx, _ptr(m), m.shape[0], _ptr(out)), "lg_reed_solomon")
         return out
 
+    # -- sub-proof polynomials on the resident commitment (mod.rs:658, 723-736, 842-848)
+    def interleaved_row_mul(self, r, proof: int = 0) -> np.ndarray:
+        """prove_interleaved: preenc_u.row_mul(r_interleaved) (mod.rs:658); r: (rows, 4) -> (k, 4)"""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.rows, 4)
+        out = np.empty((self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_interleaved_row_mul(self._ctx, proof, _ptr(r), _ptr(out)), "lg_interleaved_row_mul")
+        return out
+
+    def linear_constraint_poly(self, r_a, proof: int = 0) -> np.ndarray:
+        """prove_linear_constraints (mod.rs:723-736): r_a = A.row_mul(r_linear) as (rows, k, 4) ->
+        2k coefficients of sum_i u_polys[i] * ifft(r_a_i) (zero padded)"""
+        r_a = np.ascontiguousarray(r_a, dtype=np.uint64).reshape(self.rows, self.k, 4)
+        out = np.empty((2 * self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_linear_constraint_poly(self._ctx, proof, _ptr(r_a), _ptr(out)), "lg_linear_constraint_poly")
+        return out
+
+    def quadratic_constraint_poly(self, r, proof: int = 0) -> np.ndarray:
+        """prove_quadratic_constraints (mod.rs:842-848): r: (rows/4, 4) -> 2k coefficients"""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.rows // 4, 4)
+        out = np.empty((2 * self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_quadratic_constraint_poly(self._ctx, proof, _ptr(r), _ptr(out)), "lg_quadratic_constraint_poly")
+        return out
+
     def pipeline_chunks(self) -> int:
         """launches of the evaluate / column-hash kernels per commit (1 for small commits)"""
         n = ctypes.c_uint32(0)

@@ -49,6 +49,9 @@ def lib():
         L.orc_merkle_tree.argtypes = [_u32, _vp, _vp]
         L.orc_encode_commit.argtypes = [_u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]
         L.orc_open_columns.argtypes = [_u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]
+        L.orc_dense_row_mul.argtypes = [_u32, _u32, _vp, _vp, _vp]
+        L.orc_linear_constraint_poly.argtypes = [_u32, _u32, _vp, _vp, _vp]
+        L.orc_quadratic_constraint_poly.argtypes = [_u32, _u32, _vp, _vp, _vp]
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -167,3 +170,32 @@ def open_columns(u: np.ndarray, leaves: np.ndarray, nodes: np.ndarray, idx):
     rc = lib().orc_open_columns(rows, n, _p(u), _p(leaves), _p(nodes), _p(idx), t, _p(cols), _p(sib), _p(paths))
     assert rc == 0, rc
     return cols, sib, paths
+
+
+def dense_row_mul(mat: np.ndarray, r: np.ndarray) -> np.ndarray:
+    """mat: (rows, cols, 4), r: (rows, 4) -> (cols, 4)"""
+    mat = np.ascontiguousarray(mat, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    rows, cols = mat.shape[0], mat.shape[1]
+    out = np.empty((cols, 4), dtype=np.uint64)
+    lib().orc_dense_row_mul(rows, cols, _p(mat), _p(r), _p(out))
+    return out
+
+
+def linear_constraint_poly(coeffs: np.ndarray, r_a: np.ndarray) -> np.ndarray:
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    r_a = np.ascontiguousarray(r_a, dtype=np.uint64).reshape(coeffs.shape)
+    rows, k = coeffs.shape[0], coeffs.shape[1]
+    out = np.empty((2 * k, 4), dtype=np.uint64)
+    assert lib().orc_linear_constraint_poly(rows, k, _p(coeffs), _p(r_a), _p(out)) == 0
+    return out
+
+
+def quadratic_constraint_poly(coeffs: np.ndarray, r: np.ndarray) -> np.ndarray:
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    rows, k = coeffs.shape[0], coeffs.shape[1]
+    assert rows % 4 == 0 and r.shape[0] == rows // 4
+    out = np.empty((2 * k, 4), dtype=np.uint64)
+    assert lib().orc_quadratic_constraint_poly(rows // 4, k, _p(coeffs), _p(r), _p(out)) == 0
+    return out

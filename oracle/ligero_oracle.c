@@ -462,6 +462,76 @@ int orc_open_columns(uint32_t rows, uint32_t n, const uint64_t *u, const uint8_t
     return 0;
 }
 
+/* ---- sub-proof polynomials: arithmetic of prove_interleaved (mod.rs:658),
+ * prove_linear_constraints (mod.rs:723-736), prove_quadratic_constraints (mod.rs:842-848).
+ * Challenges are inputs (Fiat-Shamir stays with the caller).  Polynomial products are done the
+ * way ark-poly's DensePolynomial does large ones: evaluate on a domain of size >= 2k, multiply
+ * point-wise, interpolate -- exact, so any method yields the same coefficients. ---- */
+
+/* DenseMatrix::row_mul, src/matrices/mod.rs:138-149: out[c] = sum_i mat[i][c] * r[i] */
+void orc_dense_row_mul(uint32_t rows, uint32_t cols, const uint64_t *mat, const uint64_t *r, uint64_t *out) {
+    fr_t *o = (fr_t *)out;
+    memset(o, 0, sizeof(fr_t) * cols);
+    for (uint32_t i = 0; i < rows; i++)
+        for (uint32_t c = 0; c < cols; c++) {
+            fr_t t;
+            fr_mul(&t, (const fr_t *)mat + (size_t)i * cols + c, (const fr_t *)r + i);
+            fr_add(&o[c], &o[c], &t);
+        }
+}
+
+/* coeffs: rows x k (u_polynomial_coeffs); r_a: rows x k (A.row_mul(r_linear) in k-chunks);
+ * out: 2k coefficients of sum_i u_i * ifft_k(r_a_i), zero padded */
+int orc_linear_constraint_poly(uint32_t rows, uint32_t k, const uint64_t *coeffs, const uint64_t *r_a, uint64_t *out) {
+    if (log2_exact(k) < 0) return -1;
+    const uint32_t d = 2 * k;
+    fr_t *acc = (fr_t *)calloc(d, sizeof(fr_t)), *a = (fr_t *)malloc(sizeof(fr_t) * d), *b = (fr_t *)malloc(sizeof(fr_t) * d);
+    for (uint32_t i = 0; i < rows; i++) {
+        memset(a, 0, sizeof(fr_t) * d);
+        memset(b, 0, sizeof(fr_t) * d);
+        memcpy(a, (const fr_t *)coeffs + (size_t)i * k, sizeof(fr_t) * k);
+        memcpy(b, (const fr_t *)r_a + (size_t)i * k, sizeof(fr_t) * k);
+        orc_ifft(k, (uint64_t *)b); /* r_poly_i */
+        orc_fft(d, (uint64_t *)a);
+        orc_fft(d, (uint64_t *)b);
+        for (uint32_t j = 0; j < d; j++) {
+            fr_t t;
+            fr_mul(&t, &a[j], &b[j]);
+            fr_add(&acc[j], &acc[j], &t);
+        }
+    }
+    orc_ifft(d, (uint64_t *)acc);
+    memcpy(out, acc, sizeof(fr_t) * d);
+    free(acc); free(a); free(b);
+    return 0;
+}
+
+/* coeffs: rows = 4m rows x k ([X; Y; Z; W]); r: m challenges; out: 2k coefficients of
+ * sum_i r_i (p_x_i p_y_i - p_z_i), zero padded */
+int orc_quadratic_constraint_poly(uint32_t m, uint32_t k, const uint64_t *coeffs, const uint64_t *r, uint64_t *out) {
+    if (log2_exact(k) < 0) return -1;
+    const uint32_t d = 2 * k;
+    fr_t *acc = (fr_t *)calloc(d, sizeof(fr_t)), *x = (fr_t *)malloc(sizeof(fr_t) * d), *y = (fr_t *)malloc(sizeof(fr_t) * d), *z = (fr_t *)malloc(sizeof(fr_t) * d);
+    for (uint32_t i = 0; i < m; i++) {
+        memset(x, 0, sizeof(fr_t) * d); memset(y, 0, sizeof(fr_t) * d); memset(z, 0, sizeof(fr_t) * d);
+        memcpy(x, (const fr_t *)coeffs + (size_t)i * k, sizeof(fr_t) * k);
+        memcpy(y, (const fr_t *)coeffs + (size_t)(m + i) * k, sizeof(fr_t) * k);
+        memcpy(z, (const fr_t *)coeffs + (size_t)(2 * m + i) * k, sizeof(fr_t) * k);
+        orc_fft(d, (uint64_t *)x); orc_fft(d, (uint64_t *)y); orc_fft(d, (uint64_t *)z);
+        for (uint32_t j = 0; j < d; j++) {
+            fr_t t;
+            fr_mul(&t, &x[j], &y[j]);
+            fr_sub(&t, &t, &z[j]);
+            fr_mul(&t, &t, (const fr_t *)r + i);
+            fr_add(&acc[j], &acc[j], &t);
+        }
+    }
+    orc_ifft(d, (uint64_t *)acc);
+    memcpy(out, acc, sizeof(fr_t) * d);
+    free(acc); free(x); free(y); free(z);
+    return 0;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -436,3 +436,53 @@ def random_elements(seed: int, count: int) -> List[int]:
         v = next(g) | (next(g) << 64) | (next(g) << 128) | (next(g) << 192)
         out.append(v % P)
     return out
+
+
+# --------------------------------------------------------------------------
+# The three sub-proof polynomials: the device-friendly arithmetic of
+# prove_interleaved / prove_linear_constraints / prove_quadratic_constraints.  Challenges
+# (r vectors) are inputs: deriving them is Fiat-Shamir, host side.
+# --------------------------------------------------------------------------
+def poly_mul(a: Sequence[int], b: Sequence[int]) -> List[int]:
+    """DensePolynomial * DensePolynomial (exact; any algorithm gives these coefficients)"""
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                out[i + j] = (out[i + j] + x * y) % P
+    return out
+
+
+def dense_row_mul(rows: Sequence[Sequence[int]], r: Sequence[int]) -> List[int]:
+    """DenseMatrix::row_mul (src/matrices/mod.rs:138-149): result[c] = sum_i rows[i][c] * r[i];
+    prove_interleaved calls it as preenc_u.row_mul(&r_interleaved) (src/ligero/mod.rs:658)"""
+    out = [0] * len(rows[0])
+    for c, row in zip(r, rows):
+        for j, v in enumerate(row):
+            out[j] = (out[j] + v * c) % P
+    return out
+
+
+def linear_constraint_poly(u_coeffs: Sequence[Sequence[int]], r_a_rows: Sequence[Sequence[int]], k: int) -> List[int]:
+    """src/ligero/mod.rs:723-736: r_polys = small_domain.ifft(row) for each k-chunk of
+    r_a = A.row_mul(r_linear); result = sum_i u_polys[i] * r_polys[i].  Returned zero-padded to
+    2k coefficients (the reference's DensePolynomial trims trailing zeros)."""
+    w = domain_generator(k)
+    acc = [0] * (2 * k)
+    for u, ra in zip(u_coeffs, r_a_rows):
+        rp = intt(list(ra), w)
+        for i, v in enumerate(poly_mul(u, rp)):
+            acc[i] = (acc[i] + v) % P
+    return acc
+
+
+def quadratic_constraint_poly(u_coeffs: Sequence[Sequence[int]], r: Sequence[int], m: int, k: int) -> List[int]:
+    """src/ligero/mod.rs:842-848: sum_i ((p_x_i * p_y_i) - p_z_i) * r_i over the first 3m rows
+    split as [X; Y; Z].  Zero-padded to 2k coefficients."""
+    acc = [0] * (2 * k)
+    for i in range(m):
+        prod = poly_mul(u_coeffs[i], u_coeffs[m + i])
+        for j in range(len(prod)):
+            z = u_coeffs[2 * m + i][j] if j < k else 0
+            acc[j] = (acc[j] + (prod[j] - z) * r[i]) % P
+    return acc

@@ -285,3 +285,72 @@ def test_staged_commit_matches_oracle(lg, oracle, rows, k):
         assert sc.commit(pre) == ref["root"]
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("rows,k,batch", [(12, 8, 1), (344, 128, 1), (20, 64, 3), (8, 4096, 1), (4, 8192, 1)])
+def test_subproof_polynomials_match_oracle(lg, oracle, rows, k, batch):
+    """next rows of the path: the arithmetic of prove_interleaved (mod.rs:658),
+    prove_linear_constraints (mod.rs:723-736) and prove_quadratic_constraints (mod.rs:842-848) on
+    the resident commitment, bit-exact against the oracle; challenges are seeded stand-ins for the
+    Fiat-Shamir output"""
+    pre = random_mont(5 * rows + k, batch * rows * k).reshape(batch * rows, k, 4)
+    r_int = random_mont(11, rows).reshape(rows, 4)
+    r_a = random_mont(12, rows * k).reshape(rows, k, 4)
+    r_q = random_mont(13, rows // 4).reshape(rows // 4, 4)
+    with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+        coeffs, _ = c.encode_commit(pre)
+        for b in sorted({0, batch - 1}):
+            pb, cb = pre[b * rows:(b + 1) * rows], coeffs[b * rows:(b + 1) * rows]
+            assert np.array_equal(c.interleaved_row_mul(r_int, proof=b), oracle.dense_row_mul(pb, r_int))
+            lin = c.linear_constraint_poly(r_a, proof=b)
+            assert np.array_equal(lin, oracle.linear_constraint_poly(cb, r_a))
+            quad = c.quadratic_constraint_poly(r_q, proof=b)
+            assert np.array_equal(quad, oracle.quadratic_constraint_poly(cb, r_q))
+            assert not lin[2 * k - 1].any() and not quad[2 * k - 1].any()     # degree < 2k - 1 (mod.rs:782, 886)
+        # the commitment is untouched by the sub-proof scratch work
+        assert np.array_equal(c.coeffs(), coeffs)
+
+
+def test_subproofs_at_s20_scale_properties(lg, oracle):
+    """full-size rows x k = 10036 x 4096: the oracle is too slow, so check q(x) = sum_i u_i(x) r_i(x)
+    at random points of the size-2k domain through independent means: q evaluated from the returned
+    coefficients equals the row sum computed from opened codeword columns and the encoded r rows"""
+    rows, k = 10036, 4096
+    base = random_mont(21, 32 * k).reshape(32, k, 4)
+    rng = np.random.default_rng(5)
+    pre = base[rng.integers(0, 32, size=rows)]
+    r_a = base[rng.integers(0, 32, size=rows)][:, ::-1, :].copy()
+    r_q = random_mont(22, rows // 4).reshape(rows // 4, 4)
+    with lg.LigeroCommitter(rows=rows, k=k) as c:
+        c.encode_commit(pre, want_coeffs=False)
+        lin = c.linear_constraint_poly(r_a)
+        quad = c.quadratic_constraint_poly(r_q)
+        assert not lin[2 * k - 1].any() and not quad[2 * k - 1].any()
+        # evaluate both polynomials on the whole size-2k domain with the oracle's FFT
+        lin_ev, quad_ev = oracle.fft(lin), oracle.fft(quad)
+        # point j of the 2k domain = codeword column 4j; check a few against opened columns
+        js = [0, 1, 2, 4097, 8191]
+        cols, _, _ = c.open_columns([4 * j for j in js])
+        L = oracle.lib()
+        m = rows // 4
+        for t, j in enumerate(js):
+            # r_i at that point: encode r_a rows on the fly for a few rows only is too costly; use linearity instead:
+            # sum_i u_i(x) r_i(x) with r_i(x) = codeword of r_a row -> take distinct rows (only 32 distinct messages)
+            acc = np.zeros(4, dtype=np.uint64)
+            tmp = np.zeros(4, dtype=np.uint64)
+            z = np.zeros(4, dtype=np.uint64)
+            for i in range(m):
+                L.orc_fr_mul(cols[t, i].ctypes.data, cols[t, m + i].ctypes.data, tmp.ctypes.data)
+                L.orc_fr_sub(tmp.ctypes.data, cols[t, 2 * m + i].ctypes.data, tmp.ctypes.data)
+                L.orc_fr_mul(tmp.ctypes.data, r_q[i].ctypes.data, tmp.ctypes.data)
+                L.orc_fr_add(acc.ctypes.data, tmp.ctypes.data, acc.ctypes.data)
+            assert np.array_equal(acc, quad_ev[j]), j
+        # linear: sum over the 2k-domain points with even index = sum_c sum_i r_a[i][c] * u_i(zeta_c)
+        # (the check the verifier makes at mod.rs:794 is that this is what the prover claims); here:
+        # q(zeta_c) for c = 0: sum_i preenc[i][0] * r_a[i][0]
+        acc = np.zeros(4, dtype=np.uint64)
+        tmp = np.zeros(4, dtype=np.uint64)
+        for i in range(rows):
+            L.orc_fr_mul(pre[i, 0].ctypes.data, r_a[i, 0].ctypes.data, tmp.ctypes.data)
+            L.orc_fr_add(acc.ctypes.data, tmp.ctypes.data, acc.ctypes.data)
+        assert np.array_equal(acc, lin_ev[0])

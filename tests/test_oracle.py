@@ -171,3 +171,31 @@ def test_oracle_properties_random(oracle, model):
     for j in range(n):
         L.orc_fr_add(u[0, j].ctypes.data, u[1, j].ctypes.data, t[j].ctypes.data)
     assert np.array_equal(es, t)
+
+
+def test_subproof_polynomials_model_vs_c(oracle, model):
+    """SURVEY 8f #1-2 arithmetic: C restatement (FFT products) vs big-int model (schoolbook)"""
+    m, k = 3, 8
+    rows = 4 * m
+    pre = model.random_elements(61, rows * k)
+    pre_rows = [pre[i * k:(i + 1) * k] for i in range(rows)]
+    coeffs = [model.reed_solomon_interpolate(r, k) for r in pre_rows]
+    r_int = model.random_elements(62, rows)
+    r_a = model.random_elements(63, rows * k)
+    r_a_rows = [r_a[i * k:(i + 1) * k] for i in range(rows)]
+    r_q = model.random_elements(64, m)
+    to_m = lambda vals: oracle.to_mont(oracle.ints_to_limbs(vals))
+    from_m = lambda a: oracle.limbs_to_ints(oracle.from_mont(a))
+    lc = oracle.dense_row_mul(to_m(pre).reshape(rows, k, 4), to_m(r_int))
+    assert from_m(lc) == model.dense_row_mul(pre_rows, r_int)
+    cm = to_m([v for r in coeffs for v in r]).reshape(rows, k, 4)
+    lin = oracle.linear_constraint_poly(cm, to_m(r_a).reshape(rows, k, 4))
+    assert from_m(lin) == model.linear_constraint_poly(coeffs, r_a_rows, k)
+    quad = oracle.quadratic_constraint_poly(cm, to_m(r_q))
+    assert from_m(quad) == model.quadratic_constraint_poly(coeffs, r_q, m, k)
+    # degree bound the verifier checks (mod.rs:782, 886): degree < 2k - 1
+    assert from_m(lin)[2 * k - 1] == 0 and from_m(quad)[2 * k - 1] == 0
+    # known answer of the reference's own unit test (src/matrices/mod.rs:181-194)
+    P = model.P
+    mat = to_m([1, 2, 8, 3, 4, 5]).reshape(2, 3, 4)
+    assert from_m(oracle.dense_row_mul(mat, to_m([P - 5, 17]))) == [46, 58, 45]
