@@ -101,6 +101,10 @@ int lg_read_codeword_rows(lg_ctx* ctx, uint32_t proof, uint32_t row0, uint32_t n
  */
 int lg_open_columns(lg_ctx* ctx, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out,
                     uint8_t* sib_out, uint8_t* paths_out);
+/* The same for every proof of the batch in one launch: idx holds batch * t indices (t per proof,
+ * each proof has its own Fiat-Shamir indices), outputs are the per-proof outputs concatenated. */
+int lg_open_columns_batch(lg_ctx* ctx, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out,
+                          uint8_t* paths_out);
 
 /* Row-level operators, independent of the resident commitment (own scratch):
  *   reed_solomon_interpolate  mod.rs:998-1002   nrows * k -> nrows * k
@@ -113,20 +117,21 @@ int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* 
 
 /*
  * The arithmetic of the three sub-proofs on the resident commitment (next rows of the path,
- * SURVEY.md 8f #1-2).  The challenge vectors come from the caller's Fiat-Shamir transcript.
+ * SURVEY.md 8f #1-2), for every proof of the batch per call (arrays are the per-proof arrays
+ * concatenated).  The challenge vectors come from the caller's Fiat-Shamir transcript.
  *   lg_interleaved_row_mul        mod.rs:658       preenc_u.row_mul(r)  (src/matrices/mod.rs:138-149);
- *                                                  r: rows elements, out: k elements
- *   lg_linear_constraint_poly     mod.rs:723-736   r_a = A.row_mul(r_linear) (rows * k elements, the
- *                                                  k-chunks of mod.rs:723) -> coefficients of
- *                                                  sum_i u_polys[i] * ifft(r_a_i), 2k of them (zero padded;
- *                                                  the reference's DensePolynomial trims trailing zeros)
- *   lg_quadratic_constraint_poly  mod.rs:842-848   r: m = rows/4 elements -> coefficients of
- *                                                  sum_i r_i (p_x_i p_y_i - p_z_i), 2k of them
- * All need a commitment (lg_encode_commit) on this context; k <= 8192.
+ *                                                  r: batch * rows elements, out: batch * k elements
+ *   lg_linear_constraint_poly     mod.rs:723-736   r_a = A.row_mul(r_linear) (batch * rows * k elements,
+ *                                                  the k-chunks of mod.rs:723) -> coefficients of
+ *                                                  sum_i u_polys[i] * ifft(r_a_i): batch * 2k of them (zero
+ *                                                  padded; the reference's DensePolynomial trims trailing zeros)
+ *   lg_quadratic_constraint_poly  mod.rs:842-848   r: batch * (rows/4) elements -> coefficients of
+ *                                                  sum_i r_i (p_x_i p_y_i - p_z_i): batch * 2k of them
+ * The last two need a commitment (lg_encode_commit) on this context; k <= 8192.
  */
-int lg_interleaved_row_mul(lg_ctx* ctx, uint32_t proof, const uint64_t* r, uint64_t* out);
-int lg_linear_constraint_poly(lg_ctx* ctx, uint32_t proof, const uint64_t* r_a, uint64_t* coeffs_out);
-int lg_quadratic_constraint_poly(lg_ctx* ctx, uint32_t proof, const uint64_t* r, uint64_t* coeffs_out);
+int lg_interleaved_row_mul(lg_ctx* ctx, const uint64_t* r, uint64_t* out);
+int lg_linear_constraint_poly(lg_ctx* ctx, const uint64_t* r_a, uint64_t* coeffs_out);
+int lg_quadratic_constraint_poly(lg_ctx* ctx, const uint64_t* r, uint64_t* coeffs_out);
 
 /*
  * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU

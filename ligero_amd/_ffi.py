@@ -17,7 +17,7 @@ SYMBOLS = [
     "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_destroy",
     "lg_encode_commit", "lg_upload_preenc", "lg_commit_resident", "lg_sync",
     "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
-    "lg_open_columns",
+    "lg_open_columns", "lg_open_columns_batch",
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
     "lg_interleaved_row_mul", "lg_linear_constraint_poly", "lg_quadratic_constraint_poly",
     "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_merkle", "lg_device_buffer",
@@ -77,12 +77,13 @@ def lib():
     L.lg_read_nodes.argtypes = [_vp, _vp]
     L.lg_read_codeword_rows.argtypes = [_vp, _u32, _u32, _u32, _vp]
     L.lg_open_columns.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _vp]
+    L.lg_open_columns_batch.argtypes = [_vp, _vp, _u32, _vp, _vp, _vp]
     L.lg_reed_solomon_interpolate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon_evaluate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon.argtypes = [_vp, _vp, _u32, _vp]
-    L.lg_interleaved_row_mul.argtypes = [_vp, _u32, _vp, _vp]
-    L.lg_linear_constraint_poly.argtypes = [_vp, _u32, _vp, _vp]
-    L.lg_quadratic_constraint_poly.argtypes = [_vp, _u32, _vp, _vp]
+    L.lg_interleaved_row_mul.argtypes = [_vp, _vp, _vp]
+    L.lg_linear_constraint_poly.argtypes = [_vp, _vp, _vp]
+    L.lg_quadratic_constraint_poly.argtypes = [_vp, _vp, _vp]
     L.lg_stage_interpolate.argtypes = [_vp, _vp, _u32, _u32]
     L.lg_stage_evaluate_hash.argtypes = [_vp, _u32]
     L.lg_stage_merkle.argtypes = [_vp]

@@ -147,12 +147,23 @@ struct GatherArgs {
     uint64_t row_base;       // proof * rows
     uint32_t rows, k, n, logn, t;  // k = plane row length ki
     uint32_t lognp;                // log2 of the number of planes
+    uint32_t proof0;               // blockIdx.y = p serves proof proof0 + p: inputs/outputs advance by one proof each
 };
 
 // u.column(i) for the opened indices (src/matrices/mod.rs:169-171) + generate_proof pieces
-__global__ void __launch_bounds__(256) gather_columns_kernel(const GatherArgs a) {
+__global__ void __launch_bounds__(256) gather_columns_kernel(GatherArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t ncol_elems = (uint64_t)a.t * a.rows;
+    {
+        const uint32_t p = blockIdx.y, plen = a.logn - 1;
+        a.leaves += 32 * (uint64_t)(a.proof0 + p) * a.n;
+        a.nodes += 32 * (uint64_t)(a.proof0 + p) * (a.n - 1);
+        a.row_base = (uint64_t)(a.proof0 + p) * a.rows;
+        a.idx += (uint64_t)p * a.t;
+        a.cols += (uint64_t)p * ncol_elems;
+        a.sib += 32 * (uint64_t)p * a.t;
+        a.paths += 32 * (uint64_t)p * a.t * plen;
+    }
     if (gid < ncol_elems) {
         const uint32_t c = (uint32_t)(gid / a.rows), i = (uint32_t)(gid % a.rows);
         const uint32_t j = a.idx[c];
@@ -687,62 +698,75 @@ int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nro
     return read_back(c, out, c->d_scratch_c, elems * sizeof(fr));
 }
 
-int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
+// opens t columns of each of `nproofs` consecutive proofs starting at `proof0` (one launch)
+static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out,
+                             uint8_t* paths_out) {
     if (!c || !idx || !cols_out || !sib_out || (!paths_out && c->logn > 1)) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
-    if (proof >= c->batch) return LG_ERR_BAD_ARG;
-    for (uint32_t i = 0; i < t; i++)
+    if ((uint64_t)proof0 + nproofs > c->batch) return LG_ERR_BAD_ARG;
+    const size_t nidx = (size_t)nproofs * t;
+    for (size_t i = 0; i < nidx; i++)
         if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
-    if (t == 0) return LG_OK;
+    if (nidx == 0) return LG_OK;
     LG_HIP(c, hipSetDevice(c->device));
     const uint32_t plen = (uint32_t)c->logn - 1;
-    if (c->idx_cap < t) {
+    if (c->idx_cap < nidx) {
         if (c->d_idx) LG_HIP(c, hipFree(c->d_idx));
         c->d_idx = nullptr; c->idx_cap = 0;
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_idx), (size_t)t * sizeof(uint32_t)));
-        c->idx_cap = t;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_idx), nidx * sizeof(uint32_t)));
+        c->idx_cap = nidx;
     }
-    const size_t path_bytes = (size_t)t * (plen + 1) * 32;
+    const size_t path_bytes = nidx * (plen + 1) * 32;
     if (c->path_cap < path_bytes) {
         if (c->d_path_out) LG_HIP(c, hipFree(c->d_path_out));
         c->d_path_out = nullptr; c->path_cap = 0;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_path_out), path_bytes));
         c->path_cap = path_bytes;
     }
-    int rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, (size_t)t * c->rows);
+    int rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, nidx * c->rows);
     if (rc != LG_OK) return rc;
-    LG_HIP(c, hipMemcpyAsync(c->d_idx, idx, (size_t)t * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    LG_HIP(c, hipMemcpyAsync(c->d_idx, idx, nidx * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     lg::GatherArgs g;
     memset(&g, 0, sizeof(g));
     g.u = c->d_u;
-    g.leaves = c->d_leaves + (size_t)proof * c->n * 32;
-    g.nodes = c->d_nodes + (size_t)proof * (c->n - 1) * 32;
+    g.leaves = c->d_leaves;
+    g.nodes = c->d_nodes;
     g.idx = c->d_idx;
     g.cols = c->d_scratch_c;
     g.sib = c->d_path_out;
-    g.paths = c->d_path_out + (size_t)t * 32;
+    g.paths = c->d_path_out + nidx * 32;
     g.r2 = c->r2;
     g.plane_stride = c->total_rows * c->ki;
     g.lognp = (uint32_t)c->lognp;
-    g.row_base = (uint64_t)proof * c->rows;
+    g.proof0 = proof0;
     g.rows = c->rows; g.k = c->ki; g.n = c->n; g.logn = (uint32_t)c->logn; g.t = t;
     const uint64_t threads = (uint64_t)t * c->rows + (uint64_t)t * (plen + 1);
-    hipLaunchKernelGGL(lg::gather_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, g);
+    hipLaunchKernelGGL(lg::gather_columns_kernel, dim3((uint32_t)((threads + 255) / 256), nproofs), dim3(256), 0, c->stream, g);
     LG_HIP(c, hipGetLastError());
-    LG_HIP(c, hipMemcpyAsync(cols_out, c->d_scratch_c, (size_t)t * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->stream));
-    LG_HIP(c, hipMemcpyAsync(sib_out, g.sib, (size_t)t * 32, hipMemcpyDeviceToHost, c->stream));
-    if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, g.paths, (size_t)t * plen * 32, hipMemcpyDeviceToHost, c->stream));
+    LG_HIP(c, hipMemcpyAsync(cols_out, c->d_scratch_c, nidx * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->stream));
+    LG_HIP(c, hipMemcpyAsync(sib_out, g.sib, nidx * 32, hipMemcpyDeviceToHost, c->stream));
+    if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, g.paths, nidx * plen * 32, hipMemcpyDeviceToHost, c->stream));
     LG_HIP(c, hipStreamSynchronize(c->stream));
     return LG_OK;
 }
 
+int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
+    return open_columns_impl(c, proof, 1, idx, t, cols_out, sib_out, paths_out);
+}
+
+int lg_open_columns_batch(lg_ctx* c, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
+    if (!c) return LG_ERR_BAD_ARG;
+    return open_columns_impl(c, 0, c->batch, idx, t, cols_out, sib_out, paths_out);
+}
+
 // ---- sub-proof polynomials on the resident commitment -------------------------
+// Every call serves all proofs of the batch in one set of launches (proof index = blockIdx.z).
 static int sub_buffers(lg_ctx* c, size_t partial_elems, size_t r_elems) {
     int rc = grow(c, &c->d_sub_partial, &c->sub_partial_elems, partial_elems);
     if (rc != LG_OK) return rc;
     rc = grow(c, &c->d_sub_r, &c->sub_r_elems, r_elems);
     if (rc != LG_OK) return rc;
-    if (!c->d_sub_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_sub_q), 2 * (size_t)c->k * sizeof(fr)));
+    if (!c->d_sub_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_sub_q), (size_t)c->batch * 2 * c->k * sizeof(fr)));
     return LG_OK;
 }
 static uint32_t sub_chunks(uint32_t rows, uint32_t* per_chunk) {
@@ -751,113 +775,110 @@ static uint32_t sub_chunks(uint32_t rows, uint32_t* per_chunk) {
     *per_chunk = per;
     return (rows + per - 1) / per;
 }
-static int sub_finish(lg_ctx* c, uint32_t nchunks, uint32_t cols, const fr& post, fr* out, uint32_t stride, uint32_t off) {
-    hipLaunchKernelGGL(lg::rowsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, c->stream, c->d_sub_partial, nchunks, cols, post, out, stride, off);
+static int sub_finish(lg_ctx* c, uint32_t nchunks, uint32_t cols, const fr& post, fr* out, uint32_t stride, uint32_t off, uint64_t out_proof) {
+    hipLaunchKernelGGL(lg::rowsum_finish_kernel, dim3((cols + 255) / 256, 1, c->batch), dim3(256), 0, c->stream, c->d_sub_partial, nchunks, cols, post,
+                       out, stride, off, out_proof);
     LG_HIP(c, hipGetLastError());
     return LG_OK;
 }
-// size-2k inverse NTT of d_sub_q in place-ish (intermediate_domain of mod.rs:212), then copy out
+// size-2k inverse NTT of the batch rows in d_sub_q (intermediate_domain of mod.rs:212), then copy out
 static int sub_interpolate_2k(lg_ctx* c, uint64_t* coeffs_out) {
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     if (!c->aux2k) {
-        int rc = lg_ctx_create_batched(&c->aux2k, c->device, 1, 2 * c->k, 16 * c->k, 1);
+        int rc = lg_ctx_create_batched(&c->aux2k, c->device, 1, 2 * c->k, 16 * c->k, c->batch);
         if (rc != LG_OK) return rc;
         LG_HIP(c, hipSetDevice(c->device));
     }
     lg_ctx* x = c->aux2k;
-    lg::NttArgs a = interp_args(x, c->d_sub_q, x->d_coeffs, nullptr, 0, 1);
+    lg::NttArgs a = interp_args(x, c->d_sub_q, x->d_coeffs, nullptr, 0, c->batch);
     LG_HIP(c, lg::launch_ntt(x->logki, x->logo, false, c->stream, a));
-    return read_back(c, coeffs_out, x->d_coeffs, 2 * (size_t)c->k * sizeof(fr));
+    return read_back(c, coeffs_out, x->d_coeffs, (size_t)c->batch * 2 * c->k * sizeof(fr));
 }
 
-int lg_interleaved_row_mul(lg_ctx* c, uint32_t proof, const uint64_t* r, uint64_t* out) {
+int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
     if (!c || !r || !out) return LG_ERR_BAD_ARG;
-    if (proof >= c->batch) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
     uint32_t per;
     const uint32_t nch = sub_chunks(c->rows, &per);
-    int rc = sub_buffers(c, (size_t)nch * 2 * c->k, c->rows);
+    int rc = sub_buffers(c, (size_t)c->batch * nch * 2 * c->k, c->total_rows);
     if (rc != LG_OK) return rc;
-    LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)c->rows * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)c->total_rows * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     lg::RowSumArgs a;
     memset(&a, 0, sizeof(a));
-    a.a = c->d_preenc + (size_t)proof * c->rows * c->k; a.a_row = c->k; a.a_col = 1;
+    a.a = c->d_preenc; a.a_proof = (uint64_t)c->rows * c->k; a.a_row = c->k; a.a_col = 1;
     a.b = nullptr; a.r = c->d_sub_r;
     a.partial = c->d_sub_partial;
-    a.rows = c->rows; a.cols = c->k; a.rows_per_chunk = per;
-    hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->k + 255) / 256, nch), dim3(256), 0, c->stream, a);
+    a.rows = c->rows; a.cols = c->k; a.rows_per_chunk = per; a.nchunks = nch;
+    hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->k + 255) / 256, nch, c->batch), dim3(256), 0, c->stream, a);
     LG_HIP(c, hipGetLastError());
     // Montgomery x Montgomery -> Montgomery already: multiply by one (R) only to normalise
-    lg_host::Fr one = lg_host::kOneMont;
-    rc = sub_finish(c, nch, c->k, to_dev(one), c->d_sub_q, 1, 0);
+    rc = sub_finish(c, nch, c->k, to_dev(lg_host::kOneMont), c->d_sub_q, 1, 0, c->k);
     if (rc != LG_OK) return rc;
-    return read_back(c, out, c->d_sub_q, (size_t)c->k * sizeof(fr));
+    return read_back(c, out, c->d_sub_q, (size_t)c->batch * c->k * sizeof(fr));
 }
 
-int lg_linear_constraint_poly(lg_ctx* c, uint32_t proof, const uint64_t* r_a, uint64_t* coeffs_out) {
+int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_out) {
     if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
-    if (proof >= c->batch) return LG_ERR_BAD_ARG;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     LG_HIP(c, hipSetDevice(c->device));
     const uint32_t rows = c->rows, O = 1u << c->logo;
-    const size_t mat = (size_t)rows * c->k;
+    const uint64_t R = c->total_rows;
+    const size_t mat = (size_t)R * c->k;
     uint32_t per;
     const uint32_t nch = sub_chunks(rows, &per);
-    int rc = sub_buffers(c, (size_t)nch * 2 * c->k, 1);
+    int rc = sub_buffers(c, (size_t)c->batch * nch * 2 * c->k, 1);
     if (rc != LG_OK) return rc;
     rc = grow(c, &c->d_scratch_a, &c->scratch_a_elems, 2 * mat);   // r_a rows | their coefficients
     if (rc != LG_OK) return rc;
-    rc = grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)c->nplanes * rows * c->ki);
+    rc = grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)c->nplanes * R * c->ki);
     if (rc != LG_OK) return rc;
     fr* d_ra = c->d_scratch_a;
     fr* d_rc = c->d_scratch_a + mat;
     LG_HIP(c, hipMemcpyAsync(d_ra, r_a, mat * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     // r_polys = small_domain.ifft(row) (mod.rs:726-729), then their values on the odd points of the
     // size-2k domain = planes s = 4 (mod 8) of their encoding
+    const uint64_t plane = R * c->ki;
     {
-        lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, rows);
+        lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, (uint32_t)R);
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
-        const uint64_t sstride = (uint64_t)rows * c->ki;
-        lg::NttArgs e = eval_args(c, d_rc, c->d_scratch_b, sstride, 0, rows, true);
+        lg::NttArgs e = eval_args(c, d_rc, c->d_scratch_b, plane, 0, (uint32_t)R, true);
         e.ncos = 0;
         for (uint32_t s = 4; s < c->nplanes; s += 8) e.cosets[e.ncos++] = (uint8_t)s;
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, e));
     }
-    const uint64_t plane = c->total_rows * c->ki, splane = (uint64_t)rows * c->ki;
-    const uint64_t row_base = (uint64_t)proof * rows;
     for (uint32_t s = 0; s < c->nplanes; s += 4) {
         lg::RowSumArgs a;
         memset(&a, 0, sizeof(a));
-        a.a = c->d_u + (uint64_t)s * plane + row_base * c->ki; a.a_row = c->ki; a.a_col = 1;   // u_i on this plane (canonical)
+        a.a = c->d_u + (uint64_t)s * plane; a.a_proof = (uint64_t)rows * c->ki; a.a_row = c->ki; a.a_col = 1;   // u_i on this plane (canonical)
         if ((s & 7) == 0) {  // message plane 8c': r_i there = r_a[i][O j + c'] (Montgomery)
-            a.b = d_ra + (s >> 3); a.b_row = c->k; a.b_col = O;
+            a.b = d_ra + (s >> 3); a.b_proof = (uint64_t)rows * c->k; a.b_row = c->k; a.b_col = O;
         } else {             // computed plane (canonical)
-            a.b = c->d_scratch_b + (uint64_t)s * splane; a.b_row = c->ki; a.b_col = 1;
+            a.b = c->d_scratch_b + (uint64_t)s * plane; a.b_proof = (uint64_t)rows * c->ki; a.b_row = c->ki; a.b_col = 1;
         }
         a.partial = c->d_sub_partial;
-        a.rows = rows; a.cols = c->ki; a.rows_per_chunk = per;
-        hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->ki + 255) / 256, nch), dim3(256), 0, c->stream, a);
+        a.rows = rows; a.cols = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
+        hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->ki + 255) / 256, nch, c->batch), dim3(256), 0, c->stream, a);
         LG_HIP(c, hipGetLastError());
         // canonical x Montgomery = plain -> x R^2; canonical x canonical = plain / R -> x R^3; point index j = (np/4) q + s/4
-        rc = sub_finish(c, nch, c->ki, (s & 7) == 0 ? c->r2 : c->r3, c->d_sub_q, c->nplanes / 4, s / 4);
+        rc = sub_finish(c, nch, c->ki, (s & 7) == 0 ? c->r2 : c->r3, c->d_sub_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);
         if (rc != LG_OK) return rc;
     }
     return sub_interpolate_2k(c, coeffs_out);
 }
 
-int lg_quadratic_constraint_poly(lg_ctx* c, uint32_t proof, const uint64_t* r, uint64_t* coeffs_out) {
+int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_out) {
     if (!c || !r || !coeffs_out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
-    if (proof >= c->batch || (c->rows & 3) != 0) return LG_ERR_BAD_ARG;
+    if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     LG_HIP(c, hipSetDevice(c->device));
     const uint32_t m = c->rows / 4;
     uint32_t per;
     const uint32_t nch = sub_chunks(m, &per);
-    int rc = sub_buffers(c, (size_t)nch * 2 * c->k, m);
+    int rc = sub_buffers(c, (size_t)c->batch * nch * 2 * c->k, (size_t)c->batch * m);
     if (rc != LG_OK) return rc;
-    LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)m * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)c->batch * m * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     const uint64_t plane = c->total_rows * c->ki;
     for (uint32_t s = 0; s < c->nplanes; s += 4) {
         lg::QuadSumArgs a;
@@ -866,11 +887,10 @@ int lg_quadratic_constraint_poly(lg_ctx* c, uint32_t proof, const uint64_t* r, u
         a.r = c->d_sub_r;
         a.partial = c->d_sub_partial;
         a.r2 = c->r2;
-        a.row_base = (uint64_t)proof * c->rows;
-        a.m = m; a.ki = c->ki; a.rows_per_chunk = per;
-        hipLaunchKernelGGL(lg::quadsum_kernel, dim3((c->ki + 255) / 256, nch), dim3(256), 0, c->stream, a);
+        a.m = m; a.ki = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
+        hipLaunchKernelGGL(lg::quadsum_kernel, dim3((c->ki + 255) / 256, nch, c->batch), dim3(256), 0, c->stream, a);
         LG_HIP(c, hipGetLastError());
-        rc = sub_finish(c, nch, c->ki, c->r2, c->d_sub_q, c->nplanes / 4, s / 4);   // plain -> Montgomery
+        rc = sub_finish(c, nch, c->ki, c->r2, c->d_sub_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);   // plain -> Montgomery
         if (rc != LG_OK) return rc;
     }
     return sub_interpolate_2k(c, coeffs_out);

@@ -16,20 +16,25 @@
 
 namespace lg {
 
+// All kernels take the proof index from blockIdx.z: one launch serves every proof of a batch.
 struct RowSumArgs {
-    const fr* a;            // operand A: element (i, c) at a[i * a_row + c * a_col]
-    const fr* b;            // operand B: element (i, c) at b[i * b_row + c * b_col]; null => b = r[i] (per-row scalar)
+    const fr* a;            // operand A: element (proof p, row i, col c) at a[p * a_proof + i * a_row + c * a_col]
+    const fr* b;            // operand B likewise; null => b = r[p * rows + i] (per-row scalar)
     const fr* r;            // per-row scalars (Montgomery), used when b == null
-    fr* partial;            // [nchunks][cols] lazy sums
-    uint64_t a_row, a_col, b_row, b_col;
-    uint32_t rows, cols, rows_per_chunk;
+    fr* partial;            // [batch][nchunks][cols] lazy sums
+    uint64_t a_proof, a_row, a_col, b_proof, b_row, b_col;
+    uint32_t rows, cols, rows_per_chunk, nchunks;
 };
 
-// partial[chunk][c] = sum_{i in chunk} A[i][c] (*) B[i][c]     ((*) = Montgomery product)
-__global__ void __launch_bounds__(256) rowsum_mul_kernel(const RowSumArgs a) {
+// partial[p][chunk][c] = sum_{i in chunk} A[p][i][c] (*) B[p][i][c]     ((*) = Montgomery product)
+__global__ void __launch_bounds__(256) rowsum_mul_kernel(RowSumArgs a) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t chunk = blockIdx.y;
+    const uint32_t chunk = blockIdx.y, p = blockIdx.z;
     if (c >= a.cols) return;
+    a.a += (uint64_t)p * a.a_proof;
+    if (a.b != nullptr) a.b += (uint64_t)p * a.b_proof;
+    a.r += (uint64_t)p * a.rows;
+    a.partial += (uint64_t)p * a.nchunks * a.cols;
     const uint32_t i0 = chunk * a.rows_per_chunk;
     const uint32_t i1 = (i0 + a.rows_per_chunk < a.rows) ? i0 + a.rows_per_chunk : a.rows;
     fr acc;
@@ -46,28 +51,30 @@ __global__ void __launch_bounds__(256) rowsum_mul_kernel(const RowSumArgs a) {
 }
 
 struct QuadSumArgs {
-    const fr* u;            // one codeword plane [rows][ki], canonical; rows = 4m as [X; Y; Z; W]
-    const fr* r;            // m challenges, Montgomery
-    fr* partial;            // [nchunks][ki]
+    const fr* u;            // one codeword plane [batch * 4m][ki], canonical; each proof's rows are [X; Y; Z; W]
+    const fr* r;            // [batch][m] challenges, Montgomery
+    fr* partial;            // [batch][nchunks][ki]
     fr r2;                  // 2^512 mod p
-    uint64_t row_base;      // first row of the proof in the plane
-    uint32_t m, ki, rows_per_chunk;
+    uint32_t m, ki, rows_per_chunk, nchunks;
 };
 
-// partial[chunk][q] = sum_{i in chunk} r_i (x_i y_i - z_i) as a plain integer (not Montgomery)
-__global__ void __launch_bounds__(256) quadsum_kernel(const QuadSumArgs a) {
+// partial[p][chunk][q] = sum_{i in chunk} r_i (x_i y_i - z_i) as a plain integer (not Montgomery)
+__global__ void __launch_bounds__(256) quadsum_kernel(QuadSumArgs a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t chunk = blockIdx.y;
+    const uint32_t chunk = blockIdx.y, p = blockIdx.z;
     if (q >= a.ki) return;
+    a.u += (uint64_t)p * 4 * a.m * a.ki;
+    a.r += (uint64_t)p * a.m;
+    a.partial += (uint64_t)p * a.nchunks * a.ki;
     const uint32_t i0 = chunk * a.rows_per_chunk;
     const uint32_t i1 = (i0 + a.rows_per_chunk < a.m) ? i0 + a.rows_per_chunk : a.m;
     fr acc;
 #pragma unroll
     for (int l = 0; l < 8; l++) acc.v[l] = 0;
     for (uint32_t i = i0; i < i1; i++) {
-        const fr x = fr_load(a.u + (a.row_base + i) * a.ki + q);
-        const fr y = fr_load(a.u + (a.row_base + a.m + i) * a.ki + q);
-        const fr z = fr_load(a.u + (a.row_base + 2 * (uint64_t)a.m + i) * a.ki + q);
+        const fr x = fr_load(a.u + (uint64_t)i * a.ki + q);
+        const fr y = fr_load(a.u + ((uint64_t)a.m + i) * a.ki + q);
+        const fr z = fr_load(a.u + (2 * (uint64_t)a.m + i) * a.ki + q);
         const fr ri = fr_load(a.r + i);  // r * 2^256
         fr rr, xy, t1, t2, d;
         fr_mul_lazy(rr, ri, a.r2);       // r * 2^512
@@ -80,11 +87,13 @@ __global__ void __launch_bounds__(256) quadsum_kernel(const QuadSumArgs a) {
     fr_store(a.partial + (uint64_t)chunk * a.ki + q, acc);
 }
 
-// out[c * out_stride + out_off] = (sum_chunks partial[chunk][c]) (*) post, fully reduced
+// out[p * out_proof + c * out_stride + out_off] = (sum_chunks partial[p][chunk][c]) (*) post, fully reduced
 __global__ void __launch_bounds__(256) rowsum_finish_kernel(const fr* partial, uint32_t nchunks, uint32_t cols, fr post, fr* out,
-                                                           uint32_t out_stride, uint32_t out_off) {
+                                                           uint32_t out_stride, uint32_t out_off, uint64_t out_proof) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
+    partial += (uint64_t)blockIdx.z * nchunks * cols;
+    out += (uint64_t)blockIdx.z * out_proof;
     fr acc;
 #pragma unroll
     for (int l = 0; l < 8; l++) acc.v[l] = 0;

@@ -165,6 +165,18 @@ class LigeroCommitter:
         self._chk(self._L.lg_open_columns(self._ctx, proof, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns")
         return cols, sib, paths
 
+    def open_columns_batch(self, indices):
+        """open_columns for every proof of the batch in one launch; indices: (batch, t).
+        Returns (columns (batch, t, rows, 4), leaf_sibling_hash (batch, t, 32), auth_path (batch, t, log2 n - 1, 32))."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(self.batch, -1)
+        t = idx.shape[1]
+        plen = self.n.bit_length() - 2
+        cols = np.empty((self.batch, t, self.rows, 4), dtype=np.uint64)
+        sib = np.empty((self.batch, t, 32), dtype=np.uint8)
+        paths = np.empty((self.batch, t, plen, 32), dtype=np.uint8)
+        self._chk(self._L.lg_open_columns_batch(self._ctx, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns_batch")
+        return cols, sib, paths
+
     # -- row operators, mod.rs:998-1012
     def reed_solomon_interpolate(self, msg) -> np.ndarray:
         m = self._mat(msg, self.k, "msg")
@@ -184,27 +196,27 @@ class LigeroCommitter:
         self._chk(self._L.lg_reed_solomon(self._ctx, _ptr(m), m.shape[0], _ptr(out)), "lg_reed_solomon")
         return out
 
-    # -- sub-proof polynomials on the resident commitment (mod.rs:658, 723-736, 842-848)
-    def interleaved_row_mul(self, r, proof: int = 0) -> np.ndarray:
-        """prove_interleaved: preenc_u.row_mul(r_interleaved) (mod.rs:658); r: (rows, 4) -> (k, 4)"""
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.rows, 4)
-        out = np.empty((self.k, 4), dtype=np.uint64)
-        self._chk(self._L.lg_interleaved_row_mul(self._ctx, proof, _ptr(r), _ptr(out)), "lg_interleaved_row_mul")
+    # -- sub-proof polynomials on the resident commitment (mod.rs:658, 723-736, 842-848), whole batch per call
+    def interleaved_row_mul(self, r) -> np.ndarray:
+        """prove_interleaved: preenc_u.row_mul(r_interleaved) (mod.rs:658); r: (batch*rows, 4) -> (batch, k, 4)"""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * self.rows, 4)
+        out = np.empty((self.batch, self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_interleaved_row_mul(self._ctx, _ptr(r), _ptr(out)), "lg_interleaved_row_mul")
         return out
 
-    def linear_constraint_poly(self, r_a, proof: int = 0) -> np.ndarray:
-        """prove_linear_constraints (mod.rs:723-736): r_a = A.row_mul(r_linear) as (rows, k, 4) ->
-        2k coefficients of sum_i u_polys[i] * ifft(r_a_i) (zero padded)"""
-        r_a = np.ascontiguousarray(r_a, dtype=np.uint64).reshape(self.rows, self.k, 4)
-        out = np.empty((2 * self.k, 4), dtype=np.uint64)
-        self._chk(self._L.lg_linear_constraint_poly(self._ctx, proof, _ptr(r_a), _ptr(out)), "lg_linear_constraint_poly")
+    def linear_constraint_poly(self, r_a) -> np.ndarray:
+        """prove_linear_constraints (mod.rs:723-736): r_a = A.row_mul(r_linear) as (batch*rows, k, 4) ->
+        (batch, 2k, 4) coefficients of sum_i u_polys[i] * ifft(r_a_i) (zero padded)"""
+        r_a = np.ascontiguousarray(r_a, dtype=np.uint64).reshape(self.batch * self.rows, self.k, 4)
+        out = np.empty((self.batch, 2 * self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_linear_constraint_poly(self._ctx, _ptr(r_a), _ptr(out)), "lg_linear_constraint_poly")
         return out
 
-    def quadratic_constraint_poly(self, r, proof: int = 0) -> np.ndarray:
-        """prove_quadratic_constraints (mod.rs:842-848): r: (rows/4, 4) -> 2k coefficients"""
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.rows // 4, 4)
-        out = np.empty((2 * self.k, 4), dtype=np.uint64)
-        self._chk(self._L.lg_quadratic_constraint_poly(self._ctx, proof, _ptr(r), _ptr(out)), "lg_quadratic_constraint_poly")
+    def quadratic_constraint_poly(self, r) -> np.ndarray:
+        """prove_quadratic_constraints (mod.rs:842-848): r: (batch*rows/4, 4) -> (batch, 2k, 4) coefficients"""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * (self.rows // 4), 4)
+        out = np.empty((self.batch, 2 * self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_quadratic_constraint_poly(self._ctx, _ptr(r), _ptr(out)), "lg_quadratic_constraint_poly")
         return out
 
     def pipeline_chunks(self) -> int:

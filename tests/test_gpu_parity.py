@@ -165,6 +165,15 @@ def test_poseidon_batch64(lg, oracle, model, vectors):
         ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], [3, 700])
         assert np.array_equal(cols, ecols) and np.array_equal(sib, esib) and np.array_equal(paths, epaths)
         assert np.array_equal(c.codeword_rows(row0=100, nrows=5, proof=17), ref["u"][100:105])
+        # all proofs in one launch, each with its own indices
+        rng = np.random.default_rng(3)
+        idx = np.sort(rng.integers(0, 1024, size=(64, 6)), axis=1)
+        bc, bs, bp = c.open_columns_batch(idx)
+        for b in (0, 17, 63):
+            sc, ss, sp = c.open_columns(idx[b], proof=b)
+            assert np.array_equal(bc[b], sc) and np.array_equal(bs[b], ss) and np.array_equal(bp[b], sp)
+        ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], idx[17])
+        assert np.array_equal(bc[17], ecols) and np.array_equal(bs[17], esib) and np.array_equal(bp[17], epaths)
 
 
 @pytest.mark.parametrize("rows,k", [(1, 2), (3, 2), (5, 8), (7, 16), (12, 32), (9, 64), (33, 256), (4, 1024), (2, 4096),
@@ -287,26 +296,28 @@ def test_staged_commit_matches_oracle(lg, oracle, rows, k):
         be.close()
 
 
-@pytest.mark.parametrize("rows,k,batch", [(12, 8, 1), (344, 128, 1), (20, 64, 3), (8, 4096, 1), (4, 8192, 1)])
+@pytest.mark.parametrize("rows,k,batch", [(12, 8, 1), (344, 128, 1), (20, 64, 3), (344, 128, 5), (8, 4096, 1), (4, 8192, 2)])
 def test_subproof_polynomials_match_oracle(lg, oracle, rows, k, batch):
     """next rows of the path: the arithmetic of prove_interleaved (mod.rs:658),
     prove_linear_constraints (mod.rs:723-736) and prove_quadratic_constraints (mod.rs:842-848) on
-    the resident commitment, bit-exact against the oracle; challenges are seeded stand-ins for the
-    Fiat-Shamir output"""
+    the resident commitment, for the whole batch per call, bit-exact against the oracle;
+    challenges are seeded stand-ins for the Fiat-Shamir output"""
+    m = rows // 4
     pre = random_mont(5 * rows + k, batch * rows * k).reshape(batch * rows, k, 4)
-    r_int = random_mont(11, rows).reshape(rows, 4)
-    r_a = random_mont(12, rows * k).reshape(rows, k, 4)
-    r_q = random_mont(13, rows // 4).reshape(rows // 4, 4)
+    r_int = random_mont(11, batch * rows).reshape(batch * rows, 4)
+    r_a = random_mont(12, batch * rows * k).reshape(batch * rows, k, 4)
+    r_q = random_mont(13, batch * m).reshape(batch * m, 4)
     with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
         coeffs, _ = c.encode_commit(pre)
-        for b in sorted({0, batch - 1}):
-            pb, cb = pre[b * rows:(b + 1) * rows], coeffs[b * rows:(b + 1) * rows]
-            assert np.array_equal(c.interleaved_row_mul(r_int, proof=b), oracle.dense_row_mul(pb, r_int))
-            lin = c.linear_constraint_poly(r_a, proof=b)
-            assert np.array_equal(lin, oracle.linear_constraint_poly(cb, r_a))
-            quad = c.quadratic_constraint_poly(r_q, proof=b)
-            assert np.array_equal(quad, oracle.quadratic_constraint_poly(cb, r_q))
-            assert not lin[2 * k - 1].any() and not quad[2 * k - 1].any()     # degree < 2k - 1 (mod.rs:782, 886)
+        lc = c.interleaved_row_mul(r_int)
+        lin = c.linear_constraint_poly(r_a)
+        quad = c.quadratic_constraint_poly(r_q)
+        for b in range(batch):
+            sl = slice(b * rows, (b + 1) * rows)
+            assert np.array_equal(lc[b], oracle.dense_row_mul(pre[sl], r_int[sl]))
+            assert np.array_equal(lin[b], oracle.linear_constraint_poly(coeffs[sl], r_a[sl]))
+            assert np.array_equal(quad[b], oracle.quadratic_constraint_poly(coeffs[sl], r_q[b * m:(b + 1) * m]))
+            assert not lin[b, 2 * k - 1].any() and not quad[b, 2 * k - 1].any()     # degree < 2k - 1 (mod.rs:782, 886)
         # the commitment is untouched by the sub-proof scratch work
         assert np.array_equal(c.coeffs(), coeffs)
 
@@ -323,8 +334,8 @@ def test_subproofs_at_s20_scale_properties(lg, oracle):
     r_q = random_mont(22, rows // 4).reshape(rows // 4, 4)
     with lg.LigeroCommitter(rows=rows, k=k) as c:
         c.encode_commit(pre, want_coeffs=False)
-        lin = c.linear_constraint_poly(r_a)
-        quad = c.quadratic_constraint_poly(r_q)
+        lin = c.linear_constraint_poly(r_a)[0]
+        quad = c.quadratic_constraint_poly(r_q)[0]
         assert not lin[2 * k - 1].any() and not quad[2 * k - 1].any()
         # evaluate both polynomials on the whole size-2k domain with the oracle's FFT
         lin_ev, quad_ev = oracle.fft(lin), oracle.fft(quad)
