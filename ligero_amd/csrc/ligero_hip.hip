@@ -53,6 +53,7 @@ struct lg_ctx {
     uint8_t* d_tw_inv = nullptr;    // same for the inverse transform
     uint8_t* d_coset_tw = nullptr;  // [plane s < 8 O][d < k] = omega_n^(s d)
     uint8_t* d_fold_inv = nullptr;  // O > 1: [h < O][d < k] = omega_k^(-h d)
+    uint8_t* d_first2 = nullptr;    // log2 k = 1 (mod 3): coefficients of the dot-product radix-2 first pass (ntt_kernels.h)
     uint32_t n_pass_tw = 0;
     lg::f29 w8_fwd[3], w8_inv[3], one29, scale29;
     fr r2;
@@ -252,6 +253,7 @@ static lg::NttArgs eval_args(const lg_ctx* c, const fr* coeffs, fr* planes, uint
     a.in = coeffs; a.out = planes; a.canon_out = nullptr;
     a.tw = planes_of(c->d_tw_fwd, c->n_pass_tw);
     a.coset_tw = planes_of(c->d_coset_tw, (size_t)c->k * c->nplanes);
+    a.first2 = planes_of(c->d_first2, (size_t)c->nplanes * 2 * c->k);
     for (int i = 0; i < 3; i++) a.w8[i] = c->w8_fwd[i];
     a.one = c->one29;
     a.scale = c->scale29;
@@ -349,7 +351,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r};
     for (void* b : bufs2)
         if (b) hipFree(b);
-    void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv,
+    void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
                     c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -449,6 +451,29 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
                 for (uint32_t d = 0; d < k; d++) fill_planes(ct, cnt, (size_t)sp * k + d, to_f29(pn[((uint64_t)sp * d) & (n - 1)]));
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), ct.size()));
             LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size(), hipMemcpyHostToDevice));
+        }
+        // dot-product coefficients of the radix-2 first pass (k = 2, 16, 128, 1024): [plane][4][i0 < k/2]
+        if (c->logo == 0 && logk % 3 == 1 && logk > 1) {
+            const uint32_t half = k / 2;
+            const size_t cnt = (size_t)c->nplanes * 2 * k;
+            std::vector<uint8_t> ft(cnt * 36);
+            std::vector<Fr> pk(half);  // wk^i0
+            Fr a = kOneMont;
+            for (uint32_t i = 0; i < half; i++) { pk[i] = a; a = mul(a, wk); }
+            for (uint32_t sp = 0; sp < c->nplanes; sp++)
+                for (uint32_t i0 = 0; i0 < half; i0++) {
+                    const Fr pre0 = pn[((uint64_t)sp * i0) & (n - 1)], pre1 = pn[((uint64_t)sp * (i0 + half)) & (n - 1)];
+                    const Fr c10 = mul(pre0, pk[i0]), t = mul(pre1, pk[i0]);
+                    const Fr zero = {{0, 0, 0, 0}};
+                    const Fr c11 = (t.l[0] | t.l[1] | t.l[2] | t.l[3]) ? sub_raw(kP, t) : zero;
+                    const size_t base = (size_t)sp * 4 * half + i0;
+                    fill_planes(ft, cnt, base, to_f29(pre0));
+                    fill_planes(ft, cnt, base + half, to_f29(pre1));
+                    fill_planes(ft, cnt, base + 2 * (size_t)half, to_f29(c10));
+                    fill_planes(ft, cnt, base + 3 * (size_t)half, to_f29(c11));
+                }
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_first2), ft.size()));
+            LG_HIP(c, hipMemcpy(c->d_first2, ft.data(), ft.size(), hipMemcpyHostToDevice));
         }
         // outer-fold factors of the inverse transform [h][d] = wk^(-h d mod k)
         {

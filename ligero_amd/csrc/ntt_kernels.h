@@ -39,6 +39,8 @@ struct NttArgs {
                          // root = omega_ki^-1 (interpolate) or omega_ki (evaluate)
     Tw29 coset_tw;       // evaluate: [plane s][d < k] = omega_n^(s d) * 2^261, the pre-scale of coefficient d;
                          // interpolate with O > 1: [h < O][d < k] = omega_k^(-h d) * 2^261
+    Tw29 first2;         // evaluate, k = 2 (mod 8 stages: log2 k = 1 mod 3), O = 1: the radix-2 first pass as two dot
+                         // products, [plane s][4][i0 < k/2] = pre(i0), pre(i0 + k/2), pre(i0) w^i0, -pre(i0 + k/2) w^i0
     f29 w8[3];           // w_8^1, w_8^2 (= w_4), w_8^3 of this direction, * 2^261
     f29 one;             // 2^261 mod p: the multiplier that only normalises (output 0 of each butterfly)
     f29 scale;           // interpolate only: 2^261 / k
@@ -194,6 +196,7 @@ __device__ __forceinline__ int dif_position(int j) {
 // in scalar registers.
 struct NttConsts {
     Tw29 tw;
+    Tw29 first2;
     f29 w8[3];
     f29 one;
     f29 last;  // multiplier applied to every output of the last pass (interpolate: 2^261 / k)
@@ -235,6 +238,24 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
         const int base = (blk << LOGS) + i0;
         const int sbase = lds_swz<LOGK>(slot_base + base);  // element q of this butterfly: sbase ^ sigma(q << LOGSUB)
         f29 e[R];
+        if constexpr (FIRST && EVALUATE && LOGO == 0 && LOGR == 1 && (LOGSUB > 0)) {
+            // radix-2 first pass of a coset evaluation: pre-scale, butterfly and twiddle collapse into
+            // y0 = x0 c00 + x1 c01, y1 = x0 c10 + x1 c11 -- two dot products (3 multiply-equivalents)
+            // instead of two pre-scales, the normalising product of y0 and the twiddle of y1 (4)
+            f29 x[2], c0[2], c1[2];
+            x[0] = unpack29(fr_load(gin + base));
+            x[1] = unpack29(fr_load(gin + base + SUB));
+            const size_t t0 = ((size_t)sel * 4) << LOGSUB;
+            c0[0] = tw29_load(a.first2, t0 + i0);
+            c0[1] = tw29_load(a.first2, t0 + SUB + i0);
+            c1[0] = tw29_load(a.first2, t0 + 2 * SUB + i0);
+            c1[1] = tw29_load(a.first2, t0 + 3 * SUB + i0);
+            mul29_dot<2>(e[0], x, c0);
+            mul29_dot<2>(e[1], x, c1);
+            row.put(sbase, e[0]);
+            row.put(sbase ^ lds_swz<LOGK>(SUB), e[1]);
+            continue;
+        }
         if constexpr (FIRST && LOGO == 0) {
             fr raw[R];
             static_for<0, R>([&](auto qc) {
@@ -287,7 +308,10 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
         }
         dft_regs<LOGR>(e, a.w8);
         if constexpr (LOGSUB > 0) {
-            mul29(e[0], e[0], a.one);
+            if constexpr (FIRST && !EVALUATE && LOGO == 0 && LOGR == 1)
+                norm29_strict(e[0]);  // sum of two canonical inputs: already < 2p, only the limbs need carrying
+            else
+                mul29(e[0], e[0], a.one);
             static_for<1, R>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
 #ifdef LG_ABL_NO_TW  // ablation builds only (tools/ntt_bench.hip)
@@ -364,6 +388,7 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
 
     NttConsts cs;
     cs.tw = a.tw;
+    cs.first2 = a.first2;
     cs.w8[0] = a.w8[0];
     cs.w8[1] = a.w8[1];
     cs.w8[2] = a.w8[2];
