@@ -17,6 +17,7 @@ Workloads
   s20       BASELINE.json configs[2]: one synthetic 2^20-constraint commitment,
             10036 x 4096 -> 32768 (U = 10.5 GB), the HBM-roofline report shape
   s18       a quarter-size variant of s20 for quick runs (rows 2509)
+  s22       BASELINE.json configs[3] shape (20068 x 8192 -> 65536, U = 42 GB) on a single GPU
 
 Prints ONE JSON line on rank 0.
 """
@@ -39,6 +40,7 @@ WORKLOADS = {
     "poseidon": (344, 128, 64),
     "s20": (10036, 4096, 1),
     "s18": (2509, 4096, 1),
+    "s22": (20068, 8192, 1),      # BASELINE configs[3] shape on ONE GPU (53 GB resident)
 }
 
 

@@ -1,0 +1,69 @@
+/*
+ * ligero_host.h -- C ABI of the host-side input pipeline (no GPU): the C++ mirror
+ * (ligero_amd/host/circuit.hpp) of what sits in front of the encode-and-commit path in
+ * NP-Eng/ligero, so that the reference's own fixtures (.r1cs + witness) can be taken to the
+ * matrix `preenc_u` and to the linear-test operand r_a without the reference's toolchain.
+ *
+ *   circuit builders            src/arithmetic_circuit/mod.rs:65-239
+ *   lgh_circuit_from_r1cs       src/reader.rs:6-19 + ArithmeticCircuit::from_constraint_system (mod.rs:455-520)
+ *   lgh_instance_new            LigeroCircuit::new (src/ligero/mod.rs:147-228, 275-433): insert_one / bump_index,
+ *                               dimensions m, k, n, t, the sparse constraint matrix A
+ *   lgh_build_preenc            prove + prove_inner up to preenc_u (src/ligero/mod.rs:449-452, 476-516)
+ *   lgh_a_row_mul               SparseMatrix::row_mul (src/matrices/mod.rs:100-110) as called at mod.rs:722
+ *
+ * Field elements: BN254 Fr, 4 x u64 LE limbs, Montgomery form (as in ligero_hip.h).
+ * Where the reference panics these functions return LGH_ERR_PANIC and lgh_last_error() carries
+ * the message.
+ */
+#ifndef LIGERO_HOST_H
+#define LIGERO_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lgh_circuit lgh_circuit;
+typedef struct lgh_instance lgh_instance;
+
+enum { LGH_OK = 0, LGH_ERR_BAD_ARG = -1, LGH_ERR_PANIC = -2, LGH_ERR_OOM = -3 };
+
+const char* lgh_last_error(void);
+
+/* ArithmeticCircuit by hand; node-returning calls give the new node's index (>= 0) or an error (< 0) */
+lgh_circuit* lgh_circuit_new(void);
+void lgh_circuit_destroy(lgh_circuit* c);
+int64_t lgh_circuit_num_nodes(const lgh_circuit* c);
+int64_t lgh_constant(lgh_circuit* c, const uint64_t value[4]);
+int64_t lgh_new_variable(lgh_circuit* c);
+int64_t lgh_add(lgh_circuit* c, uint64_t left, uint64_t right);
+int64_t lgh_mul(lgh_circuit* c, uint64_t left, uint64_t right);
+int64_t lgh_pow(lgh_circuit* c, uint64_t node, uint64_t exponent);
+int64_t lgh_minus(lgh_circuit* c, uint64_t node);
+
+/* read a circom .r1cs (v1, BN254) and compile it; the output nodes are kept with the circuit */
+int lgh_circuit_from_r1cs(lgh_circuit** out, const char* r1cs_path);
+int64_t lgh_circuit_num_outputs(const lgh_circuit* c);
+int lgh_circuit_outputs(const lgh_circuit* c, uint64_t* outputs_out);
+
+/* LigeroCircuit::new(circuit, outputs, lambda); the circuit is copied */
+int lgh_instance_new(lgh_instance** out, const lgh_circuit* c, const uint64_t* outputs, uint64_t n_outputs, uint32_t lambda);
+void lgh_instance_destroy(lgh_instance* inst);
+/* info_out = { m, k, n, t, num_nodes, num_constants, num_outputs, nnz(A) } */
+int lgh_instance_info(const lgh_instance* inst, uint64_t info_out[8]);
+
+/* var assignment (ORIGINAL node indices, as given to LigeroCircuit::prove) -> preenc_u, 4m * k
+ * elements row-major; *all_outputs_one (may be NULL) tells whether every output evaluated to 1 */
+int lgh_build_preenc(const lgh_instance* inst, const uint64_t* node_idx, const uint64_t* values, uint64_t count,
+                     uint64_t* preenc_out, int* all_outputs_one);
+
+/* r_a = A.row_mul(r): r and out have 4 * m * k elements */
+int lgh_a_row_mul(const lgh_instance* inst, const uint64_t* r, uint64_t* out);
+/* COO dump of A (nnz entries each), row-major order */
+int lgh_a_entries(const lgh_instance* inst, uint64_t* row_idx, uint64_t* col_idx, uint64_t* values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGERO_HOST_H */

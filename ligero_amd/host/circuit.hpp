@@ -1,0 +1,460 @@
+// Host side of the path, input end (SURVEY.md section 8f #3 and the host part of #1): everything
+// between the reference's fixtures (.r1cs + witness) and the matrix `preenc_u` the device
+// commits to, plus the sparse constraint matrix A whose product with the linear-test challenge
+// feeds lg_linear_constraint_poly.  Mirrors, with the reference's names and behaviour:
+//
+//   read_r1cs                                   circom .r1cs v1 (what src/reader.rs gets via ark-circom)
+//   ArithmeticCircuit::{constant, new_variable, add, mul, add_nodes, pow, minus,
+//       compile_sparse_scalar_product, from_constraint_system,
+//       evaluation_trace_multioutput}           src/arithmetic_circuit/mod.rs:65-239, 247-271, 325-358, 455-520
+//   SparseMatrix::{row_mul, h_stack, v_stack, identity, zero, neg}   src/matrices/mod.rs:6-126
+//   LigeroCircuit::{new, insert_one, bump_index, compute_dimensions,
+//       reed_solomon_parameters, generate_matrices}                  src/ligero/mod.rs:147-433
+//   prove_inner's x/y/z/w assembly + as_matrix -> preenc_u           src/ligero/mod.rs:476-516, 1014-1017
+//
+// Field: ark_bn254::Fr, Montgomery form, same limbs as the C ABI.  Where the reference panics
+// this layer throws std::runtime_error with the reference's message.  Product code: independent
+// of oracle/.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../csrc/host_fr.h"
+
+namespace ligero {
+
+using lg_host::Fr;
+
+inline bool fr_is_zero(const Fr& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+inline bool fr_eq(const Fr& a, const Fr& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+inline Fr fr_zero() { return Fr{{0, 0, 0, 0}}; }
+inline Fr fr_one() { return lg_host::kOneMont; }
+inline Fr fr_neg(const Fr& a) { return fr_is_zero(a) ? a : lg_host::sub_raw(lg_host::kP, a); }
+inline Fr fr_add(const Fr& a, const Fr& b) {
+    Fr r;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (unsigned __int128)a.l[i] + b.l[i];
+        r.l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (c || lg_host::geq(r, lg_host::kP)) r = lg_host::sub_raw(r, lg_host::kP);
+    return r;
+}
+inline Fr fr_sub(const Fr& a, const Fr& b) { return fr_add(a, fr_neg(b)); }
+inline Fr fr_mul(const Fr& a, const Fr& b) { return lg_host::mul(a, b); }
+inline Fr fr_from_u64(uint64_t v) { return lg_host::to_mont(Fr{{v, 0, 0, 0}}); }
+struct FrLess {
+    bool operator()(const Fr& a, const Fr& b) const {
+        for (int i = 3; i >= 0; i--)
+            if (a.l[i] != b.l[i]) return a.l[i] < b.l[i];
+        return false;
+    }
+};
+
+// ---------------------------------------------------------------- .r1cs v1
+struct R1cs {
+    uint32_t n_wires = 0, n_pub_out = 0, n_pub_in = 0, n_prv_in = 0;
+    std::vector<uint8_t> prime;                                   // little endian
+    using Lc = std::vector<std::pair<Fr, uint32_t>>;              // (coefficient [Montgomery], wire)
+    std::vector<Lc> a, b, c;
+};
+
+inline R1cs read_r1cs(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<uint8_t> d;
+    uint8_t buf[65536];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + got);
+    std::fclose(f);
+    auto need = [&](size_t o, size_t len) { if (o + len > d.size()) throw std::runtime_error("r1cs: truncated file"); };
+    auto u32 = [&](size_t o) { need(o, 4); uint32_t v; std::memcpy(&v, d.data() + o, 4); return v; };
+    auto u64 = [&](size_t o) { need(o, 8); uint64_t v; std::memcpy(&v, d.data() + o, 8); return v; };
+    if (d.size() < 12 || std::memcmp(d.data(), "r1cs", 4) != 0 || u32(4) != 1) throw std::runtime_error("not a circom r1cs v1 file");
+    const uint32_t nsec = u32(8);
+    size_t off = 12, hdr = 0, cons = 0;
+    for (uint32_t s = 0; s < nsec; s++) {
+        const uint32_t typ = u32(off);
+        const uint64_t len = u64(off + 4);
+        off += 12;
+        if (typ == 1) hdr = off;
+        if (typ == 2) cons = off;
+        off += len;
+    }
+    if (!hdr || !cons) throw std::runtime_error("r1cs: missing header or constraint section");
+    R1cs r;
+    const uint32_t fs = u32(hdr);
+    if (fs != 32) throw std::runtime_error("r1cs: only 32-byte fields are supported");
+    need(hdr + 4, fs + 28);
+    r.prime.assign(d.begin() + hdr + 4, d.begin() + hdr + 4 + fs);
+    uint8_t pbytes[32];
+    for (int i = 0; i < 4; i++) std::memcpy(pbytes + 8 * i, &lg_host::kP.l[i], 8);
+    if (std::memcmp(pbytes, r.prime.data(), 32) != 0) throw std::runtime_error("r1cs: prime is not the BN254 scalar field");
+    size_t o = hdr + 4 + fs;
+    r.n_wires = u32(o); r.n_pub_out = u32(o + 4); r.n_pub_in = u32(o + 8); r.n_prv_in = u32(o + 12);
+    const uint32_t ncons = u32(o + 24);
+    o = cons;
+    auto read_lc = [&]() {
+        R1cs::Lc lc;
+        const uint32_t nnz = u32(o);
+        o += 4;
+        for (uint32_t i = 0; i < nnz; i++) {
+            const uint32_t wire = u32(o);
+            Fr v;
+            need(o + 4, 32);
+            std::memcpy(v.l, d.data() + o + 4, 32);
+            o += 4 + 32;
+            lc.emplace_back(lg_host::to_mont(v), wire);
+        }
+        return lc;
+    };
+    for (uint32_t i = 0; i < ncons; i++) {
+        r.a.push_back(read_lc());
+        r.b.push_back(read_lc());
+        r.c.push_back(read_lc());
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- arithmetic circuit
+struct Node {
+    enum Kind : uint8_t { Variable, Constant, Add, Mul } kind;
+    size_t l = 0, r = 0;   // Add / Mul operands
+    Fr value{};            // Constant
+    std::string label;     // Variable
+};
+
+class ArithmeticCircuit {
+public:
+    std::vector<Node> nodes;
+    std::map<Fr, size_t, FrLess> constants;               // value -> index (mod.rs:31)
+    std::unordered_map<std::string, size_t> variables;    // label -> index (mod.rs:33)
+
+    size_t num_nodes() const { return nodes.size(); }
+    size_t num_constants() const { return constants.size(); }
+    size_t num_variables() const { return variables.size(); }
+    size_t last() const { return nodes.size() - 1; }
+
+    size_t constant(const Fr& v) {                         // mod.rs:76-84
+        auto it = constants.find(v);
+        if (it != constants.end()) return it->second;
+        nodes.push_back(Node{Node::Constant, 0, 0, v, {}});
+        constants[v] = nodes.size() - 1;
+        return nodes.size() - 1;
+    }
+    size_t new_variable_with_label(const std::string& label) {   // mod.rs:92-100
+        if (variables.count(label)) throw std::runtime_error("Variable label already in use: " + label);
+        nodes.push_back(Node{Node::Variable, 0, 0, {}, label});
+        variables[label] = nodes.size() - 1;
+        return nodes.size() - 1;
+    }
+    size_t new_variable() { return new_variable_with_label("var_" + std::to_string(num_variables())); }   // mod.rs:107-109
+    size_t add(size_t l, size_t r) {                       // mod.rs:125-131
+        if (l >= nodes.size()) throw std::runtime_error("Left operand to Add not in circuit:");
+        if (r >= nodes.size()) throw std::runtime_error("Right operand to Add not in circuit:");
+        nodes.push_back(Node{Node::Add, l, r, {}, {}});
+        return nodes.size() - 1;
+    }
+    size_t mul(size_t l, size_t r) {                       // mod.rs:139-145
+        if (l >= nodes.size()) throw std::runtime_error("Left operand to Mul not in circuit:");
+        if (r >= nodes.size()) throw std::runtime_error("Right operand to Mul not in circuit:");
+        nodes.push_back(Node{Node::Mul, l, r, {}, {}});
+        return nodes.size() - 1;
+    }
+    size_t add_nodes(const std::vector<size_t>& idx) {     // mod.rs:148-153
+        if (idx.empty()) throw std::runtime_error("add_nodes: empty list");   // reduce().unwrap() panics upstream
+        size_t acc = idx[0];
+        for (size_t i = 1; i < idx.size(); i++) acc = add(acc, idx[i]);
+        return acc;
+    }
+    size_t pow(size_t node, uint64_t exponent) {           // mod.rs:164-200: square-and-multiply, MSB first
+        if (node >= nodes.size()) throw std::runtime_error("Base node not in the circuit");
+        if (exponent == 0) throw std::runtime_error("pow: exponent 0");
+        int top = 63;
+        while (!((exponent >> top) & 1)) top--;
+        size_t cur = node;
+        for (int b = top - 1; b >= 0; b--) {
+            cur = mul(cur, cur);
+            if ((exponent >> b) & 1) cur = mul(cur, node);
+        }
+        return cur;
+    }
+    size_t minus(size_t node) {                            // mod.rs:220-223
+        const size_t m1 = constant(fr_neg(fr_one()));
+        return mul(m1, node);
+    }
+    size_t compile_sparse_scalar_product(const R1cs::Lc& row) {   // mod.rs:501-520
+        std::vector<std::pair<size_t, size_t>> consts;
+        for (const auto& t : row) consts.emplace_back(constant(t.first), (size_t)t.second);
+        std::vector<size_t> products;
+        for (const auto& cv : consts)
+            products.push_back((cv.first == 0 || cv.second == 0) ? cv.first + cv.second : mul(cv.first, cv.second));
+        return add_nodes(products);
+    }
+    // mod.rs:455-495.  Zero coefficients are dropped, as ark-relations' to_matrices does.
+    static std::pair<ArithmeticCircuit, std::vector<size_t>> from_constraint_system(const R1cs& cs) {
+        ArithmeticCircuit c;
+        const size_t one = c.constant(fr_one());
+        for (uint32_t i = 1; i < cs.n_wires; i++) c.new_variable();
+        auto rows = [&](const std::vector<R1cs::Lc>& mat) {
+            std::vector<size_t> out;
+            for (const auto& lc : mat) {
+                R1cs::Lc nz;
+                for (const auto& t : lc)
+                    if (!fr_is_zero(t.first)) nz.push_back(t);
+                out.push_back(c.compile_sparse_scalar_product(nz));
+            }
+            return out;
+        };
+        const auto a = rows(cs.a), b = rows(cs.b), cc = rows(cs.c);
+        std::vector<size_t> ab, minus_c, outputs;
+        for (size_t i = 0; i < a.size(); i++) ab.push_back(c.mul(a[i], b[i]));
+        const size_t m1 = c.constant(fr_neg(fr_one()));
+        for (size_t i = 0; i < cc.size(); i++) minus_c.push_back(c.mul(cc[i], m1));
+        for (size_t i = 0; i < ab.size(); i++) outputs.push_back(c.add_nodes({ab[i], minus_c[i], one}));
+        return {std::move(c), std::move(outputs)};
+    }
+    // mod.rs:325-358 (values of every node the outputs depend on; nodes only reference earlier
+    // nodes, so one forward sweep gives what the reference's recursion gives).  An unassigned
+    // variable is the reference's "Uninitialised variable" panic.
+    std::vector<Fr> evaluation_trace(const std::vector<std::pair<size_t, Fr>>& vars) const {
+        std::vector<Fr> val(nodes.size(), fr_zero());
+        std::vector<uint8_t> set(nodes.size(), 0);
+        for (const auto& v : vars) {
+            if (v.first >= nodes.size() || nodes[v.first].kind != Node::Variable) throw std::runtime_error("Value supplied for non-variable node");
+            val[v.first] = v.second;
+            set[v.first] = 1;
+        }
+        for (size_t i = 0; i < nodes.size(); i++) {
+            const Node& nd = nodes[i];
+            switch (nd.kind) {
+                case Node::Constant: val[i] = nd.value; break;
+                case Node::Variable:
+                    if (!set[i]) throw std::runtime_error("Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
+                    break;
+                case Node::Add: val[i] = fr_add(val[nd.l], val[nd.r]); break;
+                case Node::Mul: val[i] = fr_mul(val[nd.l], val[nd.r]); break;
+            }
+        }
+        return val;
+    }
+};
+
+// ---------------------------------------------------------------- sparse matrix (src/matrices/mod.rs:6-126)
+struct SparseMatrix {
+    size_t num_cols = 0;
+    std::vector<std::vector<std::pair<Fr, size_t>>> rows;
+    explicit SparseMatrix(size_t cols = 0) : num_cols(cols) {}
+    size_t num_rows() const { return rows.size(); }
+    void push_row(std::vector<std::pair<Fr, size_t>> r) { rows.push_back(std::move(r)); }
+    void push_empty_row() { rows.emplace_back(); }
+    void push_empty_rows(size_t n) { rows.resize(rows.size() + n); }
+    static SparseMatrix identity(size_t n) {
+        SparseMatrix m(n);
+        for (size_t i = 0; i < n; i++) m.rows.push_back({{fr_one(), i}});
+        return m;
+    }
+    static SparseMatrix zero(size_t nr, size_t nc) {
+        SparseMatrix m(nc);
+        m.rows.resize(nr);
+        return m;
+    }
+    SparseMatrix h_stack(const SparseMatrix& o) && {
+        if (num_rows() != o.num_rows()) throw std::runtime_error("Row number mismatch in when stacking matrices horizontally");
+        for (size_t i = 0; i < rows.size(); i++)
+            for (const auto& e : o.rows[i]) rows[i].emplace_back(e.first, e.second + num_cols);
+        num_cols += o.num_cols;
+        return std::move(*this);
+    }
+    SparseMatrix v_stack(SparseMatrix o) && {
+        if (num_cols != o.num_cols) throw std::runtime_error("Column number mismatch in when stacking matrices vertically");
+        for (auto& r : o.rows) rows.push_back(std::move(r));
+        return std::move(*this);
+    }
+    SparseMatrix neg() && {
+        for (auto& r : rows)
+            for (auto& e : r) e.first = fr_neg(e.first);
+        return std::move(*this);
+    }
+    // mod.rs:100-110: result[col] += row[i] * value for every entry of row i
+    std::vector<Fr> row_mul(const std::vector<Fr>& row) const {
+        std::vector<Fr> out(num_cols, fr_zero());
+        const size_t n = row.size() < rows.size() ? row.size() : rows.size();
+        for (size_t i = 0; i < n; i++)
+            for (const auto& e : rows[i]) out[e.second] = fr_add(out[e.second], fr_mul(row[i], e.first));
+        return out;
+    }
+    size_t nnz() const {
+        size_t n = 0;
+        for (const auto& r : rows) n += r.size();
+        return n;
+    }
+};
+
+// ---------------------------------------------------------------- LigeroCircuit::new and the x/y/z/w assembly
+// calculate_t of ark-poly-commit's linear_codes::utils (called at mod.rs:287-292), f64 arithmetic
+inline size_t calculate_t(size_t sec_param, size_t d_num, size_t d_den, size_t codeword_len, int field_bits = 254) {
+    const double residual = (double)codeword_len / std::pow(2.0, field_bits);
+    const double rhs = std::log2(std::pow(2.0, -(double)sec_param) - residual);
+    if (!std::isnormal(rhs)) throw std::runtime_error("For the given codeword length and the required security guarantee, the field is not big enough.");
+    const double denom = std::log2(1.0 - 0.5 * (double)d_num / (double)d_den);
+    if (!std::isnormal(denom)) throw std::runtime_error("The distance is wrong");
+    const size_t t = (size_t)std::ceil((rhs - 1.0) / denom);
+    return t < codeword_len ? t : codeword_len;
+}
+
+class LigeroInstance {
+public:
+    ArithmeticCircuit circuit;
+    std::vector<size_t> outputs;
+    size_t one_index = 0;
+    bool one_found = false;
+    size_t m = 0, k = 0, n = 0, t = 0;
+    SparseMatrix a;
+
+    // mod.rs:147-228
+    LigeroInstance(ArithmeticCircuit c, std::vector<size_t> outs, size_t lambda) : circuit(std::move(c)) {
+        auto it = circuit.constants.find(fr_one());
+        if (it != circuit.constants.end()) { one_index = it->second; one_found = true; } else { one_index = 1; one_found = false; }
+        if (one_index != 0) insert_one();
+        const size_t sol_vec_length = 1 + circuit.num_nodes() - circuit.num_constants() + outs.size();
+        m = (size_t)std::ceil(std::sqrt((double)sol_vec_length));       // compute_dimensions, mod.rs:275-279
+        k = 1;
+        while (k < m) k <<= 1;
+        n = 8 * k;                                                       // reed_solomon_parameters, mod.rs:283-294
+        t = calculate_t(lambda, n - k + 1, n, n);
+        std::unordered_map<size_t, size_t> index_map;                    // mod.rs:179-194
+        index_map[0] = 0;
+        size_t seen = 0;
+        for (size_t i = 1; i < circuit.nodes.size(); i++) {
+            if (circuit.nodes[i].kind == Node::Constant) seen++;
+            else index_map[i] = i - seen;
+        }
+        for (size_t o : outs) outputs.push_back(bump_index(o));
+        a = generate_matrices(index_map, m * k);
+    }
+
+    size_t bump_index(size_t index) const {                              // mod.rs:230-242
+        if (one_found) return index < one_index ? index + 1 : (index == one_index ? 0 : index);
+        return index + 1;
+    }
+
+    // prove (mod.rs:449-452) + prove_inner (mod.rs:476-516): assignment by ORIGINAL node index
+    std::vector<std::vector<Fr>> build_preenc_u(const std::vector<std::pair<size_t, Fr>>& var_assignment, bool* all_outputs_one = nullptr) const {
+        std::vector<std::pair<size_t, Fr>> bumped;
+        for (const auto& v : var_assignment) bumped.emplace_back(bump_index(v.first), v.second);
+        const std::vector<Fr> sol = circuit.evaluation_trace(bumped);
+        if (all_outputs_one) {
+            *all_outputs_one = true;
+            for (size_t o : outputs)
+                if (!fr_eq(sol[o], fr_one())) *all_outputs_one = false;
+        }
+        std::vector<Fr> x, y, z, w;
+        for (size_t i = 0; i < circuit.nodes.size(); i++) {
+            const Node& nd = circuit.nodes[i];
+            if (nd.kind == Node::Constant && i != 0) continue;
+            w.push_back(sol[i]);
+            if (nd.kind == Node::Mul) { x.push_back(sol[nd.l]); y.push_back(sol[nd.r]); z.push_back(sol[i]); }
+            else { x.push_back(fr_zero()); y.push_back(fr_zero()); z.push_back(fr_zero()); }
+        }
+        if (w.size() > m * k) throw std::runtime_error("solution vector longer than m * k");
+        std::vector<std::vector<Fr>> rows;
+        for (auto* vec : {&x, &y, &z, &w}) {
+            vec->resize(m * k, fr_zero());
+            for (size_t i = 0; i < m; i++) rows.emplace_back(vec->begin() + i * k, vec->begin() + (i + 1) * k);   // as_matrix, mod.rs:1014-1017
+        }
+        return rows;
+    }
+
+private:
+    void insert_one() {                                                  // mod.rs:244-271
+        if (one_found) circuit.nodes.erase(circuit.nodes.begin() + one_index);
+        circuit.nodes.insert(circuit.nodes.begin(), Node{Node::Constant, 0, 0, fr_one(), {}});
+        for (auto& nd : circuit.nodes)
+            if (nd.kind == Node::Add || nd.kind == Node::Mul) { nd.l = bump_index(nd.l); nd.r = bump_index(nd.r); }
+        for (auto& kv : circuit.constants) kv.second = bump_index(kv.second);
+        circuit.constants[fr_one()] = 0;
+        for (auto& kv : circuit.variables) kv.second = bump_index(kv.second);
+    }
+
+    static size_t at(const std::unordered_map<size_t, size_t>& m, size_t key) {
+        auto it = m.find(key);
+        // the reference unwraps here (mod.rs:345 etc.): a gate whose operands are both constants panics
+        if (it == m.end()) throw std::runtime_error("called `Option::unwrap()` on a `None` value: gate operand is a constant without an index (mul/add of two constants)");
+        return it->second;
+    }
+
+    SparseMatrix generate_matrices(const std::unordered_map<size_t, size_t>& index_map, size_t num_cols) const {   // mod.rs:296-433
+        const auto& nodes = circuit.nodes;
+        SparseMatrix p_x(num_cols), p_y(num_cols), p_z(num_cols), p_add(num_cols);
+        const Fr one = fr_one(), minus_one = fr_neg(fr_one());
+        auto add_row = [&](size_t l, size_t r) {
+            std::vector<std::pair<Fr, size_t>> row;
+            if (nodes[l].kind == Node::Constant) row = {{nodes[l].value, 0}, {one, at(index_map, r)}};
+            else if (nodes[r].kind == Node::Constant) row = {{one, at(index_map, l)}, {nodes[r].value, 0}};
+            else row = {{one, at(index_map, l)}, {one, at(index_map, r)}};
+            return row;
+        };
+        auto mul_rows = [&](size_t l, size_t r) {
+            if (nodes[l].kind == Node::Constant) { p_x.push_row({{nodes[l].value, 0}}); p_y.push_row({{one, at(index_map, r)}}); }
+            else if (nodes[r].kind == Node::Constant) { p_x.push_row({{one, at(index_map, l)}}); p_y.push_row({{nodes[r].value, 0}}); }
+            else { p_x.push_row({{one, at(index_map, l)}}); p_y.push_row({{one, at(index_map, r)}}); }
+        };
+        for (size_t i = 0; i < nodes.size(); i++) {
+            const Node& nd = nodes[i];
+            switch (nd.kind) {
+                case Node::Variable:
+                    p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row(); p_add.push_empty_row();
+                    break;
+                case Node::Add: {
+                    p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row();
+                    auto row = add_row(nd.l, nd.r);
+                    row.emplace_back(minus_one, at(index_map, i));
+                    p_add.push_row(std::move(row));
+                    break;
+                }
+                case Node::Mul:
+                    p_add.push_empty_row();
+                    mul_rows(nd.l, nd.r);
+                    p_z.push_row({{one, at(index_map, i)}});
+                    break;
+                case Node::Constant:
+                    if (i == 0) { p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row(); p_add.push_empty_row(); }
+                    break;
+            }
+        }
+        for (size_t o : outputs) {                                       // the constraint o = 1 for each output node
+            const Node& nd = nodes.at(o);
+            if (nd.kind == Node::Add) {
+                p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row();
+                auto row = add_row(nd.l, nd.r);
+                row.emplace_back(minus_one, 0);
+                p_add.push_row(std::move(row));
+            } else if (nd.kind == Node::Mul) {
+                p_add.push_empty_row();
+                mul_rows(nd.l, nd.r);
+                p_z.push_row({{one, 0}});
+            } else {
+                throw std::runtime_error("The output node must be an addition or multiplication gate");
+            }
+        }
+        if (p_x.num_rows() > num_cols) throw std::runtime_error("attempt to subtract with overflow (more rows than m * k)");
+        const size_t padding = num_cols - p_x.num_rows();
+        p_x.push_empty_rows(padding); p_y.push_empty_rows(padding); p_z.push_empty_rows(padding); p_add.push_empty_rows(padding);
+        SparseMatrix upper_right = std::move(p_x).v_stack(std::move(p_y)).v_stack(std::move(p_z)).neg();
+        SparseMatrix upper = SparseMatrix::identity(3 * num_cols).h_stack(upper_right);
+        SparseMatrix lower = SparseMatrix::zero(num_cols, 3 * num_cols).h_stack(p_add);
+        return std::move(upper).v_stack(std::move(lower));
+    }
+};
+
+}  // namespace ligero

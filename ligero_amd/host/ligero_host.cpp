@@ -1,0 +1,163 @@
+// C ABI over the host-side input pipeline (circuit.hpp): lets the pytest suite, and any other
+// FFI caller, drive the C++ mirror of the reference's front end of the path.  No GPU code.
+#include <cstring>
+#include <exception>
+#include <new>
+#include <string>
+
+#include "../../include/ligero_host.h"
+#include "circuit.hpp"
+
+using namespace ligero;
+
+struct lgh_circuit {
+    ArithmeticCircuit c;
+    std::vector<size_t> outputs;   // set by lgh_circuit_from_r1cs
+    uint32_t n_wires = 0;
+};
+struct lgh_instance {
+    LigeroInstance inst;
+    uint32_t n_wires;
+    lgh_instance(ArithmeticCircuit c, std::vector<size_t> outs, size_t lambda, uint32_t wires) : inst(std::move(c), std::move(outs), lambda), n_wires(wires) {}
+};
+
+static thread_local std::string g_err;
+template <class F>
+static int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        g_err = "out of memory";
+        return LGH_ERR_OOM;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return LGH_ERR_PANIC;
+    }
+}
+static Fr load_fr(const uint64_t* p) { Fr v; std::memcpy(v.l, p, 32); return v; }
+static void store_fr(uint64_t* p, const Fr& v) { std::memcpy(p, v.l, 32); }
+
+extern "C" {
+
+const char* lgh_last_error(void) { return g_err.c_str(); }
+
+lgh_circuit* lgh_circuit_new(void) { return new (std::nothrow) lgh_circuit(); }
+void lgh_circuit_destroy(lgh_circuit* c) { delete c; }
+int64_t lgh_circuit_num_nodes(const lgh_circuit* c) { return c ? (int64_t)c->c.num_nodes() : (int64_t)LGH_ERR_BAD_ARG; }
+int64_t lgh_constant(lgh_circuit* c, const uint64_t v[4]) {
+    if (!c || !v) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.constant(load_fr(v)); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_new_variable(lgh_circuit* c) {
+    if (!c) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.new_variable(); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_add(lgh_circuit* c, uint64_t l, uint64_t r_) {
+    if (!c) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.add(l, r_); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_mul(lgh_circuit* c, uint64_t l, uint64_t r_) {
+    if (!c) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.mul(l, r_); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_pow(lgh_circuit* c, uint64_t node, uint64_t exponent) {
+    if (!c) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.pow(node, exponent); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_minus(lgh_circuit* c, uint64_t node) {
+    if (!c) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.minus(node); return 0; });
+    return rc ? rc : r;
+}
+
+int lgh_circuit_from_r1cs(lgh_circuit** out, const char* r1cs_path) {
+    if (!out || !r1cs_path) return LGH_ERR_BAD_ARG;
+    *out = nullptr;
+    return guarded([&] {
+        const R1cs cs = read_r1cs(r1cs_path);
+        auto co = ArithmeticCircuit::from_constraint_system(cs);
+        lgh_circuit* c = new lgh_circuit();
+        c->c = std::move(co.first);
+        c->outputs = std::move(co.second);
+        c->n_wires = cs.n_wires;
+        *out = c;
+        return LGH_OK;
+    });
+}
+int64_t lgh_circuit_num_outputs(const lgh_circuit* c) { return c ? (int64_t)c->outputs.size() : (int64_t)LGH_ERR_BAD_ARG; }
+int lgh_circuit_outputs(const lgh_circuit* c, uint64_t* out) {
+    if (!c || !out) return LGH_ERR_BAD_ARG;
+    for (size_t i = 0; i < c->outputs.size(); i++) out[i] = c->outputs[i];
+    return LGH_OK;
+}
+
+int lgh_instance_new(lgh_instance** out, const lgh_circuit* c, const uint64_t* outputs, uint64_t n_outputs, uint32_t lambda) {
+    if (!out || !c || (!outputs && n_outputs)) return LGH_ERR_BAD_ARG;
+    *out = nullptr;
+    return guarded([&] {
+        std::vector<size_t> outs(outputs, outputs + n_outputs);
+        *out = new lgh_instance(c->c, std::move(outs), lambda, c->n_wires);
+        return LGH_OK;
+    });
+}
+void lgh_instance_destroy(lgh_instance* i) { delete i; }
+
+int lgh_instance_info(const lgh_instance* i, uint64_t out[8]) {
+    if (!i || !out) return LGH_ERR_BAD_ARG;
+    out[0] = i->inst.m; out[1] = i->inst.k; out[2] = i->inst.n; out[3] = i->inst.t;
+    out[4] = i->inst.circuit.num_nodes(); out[5] = i->inst.circuit.num_constants();
+    out[6] = i->inst.outputs.size(); out[7] = i->inst.a.nnz();
+    return LGH_OK;
+}
+
+int lgh_build_preenc(const lgh_instance* i, const uint64_t* node_idx, const uint64_t* values, uint64_t count, uint64_t* preenc_out, int* all_outputs_one) {
+    if (!i || (count && (!node_idx || !values)) || !preenc_out) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::vector<std::pair<size_t, Fr>> vars;
+        for (uint64_t j = 0; j < count; j++) vars.emplace_back((size_t)node_idx[j], load_fr(values + 4 * j));
+        bool ok = false;
+        const auto rows = i->inst.build_preenc_u(vars, &ok);
+        if (all_outputs_one) *all_outputs_one = ok ? 1 : 0;
+        size_t o = 0;
+        for (const auto& r : rows)
+            for (const auto& v : r) { store_fr(preenc_out + 4 * o, v); o++; }
+        return LGH_OK;
+    });
+}
+
+int lgh_a_row_mul(const lgh_instance* i, const uint64_t* r, uint64_t* out) {
+    if (!i || !r || !out) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const size_t len = 4 * i->inst.m * i->inst.k;
+        std::vector<Fr> row(len);
+        for (size_t j = 0; j < len; j++) row[j] = load_fr(r + 4 * j);
+        const auto res = i->inst.a.row_mul(row);
+        for (size_t j = 0; j < res.size(); j++) store_fr(out + 4 * j, res[j]);
+        return LGH_OK;
+    });
+}
+
+int lgh_a_entries(const lgh_instance* i, uint64_t* row_idx, uint64_t* col_idx, uint64_t* values) {
+    if (!i || !row_idx || !col_idx || !values) return LGH_ERR_BAD_ARG;
+    size_t o = 0;
+    for (size_t r = 0; r < i->inst.a.rows.size(); r++)
+        for (const auto& e : i->inst.a.rows[r]) {
+            row_idx[o] = r; col_idx[o] = e.second;
+            store_fr(values + 4 * o, e.first);
+            o++;
+        }
+    return LGH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""ctypes mirror of include/ligero_host.h (ligero_amd/lib/libligero_host.so): the C++ host
+side in front of the encode-and-commit path -- circuit builders, circom .r1cs ->
+ArithmeticCircuit (src/arithmetic_circuit/mod.rs:455-520), LigeroCircuit::new
+(src/ligero/mod.rs:147-433: dimensions, constraint matrix A), witness -> preenc_u
+(mod.rs:476-516) and A.row_mul (src/matrices/mod.rs:100-110).  No GPU involved.
+
+Field elements are numpy uint64 (..., 4) arrays in Montgomery form, as everywhere else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libligero_host.so")
+
+SYMBOLS = [
+    "lgh_last_error", "lgh_circuit_new", "lgh_circuit_destroy", "lgh_circuit_num_nodes", "lgh_constant", "lgh_new_variable",
+    "lgh_add", "lgh_mul", "lgh_pow", "lgh_minus", "lgh_circuit_from_r1cs", "lgh_circuit_num_outputs", "lgh_circuit_outputs",
+    "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_a_row_mul", "lgh_a_entries",
+]
+
+_vp, _u64, _i64, _u32, _int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
+_lib = None
+
+
+class HostPanic(RuntimeError):
+    """the reference would have panicked here (message = the reference's)"""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C ligero_amd/host`")
+        L = ctypes.CDLL(LIB_PATH)
+        L.lgh_last_error.restype = ctypes.c_char_p
+        L.lgh_circuit_new.restype = _vp
+        L.lgh_circuit_destroy.argtypes = [_vp]
+        L.lgh_circuit_destroy.restype = None
+        for name, args in (("lgh_circuit_num_nodes", [_vp]), ("lgh_constant", [_vp, _vp]), ("lgh_new_variable", [_vp]),
+                           ("lgh_add", [_vp, _u64, _u64]), ("lgh_mul", [_vp, _u64, _u64]), ("lgh_pow", [_vp, _u64, _u64]),
+                           ("lgh_minus", [_vp, _u64]), ("lgh_circuit_num_outputs", [_vp])):
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = _i64
+        L.lgh_circuit_from_r1cs.argtypes = [ctypes.POINTER(_vp), ctypes.c_char_p]
+        L.lgh_circuit_outputs.argtypes = [_vp, _vp]
+        L.lgh_instance_new.argtypes = [ctypes.POINTER(_vp), _vp, _vp, _u64, _u32]
+        L.lgh_instance_destroy.argtypes = [_vp]
+        L.lgh_instance_destroy.restype = None
+        L.lgh_instance_info.argtypes = [_vp, _vp]
+        L.lgh_build_preenc.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
+        L.lgh_a_row_mul.argtypes = [_vp, _vp, _vp]
+        L.lgh_a_entries.argtypes = [_vp, _vp, _vp, _vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        msg = lib().lgh_last_error().decode()
+        if rc == -2:
+            raise HostPanic(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: status {rc} ({msg})")
+    return rc
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class ArithmeticCircuit:
+    """src/arithmetic_circuit/mod.rs: builders + from_constraint_system"""
+
+    def __init__(self, _handle=None):
+        self._L = lib()
+        self._h = _vp(_handle) if _handle is not None else _vp(self._L.lgh_circuit_new())
+        self.outputs = []
+
+    @classmethod
+    def from_r1cs(cls, path: str) -> "ArithmeticCircuit":
+        L = lib()
+        h = _vp()
+        _check(L.lgh_circuit_from_r1cs(ctypes.byref(h), path.encode()), "from_constraint_system")
+        c = cls(h.value)
+        n = _check(L.lgh_circuit_num_outputs(c._h), "num_outputs")
+        out = np.zeros(n, dtype=np.uint64)
+        _check(L.lgh_circuit_outputs(c._h, _p(out)), "outputs")
+        c.outputs = [int(x) for x in out]
+        return c
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lgh_circuit_destroy(self._h)
+            self._h = None
+
+    def num_nodes(self) -> int:
+        return _check(self._L.lgh_circuit_num_nodes(self._h), "num_nodes")
+
+    def constant(self, value_mont: np.ndarray) -> int:
+        v = np.ascontiguousarray(value_mont, dtype=np.uint64).reshape(4)
+        return _check(self._L.lgh_constant(self._h, _p(v)), "constant")
+
+    def new_variable(self) -> int:
+        return _check(self._L.lgh_new_variable(self._h), "new_variable")
+
+    def add(self, l: int, r: int) -> int:
+        return _check(self._L.lgh_add(self._h, l, r), "add")
+
+    def mul(self, l: int, r: int) -> int:
+        return _check(self._L.lgh_mul(self._h, l, r), "mul")
+
+    def pow(self, node: int, e: int) -> int:
+        return _check(self._L.lgh_pow(self._h, node, e), "pow")
+
+    def minus(self, node: int) -> int:
+        return _check(self._L.lgh_minus(self._h, node), "minus")
+
+
+class LigeroInstance:
+    """LigeroCircuit::new (src/ligero/mod.rs:147-228): dimensions + constraint matrix A"""
+
+    def __init__(self, circuit: ArithmeticCircuit, outputs: Optional[Sequence[int]] = None, lam: int = 128):
+        self._L = lib()
+        outs = np.ascontiguousarray(circuit.outputs if outputs is None else outputs, dtype=np.uint64)
+        self._h = _vp()
+        _check(self._L.lgh_instance_new(ctypes.byref(self._h), circuit._h, _p(outs), outs.shape[0], lam), "LigeroCircuit::new")
+        info = np.zeros(8, dtype=np.uint64)
+        _check(self._L.lgh_instance_info(self._h, _p(info)), "info")
+        (self.m, self.k, self.n, self.t, self.num_nodes, self.num_constants, self.num_outputs, self.a_nnz) = (int(x) for x in info)
+        self.rows = 4 * self.m
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lgh_instance_destroy(self._h)
+            self._h = None
+
+    def build_preenc_u(self, node_idx: Sequence[int], values_mont: np.ndarray) -> Tuple[np.ndarray, bool]:
+        """prove + prove_inner up to preenc_u (mod.rs:449-452, 476-516).  Returns ((4m, k, 4), all_outputs_one)."""
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(idx.shape[0], 4)
+        out = np.empty((self.rows, self.k, 4), dtype=np.uint64)
+        ok = _int(0)
+        _check(self._L.lgh_build_preenc(self._h, _p(idx), _p(vals), idx.shape[0], _p(out), ctypes.cast(ctypes.byref(ok), _vp)), "prove_inner")
+        return out, bool(ok.value)
+
+    def a_row_mul(self, r_mont: np.ndarray) -> np.ndarray:
+        """self.a.row_mul(&r_linear) (mod.rs:722): (4mk, 4) -> (4mk, 4)"""
+        r = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(self.rows * self.k, 4)
+        out = np.empty_like(r)
+        _check(self._L.lgh_a_row_mul(self._h, _p(r), _p(out)), "A.row_mul")
+        return out
+
+    def a_entries(self):
+        """COO dump of A: (row, col, value[4]) arrays"""
+        rows = np.empty(self.a_nnz, dtype=np.uint64)
+        cols = np.empty(self.a_nnz, dtype=np.uint64)
+        vals = np.empty((self.a_nnz, 4), dtype=np.uint64)
+        _check(self._L.lgh_a_entries(self._h, _p(rows), _p(cols), _p(vals)), "a_entries")
+        return rows, cols, vals

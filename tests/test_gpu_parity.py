@@ -365,3 +365,39 @@ def test_subproofs_at_s20_scale_properties(lg, oracle):
             L.orc_fr_mul(pre[i, 0].ctypes.data, r_a[i, 0].ctypes.data, tmp.ctypes.data)
             L.orc_fr_add(acc.ctypes.data, tmp.ctypes.data, acc.ctypes.data)
         assert np.array_equal(acc, lin_ev[0])
+
+
+def test_poseidon_end_to_end_from_fixtures(lg, oracle, model, vectors):
+    """product code only, from the reference's fixtures to a commitment: C++ host pipeline
+    (.r1cs -> circuit -> LigeroCircuit::new -> preenc_u, A) -> GPU commit -> the committed golden
+    root; then r_a = A.row_mul(r_linear) on the host feeds the device's linear-test polynomial,
+    checked against the oracle"""
+    from ligero_amd import host_pipeline as hp
+    circ = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+    inst = hp.LigeroInstance(circ)
+    w = model.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))
+    pre, ok = inst.build_preenc_u(list(range(1, len(w))), oracle.to_mont(oracle.ints_to_limbs(w[1:])))
+    assert ok
+    with lg.LigeroCommitter(rows=inst.rows, k=inst.k) as c:
+        coeffs, root = c.encode_commit(pre)
+        assert root.hex() == vectors["poseidon"]["root"]
+        r_linear = random_mont(321, inst.rows * inst.k)
+        r_a = inst.a_row_mul(r_linear).reshape(inst.rows, inst.k, 4)
+        lin = c.linear_constraint_poly(r_a)[0]
+        assert np.array_equal(lin, oracle.linear_constraint_poly(coeffs, r_a))
+        # the identity the verifier checks (mod.rs:794): sum of q over the small domain is 0 for a
+        # satisfying witness (b = 0): the even-index evaluations of q on the size-2k domain
+        ev = oracle.fft(lin)
+        L = oracle.lib()
+        acc = np.zeros(4, dtype=np.uint64)
+        for j in range(0, 2 * inst.k, 2):
+            L.orc_fr_add(acc.ctypes.data, ev[j].ctypes.data, acc.ctypes.data)
+        assert not acc.any()
+        # and the quadratic test's (mod.rs:896): p_0 vanishes on the whole small domain
+        quad = c.quadratic_constraint_poly(random_mont(322, inst.m))[0]
+        assert not oracle.fft(quad)[0::2].any()
+        # a witness that violates a constraint breaks it
+        bad = pre.copy()
+        bad[0, 5] = random_mont(9, 1)[0]
+        c.encode_commit(bad, want_coeffs=False)
+        assert oracle.fft(c.quadratic_constraint_poly(random_mont(322, inst.m))[0])[0::2].any()

@@ -1,0 +1,150 @@
+"""CPU tests of the C++ host-side input pipeline (ligero_amd/host/circuit.hpp through
+include/ligero_host.h): the reference's own assertions about this code, restated --
+
+  * src/arithmetic_circuit/tests.rs:189-241  cube.r1cs compiles to exactly 15 nodes
+  * src/ligero/tests.rs:35-142               exact constraint matrix A of the curve-equation circuit
+  * src/ligero/tests.rs:245-346              exact A of the three-output circuit (exercises insert_one)
+  * src/ligero/tests.rs:364-415              Poseidon: every output evaluates to 1; dimensions
+and the pins we can add: preenc_u equals the oracle model's on cube-free fixtures, A.row_mul
+equals a big-int model of SparseMatrix::row_mul.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, mont_matrix, random_mont
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from ligero_amd import host_pipeline
+    host_pipeline.lib()
+    return host_pipeline
+
+
+def _mont(oracle, v):
+    return oracle.to_mont(oracle.ints_to_limbs([v % P]))[0]
+
+
+def _a_as_dict(oracle, inst):
+    """A as {row: [(value, column), ...]} with the entry order of the rows preserved (the
+    reference compares SparseMatrix row vectors, duplicates included)"""
+    rows, cols, vals = inst.a_entries()
+    ints = oracle.limbs_to_ints(oracle.from_mont(vals))
+    out = {}
+    for r, c, v in zip(rows, cols, ints):
+        out.setdefault(int(r), []).append((v if v < P // 2 else v - P, int(c)))
+    return out
+
+
+def _expected_a(mk, p_x, p_y, p_z, p_add):
+    """A = [[I | -P_x; -P_y; -P_z], [0 | P_add]] (src/ligero/mod.rs:423-432) from the tables the
+    reference's tests spell out (row index -> [(value, column)])"""
+    a = {i: [(1, i)] for i in range(3 * mk)}
+    for blk, tab in enumerate((p_x, p_y, p_z)):
+        for r, entries in tab.items():
+            a[blk * mk + r] += [(-v, 3 * mk + c) for v, c in entries]
+    for r, entries in p_add.items():
+        a[3 * mk + r] = [(v, 3 * mk + c) for v, c in entries]
+    return a
+
+
+def test_cube_compiles_to_15_nodes_and_new_panics(hp):
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "cube.r1cs"))
+    assert c.num_nodes() == 15 and c.outputs == [12, 14]                 # arithmetic_circuit/tests.rs:239
+    # the reference cannot build LigeroCircuit for cube (Mul of two constants, mod.rs:345)
+    with pytest.raises(hp.HostPanic):
+        hp.LigeroInstance(c)
+
+
+def test_construction_curve_equation_matrix(hp, oracle):
+    """src/ligero/tests.rs:35-142 (there over BLS12-377 Fq; the matrix has only +-1 entries, so the
+    same table must come out over BN254 Fr)"""
+    c = hp.ArithmeticCircuit()
+    one = c.constant(_mont(oracle, 1))
+    x, y = c.new_variable(), c.new_variable()
+    y2 = c.pow(y, 2)
+    my2 = c.minus(y2)
+    x3 = c.pow(x, 3)
+    out = c.add(c.add(c.add(x3, one), my2), one)                         # add_nodes([x_cubed, one, minus_y_squared, one])
+    inst = hp.LigeroInstance(c, [out])
+    assert (inst.m, inst.k) == (4, 4)
+    p_x = {3: [(1, 2)], 4: [(-1, 0)], 5: [(1, 1)], 6: [(1, 5)]}
+    p_y = {3: [(1, 2)], 4: [(1, 3)], 5: [(1, 1)], 6: [(1, 1)]}
+    p_z = {3: [(1, 3)], 4: [(1, 4)], 5: [(1, 5)], 6: [(1, 6)]}
+    p_add = {7: [(1, 6), (1, 0), (-1, 7)], 8: [(1, 7), (1, 4), (-1, 8)], 9: [(1, 8), (1, 0), (-1, 9)], 10: [(1, 8), (1, 0), (-1, 0)]}
+    assert _a_as_dict(oracle, inst) == _expected_a(16, p_x, p_y, p_z, p_add)
+
+
+def test_multioutput_1_matrix(hp, oracle):
+    """src/ligero/tests.rs:245-346: no constant 1 in the circuit -> insert_one shifts every index"""
+    c = hp.ArithmeticCircuit()
+    x, y = c.new_variable(), c.new_variable()
+    c1, c2, c3 = c.constant(_mont(oracle, -8)), c.constant(_mont(oracle, -63)), c.constant(_mont(oracle, -6))
+    x2 = c.mul(x, x)
+    y3 = c.pow(y, 3)
+    s = c.add(x, y)
+    o1, o2, o3 = c.add(x2, c1), c.add(y3, c2), c.add(s, c3)
+    inst = hp.LigeroInstance(c, [o1, o2, o3])
+    assert (inst.m, inst.k, inst.m * inst.k) == (4, 4, 16)
+    p_x = {3: [(1, 1)], 4: [(1, 2)], 5: [(1, 4)]}
+    p_y = {3: [(1, 1)], 4: [(1, 2)], 5: [(1, 2)]}
+    p_z = {3: [(1, 3)], 4: [(1, 4)], 5: [(1, 5)]}
+    p_add = {6: [(1, 1), (1, 2), (-1, 6)], 7: [(1, 3), (-8, 0), (-1, 7)], 8: [(1, 5), (-63, 0), (-1, 8)], 9: [(1, 6), (-6, 0), (-1, 9)],
+             10: [(1, 3), (-8, 0), (-1, 0)], 11: [(1, 5), (-63, 0), (-1, 0)], 12: [(1, 6), (-6, 0), (-1, 0)]}
+    assert _a_as_dict(oracle, inst) == _expected_a(16, p_x, p_y, p_z, p_add)
+    # a satisfying assignment (x = 3, y = 4) makes all three outputs 1; a wrong one does not
+    pre, ok = inst.build_preenc_u([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 4)]))
+    assert ok and pre.shape == (16, 4, 4)
+    _, bad = inst.build_preenc_u([x, y], np.stack([_mont(oracle, 4), _mont(oracle, 4)]))
+    assert not bad
+
+
+def test_poseidon_from_fixture_matches_model(hp, oracle, model, poseidon_case):
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+    inst = hp.LigeroInstance(c)
+    assert (inst.m, inst.k, inst.n, inst.t) == (86, 128, 1024, 156)
+    assert (inst.num_nodes, inst.num_constants, inst.num_outputs) == (7787, 775, 261)
+    assert c.outputs == poseidon_case["outputs"]
+    w = model.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))
+    vals = oracle.to_mont(oracle.ints_to_limbs(w[1:]))
+    pre, ok = inst.build_preenc_u(list(range(1, len(w))), vals)          # tests.rs:389: enumerate().skip(1)
+    assert ok                                                            # tests.rs:391-394
+    assert np.array_equal(pre, mont_matrix(oracle, poseidon_case["preenc"], 128))
+    bad = vals.copy()
+    bad[0] = _mont(oracle, w[1] + 1)
+    assert not inst.build_preenc_u(list(range(1, len(w))), bad)[1]       # tests.rs:160-170 style rejection
+    with pytest.raises(hp.HostPanic):                                    # missing variable: mod.rs:477 panic
+        inst.build_preenc_u(list(range(2, len(w))), vals[1:])
+
+
+def test_a_row_mul_matches_model(hp, oracle, model):
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+    inst = hp.LigeroInstance(c)
+    r_int = model.random_elements(5, 4 * inst.m * inst.k)
+    got = oracle.limbs_to_ints(oracle.from_mont(inst.a_row_mul(oracle.to_mont(oracle.ints_to_limbs(r_int)))))
+    rows, cols, vals = inst.a_entries()
+    ints = oracle.limbs_to_ints(oracle.from_mont(vals))
+    exp = [0] * (4 * inst.m * inst.k)
+    for r, cidx, v in zip(rows, cols, ints):                             # src/matrices/mod.rs:100-110
+        exp[int(cidx)] = (exp[int(cidx)] + r_int[int(r)] * v) % P
+    assert got == exp
+    # reference's own known answer for SparseMatrix::row_mul is covered structurally: identity block
+    mk = inst.m * inst.k
+    assert got[:3 * mk] == r_int[:3 * mk]
+
+
+def test_host_library_exports(hp):
+    import re, subprocess
+    from conftest import ROOT
+    hdr = open(os.path.join(ROOT, "include", "ligero_host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lgh_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(hp.SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", hp.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (lgh_[a-z0-9_]+)", out))
+    assert set(declared) <= exported
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "ligero_host.h")])
