@@ -398,6 +398,7 @@ def test_poseidon_end_to_end_from_fixtures(lg, oracle, model, vectors):
         assert not oracle.fft(quad)[0::2].any()
         # a witness that violates a constraint breaks it
         bad = pre.copy()
-        bad[0, 5] = random_mont(9, 1)[0]
+        zr, zc = [(r, cc) for r in range(2 * inst.m, 3 * inst.m) for cc in range(inst.k) if pre[r, cc].any()][0]
+        bad[zr, zc] = random_mont(9, 1)[0]                                 # a z entry of a multiplication gate
         c.encode_commit(bad, want_coeffs=False)
         assert oracle.fft(c.quadratic_constraint_poly(random_mont(322, inst.m))[0])[0::2].any()
