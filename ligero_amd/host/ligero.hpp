@@ -147,6 +147,29 @@ public:
         return out;
     }
 
+    // prove_interleaved's preenc_u.row_mul(&r_interleaved) (mod.rs:658, src/matrices/mod.rs:138-149)
+    std::vector<Fr> interleaved_row_mul(const std::vector<Fr>& r) {
+        if (r.size() != 4 * m_) throw Error(LG_ERR_BAD_ARG, "interleaved_row_mul: r must have 4m entries");
+        std::vector<Fr> out(k_);
+        check(lg_interleaved_row_mul(ctx_, r[0].limbs, out[0].limbs), "interleaved_row_mul");
+        return out;
+    }
+    // prove_linear_constraints (mod.rs:723-736): r_a = self.a.row_mul(&r_linear), 4m*k entries ->
+    // coefficients of sum_i u_polys[i] * ifft(r_a_i), 2k of them (trailing zeros are NOT trimmed)
+    std::vector<Fr> linear_constraint_poly(const std::vector<Fr>& r_a) {
+        if (r_a.size() != 4 * m_ * k_) throw Error(LG_ERR_BAD_ARG, "linear_constraint_poly: r_a must have 4mk entries");
+        std::vector<Fr> out(2 * k_);
+        check(lg_linear_constraint_poly(ctx_, r_a[0].limbs, out[0].limbs), "linear_constraint_poly");
+        return out;
+    }
+    // prove_quadratic_constraints (mod.rs:842-848): r has m entries -> 2k coefficients
+    std::vector<Fr> quadratic_constraint_poly(const std::vector<Fr>& r) {
+        if (r.size() != m_) throw Error(LG_ERR_BAD_ARG, "quadratic_constraint_poly: r must have m entries");
+        std::vector<Fr> out(2 * k_);
+        check(lg_quadratic_constraint_poly(ctx_, r[0].limbs, out[0].limbs), "quadratic_constraint_poly");
+        return out;
+    }
+
     // leaf digests, for a host that wants to own an ark MerkleTree (mod.rs:544-549)
     std::vector<Digest> leaves() {
         std::vector<Digest> out(n_);
