@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun) and regenerates everything under profiles/ that the bench
+# line's roofline refers to.  Usage: tools/collect_profiles.sh <round tag, e.g. r01>
+# Trace pass and the two PMC passes are separate rocprofv3 runs (MI355X guide, HBM section).
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/profiles
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+for WL in poseidon s20; do
+  STEPS=20; [ "$WL" = s20 ] && STEPS=5
+  python3 bench.py --workload $WL --steps $STEPS --warmup 3 > "$OUT/${TAG}_${WL}_bench.json" 2> "$OUT/${TAG}_${WL}_bench.err"
+  D=/tmp/prof_${WL}_trace; rm -rf $D
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline \
+      > "$OUT/${TAG}_${WL}_bench_under_rocprof.json" 2> "$OUT/${TAG}_${WL}_rocprof.err"
+  cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_${WL}_kernel_stats.csv"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    D=/tmp/prof_${WL}_$C; rm -rf $D
+    rocprofv3 --pmc $C --output-format csv -d $D -- python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline \
+        > /dev/null 2> "$OUT/${TAG}_${WL}_pmc_${C}.err"
+    lc=$(echo $C | tr A-Z a-z)
+    # keep the per-dispatch rows of our kernels only (file is otherwise MBs of torch fill kernels)
+    f=$(find $D -name '*counter_collection.csv' | head -1)
+    (head -1 "$f"; grep -E 'ntt_rows_kernel|blake2s_columns_kernel|merkle_subtree_kernel' "$f") > "$OUT/${TAG}_${WL}_pmc_${lc}.csv"
+  done
+done
+ls -la "$OUT"
