@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 P_LIMBS = (0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MULMOD_PEAK_G = 175.0          # measured: chip-wide 254-bit Montgomery products/s of the kernel's own
+                               # mul29 (tools/microbench3.hip, profiles/r01_microbench3_mulmod.log)
 
 WORKLOADS = {
     #            rows   k     batch
@@ -60,6 +62,29 @@ def algorithmic_bytes(rows: int, k: int, n: int, batch: int):
     commit = batch * (rows * 320 * k + 64 * n - 32)
     evaluate = batch * rows * 256 * k
     return commit, evaluate
+
+
+def algorithmic_mulmods(rows: int, k: int, n: int, batch: int):
+    """SURVEY §8(d) secondary roof: per row (k/2*log2 k + k) for the iNTT, 7x that for the pruned
+    NTT, + n de-Montgomery products for hashing.  Returns (whole commit, evaluate kernel)."""
+    lg = k.bit_length() - 1
+    ntt = k // 2 * lg + k
+    return batch * rows * (8 * ntt + n), batch * rows * (7 * ntt + 7 * k)
+
+
+def device_copy_gbs(torch, nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """measured HBM copy bandwidth (read + write bytes) of a plain device-to-device copy"""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
@@ -170,6 +195,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+        copy_gbs = device_copy_gbs(torch) if world == 1 else None
+        mm_commit, mm_eval = algorithmic_mulmods(rows, k, n, batch)
         line = {
             "metric": "RS-encoded field-elems/sec (Ligero encode+commit, Poseidon R1CS shape)" if args.workload == "poseidon"
                       else "RS-encoded field-elems/sec (Ligero encode+commit)",
@@ -190,6 +217,17 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
                          "launches_per_step": dom_launches, "samples": stage["samples"] * dom_launches},
             "root0": root[:32].hex(),
+        }
+        if copy_gbs:
+            line["roofline"]["measured_copy_GBs"] = copy_gbs
+            line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+        # secondary roof: the path is integer-multiply bound, not HBM bound
+        line["valu_roofline"] = {
+            "unit": "G mulmod/s", "peak": MULMOD_PEAK_G, "peak_source": "measured mul29 microbenchmark, whole chip",
+            "commit": mm_commit * args.steps / elapsed / 1e9,
+            "evaluate_kernel": mm_eval / (stage["evaluate"] * 1e-3) / 1e9,
+            "evaluate_frac": mm_eval / (stage["evaluate"] * 1e-3) / 1e9 / MULMOD_PEAK_G,
+            "note": "algorithmic (k/2 log2 k + k) products per transform; the radix-8 kernel executes ~15% more",
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)

@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libligero_hip.so")
+# LIGERO_HIP_LIB: developer knob to load an experimental build of the same library (A/B timing)
+LIB_PATH = os.environ.get("LIGERO_HIP_LIB") or os.path.join(_HERE, "lib", "libligero_hip.so")
 
 # every symbol include/ligero_hip.h declares (tests check the export list against this)
 SYMBOLS = [
@@ -57,6 +58,14 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ligero_amd/csrc`.  ligero_amd has no CPU fallback.")
+    # torch ships its own copy of the HIP runtime; if it is initialised after ours, torch.cuda
+    # reports "No HIP GPUs are available" (observed on MI355X / ROCm 7).  The multi-GPU layer
+    # (sharded.py) aliases our device buffers as torch tensors, so let torch's runtime load first
+    # whenever torch is installed.  Nothing else here depends on torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     L.lg_status_string.restype = ctypes.c_char_p
     L.lg_status_string.argtypes = [_int]

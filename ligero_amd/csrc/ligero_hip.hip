@@ -55,7 +55,7 @@ struct lg_ctx {
     uint8_t* d_fold_inv = nullptr;  // O > 1: [h < O][d < k] = omega_k^(-h d)
     uint8_t* d_first2 = nullptr;    // log2 k = 1 (mod 3): coefficients of the dot-product radix-2 first pass (ntt_kernels.h)
     uint32_t n_pass_tw = 0;
-    lg::f29 w8_fwd[3], w8_inv[3], one29, scale29;
+    lg::f29 w8_fwd[3], w8_inv[3], w8q_fwd[3], w8q_inv[3], one29, oneq29, scale29, invk29, invkq29;
     fr r2;
     // scratch for row operators / openings (grown on demand)
     fr* d_scratch_a = nullptr; size_t scratch_a_elems = 0;  // inputs / coefficients
@@ -95,6 +95,36 @@ static lg::f29 to_f29(const lg_host::Fr& a_mont) {
     }
     return r;
 }
+// canonical value of a Montgomery-form host element -> 29-bit limbs (plain operand of shoup29)
+static lg::f29 split29(const uint64_t (&t)[5]) {
+    lg::f29 r;
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t x = t[w] >> sh;
+        if (sh > 35) x |= t[w + 1] << (64 - sh);
+        r.v[i] = (uint32_t)(x & 0x1fffffffu);
+    }
+    return r;
+}
+static lg::f29 to_f29_plain(const lg_host::Fr& a_mont) {
+    const lg_host::Fr a = lg_host::from_mont(a_mont);
+    const uint64_t t[5] = {a.l[0], a.l[1], a.l[2], a.l[3], 0};
+    return split29(t);
+}
+// Barrett quotient floor(w * 2^261 / p) of the canonical value w < p (second operand of shoup29)
+static lg::f29 to_f29_quot(const lg_host::Fr& a_mont) {
+    lg_host::Fr rem = lg_host::from_mont(a_mont);
+    uint64_t q[5] = {0, 0, 0, 0, 0};
+    for (int bit = 260; bit >= 0; bit--) {
+        // rem < p < 2^254: the doubled value fits four words
+        rem = lg_host::Fr{{rem.l[0] << 1, (rem.l[1] << 1) | (rem.l[0] >> 63), (rem.l[2] << 1) | (rem.l[1] >> 63), (rem.l[3] << 1) | (rem.l[2] >> 63)}};
+        if (lg_host::geq(rem, lg_host::kP)) {
+            rem = lg_host::sub_raw(rem, lg_host::kP);
+            q[bit >> 6] |= 1ull << (bit & 63);
+        }
+    }
+    return split29(q);
+}
 // three-plane table image of `count` constants
 static void fill_planes(std::vector<uint8_t>& img, size_t count, size_t e, const lg::f29& v) {
     uint32_t* lo = reinterpret_cast<uint32_t*>(img.data());
@@ -108,6 +138,22 @@ static lg::Tw29 planes_of(const uint8_t* base, size_t count) {
     t.lo = reinterpret_cast<const uint4*>(base);
     t.mid = reinterpret_cast<const uint4*>(base + 16 * count);
     t.hi = reinterpret_cast<const uint32_t*>(base + 32 * count);
+    return t;
+}
+// six-plane image (constants, then their quotients) for shoup29: 72 bytes per constant
+static void fill_planes_q(std::vector<uint8_t>& img, size_t count, size_t e, const lg_host::Fr& a_mont) {
+    fill_planes(img, count, e, to_f29_plain(a_mont));
+    const lg::f29 q = to_f29_quot(a_mont);
+    uint32_t* lo = reinterpret_cast<uint32_t*>(img.data() + 36 * count);
+    uint32_t* mid = lo + 4 * count;
+    uint32_t* hi = mid + 4 * count;
+    for (int i = 0; i < 4; i++) { lo[4 * e + i] = q.v[i]; mid[4 * e + i] = q.v[4 + i]; }
+    hi[e] = q.v[8];
+}
+static lg::Tw29q planes_q_of(const uint8_t* base, size_t count) {
+    lg::Tw29q t;
+    t.w = planes_of(base, count);
+    t.q = planes_of(base + 36 * count, count);
     return t;
 }
 
@@ -235,10 +281,15 @@ static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon
     lg::NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.canon_out = canon_out;
-    a.tw = planes_of(c->d_tw_inv, c->n_pass_tw);
-    a.coset_tw = planes_of(c->d_fold_inv, (size_t)c->k << c->logo);
-    for (int i = 0; i < 3; i++) a.w8[i] = c->w8_inv[i];
+    a.tw = planes_q_of(c->d_tw_inv, c->n_pass_tw ? c->n_pass_tw : 1);
+    a.coset_tw.w = planes_of(c->d_fold_inv, (size_t)c->k << c->logo);
+    a.coset_tw.q = a.coset_tw.w;  // unused: the fold is a Montgomery dot product
+    a.first2 = a.coset_tw.w;      // unused
+    for (int i = 0; i < 3; i++) { a.w8[i] = c->w8_inv[i]; a.w8q[i] = c->w8q_inv[i]; }
     a.one = c->one29;
+    a.oneq = c->oneq29;
+    a.invk = c->invk29;
+    a.invkq = c->invkq29;
     a.scale = c->scale29;
     a.rows = rows; a.row0 = row0; a.ncos = 0;
     a.plane_stride = 0;
@@ -251,11 +302,19 @@ static lg::NttArgs eval_args(const lg_ctx* c, const fr* coeffs, fr* planes, uint
     lg::NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = coeffs; a.out = planes; a.canon_out = nullptr;
-    a.tw = planes_of(c->d_tw_fwd, c->n_pass_tw);
-    a.coset_tw = planes_of(c->d_coset_tw, (size_t)c->k * c->nplanes);
+    a.tw = planes_q_of(c->d_tw_fwd, c->n_pass_tw ? c->n_pass_tw : 1);
+    if (c->logo == 0) {
+        a.coset_tw = planes_q_of(c->d_coset_tw, (size_t)c->k * c->nplanes);
+    } else {
+        a.coset_tw.w = planes_of(c->d_coset_tw, (size_t)c->k * c->nplanes);
+        a.coset_tw.q = a.coset_tw.w;  // unused: the fold is a Montgomery dot product
+    }
     a.first2 = planes_of(c->d_first2, (size_t)c->nplanes * 2 * c->k);
-    for (int i = 0; i < 3; i++) a.w8[i] = c->w8_fwd[i];
+    for (int i = 0; i < 3; i++) { a.w8[i] = c->w8_fwd[i]; a.w8q[i] = c->w8q_fwd[i]; }
     a.one = c->one29;
+    a.oneq = c->oneq29;
+    a.invk = c->invk29;
+    a.invkq = c->invkq29;
     a.scale = c->scale29;
     a.rows = rows; a.row0 = row0;
     a.ncos = 0;
@@ -418,21 +477,24 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
             a = kOneMont;
             for (uint32_t e = 0; e < k; e++) { pk_inv[e] = a; a = mul(a, wk_inv); }
         }
+        const Fr inv_k = inverse(to_mont(Fr{{k, 0, 0, 0}}));
         // butterfly twiddles in pass order
         c->n_pass_tw = (uint32_t)lg::pass_tw_total(c->logki);
         {
             const size_t cnt = c->n_pass_tw ? c->n_pass_tw : 1;
-            std::vector<uint8_t> tf(cnt * 36), ti(cnt * 36);
+            std::vector<uint8_t> tf(cnt * 72), ti(cnt * 72);
             int logs = c->logki, logr = (c->logki < 3) ? c->logki : ((c->logki % 3) ? (c->logki % 3) : 3);
             while (logs > 0) {
                 const int logsub = logs - logr;
                 if (logsub > 0) {
                     const size_t off = (size_t)lg::pass_tw_offset(c->logki, logs);
+                    // without an outer fold the inverse transform's 1/k rides on the first pass' twiddles
+                    const bool scaled = (logs == c->logki) && c->logo == 0;
                     for (uint32_t m = 1; m < (1u << logr); m++)
                         for (uint32_t i0 = 0; i0 < (1u << logsub); i0++) {
                             const uint32_t e = (i0 * m) << (c->logki - logs);
-                            fill_planes(tf, cnt, off + ((size_t)(m - 1) << logsub) + i0, to_f29(pki[e]));
-                            fill_planes(ti, cnt, off + ((size_t)(m - 1) << logsub) + i0, to_f29(pki_inv[e]));
+                            fill_planes_q(tf, cnt, off + ((size_t)(m - 1) << logsub) + i0, pki[e]);
+                            fill_planes_q(ti, cnt, off + ((size_t)(m - 1) << logsub) + i0, scaled ? mul(pki_inv[e], inv_k) : pki_inv[e]);
                         }
                 }
                 logs -= logr;
@@ -446,9 +508,17 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         // pre-scale table [plane][d] = wn^(s d mod n)
         {
             const size_t cnt = (size_t)c->nplanes * k;
-            std::vector<uint8_t> ct(cnt * 36);
+            // O = 1: plain values + quotients (shoup29); O > 1: Montgomery operands of the fold's dot product
+            std::vector<uint8_t> ct(cnt * (c->logo == 0 ? 72 : 36));
             for (uint32_t sp = 0; sp < c->nplanes; sp++)
-                for (uint32_t d = 0; d < k; d++) fill_planes(ct, cnt, (size_t)sp * k + d, to_f29(pn[((uint64_t)sp * d) & (n - 1)]));
+                for (uint32_t d = 0; d < k; d++) {
+                    // times 2^-256: the evaluation leaves the ABI's Montgomery form with its first product
+                    const Fr w = from_mont(pn[((uint64_t)sp * d) & (n - 1)]);
+                    if (c->logo == 0)
+                        fill_planes_q(ct, cnt, (size_t)sp * k + d, w);
+                    else
+                        fill_planes(ct, cnt, (size_t)sp * k + d, to_f29(w));
+                }
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coset_tw), ct.size()));
             LG_HIP(c, hipMemcpy(c->d_coset_tw, ct.data(), ct.size(), hipMemcpyHostToDevice));
         }
@@ -467,10 +537,11 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
                     const Fr zero = {{0, 0, 0, 0}};
                     const Fr c11 = (t.l[0] | t.l[1] | t.l[2] | t.l[3]) ? sub_raw(kP, t) : zero;
                     const size_t base = (size_t)sp * 4 * half + i0;
-                    fill_planes(ft, cnt, base, to_f29(pre0));
-                    fill_planes(ft, cnt, base + half, to_f29(pre1));
-                    fill_planes(ft, cnt, base + 2 * (size_t)half, to_f29(c10));
-                    fill_planes(ft, cnt, base + 3 * (size_t)half, to_f29(c11));
+                    // all four carry 2^-256 (see the pre-scale table)
+                    fill_planes(ft, cnt, base, to_f29(from_mont(pre0)));
+                    fill_planes(ft, cnt, base + half, to_f29(from_mont(pre1)));
+                    fill_planes(ft, cnt, base + 2 * (size_t)half, to_f29(from_mont(c10)));
+                    fill_planes(ft, cnt, base + 3 * (size_t)half, to_f29(from_mont(c11)));
                 }
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_first2), ft.size()));
             LG_HIP(c, hipMemcpy(c->d_first2, ft.data(), ft.size(), hipMemcpyHostToDevice));
@@ -480,21 +551,26 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
             const size_t cnt = (size_t)k << c->logo;
             std::vector<uint8_t> ft(cnt * 36);
             for (uint32_t h = 0; h < (1u << c->logo); h++)
-                for (uint32_t d = 0; d < k; d++) fill_planes(ft, cnt, (size_t)h * k + d, to_f29(pk_inv[((uint64_t)h * d) & (k - 1)]));
+                for (uint32_t d = 0; d < k; d++) fill_planes(ft, cnt, (size_t)h * k + d, to_f29(mul(pk_inv[((uint64_t)h * d) & (k - 1)], inv_k)));
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_fold_inv), ft.size()));
             LG_HIP(c, hipMemcpy(c->d_fold_inv, ft.data(), ft.size(), hipMemcpyHostToDevice));
         }
         const Fr w8 = domain_generator(3), w8i = inverse(w8);
         Fr p = w8, pi = w8i;
         for (int i = 0; i < 3; i++) {
-            c->w8_fwd[i] = to_f29(p);
-            c->w8_inv[i] = to_f29(pi);
+            c->w8_fwd[i] = to_f29_plain(p);
+            c->w8_inv[i] = to_f29_plain(pi);
+            c->w8q_fwd[i] = to_f29_quot(p);
+            c->w8q_inv[i] = to_f29_quot(pi);
             p = mul(p, w8);
             pi = mul(pi, w8i);
         }
         Fr kk = {{k, 0, 0, 0}};
-        c->one29 = to_f29(kOneMont);
-        c->scale29 = to_f29(inverse(to_mont(kk)));
+        c->one29 = to_f29_plain(kOneMont);
+        c->oneq29 = to_f29_quot(kOneMont);
+        c->scale29 = to_f29(inv_k);
+        c->invk29 = to_f29_plain(inv_k);
+        c->invkq29 = to_f29_quot(inv_k);
         c->r2 = to_dev(kR2);
         c->r3 = to_dev(mul(kR2, kR2));  // R^2 (*) R^2 = R^4 / R = R^3
         return LG_OK;

@@ -35,15 +35,20 @@ struct NttArgs {
     const fr* in;        // interpolate: message rows [rows][k]; evaluate: coefficient rows [rows][k]  (ABI words)
     fr* out;             // interpolate: coefficient rows [rows][k]; evaluate: base of the planes [8 O][rows][ki]
     fr* canon_out;       // interpolate, O = 1 only: canonical (non-Montgomery) copy of the message = plane 0 (may be null)
-    Tw29 tw;             // butterfly twiddles of the size-ki transform in pass order (pass_tw_offset below), * 2^261;
-                         // root = omega_ki^-1 (interpolate) or omega_ki (evaluate)
-    Tw29 coset_tw;       // evaluate: [plane s][d < k] = omega_n^(s d) * 2^261, the pre-scale of coefficient d;
-                         // interpolate with O > 1: [h < O][d < k] = omega_k^(-h d) * 2^261
+    Tw29q tw;            // butterfly twiddles of the size-ki transform in pass order (pass_tw_offset below), plain
+                         // value + Barrett quotient (shoup29); root = omega_ki^-1 (interpolate) or omega_ki (evaluate)
+    Tw29q coset_tw;      // evaluate, O = 1: [plane s][d < k] = omega_n^(s d), the pre-scale of coefficient d (plain +
+                         // quotient); O > 1: the same * 2^261 (Montgomery dot product, .q unused);
+                         // interpolate with O > 1: [h < O][d < k] = omega_k^(-h d) * 2^261 (.q unused)
     Tw29 first2;         // evaluate, k = 2 (mod 8 stages: log2 k = 1 mod 3), O = 1: the radix-2 first pass as two dot
-                         // products, [plane s][4][i0 < k/2] = pre(i0), pre(i0 + k/2), pre(i0) w^i0, -pre(i0 + k/2) w^i0
-    f29 w8[3];           // w_8^1, w_8^2 (= w_4), w_8^3 of this direction, * 2^261
-    f29 one;             // 2^261 mod p: the multiplier that only normalises (output 0 of each butterfly)
-    f29 scale;           // interpolate only: 2^261 / k
+                         // products, [plane s][4][i0 < k/2] = pre(i0), pre(i0 + k/2), pre(i0) w^i0, -pre(i0 + k/2) w^i0,
+                         // all * 2^261 (mul29_dot)
+    f29 w8[3];           // w_8^1, w_8^2 (= w_4), w_8^3 of this direction, plain
+    f29 w8q[3];          // their Barrett quotients
+    f29 one, oneq;       // 1 and floor(2^261 / p): only the ablation builds of tools/ntt_bench.hip multiply by it
+    f29 scale;           // interpolate, single-pass sizes (k <= 8) only: 2^261 / k (Montgomery operand)
+    f29 invk, invkq;     // interpolate, O = 1, multi-pass: 1 / k and its quotient, applied to output 0 of the first pass
+                         // (the other outputs get it through the first pass' twiddles, which the host pre-scales)
     uint32_t rows;       // rows handled by this launch
     uint32_t row0;       // first row (offset into in/out)
     uint32_t ncos;       // evaluate only: number of planes in `cosets`
@@ -96,19 +101,19 @@ struct LdsPlanes {
 // In-register size-2^LOGR DFT, decimation in frequency, on N inputs (limbs < 2^29, value < 2p).
 // On return y[m] = sum_q e[q] w_R^(q m) in natural order m, as lazy values with limbs
 // <= 5 * 2^29 and value < 24p (tests/test_limb_bounds.py replays these networks with interval
-// arithmetic).  w8[] holds w_8^1..3 of the transform direction (* 2^261).
+// arithmetic).  w8[] holds w_8^1..3 of the transform direction, w8q[] their Barrett quotients.
 template <int LOGR>
-__device__ __forceinline__ void dft_regs(f29 (&e)[1 << LOGR], const f29 (&w8)[3]);
+__device__ __forceinline__ void dft_regs(f29 (&e)[1 << LOGR], const f29 (&w8)[3], const f29 (&w8q)[3]);
 
 template <>
-__device__ __forceinline__ void dft_regs<1>(f29 (&e)[2], const f29 (&)[3]) {
+__device__ __forceinline__ void dft_regs<1>(f29 (&e)[2], const f29 (&)[3], const f29 (&)[3]) {
     bfly29<4, 29>(e[0], e[1]);
 }
 template <>
-__device__ __forceinline__ void dft_regs<2>(f29 (&e)[4], const f29 (&w8)[3]) {
+__device__ __forceinline__ void dft_regs<2>(f29 (&e)[4], const f29 (&w8)[3], const f29 (&w8q)[3]) {
     bfly29<4, 29>(e[0], e[2]);
     bfly29<4, 29>(e[1], e[3]);
-    mul29(e[3], e[3], w8[1]);
+    shoup29(e[3], e[3], w8[1], w8q[1]);
     bfly29<8, 30>(e[0], e[1]);  // y0, y2
     bfly29<4, 29>(e[2], e[3]);  // y1, y3
     const f29 t = e[1];
@@ -116,18 +121,21 @@ __device__ __forceinline__ void dft_regs<2>(f29 (&e)[4], const f29 (&w8)[3]) {
     e[2] = t;
 }
 template <>
-__device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3]) {
+__device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3], const f29 (&w8q)[3]) {
     bfly29<4, 29>(e[0], e[4]);
     bfly29<4, 29>(e[1], e[5]);
     bfly29<4, 29>(e[2], e[6]);
     bfly29<4, 29>(e[3], e[7]);
-    mul29(e[5], e[5], w8[0]);
-    mul29(e[6], e[6], w8[1]);
-    mul29(e[7], e[7], w8[2]);
+    shoup29(e[5], e[5], w8[0], w8q[0]);
+    order29(e[5], e[6]);
+    shoup29(e[6], e[6], w8[1], w8q[1]);
+    order29(e[6], e[7]);
+    shoup29(e[7], e[7], w8[2], w8q[2]);
     // even outputs: size-4 DFT of the sums e[0..3] (limbs <= 2B, value < 4p)
     bfly29<8, 30>(e[0], e[2]);
     bfly29<8, 30>(e[1], e[3]);
-    mul29(e[3], e[3], w8[1]);
+    order29(e[7], e[3]);
+    shoup29(e[3], e[3], w8[1], w8q[1]);
     norm29(e[0]);
     norm29(e[1]);
     norm29(e[2]);
@@ -136,7 +144,8 @@ __device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3]) {
     // odd outputs: size-4 DFT of (e[4] lazy, e[5..7] products)
     bfly29<4, 29>(e[4], e[6]);
     bfly29<4, 29>(e[5], e[7]);
-    mul29(e[7], e[7], w8[1]);
+    order29(e[3], e[7]);
+    shoup29(e[7], e[7], w8[1], w8q[1]);
     norm29(e[4]);
     norm29(e[6]);
     bfly29<8, 30>(e[4], e[5]);  // y1, y5
@@ -194,12 +203,17 @@ __device__ __forceinline__ int dif_position(int j) {
 
 // Launch-invariant operands, copied out of the kernel argument block once so that they stay
 // in scalar registers.
+#ifndef LG_Y0
+#define LG_Y0(x) reduce29(x, x)
+#endif
 struct NttConsts {
-    Tw29 tw;
+    Tw29q tw;
     Tw29 first2;
     f29 w8[3];
-    f29 one;
-    f29 last;  // multiplier applied to every output of the last pass (interpolate: 2^261 / k)
+    f29 w8q[3];
+    f29 one, oneq;
+    f29 last;         // interpolate, single pass: Montgomery multiplier 2^261 / k of every output
+    f29 invk, invkq;  // interpolate, O = 1, several passes: 1 / k for output 0 of the first pass
 };
 
 // Synchronisation between passes.  When one NTT is owned by at most one wave (k <= 512) no
@@ -222,7 +236,7 @@ __device__ __forceinline__ void ntt_sync() {
 // plane id (evaluate) or the outer output index h (interpolate).
 template <int LOGK, int LOGO, int LOGS, int LOGR, bool FIRST, bool EVALUATE>
 __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, int t, bool active, const NttConsts& a,
-                                         const fr* __restrict__ gin, const Tw29& pre_tw, uint32_t sel,
+                                         const fr* __restrict__ gin, const Tw29q& pre_tw, uint32_t sel,
                                          fr* __restrict__ canon_out) {
     constexpr int K = 1 << LOGK;
     constexpr int O = 1 << LOGO;
@@ -268,11 +282,13 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
                 e[q] = unpack29(raw[q]);
                 if constexpr (EVALUATE) {
 #ifdef LG_ABL_NO_PRE
-                    const f29 pw = a.one;
+                    const f29 pw = a.one, pq = a.oneq;
 #else
-                    const f29 pw = tw29_load(pre_tw, ((size_t)sel << LOGK) + d);
+                    const f29 pw = tw29_load(pre_tw.w, ((size_t)sel << LOGK) + d);
+                    const f29 pq = tw29_load(pre_tw.q, ((size_t)sel << LOGK) + d);
 #endif
-                    mul29(e[q], e[q], pw);
+                    if constexpr (q > 0) order29(e[q - 1], e[q]);
+                    shoup29(e[q], e[q], pw, pq);
                 } else {
                     if (canon_out != nullptr) {
                         f29 c;
@@ -291,7 +307,7 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
                     constexpr int c = decltype(cc)::value;
                     const uint32_t dd = (uint32_t)d + ((uint32_t)c << LOGK);
                     x[c] = unpack29(fr_load(gin + dd));
-                    f[c] = tw29_load(pre_tw, ((size_t)sel << (LOGK + LOGO)) + dd);
+                    f[c] = tw29_load(pre_tw.w, ((size_t)sel << (LOGK + LOGO)) + dd);
                 });
                 mul29_dot<O>(e[q], x, f);
             });
@@ -306,28 +322,35 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
 #endif
             });
         }
-        dft_regs<LOGR>(e, a.w8);
+        dft_regs<LOGR>(e, a.w8, a.w8q);
+        // Constant factors ride on multiplications that happen anyway (the transform is linear):
+        //   evaluate: the pre-scale table carries 2^-256, so data leave the ABI's Montgomery form in the
+        //     first pass and the last pass only has to reduce -- the codeword is stored canonical;
+        //   interpolate: 1/k sits in the first pass (its twiddles are pre-scaled, output 0 is multiplied
+        //     explicitly; with an outer fold it is in the fold table), so the last pass only reduces.
         if constexpr (LOGSUB > 0) {
-            if constexpr (FIRST && !EVALUATE && LOGO == 0 && LOGR == 1)
-                norm29_strict(e[0]);  // sum of two canonical inputs: already < 2p, only the limbs need carrying
+            if constexpr (FIRST && !EVALUATE && LOGO == 0)
+                shoup29(e[0], e[0], a.invk, a.invkq);
             else
-                mul29(e[0], e[0], a.one);
+                reduce29(e[0], e[0]);  // output 0 has no twiddle: a partial reduction instead of a product by one
             static_for<1, R>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
 #ifdef LG_ABL_NO_TW  // ablation builds only (tools/ntt_bench.hip)
-                const f29 w = a.one;
+                const f29 w = a.one, wq = a.oneq;
 #else
-                const f29 w = tw29_load(a.tw, (size_t)(pass_tw_offset(LOGK, LOGS) + ((m - 1) << LOGSUB) + i0));
+                const size_t te = (size_t)(pass_tw_offset(LOGK, LOGS) + ((m - 1) << LOGSUB) + i0);
+                const f29 w = tw29_load(a.tw.w, te), wq = tw29_load(a.tw.q, te);
 #endif
-                mul29(e[m], e[m], w);
+                order29(e[m - 1], e[m]);
+                shoup29(e[m], e[m], w, wq);
             });
         } else {
             static_for<0, R>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                if constexpr (EVALUATE)
-                    mul29_small(e[m], e[m], 32u);  // leave Montgomery form: the codeword is stored canonical
+                if constexpr (FIRST && !EVALUATE && LOGO == 0)
+                    mul29(e[m], e[m], a.last);  // single-pass interpolation (k <= 8): nowhere earlier to put 1/k
                 else
-                    mul29(e[m], e[m], a.last);
+                    reduce29(e[m], e[m]);
             });
         }
         static_for<0, R>([&](auto mc) {
@@ -354,7 +377,7 @@ __device__ __forceinline__ void dif_rest(const LdsPlanes& row, int slot_base, in
 
 // grid: ceil(work / kNttsPerWg) workgroups; work = rows * O (interpolate) or rows * ncos (evaluate)
 template <int LOGK, int LOGO, bool EVALUATE>
-__global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(const NttArgs a) {
+__global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(const NttArgs a) {
     using Plan = NttPlan<LOGK>;
     constexpr int K = 1 << LOGK;  // LDS-resident transform size ki; the row length is K << LOGO
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -392,13 +415,21 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads) ntt_rows_kernel(con
     cs.w8[0] = a.w8[0];
     cs.w8[1] = a.w8[1];
     cs.w8[2] = a.w8[2];
+    cs.w8q[0] = a.w8q[0];
+    cs.w8q[1] = a.w8q[1];
+    cs.w8q[2] = a.w8q[2];
     cs.one = a.one;
+    cs.oneq = a.oneq;
     cs.last = a.scale;
+    cs.invk = a.invk;
+    cs.invkq = a.invkq;
     fr* canon = (!EVALUATE && LOGO == 0 && a.canon_out != nullptr) ? a.canon_out + row_in : nullptr;
     dif_pass<LOGK, LOGO, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, slot_base, t, active, cs, a.in + row_in, a.coset_tw, sel, canon);
     dif_rest<LOGK, LOGO, LOGK - Plan::kFirstLogR, EVALUATE>(row, slot_base, t, active, cs);
     ntt_sync<LOGK>();
     if (!active) return;
+    // (persistent workgroups striding over the rows were measured: no gain -- workgroup dispatch is
+    // not what limits this kernel -- and the loop-carried constants cost ~80 VGPRs of SGPR spills)
     if constexpr (EVALUATE) {
         fr* gout = a.out + (size_t)sel * a.plane_stride + ((size_t)(a.row0 + r) << LOGK);
         for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));

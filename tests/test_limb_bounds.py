@@ -5,7 +5,10 @@ with interval arithmetic and checks every bound ligero_amd/csrc/fr29_gfx950.h re
     limb-wise non-negative for the subtrahends they are used with;
   * no limb ever exceeds 32 bits, and every Montgomery-product input has limbs <= 6 * 2^29 and
     value < 2^261, so the 64-bit column accumulators of mul29 cannot overflow;
-  * mul29 / mul29_dot / mul29_small on random and extreme operands equal the big-int result.
+  * mul29 / mul29_dot / mul29_small on random and extreme operands equal the big-int result;
+  * shoup29 (product by a table constant with a precomputed Barrett quotient) and reduce29 are
+    congruent to the big-int result, stay below 2p for every input below 64p, and never
+    overflow their 64-bit column sums.
 """
 import os
 import random
@@ -38,8 +41,14 @@ def parse_tables():
 P29, BIAS = parse_tables()
 
 
+NP29 = [int(x, 16) for x in re.search(r"NP\[9\] = \{([^}]*)\}", HDR, re.S).group(1).replace("u", "").split(",")]
+MU29 = int(re.search(r"kMu29 = (\d+);", HDR).group(1))
+
+
 def test_constants():
     assert value(P29) == P and all(v < B for v in P29[:8])
+    assert value(NP29) == (1 << 261) - P and all(v < B for v in NP29)
+    assert MU29 == (1 << 261) // P
     assert int(re.search(r"kPinv29 = (0x[0-9a-f]+)u", HDR).group(1), 16) == (-pow(P, -1, B)) % B
     assert set(BIAS) == {(4, 29), (8, 30), (16, 30)}
     for (K, L), t in BIAS.items():
@@ -79,8 +88,11 @@ def norm(a):
 
 
 def mul(a):
+    """mul29 or shoup29: both need the same operand bounds; shoup29's result is below 2p only while
+    the operand is below 64p (fr29_gfx950.h), which the networks keep with room to spare"""
     assert a.limb <= MAX_MUL_LIMB, f"mul input limb {a.limb / B:.2f} * 2^29"
     assert a.val * P < (1 << 261), "mul input value >= 2^261"
+    assert a.val <= 64, "shoup29 result could reach 2p"
     # column sum: 9 products a_i * b_j (b_j < 2^29) + 9 reduction products + carry
     assert 8 * a.limb * M + max(a.top, a.limb) * M + 9 * M * M + (1 << 36) < 2**64
     return N()
@@ -124,13 +136,21 @@ def dft2(e):
     return list(bfly(e[0], e[1], 4, 29))
 
 
+def reduce(a):
+    """reduce29: any dirty operand below 2^261 with 32-bit limbs"""
+    assert a.limb < 2**32 and a.top < B and a.val * P < (1 << 261)
+    return N()
+
+
 def test_butterfly_networks_stay_in_range():
-    """every output of a pass is multiplied once (twiddle / one / scale / 32): inputs of the next
-    pass are N again, so checking one pass of each radix with N inputs covers all passes"""
+    """every output of a pass goes through a product (twiddle, 1/k) or reduce29 (output 0, last
+    pass): inputs of the next pass are N again, so checking one pass of each radix with N inputs
+    covers all passes"""
     for net, r in ((dft8, 8), (dft4, 4), (dft2, 2)):
         outs = net([N() for _ in range(r)])
         for o in outs:
             mul(o)
+            reduce(o)
 
 
 def test_network_source_matches_model():
@@ -139,7 +159,8 @@ def test_network_source_matches_model():
     src = open(os.path.join(ROOT, "ligero_amd", "csrc", "ntt_kernels.h")).read()
     body = src[src.index("dft_regs<3>(f29 (&e)[8]"):]
     body = body[:body.index("// registers now hold")]
-    ops = re.findall(r"(bfly29<\d+, \d+>\(e\[\d\], e\[\d\]\)|mul29\(e\[\d\]|norm29\(e\[\d\]\))", body)
+    ops = re.findall(r"(bfly29<\d+, \d+>\(e\[\d\], e\[\d\]\)|shoup29\(e\[\d\]|norm29\(e\[\d\]\))", body)
+    ops = [o.replace("shoup29", "mul29") for o in ops]
     expect = ["bfly29<4, 29>(e[0], e[4])", "bfly29<4, 29>(e[1], e[5])", "bfly29<4, 29>(e[2], e[6])", "bfly29<4, 29>(e[3], e[7])",
               "mul29(e[5]", "mul29(e[6]", "mul29(e[7]",
               "bfly29<8, 30>(e[0], e[2])", "bfly29<8, 30>(e[1], e[3])", "mul29(e[3]", "norm29(e[0])", "norm29(e[1])", "norm29(e[2])",
@@ -197,3 +218,71 @@ def test_mul29_model_exact():
     for a, _ in cases:
         r = mul29_model(a, None, small=32)
         assert value(r) % P == value(a) * 32 * rinv % P
+
+
+# ---- exact models of shoup29 / reduce29
+def shoup29_model(a, w, wq):
+    acc = 0
+    q = [0] * 9
+    for c in range(7, 17):
+        for i in range(max(0, c - 8), min(8, c) + 1):
+            acc += a[i] * wq[c - i]
+        assert acc < 2**64
+        if c >= 9:
+            q[c - 9] = acc & M
+        acc >>= 29
+    assert acc < 2**32
+    q[8] = acc
+    acc = 0
+    r = [0] * 9
+    for c in range(9):
+        for i in range(c + 1):
+            acc += a[i] * w[c - i] + q[i] * NP29[c - i]
+        assert acc < 2**64
+        r[c] = acc & M
+        acc >>= 29
+    return r
+
+
+def reduce29_model(a):
+    q = (a[8] * MU29) >> 29
+    assert a[8] * MU29 < 2**64
+    acc = 0
+    r = [0] * 9
+    for c in range(9):
+        acc += q * NP29[c] + a[c]
+        assert acc < 2**64
+        r[c] = acc & M
+        acc >>= 29
+    return r
+
+
+def dirty_operands(rng, count):
+    """limbs 0..7 up to the 6 * 2^29 cap, values spread over [0, 2^261)"""
+    out = [[6 * B] * 8 + [((1 << 261) - value([6 * B] * 8 + [0])) >> 232], [0] * 9, limbs29(P), limbs29((1 << 261) - 1)]
+    while len(out) < count:
+        v = [rng.randrange(0, 6 * B + 1) for _ in range(8)] + [rng.randrange(0, 1 << rng.choice((1, 8, 20, 28)))]
+        if value(v) < (1 << 261):
+            out.append(v)
+    return out
+
+
+def test_shoup29_model_exact():
+    rng = random.Random(2)
+    consts = [0, 1, P - 1, (P - 1) // 2] + [rng.randrange(P) for _ in range(12)]
+    for a in dirty_operands(rng, 300):
+        for w in consts:
+            r = shoup29_model(a, limbs29(w), limbs29((w << 261) // P))
+            assert all(v < B for v in r[:8])
+            assert value(r) % P == value(a) * w % P
+            assert value(r) < (2 * P + (value(a) * P >> 261) + 1)          # 0 <= r < (2 + a / 2^261) p
+            if value(a) < 64 * P:
+                assert value(r) < 2 * P
+
+
+def test_reduce29_model_exact():
+    rng = random.Random(3)
+    for a in dirty_operands(rng, 2000):
+        r = reduce29_model(a)
+        assert all(v < B for v in r[:8])
+        assert value(r) % P == value(a) % P and value(r) < 2 * P

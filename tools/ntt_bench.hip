@@ -18,25 +18,31 @@ int main(int argc, char** argv) {
     CK(hipMalloc((void**)&in, (size_t)rows * K * 32));
     CK(hipMalloc((void**)&out, (size_t)8 * rows * K * 32));
     const size_t ntw = pass_tw_total(LOGK) ? pass_tw_total(LOGK) : 1;
-    CK(hipMalloc((void**)&tw, ntw * 36));
-    CK(hipMalloc((void**)&ctw, (size_t)8 * K * 36));
+    uint8_t* f2;
+    CK(hipMalloc((void**)&tw, ntw * 72));
+    CK(hipMalloc((void**)&ctw, (size_t)8 * K * 72));
+    CK(hipMalloc((void**)&f2, (size_t)8 * 2 * K * 36));
     CK(hipMemset(in, 0x11, (size_t)rows * K * 32));
-    CK(hipMemset(tw, 0x05, ntw * 36));
-    CK(hipMemset(ctw, 0x03, (size_t)8 * K * 36));
+    CK(hipMemset(tw, 0x05, ntw * 72));
+    CK(hipMemset(ctw, 0x03, (size_t)8 * K * 72));
+    CK(hipMemset(f2, 0x07, (size_t)8 * 2 * K * 36));
     NttArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.canon_out = nullptr;
-    a.tw = Tw29{(const uint4*)tw, (const uint4*)(tw + 16 * ntw), (const uint32_t*)(tw + 32 * ntw)};
-    a.coset_tw = Tw29{(const uint4*)ctw, (const uint4*)(ctw + 16 * 8 * K), (const uint32_t*)(ctw + 32 * 8 * K)};
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 9; j++) a.w8[i].v[j] = 0x01234567u >> (j & 3);
-    for (int j = 0; j < 9; j++) { a.one.v[j] = 0x00abcdefu; a.scale.v[j] = 0x00123456u; }
+    auto planes = [](const uint8_t* b, size_t n) { return Tw29{(const uint4*)b, (const uint4*)(b + 16 * n), (const uint32_t*)(b + 32 * n)}; };
+    a.tw = Tw29q{planes(tw, ntw), planes(tw + 36 * ntw, ntw)};
+    a.coset_tw = Tw29q{planes(ctw, (size_t)8 * K), planes(ctw + (size_t)36 * 8 * K, (size_t)8 * K)};
+    a.first2 = planes(f2, (size_t)8 * 2 * K);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 9; j++) { a.w8[i].v[j] = 0x01234567u >> (j & 3); a.w8q[i].v[j] = 0x00765432u >> (j & 3); }
+    for (int j = 0; j < 9; j++) { a.one.v[j] = 0x00abcdefu; a.oneq.v[j] = 0x00fedcbau; a.scale.v[j] = 0x00123456u; }
     a.rows = rows; a.row0 = 0; a.ncos = 7;
     for (int s = 0; s < 7; s++) a.cosets[s] = s + 1;
     a.plane_stride = (uint64_t)rows * K;
     auto kern = ntt_rows_kernel<LOGK, 0, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Plan::kLdsBytes));
     const uint64_t work = (uint64_t)rows * 7;
-    const uint32_t grid = (uint32_t)((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg);
+    uint32_t grid = (uint32_t)((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg);
+    if (argc > 2 && atoi(argv[2]) > 0 && grid > (uint32_t)atoi(argv[2])) grid = atoi(argv[2]);  // persistent workgroups
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
@@ -48,6 +54,6 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    printf("logk=%d rows=%u evaluate(7 cosets): %.3f ms  (%.1f us per WG-slot on 256 CUs)\n", LOGK, rows, best, best * 1e3 * 256 / grid);
+    printf("logk=%d rows=%u evaluate(7 cosets): %.3f ms  (%.1f us per WG-slot on 256 CUs)\n", LOGK, rows, best, best * 1e3 * 256 / ((work + Plan::kNttsPerWg - 1) / Plan::kNttsPerWg));
     return 0;
 }
