@@ -51,6 +51,8 @@ struct NttArgs {
                          // (the other outputs get it through the first pass' twiddles, which the host pre-scales)
     uint32_t rows;       // rows handled by this launch
     uint32_t row0;       // first row (offset into in/out)
+    uint32_t chunk_rows;    // launch row r is matrix row row0 + (r / chunk_rows) * proof_stride + r % chunk_rows:
+    uint32_t proof_stride;  // the same row range of every proof of a batch (chunk_rows >= rows: contiguous rows)
     uint32_t ncos;       // evaluate only: number of planes in `cosets`
     uint8_t cosets[32];  // evaluate only: plane ids (0 .. 8 O - 1)
     uint64_t plane_stride;  // elements between planes (= total_rows * ki)
@@ -402,7 +404,8 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
         r = w / per_row;
         sel = EVALUATE ? (uint32_t)a.cosets[w % per_row] : (w % per_row);
     }
-    const size_t row_in = (size_t)(a.row0 + r) << (LOGK + LOGO);
+    const uint32_t rg = a.row0 + (r / a.chunk_rows) * a.proof_stride + (r % a.chunk_rows);  // row of the matrix
+    const size_t row_in = (size_t)rg << (LOGK + LOGO);
     LdsPlanes row;
     row.a = reinterpret_cast<uint4*>(smem);
     row.b = reinterpret_cast<uint4*>(smem) + (size_t)Plan::kNttsPerWg * K;
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
     // (persistent workgroups striding over the rows were measured: no gain -- workgroup dispatch is
     // not what limits this kernel -- and the loop-carried constants cost ~80 VGPRs of SGPR spills)
     if constexpr (EVALUATE) {
-        fr* gout = a.out + (size_t)sel * a.plane_stride + ((size_t)(a.row0 + r) << LOGK);
+        fr* gout = a.out + (size_t)sel * a.plane_stride + ((size_t)rg << LOGK);
         for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
     } else {
         fr* gout = a.out + row_in + sel;  // coefficient O j + h
