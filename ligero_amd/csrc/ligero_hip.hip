@@ -32,8 +32,12 @@ struct lg_ctx {
     uint64_t total_rows = 0;  // batch * rows
     hipStream_t stream = nullptr;    // encode stream; every public call is ordered on it
     hipStream_t stream_h = nullptr;  // column-hash / Merkle stream of the commit pipeline
+    hipStream_t stream_up = nullptr;  // host -> device copies of lg_encode_commit's row chunks
+    hipStream_t stream_dn = nullptr;  // device -> host copies of the coefficient rows
     static constexpr int kMaxChunks = 8;
     hipEvent_t ev_chunk[kMaxChunks] = {};  // "rows of chunk c are encoded"
+    hipEvent_t ev_up[kMaxChunks] = {};     // "rows of chunk c have arrived from the host"
+    hipEvent_t ev_coef[kMaxChunks] = {};   // "rows of chunk c are interpolated"
     hipEvent_t ev_done = nullptr;          // "tree of this commit is complete"
     uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
     lg_ctx* aux2k = nullptr;               // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
@@ -345,12 +349,19 @@ static int grow(lg_ctx* c, fr** p, size_t* cap, size_t need) {
 struct Chunk {
     uint32_t proof_begin, proof_count, row_begin, row_end;
 };
-static int plan_chunks(const lg_ctx* c, Chunk* out) {
+static int plan_chunks(const lg_ctx* c, Chunk* out, bool from_host = false) {
     int n = 0;
     // a chunk must be big enough (>= 2^25 codeword elements, a few ms of encoding) for the extra
     // launches and cross-stream waits to pay; small commits run as one chunk
     const uint64_t elems = c->total_rows * c->n;
     uint32_t want = c->force_chunks ? c->force_chunks : (uint32_t)(elems >> 25);
+    if (from_host && !c->force_chunks) {
+        // streamed input: the PCIe copy of chunk c+1 hides behind the encoding of chunk c, which pays
+        // from ~16 MiB of input per chunk; at least 4 chunks so that the exposed first copy is short
+        const uint64_t bytes = c->total_rows * c->k * sizeof(fr);
+        const uint32_t up = bytes >= (64ull << 20) ? 8 : (bytes >= (16ull << 20) ? 4 : 1);
+        if (up > want) want = up;
+    }
     if (want > (uint32_t)lg_ctx::kMaxChunks) want = lg_ctx::kMaxChunks;
     if (want <= 1) {
         out[0] = Chunk{0, c->batch, 0, c->rows};
@@ -402,6 +413,8 @@ void lg_ctx_destroy(lg_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream_h) hipStreamSynchronize(c->stream_h);
+    if (c->stream_up) hipStreamSynchronize(c->stream_up);
+    if (c->stream_dn) hipStreamSynchronize(c->stream_dn);
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r};
@@ -416,7 +429,13 @@ void lg_ctx_destroy(lg_ctx* c) {
             for (auto& e : set) hipEventDestroy(e);
     for (auto& e : c->ev_chunk)
         if (e) hipEventDestroy(e);
+    for (auto& e : c->ev_up)
+        if (e) hipEventDestroy(e);
+    for (auto& e : c->ev_coef)
+        if (e) hipEventDestroy(e);
     if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->stream_up) hipStreamDestroy(c->stream_up);
+    if (c->stream_dn) hipStreamDestroy(c->stream_dn);
     if (c->stream_h) hipStreamDestroy(c->stream_h);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -449,7 +468,11 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         LG_HIP(c, hipSetDevice(device));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream_dn, hipStreamNonBlocking));
         for (auto& e : c->ev_chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        for (auto& e : c->ev_up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        for (auto& e : c->ev_coef) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_done, lg_event_flags()));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
         const size_t mat = (size_t)c->total_rows * k;
@@ -621,19 +644,29 @@ int lg_profile_enable(lg_ctx* c, int on) {
     return LG_OK;
 }
 
-int lg_commit_resident(lg_ctx* c) {
-    if (!c) return LG_ERR_BAD_ARG;
+// The commit (mod.rs:521-551).  host_pre == nullptr: the matrix is resident in d_preenc.  Otherwise the
+// rows are streamed from host memory chunk by chunk (same row range of every proof: one strided copy),
+// so that the PCIe transfer of chunk c+1 overlaps the encoding of chunk c; host_coeffs (optional)
+// receives the coefficient rows the same way in the other direction.
+static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeffs) {
     LG_HIP(c, hipSetDevice(c->device));
     const uint64_t plane = c->total_rows * c->ki;
-    const bool prof = c->profiling && c->ev_valid;
+    const bool streamed = host_pre != nullptr;
+    const bool prof = c->profiling && c->ev_valid && !streamed;
     hipEvent_t* ev = c->ev[c->prof_commits % lg_ctx::kProfRing];
     Chunk chunks[lg_ctx::kMaxChunks];
-    const int nchunks = plan_chunks(c, chunks);
+    const int nchunks = plan_chunks(c, chunks, streamed);
     // one chunk: nothing to overlap, so everything stays on the encode stream (no cross-stream waits)
     hipStream_t hs = nchunks > 1 ? c->stream_h : c->stream;
     if (prof) LG_HIP(c, hipEventRecord(ev[0], c->stream));
-    // rows -> coefficients (mod.rs:521-526); also emits the canonical message = coset plane 0
-    {
+    if (streamed) {
+        // copies go on their own stream and the encode stream picks the chunks up by event.  Copy c+1 is
+        // issued after the kernels of chunk c: a copy from pageable memory blocks the calling thread, and
+        // this order lets the device work through chunk c meanwhile
+        LG_HIP(c, hipEventRecord(c->ev_done, c->stream));            // earlier work on the encode stream may still read d_preenc
+        LG_HIP(c, hipStreamWaitEvent(c->stream_up, c->ev_done, 0));
+    } else {
+        // rows -> coefficients (mod.rs:521-526) in one launch; also emits the canonical message = coset plane 0
         lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->logo == 0 ? c->d_u : nullptr, 0, (uint32_t)c->total_rows);
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
         if (c->logo > 0) {
@@ -644,11 +677,32 @@ int lg_commit_resident(lg_ctx* c) {
         }
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[1], c->stream));
+    auto upload_chunk = [&](int i) -> int {
+        const Chunk& ch = chunks[i];
+        const size_t pitch = (size_t)c->rows * c->k * sizeof(fr);    // one proof
+        const size_t off = (size_t)ch.row_begin * c->k * sizeof(fr), width = (size_t)(ch.row_end - ch.row_begin) * c->k * sizeof(fr);
+        LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + off, pitch, reinterpret_cast<const uint8_t*>(host_pre) + off, pitch,
+                                   width, c->batch, hipMemcpyHostToDevice, c->stream_up));
+        LG_HIP(c, hipEventRecord(c->ev_up[i], c->stream_up));
+        return LG_OK;
+    };
+    if (streamed) {
+        const int rc = upload_chunk(0);
+        if (rc != LG_OK) return rc;
+    }
     for (int i = 0; i < nchunks; i++) {
         const Chunk& ch = chunks[i];
         // coefficients -> cosets 1..7 of the order-n domain (mod.rs:528-533)
         const uint32_t row0 = ch.proof_begin * c->rows + ch.row_begin;
         const uint32_t nrows = ch.proof_count * (ch.row_end - ch.row_begin);
+        if (streamed) {
+            LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up[i], 0));
+            lg::NttArgs ia = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, row0, nrows);
+            ia.chunk_rows = ch.row_end - ch.row_begin;
+            ia.proof_stride = c->rows;
+            LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, ia));
+            if (host_coeffs) LG_HIP(c, hipEventRecord(c->ev_coef[i], c->stream));
+        }
         lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, false);
         a.chunk_rows = ch.row_end - ch.row_begin;  // rows [row_begin, row_end) of each proof
         a.proof_stride = c->rows;
@@ -675,6 +729,19 @@ int lg_commit_resident(lg_ctx* c) {
         const uint64_t threads = (uint64_t)ch.proof_count * c->n;
         hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
         LG_HIP(c, hipGetLastError());
+        if (streamed && i + 1 < nchunks) {
+            const int rc = upload_chunk(i + 1);
+            if (rc != LG_OK) return rc;
+        }
+        if (streamed && host_coeffs) {
+            // coefficient rows of this chunk go home while its cosets are being evaluated (issued after
+            // the kernels for the same reason as the uploads: a copy to pageable memory blocks this thread)
+            LG_HIP(c, hipStreamWaitEvent(c->stream_dn, c->ev_coef[i], 0));
+            const size_t pitch = (size_t)c->rows * c->k * sizeof(fr);
+            const size_t off = (size_t)ch.row_begin * c->k * sizeof(fr), width = (size_t)(ch.row_end - ch.row_begin) * c->k * sizeof(fr);
+            LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(host_coeffs) + off, pitch, reinterpret_cast<const uint8_t*>(c->d_coeffs) + off, pitch,
+                                       width, c->batch, hipMemcpyDeviceToHost, c->stream_dn));
+        }
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
     // Merkle tree (mod.rs:544-551): nine levels per launch
@@ -706,6 +773,25 @@ int lg_commit_resident(lg_ctx* c) {
         LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
     }
     c->committed = true;
+    if (streamed && host_coeffs) LG_HIP(c, hipStreamSynchronize(c->stream_dn));
+    return LG_OK;
+}
+
+int lg_commit_resident(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    return commit_core(c, nullptr, nullptr);
+}
+
+int lg_host_register(lg_ctx* c, void* ptr, size_t bytes) {
+    if (!c || !ptr || bytes == 0) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return LG_OK;
+}
+int lg_host_unregister(lg_ctx* c, void* ptr) {
+    if (!c || !ptr) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipHostUnregister(ptr));
     return LG_OK;
 }
 
@@ -771,13 +857,20 @@ int lg_read_nodes(lg_ctx* c, uint8_t* out) {
 
 int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out) {
     if (!c || !preenc || !root_out) return LG_ERR_BAD_ARG;
-    int rc = lg_upload_preenc(c, preenc);
-    if (rc != LG_OK) return rc;
-    rc = lg_commit_resident(c);
-    if (rc != LG_OK) return rc;
-    if (coeffs_out) {
-        rc = lg_read_coeffs(c, coeffs_out);
+    int rc;
+    if (c->logo == 0) {
+        // rows stream in (and coefficients out) while earlier rows are being encoded
+        rc = commit_core(c, preenc, coeffs_out);
         if (rc != LG_OK) return rc;
+    } else {  // k > 4096: the message planes are written by a separate pass over the whole matrix
+        rc = lg_upload_preenc(c, preenc);
+        if (rc != LG_OK) return rc;
+        rc = lg_commit_resident(c);
+        if (rc != LG_OK) return rc;
+        if (coeffs_out) {
+            rc = lg_read_coeffs(c, coeffs_out);
+            if (rc != LG_OK) return rc;
+        }
     }
     return lg_read_root(c, root_out);
 }

@@ -100,16 +100,30 @@ class LigeroCommitter:
         return a.reshape(-1, cols, 4)
 
     # -- the hot path, mod.rs:521-551
-    def encode_commit(self, preenc_u, want_coeffs: bool = True):
+    def encode_commit(self, preenc_u, want_coeffs: bool = True, coeffs_out=None):
         """preenc_u: (batch*rows, k, 4).  Returns (u_polynomial_coeffs or None, u_root bytes
-        [batch*32]).  U, the leaf digests and the tree stay on the device."""
+        [batch*32]).  U, the leaf digests and the tree stay on the device.  coeffs_out: optional
+        preallocated (batch*rows, k, 4) uint64 array to receive the coefficients (a fresh array
+        costs a page fault per 4 KiB on first touch)."""
         pre = self._mat(preenc_u, self.k, "preenc_u")
         if pre.shape[0] != self.batch * self.rows:
             raise ValueError(f"preenc_u has {pre.shape[0]} rows, expected {self.batch * self.rows}")
-        coeffs = np.empty_like(pre) if want_coeffs else None
+        if coeffs_out is not None:
+            if coeffs_out.dtype != np.uint64 or not coeffs_out.flags.c_contiguous or coeffs_out.size != pre.size:
+                raise ValueError("coeffs_out must be a C-contiguous uint64 array of preenc_u's size")
+            coeffs = coeffs_out
+        else:
+            coeffs = np.empty_like(pre) if want_coeffs else None
         root = np.empty(32 * self.batch, dtype=np.uint8)
         self._chk(self._L.lg_encode_commit(self._ctx, _ptr(pre), _ptr(coeffs), _ptr(root)), "lg_encode_commit")
         return coeffs, root.tobytes()
+
+    def host_register(self, array: np.ndarray):
+        """page-lock a host array so that encode_commit can overlap its PCIe copies with the kernels"""
+        self._chk(self._L.lg_host_register(self._ctx, _ptr(array), array.nbytes), "lg_host_register")
+
+    def host_unregister(self, array: np.ndarray):
+        self._chk(self._L.lg_host_unregister(self._ctx, _ptr(array)), "lg_host_unregister")
 
     def upload(self, preenc_u):
         pre = self._mat(preenc_u, self.k, "preenc_u")

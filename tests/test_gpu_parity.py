@@ -148,6 +148,39 @@ def test_small_batches_match_oracle(lg, oracle, batch):
             assert np.array_equal(c.codeword_rows(proof=b), ref["u"])
 
 
+@pytest.mark.parametrize("batch,rows,k", [(3, 70, 32), (1, 300, 1024)])
+def test_streamed_commit_from_registered_host_buffers(lg, oracle, batch, rows, k, monkeypatch):
+    """lg_encode_commit streams its host buffers in row chunks (input in, coefficients out) while
+    earlier chunks are encoded; forced to 4 chunks here so that small shapes take that path, with
+    page-locked (lg_host_register) and with pageable buffers"""
+    monkeypatch.setenv("LG_FORCE_CHUNKS", "4")
+    pre = random_mont(123 + batch, batch * rows * k).reshape(batch * rows, k, 4)
+    ref = [oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, 8 * k) for b in range(batch)]
+    with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+        assert c.pipeline_chunks() == 4
+        for pinned in (True, False):
+            src = pre.copy()
+            out = np.zeros_like(pre)
+            if pinned:
+                c.host_register(src)
+                c.host_register(out)
+            try:
+                got, roots = c.encode_commit(src, coeffs_out=out)
+                assert got is out
+                for b in range(batch):
+                    assert np.array_equal(out[b * rows:(b + 1) * rows], ref[b]["coeffs"])
+                    assert roots[32 * b:32 * b + 32] == ref[b]["root"]
+                    assert np.array_equal(c.codeword_rows(proof=b), ref[b]["u"])
+                # a second commit from the same buffers (the upload must wait for readers of the first)
+                src[0, 0, 0] ^= np.uint64(1)
+                _, roots2 = c.encode_commit(src, want_coeffs=False)
+                assert roots2[:32] == oracle.encode_commit(src[:rows], k, 8 * k, want_u=False)["root"]
+            finally:
+                if pinned:
+                    c.host_unregister(src)
+                    c.host_unregister(out)
+
+
 def test_poseidon_batch64(lg, oracle, model, vectors):
     """BASELINE config 5 shape: 64 independent Poseidon commitments in one batched context"""
     blob = open(os.path.join(GOLDEN, "poseidon_witness_batch64.bin"), "rb").read()
