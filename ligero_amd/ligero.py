@@ -179,15 +179,22 @@ class LigeroCommitter:
         self._chk(self._L.lg_open_columns(self._ctx, proof, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns")
         return cols, sib, paths
 
-    def open_columns_batch(self, indices):
+    def open_columns_batch(self, indices, out=None):
         """open_columns for every proof of the batch in one launch; indices: (batch, t).
-        Returns (columns (batch, t, rows, 4), leaf_sibling_hash (batch, t, 32), auth_path (batch, t, log2 n - 1, 32))."""
+        Returns (columns (batch, t, rows, 4), leaf_sibling_hash (batch, t, 32), auth_path (batch, t, log2 n - 1, 32)).
+        out: optional (columns, sibling, paths) arrays of those shapes from an earlier call, to be
+        overwritten (fresh arrays cost a page fault per 4 KiB; page-lock them with host_register)."""
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(self.batch, -1)
         t = idx.shape[1]
         plen = self.n.bit_length() - 2
-        cols = np.empty((self.batch, t, self.rows, 4), dtype=np.uint64)
-        sib = np.empty((self.batch, t, 32), dtype=np.uint8)
-        paths = np.empty((self.batch, t, plen, 32), dtype=np.uint8)
+        if out is not None:
+            cols, sib, paths = out
+            if cols.shape != (self.batch, t, self.rows, 4) or sib.shape != (self.batch, t, 32) or paths.shape != (self.batch, t, plen, 32):
+                raise ValueError("out arrays do not match this opening")
+        else:
+            cols = np.empty((self.batch, t, self.rows, 4), dtype=np.uint64)
+            sib = np.empty((self.batch, t, 32), dtype=np.uint8)
+            paths = np.empty((self.batch, t, plen, 32), dtype=np.uint8)
         self._chk(self._L.lg_open_columns_batch(self._ctx, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns_batch")
         return cols, sib, paths
 
