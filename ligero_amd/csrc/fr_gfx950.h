@@ -169,5 +169,24 @@ __device__ __forceinline__ void fr_store(fr* p, const fr& a) {
     q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
     q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
+// streaming variants for data that is touched once per kernel (matrix rows in, codeword out): the
+// nontemporal hint keeps them from evicting the twiddle tables every workgroup re-reads from L2
+typedef uint32_t lg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fr fr_load_stream(const fr* p) {
+    const lg_u32x4* q = reinterpret_cast<const lg_u32x4*>(p);
+    const lg_u32x4 lo = __builtin_nontemporal_load(q), hi = __builtin_nontemporal_load(q + 1);
+    fr r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void fr_store_stream(fr* p, const fr& a) {
+    lg_u32x4* q = reinterpret_cast<lg_u32x4*>(p);
+    lg_u32x4 lo, hi;
+    lo.x = a.v[0]; lo.y = a.v[1]; lo.z = a.v[2]; lo.w = a.v[3];
+    hi.x = a.v[4]; hi.y = a.v[5]; hi.z = a.v[6]; hi.w = a.v[7];
+    __builtin_nontemporal_store(lo, q);
+    __builtin_nontemporal_store(hi, q + 1);
+}
 
 }  // namespace lg

@@ -259,8 +259,13 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
             // y0 = x0 c00 + x1 c01, y1 = x0 c10 + x1 c11 -- two dot products (3 multiply-equivalents)
             // instead of two pre-scales, the normalising product of y0 and the twiddle of y1 (4)
             f29 x[2], c0[2], c1[2];
+#ifdef LG_ABL_NO_IN  // ablation builds only: inputs from registers
+            x[0] = a.one; x[0].v[0] += base;
+            x[1] = a.oneq; x[1].v[0] += base;
+#else
             x[0] = unpack29(fr_load(gin + base));
             x[1] = unpack29(fr_load(gin + base + SUB));
+#endif
             const size_t t0 = ((size_t)sel * 4) << LOGSUB;
             c0[0] = tw29_load(a.first2, t0 + i0);
             c0[1] = tw29_load(a.first2, t0 + SUB + i0);
@@ -295,7 +300,7 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
                     if (canon_out != nullptr) {
                         f29 c;
                         mul29_small(c, e[q], 32u);  // x * 2^256 * 32 * 2^-261 = x
-                        fr_store(canon_out + d, pack29_reduced(c));
+                        fr_store_stream(canon_out + d, pack29_reduced(c));
                     }
                 }
             });
@@ -435,11 +440,11 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
     // not what limits this kernel -- and the loop-carried constants cost ~80 VGPRs of SGPR spills)
     if constexpr (EVALUATE) {
         fr* gout = a.out + (size_t)sel * a.plane_stride + ((size_t)rg << LOGK);
-        for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
+        for (int j = t; j < K; j += Plan::kThreadsPerNtt) fr_store_stream(gout + j, pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
     } else {
         fr* gout = a.out + row_in + sel;  // coefficient O j + h
         for (int j = t; j < K; j += Plan::kThreadsPerNtt)
-            fr_store(gout + ((size_t)j << LOGO), pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
+            fr_store_stream(gout + ((size_t)j << LOGO), pack29_reduced(row.get(lds_swz<LOGK>(slot_base + dif_position<LOGK>(j)))));
     }
 }
 

@@ -25,4 +25,9 @@ for WL in poseidon s20; do
     (head -1 "$f"; grep -E 'ntt_rows_kernel|blake2s_columns_kernel|merkle_subtree_kernel' "$f") > "$OUT/${TAG}_${WL}_pmc_${lc}.csv"
   done
 done
+# constant-operand product microbenchmark (Montgomery vs Barrett with precomputed quotient) + its correctness leg
+hipcc -O3 --offload-arch=gfx950 -I ligero_amd/csrc tools/microbench4.hip -o /tmp/microbench4 2>/dev/null \
+  && python3 tools/mb4.py gen && /tmp/microbench4 > "$OUT/${TAG}_microbench4_shoup.log" 2>&1 && python3 tools/mb4.py check >> "$OUT/${TAG}_microbench4_shoup.log" 2>&1
+# PCIe-inclusive host-buffer entry point
+for m in pageable registered; do for w in root coeffs; do python3 tools/pcie_probe.py poseidon $m $w; python3 tools/pcie_probe.py s20 $m $w; done; done > "$OUT/${TAG}_pcie_inclusive.log" 2>/dev/null
 ls -la "$OUT"

@@ -34,8 +34,8 @@ int main(int argc, char** argv) {
     a.coset_tw = Tw29q{planes(ctw, (size_t)8 * K), planes(ctw + (size_t)36 * 8 * K, (size_t)8 * K)};
     a.first2 = planes(f2, (size_t)8 * 2 * K);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 9; j++) { a.w8[i].v[j] = 0x01234567u >> (j & 3); a.w8q[i].v[j] = 0x00765432u >> (j & 3); }
-    for (int j = 0; j < 9; j++) { a.one.v[j] = 0x00abcdefu; a.oneq.v[j] = 0x00fedcbau; a.scale.v[j] = 0x00123456u; }
-    a.rows = rows; a.row0 = 0; a.ncos = 7;
+    for (int j = 0; j < 9; j++) { a.one.v[j] = 0x00abcdefu; a.oneq.v[j] = 0x00fedcbau; a.scale.v[j] = 0x00123456u; a.invk.v[j] = 0x00345678u; a.invkq.v[j] = 0x00876543u; }
+    a.rows = rows; a.row0 = 0; a.ncos = 7; a.chunk_rows = rows; a.proof_stride = 0;
     for (int s = 0; s < 7; s++) a.cosets[s] = s + 1;
     a.plane_stride = (uint64_t)rows * K;
     auto kern = ntt_rows_kernel<LOGK, 0, true>;
