@@ -34,8 +34,9 @@ sys.path.insert(0, ROOT)
 
 P_LIMBS = (0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-MULMOD_PEAK_G = 175.0          # measured: chip-wide 254-bit Montgomery products/s of the kernel's own
-                               # mul29 (tools/microbench3.hip, profiles/r01_microbench3_mulmod.log)
+MAD_PEAK_T = 35.4              # measured v_mad_u64_u32 issue rate of the whole chip, lane-instructions/s / 1e12:
+                               # 1.85 ns per wave-instruction per SIMD x 1024 SIMDs x 64 lanes (tools/microbench2.hip,
+                               # profiles/r01_microbench2_instruction_issue.log)
 
 WORKLOADS = {
     #            rows   k     batch
@@ -64,12 +65,16 @@ def algorithmic_bytes(rows: int, k: int, n: int, batch: int):
     return commit, evaluate
 
 
-def algorithmic_mulmods(rows: int, k: int, n: int, batch: int):
-    """SURVEY §8(d) secondary roof: per row (k/2*log2 k + k) for the iNTT, 7x that for the pruned
-    NTT, + n de-Montgomery products for hashing.  Returns (whole commit, evaluate kernel)."""
+def multiplier_instr_per_element(k: int):
+    """v_mad_u64_u32 / v_mul_lo_u32 instructions the evaluate kernel executes per output element
+    (ligero_amd/csrc/ntt_kernels.h, k <= 4096): shoup29 = 143, reduce29 = 10, Montgomery dot<2> = 261"""
     lg = k.bit_length() - 1
-    ntt = k // 2 * lg + k
-    return batch * rows * (8 * ntt + n), batch * rows * (7 * ntt + 7 * k)
+    if lg < 4 or lg > 12:
+        return None
+    rem = lg % 3
+    first = {0: (8 + 5 + 7) * 143 / 8 + 10 / 8, 1: 261.0, 2: (4 + 1 + 3) * 143 / 4 + 10 / 4}[rem]
+    npass8 = (lg - (rem or 3)) // 3            # radix-8 passes after the first one; the last of them only reduces
+    return first + (npass8 - 1) * ((12 * 143 + 10) / 8) + (5 * 143 + 8 * 10) / 8
 
 
 def device_copy_gbs(torch, nbytes: int = 1 << 30, reps: int = 5) -> float:
@@ -196,7 +201,6 @@ def main():
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
         copy_gbs = device_copy_gbs(torch) if world == 1 else None
-        mm_commit, mm_eval = algorithmic_mulmods(rows, k, n, batch)
         line = {
             "metric": "RS-encoded field-elems/sec (Ligero encode+commit, Poseidon R1CS shape)" if args.workload == "poseidon"
                       else "RS-encoded field-elems/sec (Ligero encode+commit)",
@@ -222,13 +226,28 @@ def main():
             line["roofline"]["measured_copy_GBs"] = copy_gbs
             line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
         # secondary roof: the path is integer-multiply bound, not HBM bound
-        line["valu_roofline"] = {
-            "unit": "G mulmod/s", "peak": MULMOD_PEAK_G, "peak_source": "measured mul29 microbenchmark, whole chip",
-            "commit": mm_commit * args.steps / elapsed / 1e9,
-            "evaluate_kernel": mm_eval / (stage["evaluate"] * 1e-3) / 1e9,
-            "evaluate_frac": mm_eval / (stage["evaluate"] * 1e-3) / 1e9 / MULMOD_PEAK_G,
-            "note": "algorithmic (k/2 log2 k + k) products per transform; the radix-8 kernel executes ~15% more",
-        }
+        mi = multiplier_instr_per_element(k)
+        if mi is not None:
+            rate = batch * rows * 7 * k * mi / (stage["evaluate"] * 1e-3) / 1e12
+            line["valu_roofline"] = {
+                "unit": "T multiplier lane-instr/s", "kernel": "ntt_rows_kernel<evaluate>",
+                "multiplier_instr_per_element": mi, "achieved": rate, "peak": MAD_PEAK_T, "frac": rate / MAD_PEAK_T,
+                "peak_source": "measured v_mad_u64_u32 issue rate, whole chip (tools/microbench2.hip)",
+                "note": "the remaining issue slots go to carries, butterflies, packing and LDS traffic (DESIGN.md 4.2)",
+            }
+        if world == 1 and args.workload == "poseidon":
+            # BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
+            one = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=1, device=local_rank)
+            one.upload(pre[:rows])
+            for _ in range(5):
+                one.commit_resident()
+            one.sync()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                one.commit_resident()
+            one.sync()
+            line["single_commit_ms"] = (time.perf_counter() - t1) / 50 * 1e3
+            one.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
         print(json.dumps(line), flush=True)
