@@ -63,6 +63,26 @@ int lgh_a_row_mul(const lgh_instance* inst, const uint64_t* r, uint64_t* out);
 /* COO dump of A (nnz entries each), row-major order */
 int lgh_a_entries(const lgh_instance* inst, uint64_t* row_idx, uint64_t* col_idx, uint64_t* values);
 
+/*
+ * Fiat-Shamir pieces (ligero_amd/host/transcript.hpp): restated from the published algorithms of
+ * un-vendored crates -- PARITY UNPINNED except the ChaCha block function (RFC 8439 vector).
+ *   lgh_chacha_block                 the block function with `rounds` in {8, 12, 20}
+ *   lgh_field_elements_from_seed     get_field_elements_from_prng   (src/utils.rs:23-29)
+ *   lgh_distinct_indices_from_seed   get_distinct_indices_from_prng (src/utils.rs:31-55); *count_out = t
+ *   lgh_sponge_*                     PoseidonSponge of test_sponge(): absorb(&Vec<u8>), absorb(&Vec<F>),
+ *                                    squeeze_bytes, squeeze_native_field_elements
+ */
+typedef struct lgh_sponge lgh_sponge;
+void lgh_chacha_block(uint32_t rounds, const uint32_t key[8], const uint32_t words12_15[4], uint32_t out[16]);
+int lgh_field_elements_from_seed(const uint8_t seed[32], uint64_t n, uint64_t* out);
+int lgh_distinct_indices_from_seed(const uint8_t seed[32], uint64_t n, uint64_t t, uint64_t* out, uint64_t* count_out);
+lgh_sponge* lgh_sponge_new(void);
+void lgh_sponge_destroy(lgh_sponge* s);
+int lgh_sponge_absorb_bytes(lgh_sponge* s, const uint8_t* data, uint64_t len);
+int lgh_sponge_absorb_elements(lgh_sponge* s, const uint64_t* elems, uint64_t count);
+int lgh_sponge_squeeze_bytes(lgh_sponge* s, uint64_t n, uint8_t* out);
+int lgh_sponge_squeeze_elements(lgh_sponge* s, uint64_t n, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,47 @@
+/*
+ * C ABI of libligero_prover.so: LigeroCircuit::prove / verify (src/ligero/mod.rs:435-455, 613-644)
+ * with the device library underneath (ligero_amd/host/prover.hpp).  The instance handle comes
+ * from include/ligero_host.h (lgh_instance_new = LigeroCircuit::new).  The transcript is the
+ * restated PoseidonSponge of test_sponge() -- PARITY UNPINNED, see ligero_amd/host/transcript.hpp:
+ * a proof made here verifies here; byte equality with a proof of the Rust crate is not claimed.
+ */
+#ifndef LIGERO_PROVER_H
+#define LIGERO_PROVER_H
+
+#include <stdint.h>
+
+#include "ligero_host.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lgp_prover lgp_prover;
+typedef struct lgp_proof lgp_proof;
+
+enum { LGP_OK = 0, LGP_ERR_BAD_ARG = -1, LGP_ERR_PANIC = -2, LGP_ERR_OOM = -3, LGP_ERR_DEVICE = -4 };
+
+const char* lgp_last_error(void);
+
+/* device context for the instance's dimensions (m, k, n, t); the instance must outlive the prover */
+int lgp_prover_create(lgp_prover** out, const lgh_instance* inst, int device);
+void lgp_prover_destroy(lgp_prover* p);
+
+/* prove(var_assignment, mt_params, &mut test_sponge()): assignment by ORIGINAL node index, as for lgh_build_preenc */
+int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proof_out);
+/* verify(proof, mt_params, &mut test_sponge()) */
+int lgp_verify(lgp_prover* p, const lgp_proof* proof, int* accepted_out);
+void lgp_proof_destroy(lgp_proof* proof);
+
+/* inspection: info_out = { len(preenc_u_lc), len(linear poly), len(quadratic poly), opened columns per sub-proof,
+ * column length, auth path length }; root_out = u_root */
+int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_out[32]);
+/* test hook: corrupt one item.  what: 0 u_root byte, 1 preenc_u_lc element, 2 linear polynomial coefficient,
+ * 3 quadratic polynomial coefficient, 4 an element of an opened column (interleaved), 5 same (linear), 6 same
+ * (quadratic), 7 an auth-path digest (interleaved), 8 leaf index of an opening (linear); index selects the item */
+int lgp_proof_tamper(lgp_proof* proof, int what, uint64_t index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGERO_PROVER_H */

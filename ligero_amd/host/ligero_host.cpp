@@ -6,20 +6,10 @@
 #include <string>
 
 #include "../../include/ligero_host.h"
-#include "circuit.hpp"
+#include "host_handles.hpp"
+#include "transcript.hpp"
 
 using namespace ligero;
-
-struct lgh_circuit {
-    ArithmeticCircuit c;
-    std::vector<size_t> outputs;   // set by lgh_circuit_from_r1cs
-    uint32_t n_wires = 0;
-};
-struct lgh_instance {
-    LigeroInstance inst;
-    uint32_t n_wires;
-    lgh_instance(ArithmeticCircuit c, std::vector<size_t> outs, size_t lambda, uint32_t wires) : inst(std::move(c), std::move(outs), lambda), n_wires(wires) {}
-};
 
 static thread_local std::string g_err;
 template <class F>
@@ -158,6 +148,73 @@ int lgh_a_entries(const lgh_instance* i, uint64_t* row_idx, uint64_t* col_idx, u
             o++;
         }
     return LGH_OK;
+}
+
+// ---- Fiat-Shamir pieces (transcript.hpp; PARITY UNPINNED, see there) exposed for tests and FFI callers
+struct lgh_sponge {
+    PoseidonSponge s = PoseidonSponge::test_sponge();
+};
+
+void lgh_chacha_block(uint32_t rounds, const uint32_t key[8], const uint32_t words12_15[4], uint32_t out[16]) {
+    if (rounds == 20) ChaChaRng<20>::block(key, words12_15, out);
+    else if (rounds == 12) ChaChaRng<12>::block(key, words12_15, out);
+    else ChaChaRng<8>::block(key, words12_15, out);
+}
+int lgh_field_elements_from_seed(const uint8_t seed[32], uint64_t n, uint64_t* out) {
+    if (!seed || (!out && n)) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::array<uint8_t, 32> s;
+        std::memcpy(s.data(), seed, 32);
+        const auto v = get_field_elements_from_prng(n, s);
+        for (size_t i = 0; i < v.size(); i++) store_fr(out + 4 * i, v[i]);
+        return LGH_OK;
+    });
+}
+int lgh_distinct_indices_from_seed(const uint8_t seed[32], uint64_t n, uint64_t t, uint64_t* out, uint64_t* count_out) {
+    if (!seed || !out || !count_out || n == 0 || t > n) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::array<uint8_t, 32> s;
+        std::memcpy(s.data(), seed, 32);
+        const auto v = get_distinct_indices_from_prng(n, t, s);
+        for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+        *count_out = v.size();
+        return LGH_OK;
+    });
+}
+lgh_sponge* lgh_sponge_new(void) {
+    lgh_sponge* p = nullptr;
+    guarded([&] { p = new lgh_sponge(); return LGH_OK; });
+    return p;
+}
+void lgh_sponge_destroy(lgh_sponge* s) { delete s; }
+int lgh_sponge_absorb_bytes(lgh_sponge* s, const uint8_t* data, uint64_t len) {
+    if (!s || (!data && len)) return LGH_ERR_BAD_ARG;
+    return guarded([&] { s->s.absorb_bytes(data, len); return LGH_OK; });
+}
+int lgh_sponge_absorb_elements(lgh_sponge* s, const uint64_t* elems, uint64_t count) {
+    if (!s || (!elems && count)) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::vector<Fr> v(count);
+        for (size_t i = 0; i < count; i++) v[i] = load_fr(elems + 4 * i);
+        s->s.absorb_elements(v);
+        return LGH_OK;
+    });
+}
+int lgh_sponge_squeeze_bytes(lgh_sponge* s, uint64_t n, uint8_t* out) {
+    if (!s || (!out && n)) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const auto b = s->s.squeeze_bytes(n);
+        std::memcpy(out, b.data(), n);
+        return LGH_OK;
+    });
+}
+int lgh_sponge_squeeze_elements(lgh_sponge* s, uint64_t n, uint64_t* out) {
+    if (!s || (!out && n)) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const auto v = s->s.squeeze_native_field_elements(n);
+        for (size_t i = 0; i < v.size(); i++) store_fr(out + 4 * i, v[i]);
+        return LGH_OK;
+    });
 }
 
 }  // extern "C"

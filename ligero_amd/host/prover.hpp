@@ -1,0 +1,300 @@
+// LigeroCircuit::prove / verify (src/ligero/mod.rs:435-996) on top of the device library: the
+// host-side protocol logic a Rust prover keeps, restated in C++ because no Rust toolchain exists
+// in the build image.  Everything heavy goes through the C ABI
+// (include/ligero_hip.h):
+//
+//   prove_inner       mod.rs:457-578   lgh-side preenc_u (circuit.hpp) -> lg_encode_commit -> three sub-proofs
+//   prove_interleaved mod.rs:646-669   lg_interleaved_row_mul + open_columns
+//   prove_linear_constraints    mod.rs:712-747   A.row_mul on the host, lg_linear_constraint_poly, open_columns
+//   prove_quadratic_constraints mod.rs:832-859   lg_quadratic_constraint_poly, open_columns
+//   open_columns / verify_column_openings        mod.rs:935-996
+//   verify, verify_interleaved, verify_linear, verify_quadratic_constraints   mod.rs:613-644, 671-708, 748-830, 861-933
+//     (row encodings through lg_reed_solomon*, column hashes and Merkle paths on the host)
+//
+// The transcript is transcript.hpp's PoseidonSponge -- see the PARITY UNPINNED note there: the
+// prover and the verifier below agree with each other; byte equality of the challenges with
+// the Rust crate's is not established.  The algebra (what is computed from given challenges,
+// and every check the verifier makes) follows the reference line by line.
+#pragma once
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ligero_hip.h"
+#include "circuit.hpp"
+#include "hash_host.hpp"
+#include "transcript.hpp"
+
+namespace ligero {
+
+struct OpenedColumns {
+    std::vector<std::vector<Fr>> columns;  // t columns of 4m elements
+    std::vector<MerklePath> paths;
+};
+struct InterleavedProof {       // src/ligero/types.rs InterleavedProof
+    std::vector<Fr> preenc_u_lc;
+    OpenedColumns open;
+};
+struct ConstraintsProof {       // LinearConstraintsProof / QuadraticConstraintsProof
+    std::vector<Fr> polynomial;  // DensePolynomial coefficients, trailing zeros trimmed
+    OpenedColumns open;
+};
+struct LigeroProof {
+    Digest u_root;
+    InterleavedProof interleaved_proof;
+    ConstraintsProof linear_constraints_proof;
+    ConstraintsProof quadratic_constraints_proof;
+};
+
+struct DeviceError : std::runtime_error {
+    int status;
+    DeviceError(int st, const std::string& what) : std::runtime_error(what + ": " + lg_status_string(st)), status(st) {}
+};
+
+// natural-order radix-2 NTT on the host (the verifier's intermediate_domain.fft of 2k points, mod.rs:786, 885)
+inline std::vector<Fr> host_fft(std::vector<Fr> a) {
+    const size_t n = a.size();
+    int logn = 0;
+    while ((size_t{1} << logn) < n) logn++;
+    if ((size_t{1} << logn) != n) throw std::runtime_error("host_fft: size is not a power of two");
+    for (size_t i = 1, j = 0; i < n; i++) {  // bit reversal
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (int s = 1; s <= logn; s++) {
+        const size_t len = size_t{1} << s;
+        const Fr wlen = lg_host::domain_generator(s);
+        for (size_t i = 0; i < n; i += len) {
+            Fr w = fr_one();
+            for (size_t j = 0; j < len / 2; j++) {
+                const Fr u = a[i + j], v = fr_mul(a[i + j + len / 2], w);
+                a[i + j] = fr_add(u, v);
+                a[i + j + len / 2] = fr_sub(u, v);
+                w = fr_mul(w, wlen);
+            }
+        }
+    }
+    return a;
+}
+
+inline Fr poly_evaluate(const std::vector<Fr>& coeffs, const Fr& x) {
+    Fr acc = fr_zero();
+    for (size_t i = coeffs.size(); i-- > 0;) acc = fr_add(fr_mul(acc, x), coeffs[i]);
+    return acc;
+}
+inline void trim_zeros(std::vector<Fr>& c) {  // DensePolynomial::from_coefficients_vec
+    while (!c.empty() && fr_is_zero(c.back())) c.pop_back();
+}
+
+// FieldToBytesColHasher<F, Blake2s256>::evaluate (types.rs:18): Blake2s(LE64(len) || 32-byte LE canonical elements)
+inline Digest column_hash(const std::vector<Fr>& col) {
+    Blake2s h;
+    uint8_t len[8];
+    for (int i = 0; i < 8; i++) len[i] = (uint8_t)((uint64_t)col.size() >> (8 * i));
+    h.update(len, 8);
+    for (const Fr& e : col) {
+        const Fr c = lg_host::from_mont(e);
+        uint8_t b[32];
+        for (int i = 0; i < 32; i++) b[i] = (uint8_t)(c.l[i / 8] >> (8 * (i % 8)));
+        h.update(b, 32);
+    }
+    return h.finalize();
+}
+
+class HipLigero {
+public:
+    HipLigero(const LigeroInstance& inst, int device = 0) : inst_(inst), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t) {
+        const int st = lg_ctx_create(&ctx_, device, (uint32_t)(4 * m_), (uint32_t)k_, (uint32_t)n_);
+        if (st != LG_OK) throw DeviceError(st, "lg_ctx_create");
+        logn_ = 0;
+        while ((size_t{1} << logn_) < n_) logn_++;
+    }
+    ~HipLigero() { lg_ctx_destroy(ctx_); }
+    HipLigero(const HipLigero&) = delete;
+    HipLigero& operator=(const HipLigero&) = delete;
+
+    // ---------------------------------------------------------------- prove (mod.rs:435-578)
+    LigeroProof prove(const std::vector<std::pair<size_t, Fr>>& var_assignment, PoseidonSponge& sponge) {
+        const std::vector<std::vector<Fr>> rows = inst_.build_preenc_u(var_assignment);
+        std::vector<Fr> flat;
+        flat.reserve(4 * m_ * k_);
+        for (const auto& r : rows) flat.insert(flat.end(), r.begin(), r.end());
+        LigeroProof proof;
+        check(lg_encode_commit(ctx_, flat[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
+        sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
+
+        {   // prove_interleaved, mod.rs:646-669
+            const std::vector<Fr> r = get_field_elements_from_prng(4 * m_, sponge.squeeze_seed());
+            proof.interleaved_proof.preenc_u_lc.resize(k_);
+            check(lg_interleaved_row_mul(ctx_, r[0].l, proof.interleaved_proof.preenc_u_lc[0].l), "lg_interleaved_row_mul");
+            sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
+            proof.interleaved_proof.open = open_columns(sponge);
+        }
+        {   // prove_linear_constraints, mod.rs:712-747
+            const std::vector<Fr> r_linear = get_field_elements_from_prng(4 * m_ * k_, sponge.squeeze_seed());
+            const std::vector<Fr> r_a = inst_.a.row_mul(r_linear);
+            std::vector<Fr> poly(2 * k_);
+            check(lg_linear_constraint_poly(ctx_, r_a[0].l, poly[0].l), "lg_linear_constraint_poly");
+            trim_zeros(poly);
+            proof.linear_constraints_proof.polynomial = poly;
+            sponge.absorb_elements(poly);
+            proof.linear_constraints_proof.open = open_columns(sponge);
+        }
+        {   // prove_quadratic_constraints, mod.rs:832-859
+            const std::vector<Fr> r = get_field_elements_from_prng(m_, sponge.squeeze_seed());
+            std::vector<Fr> poly(2 * k_);
+            check(lg_quadratic_constraint_poly(ctx_, r[0].l, poly[0].l), "lg_quadratic_constraint_poly");
+            trim_zeros(poly);
+            proof.quadratic_constraints_proof.polynomial = poly;
+            sponge.absorb_elements(poly);
+            proof.quadratic_constraints_proof.open = open_columns(sponge);
+        }
+        return proof;
+    }
+
+    // ---------------------------------------------------------------- verify (mod.rs:613-644)
+    bool verify(const LigeroProof& proof, PoseidonSponge& sponge) {
+        sponge.absorb_bytes(proof.u_root.data(), 32);
+        return verify_interleaved(proof.interleaved_proof, proof.u_root, sponge) &&
+               verify_linear(proof.linear_constraints_proof, proof.u_root, sponge) &&
+               verify_quadratic_constraints(proof.quadratic_constraints_proof, proof.u_root, sponge);
+    }
+
+    size_t m() const { return m_; }
+    size_t k() const { return k_; }
+    size_t n() const { return n_; }
+    size_t t() const { return t_; }
+
+private:
+    void check(int st, const char* what) const {
+        if (st != LG_OK) throw DeviceError(st, std::string(what) + " (" + lg_last_error(ctx_) + ")");
+    }
+
+    // mod.rs:935-955
+    OpenedColumns open_columns(PoseidonSponge& sponge) {
+        const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
+        const size_t t = indices.size(), rows = 4 * m_, plen = (size_t)logn_ - 1;
+        std::vector<uint32_t> idx(indices.begin(), indices.end());
+        std::vector<Fr> cols(t * rows);
+        std::vector<uint8_t> sib(t * 32), paths(t * plen * 32 + 1);
+        check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)t, cols[0].l, sib.data(), paths.data()), "lg_open_columns");
+        OpenedColumns out;
+        for (size_t c = 0; c < t; c++) {
+            out.columns.emplace_back(cols.begin() + c * rows, cols.begin() + (c + 1) * rows);
+            MerklePath p;
+            p.leaf_index = indices[c];
+            memcpy(p.leaf_sibling_hash.data(), &sib[32 * c], 32);
+            p.auth_path.resize(plen);
+            for (size_t l = 0; l < plen; l++) memcpy(p.auth_path[l].data(), &paths[32 * (c * plen + l)], 32);
+            out.paths.push_back(std::move(p));
+        }
+        return out;
+    }
+
+    // mod.rs:957-996
+    bool verify_column_openings(const OpenedColumns& open, const Digest& root, PoseidonSponge& sponge) const {
+        const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
+        // izip! stops at the shortest of (col_hashes, indices, paths): a proof with fewer openings than t would pass
+        // the reference's zip; require the full set here as well as equality of every index
+        if (open.columns.size() != indices.size() || open.paths.size() != indices.size()) return false;
+        for (size_t c = 0; c < indices.size(); c++) {
+            if (open.columns[c].size() != 4 * m_) return false;
+            if (open.paths[c].leaf_index != indices[c]) return false;
+            if (open.paths[c].auth_path.size() != (size_t)logn_ - 1) return false;
+            if (!merkle_path_verify(open.paths[c], root, column_hash(open.columns[c]))) return false;
+        }
+        return true;
+    }
+
+    // mod.rs:671-708
+    bool verify_interleaved(const InterleavedProof& p, const Digest& root, PoseidonSponge& sponge) {
+        const std::vector<Fr> r = get_field_elements_from_prng(4 * m_, sponge.squeeze_seed());
+        sponge.absorb_elements(p.preenc_u_lc);
+        if (!verify_column_openings(p.open, root, sponge)) return false;
+        if (p.preenc_u_lc.size() > k_) return false;
+        std::vector<Fr> msg = p.preenc_u_lc;
+        msg.resize(k_, fr_zero());
+        std::vector<Fr> w(n_);
+        check(lg_reed_solomon(ctx_, msg[0].l, 1, w[0].l), "lg_reed_solomon");   // mod.rs:702
+        for (size_t c = 0; c < p.open.columns.size(); c++) {
+            Fr acc = fr_zero();
+            for (size_t i = 0; i < 4 * m_; i++) acc = fr_add(acc, fr_mul(r[i], p.open.columns[c][i]));
+            if (!fr_eq(w[p.open.paths[c].leaf_index], acc)) return false;
+        }
+        return true;
+    }
+
+    // mod.rs:748-830
+    bool verify_linear(const ConstraintsProof& p, const Digest& root, PoseidonSponge& sponge) {
+        const std::vector<Fr> r_linear = get_field_elements_from_prng(4 * m_ * k_, sponge.squeeze_seed());
+        const std::vector<Fr> r_a = inst_.a.row_mul(r_linear);
+        // r_polys = small_domain.ifft of every k-chunk of r_a (mod.rs:773-781)
+        std::vector<Fr> r_polys(4 * m_ * k_);
+        check(lg_reed_solomon_interpolate(ctx_, r_a[0].l, (uint32_t)(4 * m_), r_polys[0].l), "lg_reed_solomon_interpolate");
+        if (!p.polynomial.empty() && p.polynomial.size() - 1 >= 2 * k_ - 1) return false;      // degree check, mod.rs:783
+        std::vector<Fr> q = p.polynomial;
+        q.resize(2 * k_, fr_zero());
+        const std::vector<Fr> inter = host_fft(q);                                             // intermediate_domain.fft
+        Fr sum = fr_zero();
+        for (size_t c = 0; c < 2 * k_; c += 2) sum = fr_add(sum, inter[c]);
+        if (!fr_is_zero(sum)) return false;                                                    // mod.rs:794
+        sponge.absorb_elements(p.polynomial);
+        if (!verify_column_openings(p.open, root, sponge)) return false;
+        // r_polys_evals (mod.rs:815-818): every r_i encoded on the large domain; done in row chunks so that the
+        // host never holds more than ~256 MB of encodings (the reference materialises all 4m x n of them)
+        const size_t nopen = p.open.columns.size();
+        std::vector<Fr> acc(nopen, fr_zero());
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(4 * m_, (size_t{256} << 20) / (n_ * sizeof(Fr))));
+        std::vector<Fr> r_evals(chunk * n_);
+        for (size_t i0 = 0; i0 < 4 * m_; i0 += chunk) {
+            const size_t rows = std::min(chunk, 4 * m_ - i0);
+            check(lg_reed_solomon_evaluate(ctx_, r_polys[i0 * k_].l, (uint32_t)rows, r_evals[0].l), "lg_reed_solomon_evaluate");
+            for (size_t c = 0; c < nopen; c++) {
+                const size_t j = p.open.paths[c].leaf_index;
+                for (size_t i = 0; i < rows; i++) acc[c] = fr_add(acc[c], fr_mul(r_evals[i * n_ + j], p.open.columns[c][i0 + i]));
+            }
+        }
+        const size_t cofactor = n_ / (2 * k_);
+        const Fr wn = lg_host::domain_generator(logn_);
+        for (size_t c = 0; c < nopen; c++) {   // sum_i r_i(eta_j) * U_{i, j} = q(eta_j), mod.rs:820-829
+            const size_t j = p.open.paths[c].leaf_index;
+            const Fr eval = (j % cofactor == 0) ? inter[j / cofactor] : poly_evaluate(p.polynomial, lg_host::pow_u64(wn, j));
+            if (!fr_eq(acc[c], eval)) return false;
+        }
+        return true;
+    }
+
+    // mod.rs:861-933
+    bool verify_quadratic_constraints(const ConstraintsProof& p, const Digest& root, PoseidonSponge& sponge) {
+        const std::vector<Fr> r = get_field_elements_from_prng(m_, sponge.squeeze_seed());
+        if (!p.polynomial.empty() && p.polynomial.size() - 1 >= 2 * k_ - 1) return false;
+        std::vector<Fr> p0 = p.polynomial;
+        p0.resize(2 * k_, fr_zero());
+        const std::vector<Fr> inter = host_fft(p0);
+        for (size_t c = 0; c < k_; c++)
+            if (!fr_is_zero(inter[2 * c])) return false;                                       // mod.rs:889
+        const size_t cofactor = n_ / (2 * k_);
+        sponge.absorb_elements(p.polynomial);
+        if (!verify_column_openings(p.open, root, sponge)) return false;
+        const Fr wn = lg_host::domain_generator(logn_);
+        for (size_t c = 0; c < p.open.columns.size(); c++) {
+            const size_t col = p.open.paths[c].leaf_index;
+            const std::vector<Fr>& column = p.open.columns[c];
+            const Fr lhs = (col % cofactor == 0) ? inter[col / cofactor] : poly_evaluate(p.polynomial, lg_host::pow_u64(wn, col));
+            Fr rhs = fr_zero();
+            for (size_t i = 0; i < m_; i++)
+                rhs = fr_add(rhs, fr_mul(r[i], fr_sub(fr_mul(column[i], column[i + m_]), column[i + 2 * m_])));
+            if (!fr_eq(lhs, rhs)) return false;
+        }
+        return true;
+    }
+
+    const LigeroInstance& inst_;
+    size_t m_, k_, n_, t_;
+    int logn_ = 0;
+    lg_ctx* ctx_ = nullptr;
+};
+
+}  // namespace ligero

@@ -1,0 +1,284 @@
+// Fiat-Shamir side of the prover and verifier: everything the reference
+// derives from its sponge.
+//
+//   ChaChaRng<ROUNDS>                 rand_chacha 0.3 ChaCha20Rng (src/utils.rs:27, 36) and, with 12 rounds,
+//                                     rand 0.8 StdRng behind ark_std::test_rng() (round constants of test_sponge)
+//   fr_rand                           ark-ff 0.4 `impl Distribution<Fp<P, N>> for Standard` (F::rand, src/utils.rs:28)
+//   get_field_elements_from_prng      src/utils.rs:23-29
+//   get_distinct_indices_from_prng    src/utils.rs:31-55 (rand 0.8 gen_range on usize)
+//   PoseidonSponge                    ark-crypto-primitives 0.4 sponge::poseidon::PoseidonSponge with the parameters of
+//                                     ark-poly-commit's test_sponge() (src/ligero/tests.rs:151, 399; README.md:98):
+//                                     absorb(&Vec<u8>) mod.rs:560, 634; absorb(&Vec<F>) mod.rs:660, 738, 850;
+//                                     squeeze_bytes(32) mod.rs:653, 719, 839, 941
+//
+// PARITY UNPINNED.  None of these crates is vendored under /root/reference and the reference's
+// tests hold no transcript bytes, so this file restates the published algorithms from the
+// crates' documented behaviour and cannot be checked against a run of the reference here.  What
+// IS pinned: the ChaCha20 block function against the RFC 8439 section 2.3.2 vector
+// (tests/test_transcript.py).  The prover and the verifier of this repository agree with each
+// other by construction; byte equality with a Rust prover's transcript is a claim this file
+// does not make.  Every device call takes its challenges as plain inputs, so a host that links
+// the real arkworks sponge can ignore this file entirely.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <set>
+#include <vector>
+
+#include "circuit.hpp"
+
+namespace ligero {
+
+constexpr size_t kChachaSeedBytes = 32;  // CHACHA_SEED_BYTES, src/lib.rs
+
+// ---- ChaCha block function (RFC 8439 layout with a 64-bit counter + 64-bit stream id, as rand_chacha)
+template <int ROUNDS>
+class ChaChaRng {
+public:
+    explicit ChaChaRng(const std::array<uint8_t, 32>& seed) {
+        for (int i = 0; i < 8; i++)
+            key_[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    }
+    // BlockRng::next_u32 / next_u64: words are consumed in order, a u64 is (low word, high word)
+    uint32_t next_u32() {
+        if (index_ >= 16) refill();
+        return buf_[index_++];
+    }
+    uint64_t next_u64() {
+        const uint64_t lo = next_u32();
+        const uint64_t hi = next_u32();
+        return lo | (hi << 32);
+    }
+    // one 64-byte block for a given counter / nonce words (tests: RFC 8439 2.3.2 uses a 32-bit counter and a 96-bit
+    // nonce, i.e. words 12..15 = counter, n0, n1, n2)
+    static void block(const uint32_t key[8], const uint32_t w12_15[4], uint32_t out[16]) {
+        uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+        for (int i = 0; i < 8; i++) s[4 + i] = key[i];
+        for (int i = 0; i < 4; i++) s[12 + i] = w12_15[i];
+        uint32_t x[16];
+        memcpy(x, s, sizeof(x));
+        auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+        auto qr = [&](int a, int b, int c, int d) {
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        };
+        for (int r = 0; r < ROUNDS / 2; r++) {
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+    }
+
+private:
+    void refill() {
+        const uint32_t w[4] = {(uint32_t)counter_, (uint32_t)(counter_ >> 32), 0, 0};  // stream id 0
+        block(key_, w, buf_);
+        counter_++;
+        index_ = 0;
+    }
+    uint32_t key_[8];
+    uint64_t counter_ = 0;
+    uint32_t buf_[16];
+    int index_ = 16;
+};
+using ChaCha20Rng = ChaChaRng<20>;
+using StdRng = ChaChaRng<12>;  // rand 0.8
+
+// F::rand: four u64 limbs, top two bits masked off (256 - 254), rejected while >= p; the limbs are the
+// element's internal (Montgomery) representation as they are
+template <class Rng>
+inline Fr fr_rand(Rng& rng) {
+    for (;;) {
+        Fr t;
+        for (int i = 0; i < 4; i++) t.l[i] = rng.next_u64();
+        t.l[3] &= ~0ull >> 2;
+        if (!lg_host::geq(t, lg_host::kP)) return t;
+    }
+}
+
+inline std::vector<Fr> get_field_elements_from_prng(size_t n, const std::array<uint8_t, 32>& seed) {
+    ChaCha20Rng rng(seed);
+    std::vector<Fr> out(n);
+    for (auto& x : out) x = fr_rand(rng);
+    return out;
+}
+
+// rand 0.8 UniformInt<usize>::sample_single (gen_range(0..n)): widening multiply with a rejection zone
+template <class Rng>
+inline uint64_t gen_range(Rng& rng, uint64_t n) {
+    const uint64_t zone = (n << __builtin_clzll(n)) - 1;
+    for (;;) {
+        const unsigned __int128 m = (unsigned __int128)rng.next_u64() * n;
+        if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
+    }
+}
+
+inline std::vector<uint64_t> get_distinct_indices_from_prng(uint64_t n, uint64_t t, const std::array<uint8_t, 32>& seed) {
+    ChaCha20Rng rng(seed);
+    std::set<uint64_t> selected;  // BTreeSet: iteration in ascending order
+    const uint64_t to_select = std::min(t, n - t);
+    while (selected.size() < to_select) selected.insert(gen_range(rng, n));
+    std::vector<uint64_t> out;
+    if (to_select == t) {
+        out.assign(selected.begin(), selected.end());
+    } else {
+        for (uint64_t i = 0; i < n; i++)
+            if (!selected.count(i)) out.push_back(i);
+    }
+    return out;
+}
+
+// ---- Poseidon duplex sponge, width 3 (rate 2 + capacity 1)
+inline Fr fr_pow_u64(Fr base, uint64_t e) { return lg_host::pow_u64(base, e); }
+
+class PoseidonSponge {
+public:
+    // test_sponge(): 8 full + 31 partial rounds, alpha = 17, mds [[1,0,1],[1,1,0],[0,1,1]], round constants
+    // 39 x 3 draws of F::rand from ark_std::test_rng() (StdRng seeded with the bytes below)
+    static PoseidonSponge test_sponge() {
+        PoseidonSponge s;
+        s.full_rounds_ = 8;
+        s.partial_rounds_ = 31;
+        s.alpha_ = 17;
+        const Fr one = fr_one(), zero = fr_zero();
+        s.mds_ = {{{{one, zero, one}}, {{one, one, zero}}, {{zero, one, one}}}};
+        std::array<uint8_t, 32> seed = {1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        StdRng rng(seed);
+        s.ark_.resize(s.full_rounds_ + s.partial_rounds_);
+        for (auto& row : s.ark_)
+            for (auto& x : row) x = fr_rand(rng);
+        return s;
+    }
+
+    // absorb(&Vec<u8>): LE64(len) || bytes, packed 31 bytes per field element, little endian
+    void absorb_bytes(const uint8_t* data, size_t len) {
+        std::vector<uint8_t> bytes(8 + len);
+        for (int i = 0; i < 8; i++) bytes[i] = (uint8_t)((uint64_t)len >> (8 * i));
+        memcpy(bytes.data() + 8, data, len);
+        std::vector<Fr> elems;
+        for (size_t off = 0; off < bytes.size(); off += 31) {
+            const size_t take = std::min<size_t>(31, bytes.size() - off);
+            Fr canon = {{0, 0, 0, 0}};
+            for (size_t i = 0; i < take; i++) canon.l[i / 8] |= (uint64_t)bytes[off + i] << (8 * (i % 8));
+            elems.push_back(lg_host::to_mont(canon));
+        }
+        absorb_elements(elems);
+    }
+    // absorb(&Vec<F>): the elements as they are
+    void absorb_elements(const std::vector<Fr>& elems) {
+        if (elems.empty()) return;
+        if (squeezing_) {
+            permute();
+            absorb_internal(0, elems);
+        } else {
+            size_t idx = next_index_;
+            if (idx == kRate) {
+                permute();
+                idx = 0;
+            }
+            absorb_internal(idx, elems);
+        }
+    }
+    std::vector<Fr> squeeze_native_field_elements(size_t n) {
+        std::vector<Fr> out(n);
+        if (!squeezing_) {
+            permute();
+            squeeze_internal(0, out);
+        } else {
+            size_t idx = next_index_;
+            if (idx == kRate) {
+                permute();
+                idx = 0;
+            }
+            squeeze_internal(idx, out);
+        }
+        return out;
+    }
+    // squeeze_bytes: ceil(n / 31) elements, the low 31 little-endian bytes of each, truncated to n
+    std::vector<uint8_t> squeeze_bytes(size_t n) {
+        const size_t usable = 31, nelem = (n + usable - 1) / usable;
+        const std::vector<Fr> src = squeeze_native_field_elements(nelem);
+        std::vector<uint8_t> bytes;
+        for (const Fr& e : src) {
+            const Fr c = lg_host::from_mont(e);
+            for (size_t i = 0; i < usable; i++) bytes.push_back((uint8_t)(c.l[i / 8] >> (8 * (i % 8))));
+        }
+        bytes.resize(n);
+        return bytes;
+    }
+    std::array<uint8_t, 32> squeeze_seed() {
+        const std::vector<uint8_t> b = squeeze_bytes(kChachaSeedBytes);
+        std::array<uint8_t, 32> s;
+        memcpy(s.data(), b.data(), 32);
+        return s;
+    }
+
+private:
+    static constexpr size_t kRate = 2, kCapacity = 1, kWidth = 3;
+    void permute() {
+        const size_t half = full_rounds_ / 2;
+        for (size_t i = 0; i < full_rounds_ + partial_rounds_; i++) {
+            for (size_t j = 0; j < kWidth; j++) state_[j] = fr_add(state_[j], ark_[i][j]);
+            const bool full = i < half || i >= half + partial_rounds_;
+            if (full) {
+                for (size_t j = 0; j < kWidth; j++) state_[j] = fr_pow_u64(state_[j], alpha_);
+            } else {
+                state_[0] = fr_pow_u64(state_[0], alpha_);
+            }
+            std::array<Fr, 3> next;
+            for (size_t r = 0; r < kWidth; r++) {
+                Fr acc = fr_zero();
+                for (size_t j = 0; j < kWidth; j++) acc = fr_add(acc, fr_mul(state_[j], mds_[r][j]));
+                next[r] = acc;
+            }
+            state_ = next;
+        }
+    }
+    void absorb_internal(size_t start, const std::vector<Fr>& elems) {
+        size_t pos = 0;
+        for (;;) {
+            const size_t left = elems.size() - pos;
+            if (start + left <= kRate) {
+                for (size_t i = 0; i < left; i++) state_[kCapacity + start + i] = fr_add(state_[kCapacity + start + i], elems[pos + i]);
+                squeezing_ = false;
+                next_index_ = start + left;
+                return;
+            }
+            const size_t take = kRate - start;
+            for (size_t i = 0; i < take; i++) state_[kCapacity + start + i] = fr_add(state_[kCapacity + start + i], elems[pos + i]);
+            permute();
+            pos += take;
+            start = 0;
+        }
+    }
+    void squeeze_internal(size_t start, std::vector<Fr>& out) {
+        size_t pos = 0;
+        for (;;) {
+            const size_t left = out.size() - pos;
+            if (start + left <= kRate) {
+                for (size_t i = 0; i < left; i++) out[pos + i] = state_[kCapacity + start + i];
+                squeezing_ = true;
+                next_index_ = start + left;
+                return;
+            }
+            const size_t take = kRate - start;
+            for (size_t i = 0; i < take; i++) out[pos + i] = state_[kCapacity + start + i];
+            if (left != kRate) permute();  // "unless we are done with squeezing in this call, permute"
+            pos += take;
+            start = 0;
+        }
+    }
+    size_t full_rounds_ = 0, partial_rounds_ = 0;
+    uint64_t alpha_ = 0;
+    std::array<std::array<Fr, 3>, 3> mds_;
+    std::vector<std::array<Fr, 3>> ark_;
+    std::array<Fr, 3> state_ = {fr_zero(), fr_zero(), fr_zero()};
+    bool squeezing_ = false;  // DuplexSpongeMode
+    size_t next_index_ = 0;
+};
+
+}  // namespace ligero

@@ -21,6 +21,8 @@ SYMBOLS = [
     "lgh_last_error", "lgh_circuit_new", "lgh_circuit_destroy", "lgh_circuit_num_nodes", "lgh_constant", "lgh_new_variable",
     "lgh_add", "lgh_mul", "lgh_pow", "lgh_minus", "lgh_circuit_from_r1cs", "lgh_circuit_num_outputs", "lgh_circuit_outputs",
     "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_a_row_mul", "lgh_a_entries",
+    "lgh_chacha_block", "lgh_field_elements_from_seed", "lgh_distinct_indices_from_seed", "lgh_sponge_new", "lgh_sponge_destroy",
+    "lgh_sponge_absorb_bytes", "lgh_sponge_absorb_elements", "lgh_sponge_squeeze_bytes", "lgh_sponge_squeeze_elements",
 ]
 
 _vp, _u64, _i64, _u32, _int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
@@ -55,6 +57,17 @@ def lib():
         L.lgh_build_preenc.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_a_row_mul.argtypes = [_vp, _vp, _vp]
         L.lgh_a_entries.argtypes = [_vp, _vp, _vp, _vp]
+        L.lgh_chacha_block.argtypes = [_u32, _vp, _vp, _vp]
+        L.lgh_chacha_block.restype = None
+        L.lgh_field_elements_from_seed.argtypes = [_vp, _u64, _vp]
+        L.lgh_distinct_indices_from_seed.argtypes = [_vp, _u64, _u64, _vp, _vp]
+        L.lgh_sponge_new.restype = _vp
+        L.lgh_sponge_destroy.argtypes = [_vp]
+        L.lgh_sponge_destroy.restype = None
+        L.lgh_sponge_absorb_bytes.argtypes = [_vp, _vp, _u64]
+        L.lgh_sponge_absorb_elements.argtypes = [_vp, _vp, _u64]
+        L.lgh_sponge_squeeze_bytes.argtypes = [_vp, _u64, _vp]
+        L.lgh_sponge_squeeze_elements.argtypes = [_vp, _u64, _vp]
         _lib = L
     return _lib
 
@@ -161,3 +174,62 @@ class LigeroInstance:
         vals = np.empty((self.a_nnz, 4), dtype=np.uint64)
         _check(self._L.lgh_a_entries(self._h, _p(rows), _p(cols), _p(vals)), "a_entries")
         return rows, cols, vals
+
+
+# ---- Fiat-Shamir pieces (ligero_amd/host/transcript.hpp; PARITY UNPINNED, see there)
+def chacha_block(rounds: int, key_words, words12_15) -> np.ndarray:
+    key = np.ascontiguousarray(key_words, dtype=np.uint32)
+    w = np.ascontiguousarray(words12_15, dtype=np.uint32)
+    out = np.empty(16, dtype=np.uint32)
+    lib().lgh_chacha_block(rounds, _p(key), _p(w), _p(out))
+    return out
+
+
+def field_elements_from_seed(seed: bytes, n: int) -> np.ndarray:
+    """get_field_elements_from_prng (src/utils.rs:23-29): (n, 4) Montgomery limbs"""
+    s = np.frombuffer(seed, dtype=np.uint8).copy()
+    out = np.empty((n, 4), dtype=np.uint64)
+    _check(lib().lgh_field_elements_from_seed(_p(s), n, _p(out)), "get_field_elements_from_prng")
+    return out
+
+
+def distinct_indices_from_seed(seed: bytes, n: int, t: int) -> np.ndarray:
+    """get_distinct_indices_from_prng (src/utils.rs:31-55)"""
+    s = np.frombuffer(seed, dtype=np.uint8).copy()
+    out = np.empty(max(t, 1), dtype=np.uint64)
+    cnt = ctypes.c_uint64(0)
+    _check(lib().lgh_distinct_indices_from_seed(_p(s), n, t, _p(out), ctypes.cast(ctypes.byref(cnt), _vp)), "get_distinct_indices_from_prng")
+    return out[:cnt.value]
+
+
+class PoseidonSponge:
+    """test_sponge() of ark-poly-commit (src/ligero/tests.rs:151)"""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = self._L.lgh_sponge_new()
+        if not self._h:
+            raise MemoryError("lgh_sponge_new")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lgh_sponge_destroy(self._h)
+            self._h = None
+
+    def absorb_bytes(self, data: bytes):
+        b = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        _check(self._L.lgh_sponge_absorb_bytes(self._h, _p(b) if b.size else None, b.size), "absorb")
+
+    def absorb_elements(self, elems_mont: np.ndarray):
+        e = np.ascontiguousarray(elems_mont, dtype=np.uint64).reshape(-1, 4)
+        _check(self._L.lgh_sponge_absorb_elements(self._h, _p(e) if e.size else None, e.shape[0]), "absorb")
+
+    def squeeze_bytes(self, n: int) -> bytes:
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        _check(self._L.lgh_sponge_squeeze_bytes(self._h, n, _p(out)), "squeeze_bytes")
+        return out[:n].tobytes()
+
+    def squeeze_elements(self, n: int) -> np.ndarray:
+        out = np.empty((max(n, 1), 4), dtype=np.uint64)
+        _check(self._L.lgh_sponge_squeeze_elements(self._h, n, _p(out)), "squeeze_native_field_elements")
+        return out[:n]

@@ -1,0 +1,103 @@
+"""ctypes mirror of include/ligero_prover.h: LigeroCircuit::prove / verify (src/ligero/mod.rs:435-455,
+613-644) over the device library.  The transcript is the restated test_sponge() -- PARITY UNPINNED
+(ligero_amd/host/transcript.hpp): proofs made here verify here; byte equality with the Rust crate's
+proofs is not claimed."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Sequence
+
+import numpy as np
+
+from . import _ffi  # noqa: F401  (loads torch's HIP runtime first when torch is installed, then libligero_hip.so)
+from .host_pipeline import LigeroInstance
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
+SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
+           "lgp_proof_info", "lgp_proof_tamper"]
+_vp = ctypes.c_void_p
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C ligero_amd/host`")
+        _ffi.lib()
+        L = ctypes.CDLL(LIB_PATH)
+        L.lgp_last_error.restype = ctypes.c_char_p
+        L.lgp_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_int]
+        L.lgp_prover_destroy.argtypes = [_vp]
+        L.lgp_prover_destroy.restype = None
+        L.lgp_prove.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(_vp)]
+        L.lgp_verify.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
+        L.lgp_proof_destroy.argtypes = [_vp]
+        L.lgp_proof_destroy.restype = None
+        L.lgp_proof_info.argtypes = [_vp, _vp, _vp]
+        L.lgp_proof_tamper.argtypes = [_vp, ctypes.c_int, ctypes.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: status {rc} ({lib().lgp_last_error().decode()})")
+
+
+class Proof:
+    def __init__(self, handle):
+        self._L = lib()
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lgp_proof_destroy(self._h)
+            self._h = None
+
+    def info(self):
+        info = np.zeros(6, dtype=np.uint64)
+        root = np.zeros(32, dtype=np.uint8)
+        _check(self._L.lgp_proof_info(self._h, info.ctypes.data_as(_vp), root.ctypes.data_as(_vp)), "lgp_proof_info")
+        keys = ("preenc_u_lc", "linear_poly", "quadratic_poly", "opened_columns", "column_len", "auth_path_len")
+        d = {k: int(v) for k, v in zip(keys, info)}
+        d["u_root"] = root.tobytes()
+        return d
+
+    def tamper(self, what: int, index: int = 0):
+        _check(self._L.lgp_proof_tamper(self._h, what, index), "lgp_proof_tamper")
+
+
+class LigeroProver:
+    def __init__(self, instance: LigeroInstance, device: int = 0):
+        self._L = lib()
+        self._inst = instance          # keeps the host instance alive
+        self._h = _vp()
+        _check(self._L.lgp_prover_create(ctypes.byref(self._h), instance._h, device), "lgp_prover_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lgp_prover_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def prove(self, node_idx: Sequence[int], values_mont: np.ndarray) -> Proof:
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(idx.shape[0], 4)
+        h = _vp()
+        _check(self._L.lgp_prove(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0], ctypes.byref(h)), "prove")
+        return Proof(h)
+
+    def verify(self, proof: Proof) -> bool:
+        ok = ctypes.c_int(0)
+        _check(self._L.lgp_verify(self._h, proof._h, ctypes.byref(ok)), "verify")
+        return bool(ok.value)

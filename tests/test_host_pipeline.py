@@ -148,3 +148,21 @@ def test_host_library_exports(hp):
     exported = set(re.findall(r" T (lgh_[a-z0-9_]+)", out))
     assert set(declared) <= exported
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "ligero_host.h")])
+
+
+def test_prover_library_exports():
+    """include/ligero_prover.h <-> libligero_prover.so <-> the ctypes mirror (no device call: loads without a GPU)"""
+    import re, subprocess
+    from conftest import ROOT
+    from ligero_amd import prover
+    hdr = open(os.path.join(ROOT, "include", "ligero_prover.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lgp_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(prover.SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", prover.LIB_PATH], text=True)
+    assert set(declared) <= set(re.findall(r" T (lgp_[a-z0-9_]+)", out))
+    L = prover.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "include", "ligero_prover.h")])
