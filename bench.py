@@ -92,6 +92,45 @@ def device_copy_gbs(torch, nbytes: int = 1 << 30, reps: int = 5) -> float:
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def usable_cpus() -> int:
+    """CPUs this process may use: os.cpu_count() capped by a cgroup v2 quota (the GPU boxes give 16 of 256)"""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def full_prover_rate(device: int, steps: int = 5):
+    """proofs/s of the complete prove() (ligero_amd/host/prover.hpp: commit + three sub-proofs + openings + transcript)
+    on the 64 committed Poseidon witnesses, batch-wide device calls + host threads.  The transcript is the restated
+    test_sponge() -- unpinned against the Rust crates -- so this is the cost of the same work, not a
+    claim of byte-identical proofs."""
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroBatchProver
+    g = os.path.join(ROOT, "tests", "golden")
+    inst = hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(os.path.join(g, "poseidon.r1cs")))
+    blob = open(os.path.join(g, "poseidon_witness_batch64.bin"), "rb").read()
+    p, mask = 21888242871839275222246405745257275088548364400416034343698204186575808495617, (1 << 64) - 1
+    vals = np.empty((64, 264, 4), dtype=np.uint64)
+    for i in range(64):
+        for j in range(1, 265):
+            v = (int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") << 256) % p      # Montgomery form
+            vals[i, j - 1] = [(v >> (64 * l)) & mask for l in range(4)]
+    idx = list(range(1, 265))
+    with LigeroBatchProver(inst, 64, device=device) as bp:
+        bp.prove(idx, vals, copy=False)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bp.prove(idx, vals, copy=False)
+        dt = (time.perf_counter() - t0) / steps
+        return {"value": 64 / dt, "unit": "proofs/s", "ms_per_64_proofs": dt * 1e3, "host_threads": bp.threads,
+                "note": "full prove() incl. transcript on host threads; transcript unpinned vs the Rust crates"}
+
+
 def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
     """The oracle (C restatement, reference-equivalent single-thread shape) timed on this
     host's cores on a bounded sample of the same workload."""
@@ -114,9 +153,9 @@ def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
     out = {"value": elems / dt, "unit": "field-elems/s", "cores": 1, "kind": "port",
            "sample": f"{sample_commits} x ({sample_rows} rows x {k} -> {n}) encode+column-hash+Merkle, serial "
                      f"reference-shaped C restatement (oracle/ligero_oracle.c), {dt:.1f} s",
-           "host_cores_available": os.cpu_count()}
+           "host_cores_available": os.cpu_count(), "host_cores_usable": usable_cpus()}
     # all-cores variant of the same restatement, reported beside it
-    nthr = min(orc.lib().orc_max_threads(), os.cpu_count() or 1)
+    nthr = min(orc.lib().orc_max_threads(), usable_cpus())
     if nthr > 1:
         t0 = time.perf_counter()
         orc.encode_commit(pre[:sample_rows], k, n, threads=nthr, want_u=False)
@@ -248,6 +287,7 @@ def main():
             one.sync()
             line["single_commit_ms"] = (time.perf_counter() - t1) / 50 * 1e3
             one.close()
+            line["full_prover"] = full_prover_rate(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
         print(json.dumps(line), flush=True)

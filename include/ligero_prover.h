@@ -18,6 +18,7 @@ extern "C" {
 
 typedef struct lgp_prover lgp_prover;
 typedef struct lgp_proof lgp_proof;
+typedef struct lgp_batch_prover lgp_batch_prover;
 
 enum { LGP_OK = 0, LGP_ERR_BAD_ARG = -1, LGP_ERR_PANIC = -2, LGP_ERR_OOM = -3, LGP_ERR_DEVICE = -4 };
 
@@ -32,6 +33,21 @@ int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, u
 /* verify(proof, mt_params, &mut test_sponge()) */
 int lgp_verify(lgp_prover* p, const lgp_proof* proof, int* accepted_out);
 void lgp_proof_destroy(lgp_proof* proof);
+
+/*
+ * Throughput mode (BASELINE configs[4]): `batch` proofs of the same circuit per call.  Each device step is one
+ * batch-wide call of the device library; the per-proof transcript work in between runs on `threads` host threads
+ * (0 = one per proof, at most the machine's).  values = batch * count elements (proof-major), node_idx is shared;
+ * proofs_out receives `batch` handles, each identical to what lgp_prove gives for that assignment.
+ */
+int lgp_batch_prover_create(lgp_batch_prover** out, const lgh_instance* inst, uint32_t batch, int device, uint32_t threads);
+void lgp_batch_prover_destroy(lgp_batch_prover* p);
+uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p);
+int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out);
+/* proofs_out may be NULL: the proofs then stay in storage the prover reuses from call to call (copies of 64 proofs are
+ * 330 MB of fresh memory) and are read through borrowed handles, valid until the next lgp_prove_batch; they can be
+ * verified and inspected, not tampered with or destroyed */
+const lgp_proof* lgp_batch_proof(const lgp_batch_prover* p, uint32_t index);
 
 /* inspection: info_out = { len(preenc_u_lc), len(linear poly), len(quadratic poly), opened columns per sub-proof,
  * column length, auth path length }; root_out = u_root */

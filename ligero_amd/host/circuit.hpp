@@ -287,11 +287,21 @@ struct SparseMatrix {
     }
     // mod.rs:100-110: result[col] += row[i] * value for every entry of row i
     std::vector<Fr> row_mul(const std::vector<Fr>& row) const {
-        std::vector<Fr> out(num_cols, fr_zero());
-        const size_t n = row.size() < rows.size() ? row.size() : rows.size();
-        for (size_t i = 0; i < n; i++)
-            for (const auto& e : rows[i]) out[e.second] = fr_add(out[e.second], fr_mul(row[i], e.first));
+        std::vector<Fr> out(num_cols);
+        row_mul_into(row.data(), row.size(), out.data());
         return out;
+    }
+    // the same into caller-owned storage of num_cols elements
+    void row_mul_into(const Fr* row, size_t row_len, Fr* out) const {
+        for (size_t c = 0; c < num_cols; c++) out[c] = fr_zero();
+        const size_t n = row_len < rows.size() ? row_len : rows.size();
+        const Fr one = fr_one(), minus_one = fr_neg(fr_one());
+        for (size_t i = 0; i < n; i++)
+            for (const auto& e : rows[i]) {  // almost every entry of A is +-1: add / subtract instead of multiplying
+                if (fr_eq(e.first, one)) out[e.second] = fr_add(out[e.second], row[i]);
+                else if (fr_eq(e.first, minus_one)) out[e.second] = fr_sub(out[e.second], row[i]);
+                else out[e.second] = fr_add(out[e.second], fr_mul(row[i], e.first));
+            }
     }
     size_t nnz() const {
         size_t n = 0;

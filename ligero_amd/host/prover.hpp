@@ -16,7 +16,16 @@
 // the Rust crate's is not established.  The algebra (what is computed from given challenges,
 // and every check the verifier makes) follows the reference line by line.
 #pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -295,6 +304,256 @@ private:
     size_t m_, k_, n_, t_;
     int logn_ = 0;
     lg_ctx* ctx_ = nullptr;
+};
+
+// ---------------------------------------------------------------- throughput mode (BASELINE configs[4])
+// `batch` independent proofs of the same circuit per call: every device step is ONE batch-wide call of
+// the C ABI (commit, the three row reductions, the three openings), the per-proof transcript work between
+// them (sponge, ChaCha challenges, A.row_mul) runs on host threads.  Same transcript and same proofs as
+// `batch` calls of HipLigero::prove.
+// CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period")
+inline unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            const unsigned q = (unsigned)((quota + period - 1) / period);
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    }
+    return n;
+}
+
+// Persistent worker threads for the per-proof host phases (a dozen short phases per batch: spawning 32 threads
+// for each costs more than some of the phases)
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n) {
+        for (unsigned w = 0; w + 1 < n; w++) threads_.emplace_back([this] { loop(); });   // the caller is worker n - 1
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    unsigned size() const { return (unsigned)threads_.size() + 1; }
+    // runs fn(i) for i in [0, count) on all workers; rethrows the first exception
+    void run(size_t count, const std::function<void(size_t)>& fn) {
+        if (threads_.empty() || count <= 1) {
+            for (size_t i = 0; i < count; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn;
+            count_ = count;
+            next_ = 0;
+            busy_ = (unsigned)threads_.size();
+            err_ = nullptr;
+            gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return busy_ == 0; });
+        fn_ = nullptr;
+        if (err_) std::rethrow_exception(err_);
+    }
+
+private:
+    void work() {
+        try {
+            for (size_t i = next_++; i < count_; i = next_++) (*fn_)(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!err_) err_ = std::current_exception();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            work();
+            std::lock_guard<std::mutex> g(mu_);
+            if (--busy_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t count_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned busy_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    std::exception_ptr err_;
+};
+
+// LG_PROVER_TIMING=1: per-phase wall time of HipLigeroBatch::prove on stderr
+struct PhaseTimer {
+    bool on = getenv("LG_PROVER_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  %-36s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
+class HipLigeroBatch {
+public:
+    HipLigeroBatch(const LigeroInstance& inst, uint32_t batch, int device = 0, unsigned threads = 0)
+        : inst_(inst), batch_(batch), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t) {
+        if (batch == 0) throw std::runtime_error("HipLigeroBatch: batch must be positive");
+        const int st = lg_ctx_create_batched(&ctx_, device, (uint32_t)(4 * m_), (uint32_t)k_, (uint32_t)n_, batch);
+        if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_batched");
+        while ((size_t{1} << logn_) < n_) logn_++;
+        threads_ = threads ? threads : std::max(1u, std::min(usable_cpus(), batch));
+        pool_.reset(new WorkerPool(threads_));
+        mat_.resize((size_t)batch_ * 4 * m_ * k_);
+        cols_.resize((size_t)batch_ * t_ * 4 * m_);
+        // page-lock the two big staging buffers so the PCIe copies overlap the kernels (lg_encode_commit streams)
+        pinned_ = lg_host_register(ctx_, mat_.data(), mat_.size() * sizeof(Fr)) == LG_OK &&
+                  lg_host_register(ctx_, cols_.data(), cols_.size() * sizeof(Fr)) == LG_OK;
+    }
+    ~HipLigeroBatch() {
+        if (pinned_) { lg_host_unregister(ctx_, mat_.data()); lg_host_unregister(ctx_, cols_.data()); }
+        lg_ctx_destroy(ctx_);
+    }
+    HipLigeroBatch(const HipLigeroBatch&) = delete;
+    HipLigeroBatch& operator=(const HipLigeroBatch&) = delete;
+    uint32_t batch() const { return batch_; }
+    unsigned threads() const { return threads_; }
+
+    // The proofs live in storage the prover owns and reuses from call to call (fresh memory for 64 proofs is 330 MB
+    // of page faults, which with 32 host threads costs more than the proving): valid until the next prove().
+    const std::vector<LigeroProof>& prove(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
+        if (assignments.size() != batch_) throw std::runtime_error("HipLigeroBatch::prove: one assignment per proof of the batch");
+        const size_t B = batch_, rows = 4 * m_, mat = rows * k_;
+        PhaseTimer tm;
+        std::vector<LigeroProof>& proofs = proofs_;
+        proofs.resize(B);
+        scratch_.resize(B * mat);
+        std::vector<PoseidonSponge> sponge(B, PoseidonSponge::test_sponge());
+        parallel_for(B, [&](size_t b) {                                  // x / y / z / w assembly, mod.rs:476-516
+            const auto r = inst_.build_preenc_u(assignments[b]);
+            for (size_t i = 0; i < rows; i++) memcpy(&mat_[b * mat + i * k_], r[i].data(), k_ * sizeof(Fr));
+        });
+        tm.mark("preenc_u (host)");
+        std::vector<uint8_t> roots(B * 32);
+        check(lg_encode_commit(ctx_, mat_[0].l, nullptr, roots.data()), "lg_encode_commit");
+        tm.mark("commit (device)");
+        // interleaved test
+        std::vector<Fr> r_int(B * rows), lc(B * k_);
+        parallel_for(B, [&](size_t b) {
+            memcpy(proofs[b].u_root.data(), &roots[32 * b], 32);
+            sponge[b].absorb_bytes(proofs[b].u_root.data(), 32);
+            const auto r = get_field_elements_from_prng(rows, sponge[b].squeeze_seed());
+            memcpy(&r_int[b * rows], r.data(), rows * sizeof(Fr));
+        });
+        tm.mark("absorb root, r_interleaved (host)");
+        check(lg_interleaved_row_mul(ctx_, r_int[0].l, lc[0].l), "lg_interleaved_row_mul");
+        tm.mark("interleaved row_mul (device)");
+        parallel_for(B, [&](size_t b) {
+            proofs[b].interleaved_proof.preenc_u_lc.assign(lc.begin() + b * k_, lc.begin() + (b + 1) * k_);
+            sponge[b].absorb_elements(proofs[b].interleaved_proof.preenc_u_lc);
+        });
+        open_all(sponge, [&](size_t b) -> OpenedColumns& { return proofs[b].interleaved_proof.open; });
+        tm.mark("absorb + open interleaved");
+        // linear test: r_a rows go into the (page-locked) matrix staging buffer
+        std::vector<Fr> poly(B * 2 * k_);
+        parallel_for(B, [&](size_t b) {
+            fill_field_elements_from_prng(&scratch_[b * mat], mat, sponge[b].squeeze_seed());   // r_linear
+            inst_.a.row_mul_into(&scratch_[b * mat], mat, &mat_[b * mat]);                        // r_a
+        });
+        tm.mark("r_linear, A.row_mul (host)");
+        check(lg_linear_constraint_poly(ctx_, mat_[0].l, poly[0].l), "lg_linear_constraint_poly");
+        tm.mark("linear poly (device)");
+        finish_poly(sponge, poly, [&](size_t b) -> ConstraintsProof& { return proofs[b].linear_constraints_proof; });
+        tm.mark("absorb + open linear");
+        // quadratic test
+        std::vector<Fr> r_q(B * m_);
+        parallel_for(B, [&](size_t b) {
+            const auto r = get_field_elements_from_prng(m_, sponge[b].squeeze_seed());
+            memcpy(&r_q[b * m_], r.data(), m_ * sizeof(Fr));
+        });
+        check(lg_quadratic_constraint_poly(ctx_, r_q[0].l, poly[0].l), "lg_quadratic_constraint_poly");
+        tm.mark("r_quadratic + quadratic poly");
+        finish_poly(sponge, poly, [&](size_t b) -> ConstraintsProof& { return proofs[b].quadratic_constraints_proof; });
+        tm.mark("absorb + open quadratic");
+        return proofs;
+    }
+
+private:
+    void check(int st, const char* what) const {
+        if (st != LG_OK) throw DeviceError(st, std::string(what) + " (" + lg_last_error(ctx_) + ")");
+    }
+    template <class F>
+    void parallel_for(size_t count, F&& fn) {
+        const std::function<void(size_t)> f = std::forward<F>(fn);
+        pool_->run(count, f);
+    }
+    template <class Get>
+    void finish_poly(std::vector<PoseidonSponge>& sponge, const std::vector<Fr>& poly, Get&& get) {
+        parallel_for(batch_, [&](size_t b) {
+            std::vector<Fr>& p = get(b).polynomial;
+            p.assign(poly.begin() + b * 2 * k_, poly.begin() + (b + 1) * 2 * k_);
+            trim_zeros(p);
+            sponge[b].absorb_elements(p);
+        });
+        open_all(sponge, [&](size_t b) -> OpenedColumns& { return get(b).open; });
+    }
+    // open_columns (mod.rs:935-955) of every proof with one gather launch and one copy
+    template <class Get>
+    void open_all(std::vector<PoseidonSponge>& sponge, Get&& get) {
+        const size_t B = batch_, rows = 4 * m_, plen = (size_t)logn_ - 1;
+        std::vector<uint32_t> idx(B * t_);
+        parallel_for(B, [&](size_t b) {
+            const auto ind = get_distinct_indices_from_prng(n_, t_, sponge[b].squeeze_seed());
+            for (size_t c = 0; c < t_; c++) idx[b * t_ + c] = (uint32_t)ind[c];
+        });
+        std::vector<uint8_t> sib(B * t_ * 32), paths(B * t_ * plen * 32 + 1);
+        check(lg_open_columns_batch(ctx_, idx.data(), (uint32_t)t_, cols_[0].l, sib.data(), paths.data()), "lg_open_columns_batch");
+        parallel_for(B, [&](size_t b) {
+            OpenedColumns& o = get(b);
+            o.columns.resize(t_);
+            o.paths.resize(t_);
+            for (size_t c = 0; c < t_; c++) {
+                const size_t e = b * t_ + c;
+                o.columns[c].assign(cols_.begin() + e * rows, cols_.begin() + (e + 1) * rows);   // keeps its capacity between calls
+                MerklePath& p = o.paths[c];
+                p.leaf_index = idx[e];
+                memcpy(p.leaf_sibling_hash.data(), &sib[32 * e], 32);
+                p.auth_path.resize(plen);
+                for (size_t l = 0; l < plen; l++) memcpy(p.auth_path[l].data(), &paths[32 * (e * plen + l)], 32);
+            }
+        });
+    }
+
+    const LigeroInstance& inst_;
+    uint32_t batch_;
+    size_t m_, k_, n_, t_;
+    int logn_ = 0;
+    unsigned threads_ = 1;
+    bool pinned_ = false;
+    lg_ctx* ctx_ = nullptr;
+    std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u, later r_a
+    std::vector<Fr> scratch_;  // [batch][4m k]: r_linear
+    std::vector<LigeroProof> proofs_;
+    std::unique_ptr<WorkerPool> pool_;
+    std::vector<Fr> cols_;  // [batch][t][4m]: opened columns
 };
 
 }  // namespace ligero

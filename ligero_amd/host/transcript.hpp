@@ -100,10 +100,13 @@ inline Fr fr_rand(Rng& rng) {
     }
 }
 
-inline std::vector<Fr> get_field_elements_from_prng(size_t n, const std::array<uint8_t, 32>& seed) {
+inline void fill_field_elements_from_prng(Fr* out, size_t n, const std::array<uint8_t, 32>& seed) {
     ChaCha20Rng rng(seed);
+    for (size_t i = 0; i < n; i++) out[i] = fr_rand(rng);
+}
+inline std::vector<Fr> get_field_elements_from_prng(size_t n, const std::array<uint8_t, 32>& seed) {
     std::vector<Fr> out(n);
-    for (auto& x : out) x = fr_rand(rng);
+    fill_field_elements_from_prng(out.data(), n, seed);
     return out;
 }
 
@@ -146,11 +149,16 @@ public:
         s.alpha_ = 17;
         const Fr one = fr_one(), zero = fr_zero();
         s.mds_ = {{{{one, zero, one}}, {{one, one, zero}}, {{zero, one, one}}}};
-        std::array<uint8_t, 32> seed = {1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        StdRng rng(seed);
-        s.ark_.resize(s.full_rounds_ + s.partial_rounds_);
-        for (auto& row : s.ark_)
-            for (auto& x : row) x = fr_rand(rng);
+        s.mds_is_test_ = true;
+        static const std::vector<std::array<Fr, 3>> ark = [] {   // drawn once per process
+            std::array<uint8_t, 32> seed = {1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            StdRng rng(seed);
+            std::vector<std::array<Fr, 3>> a(8 + 31);
+            for (auto& row : a)
+                for (auto& x : row) x = fr_rand(rng);
+            return a;
+        }();
+        s.ark_ = ark;
         return s;
     }
 
@@ -219,21 +227,36 @@ public:
 
 private:
     static constexpr size_t kRate = 2, kCapacity = 1, kWidth = 3;
+    // x^17: four squarings and one product (alpha is fixed by test_sponge)
+    static Fr sbox17(const Fr& x) {
+        Fr y = fr_mul(x, x);
+        y = fr_mul(y, y);
+        y = fr_mul(y, y);
+        y = fr_mul(y, y);
+        return fr_mul(y, x);
+    }
     void permute() {
         const size_t half = full_rounds_ / 2;
         for (size_t i = 0; i < full_rounds_ + partial_rounds_; i++) {
             for (size_t j = 0; j < kWidth; j++) state_[j] = fr_add(state_[j], ark_[i][j]);
             const bool full = i < half || i >= half + partial_rounds_;
-            if (full) {
-                for (size_t j = 0; j < kWidth; j++) state_[j] = fr_pow_u64(state_[j], alpha_);
+            if (alpha_ == 17) {
+                state_[0] = sbox17(state_[0]);
+                if (full) { state_[1] = sbox17(state_[1]); state_[2] = sbox17(state_[2]); }
             } else {
-                state_[0] = fr_pow_u64(state_[0], alpha_);
+                for (size_t j = 0; j < (full ? kWidth : 1); j++) state_[j] = fr_pow_u64(state_[j], alpha_);
             }
             std::array<Fr, 3> next;
-            for (size_t r = 0; r < kWidth; r++) {
-                Fr acc = fr_zero();
-                for (size_t j = 0; j < kWidth; j++) acc = fr_add(acc, fr_mul(state_[j], mds_[r][j]));
-                next[r] = acc;
+            if (mds_is_test_) {  // [[1,0,1],[1,1,0],[0,1,1]]: additions only
+                next[0] = fr_add(state_[0], state_[2]);
+                next[1] = fr_add(state_[0], state_[1]);
+                next[2] = fr_add(state_[1], state_[2]);
+            } else {
+                for (size_t r = 0; r < kWidth; r++) {
+                    Fr acc = fr_zero();
+                    for (size_t j = 0; j < kWidth; j++) acc = fr_add(acc, fr_mul(state_[j], mds_[r][j]));
+                    next[r] = acc;
+                }
             }
             state_ = next;
         }
@@ -275,6 +298,7 @@ private:
     size_t full_rounds_ = 0, partial_rounds_ = 0;
     uint64_t alpha_ = 0;
     std::array<std::array<Fr, 3>, 3> mds_;
+    bool mds_is_test_ = false;
     std::vector<std::array<Fr, 3>> ark_;
     std::array<Fr, 3> state_ = {fr_zero(), fr_zero(), fr_zero()};
     bool squeezing_ = false;  // DuplexSpongeMode

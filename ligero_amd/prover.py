@@ -16,7 +16,8 @@ from .host_pipeline import LigeroInstance
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
-           "lgp_proof_info", "lgp_proof_tamper"]
+           "lgp_proof_info", "lgp_proof_tamper", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
+           "lgp_prove_batch", "lgp_batch_proof"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -38,6 +39,14 @@ def lib():
         L.lgp_proof_destroy.restype = None
         L.lgp_proof_info.argtypes = [_vp, _vp, _vp]
         L.lgp_proof_tamper.argtypes = [_vp, ctypes.c_int, ctypes.c_uint64]
+        L.lgp_batch_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
+        L.lgp_batch_prover_destroy.argtypes = [_vp]
+        L.lgp_batch_prover_destroy.restype = None
+        L.lgp_batch_prover_threads.argtypes = [_vp]
+        L.lgp_batch_prover_threads.restype = ctypes.c_uint32
+        L.lgp_prove_batch.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, _vp]
+        L.lgp_batch_proof.argtypes = [_vp, ctypes.c_uint32]
+        L.lgp_batch_proof.restype = _vp
         _lib = L
     return _lib
 
@@ -48,14 +57,15 @@ def _check(rc, what):
 
 
 class Proof:
-    def __init__(self, handle):
+    def __init__(self, handle, owner=None):
         self._L = lib()
         self._h = handle
+        self._owner = owner            # a batch prover whose storage this handle borrows (not destroyed here)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and self._owner is None:
             self._L.lgp_proof_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def info(self):
         info = np.zeros(6, dtype=np.uint64)
@@ -101,3 +111,40 @@ class LigeroProver:
         ok = ctypes.c_int(0)
         _check(self._L.lgp_verify(self._h, proof._h, ctypes.byref(ok)), "verify")
         return bool(ok.value)
+
+
+class LigeroBatchProver:
+    """throughput mode: `batch` proofs of one circuit per call (include/ligero_prover.h)"""
+
+    def __init__(self, instance: LigeroInstance, batch: int, device: int = 0, threads: int = 0):
+        self._L = lib()
+        self._inst = instance
+        self.batch = batch
+        self._h = _vp()
+        _check(self._L.lgp_batch_prover_create(ctypes.byref(self._h), instance._h, batch, device, threads), "lgp_batch_prover_create")
+        self.threads = int(self._L.lgp_batch_prover_threads(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lgp_batch_prover_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def prove(self, node_idx: Sequence[int], values_mont: np.ndarray, copy: bool = True):
+        """values_mont: (batch, len(node_idx), 4).  Returns a list of `batch` Proof objects; with copy=False they
+        borrow the prover's reused storage (valid until the next prove(), read-only)."""
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(self.batch, idx.shape[0], 4)
+        if not copy:
+            _check(self._L.lgp_prove_batch(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0], None), "prove_batch")
+            return [Proof(_vp(self._L.lgp_batch_proof(self._h, b)), owner=self) for b in range(self.batch)]
+        handles = (_vp * self.batch)()
+        _check(self._L.lgp_prove_batch(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0], ctypes.cast(handles, _vp)), "prove_batch")
+        return [Proof(_vp(h)) for h in handles]

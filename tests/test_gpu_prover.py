@@ -85,3 +85,37 @@ def test_small_handbuilt_circuit(oracle):
         assert prover.verify(good)
         assert good.info()["opened_columns"] == inst.t
         assert not prover.verify(prover.prove([x], np.stack([mont(4)])))
+
+
+def test_batch_prover_matches_single_prover(poseidon, oracle, vectors):
+    """throughput mode (BASELINE configs[4]): 64 Poseidon proofs per call through batch-wide device calls and
+    host threads; every proof carries its golden root, verifies, and equals what the single prover gives"""
+    from ligero_amd.prover import LigeroBatchProver
+    inst, prover, idx, vals = poseidon
+    blob = open(os.path.join(GOLDEN, "poseidon_witness_batch64.bin"), "rb").read()
+    B = 64
+    ws = [[int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") for j in range(265)] for i in range(B)]
+    allv = np.stack([oracle.to_mont(oracle.ints_to_limbs(w[1:])) for w in ws])
+    with LigeroBatchProver(inst, B) as bp:
+        assert bp.threads >= 1
+        proofs = bp.prove(idx, allv)
+        assert len(proofs) == B
+        assert [p.info()["u_root"].hex() for p in proofs] == vectors["poseidon_batch64_roots"]
+        for b in (0, 1, 31, 63):
+            assert prover.verify(proofs[b]), b
+            single = prover.prove(idx, allv[b])
+            assert single.info() == proofs[b].info()
+        # tampering one proof of the batch does not go unnoticed
+        proofs[5].tamper(6, 99)
+        assert not prover.verify(proofs[5])
+    with LigeroBatchProver(inst, 3, threads=1) as bp3:           # odd batch, single-threaded host side
+        for p in bp3.prove(idx, allv[:3]):
+            assert prover.verify(p)
+        # borrowed views of the prover's reused storage: same proofs, read-only
+        views = bp3.prove(idx, allv[3:6], copy=False)
+        assert [v.info()["u_root"].hex() for v in views] == vectors["poseidon_batch64_roots"][3:6]
+        assert all(prover.verify(v) for v in views)
+        with pytest.raises(RuntimeError):
+            views[0].tamper(1, 0)
+        views2 = bp3.prove(idx, allv[:3], copy=False)               # storage is reused: the earlier views now show these
+        assert [v.info()["u_root"].hex() for v in views2] == vectors["poseidon_batch64_roots"][:3]
