@@ -170,7 +170,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="poseidon", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="timed workload only: no CPU baseline, no single-commit latency, no full-prover leg (profiler runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -274,8 +275,9 @@ def main():
                 "peak_source": "measured v_mad_u64_u32 issue rate, whole chip (tools/microbench2.hip)",
                 "note": "the remaining issue slots go to carries, butterflies, packing and LDS traffic (DESIGN.md 4.2)",
             }
-        if world == 1 and args.workload == "poseidon":
-            # BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
+        if world == 1 and args.workload == "poseidon" and not args.no_cpu_baseline:
+            # (skipped with --no-cpu-baseline, i.e. in profiler runs, so that every launch a profile sees belongs to the
+            # timed workload)  BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
             one = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=1, device=local_rank)
             one.upload(pre[:rows])
             for _ in range(5):

@@ -9,8 +9,10 @@
 // butterflies are radix-8 (radix-2/4 for the remainder pass) in registers over 29-bit
 // unsaturated limbs (fr29_gfx950.h), decimation in frequency, in place; the digit-reversed
 // result is read back permuted so that global stores are coalesced.  Every output of every
-// pass goes through one Montgomery product (a twiddle, or the constant one for output 0), which
-// is what keeps limbs and values bounded without any carry chain in the butterflies.
+// pass goes through one product by a table constant (shoup29) or one partial reduction
+// (reduce29: outputs without a twiddle), which is what keeps limbs and values bounded without
+// any carry chain in the butterflies.  Constant factors (2^-256 to leave the ABI's Montgomery
+// form, 1/k of the inverse transform) are folded into first-pass tables by the host.
 #pragma once
 #include <type_traits>
 
