@@ -119,3 +119,82 @@ def test_batch_prover_matches_single_prover(poseidon, oracle, vectors):
             views[0].tamper(1, 0)
         views2 = bp3.prove(idx, allv[:3], copy=False)               # storage is reused: the earlier views now show these
         assert [v.info()["u_root"].hex() for v in views2] == vectors["poseidon_batch64_roots"][:3]
+
+
+# ---- the reference's own prove-and-verify tests on BN254 (src/ligero/tests.rs:144-170, 195-243, 245-362), same circuits
+# (src/arithmetic_circuit/tests.rs:51-108), same assignments, same negative case (first variable + 1)
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _mont(oracle, v):
+    return oracle.to_mont(oracle.ints_to_limbs([v % P]))[0]
+
+
+def _fold(fn, nodes):
+    acc = nodes[0]
+    for nd in nodes[1:]:
+        acc = fn(acc, nd)
+    return acc
+
+
+def _lemniscate(hp, oracle):
+    """(x^2 + y^2)^2 - 120 x^2 + 80 y^2 + 1 = 1"""
+    c = hp.ArithmeticCircuit()
+    one = c.constant(_mont(oracle, 1))
+    x, y = c.new_variable(), c.new_variable()
+    a, b = c.constant(_mont(oracle, 120)), c.constant(_mont(oracle, 80))
+    x2, y2 = c.mul(x, x), c.mul(y, y)
+    ax2, by2 = c.mul(a, x2), c.mul(b, y2)
+    max2 = c.minus(ax2)
+    s = c.add(x2, y2)
+    d = c.add(by2, max2)
+    s2 = c.mul(s, s)
+    _fold(c.add, [s2, d, one])
+    return c, [(x, 8), (y, 4)]
+
+
+def _determinant(hp, oracle):
+    c = hp.ArithmeticCircuit()
+    one = c.constant(_mont(oracle, 1))
+    v = [c.new_variable() for _ in range(9)]
+    det = c.new_variable()
+    aei, bfg, cdh = (_fold(c.mul, [v[i] for i in t]) for t in ((0, 4, 8), (1, 5, 6), (2, 3, 7)))
+    ceg, bdi, afh = (_fold(c.mul, [v[i] for i in t]) for t in ((2, 4, 6), (1, 3, 8), (0, 5, 7)))
+    sum1 = _fold(c.add, [aei, bfg, cdh])
+    sum2 = _fold(c.add, [ceg, bdi, afh])
+    msum2, mdet = c.minus(sum2), c.minus(det)
+    _fold(c.add, [sum1, msum2, mdet, one])
+    vals = [2, 0, -1, 3, 5, 2, -4, 1, 4]
+    return c, [(v[i], vals[i]) for i in range(9)] + [(det, 13)]
+
+
+@pytest.mark.parametrize("which", ["lemniscate", "determinant"])
+def test_reference_prove_and_verify_cases(oracle, which):
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    c, assignment = (_lemniscate if which == "lemniscate" else _determinant)(hp, oracle)
+    inst = hp.LigeroInstance(c, outputs=[c.num_nodes() - 1])            # circuit.last()
+    idx = [i for i, _ in assignment]
+    good = np.stack([_mont(oracle, v) for _, v in assignment])
+    bad = good.copy()
+    bad[0] = _mont(oracle, assignment[0][1] + 1)                          # invalid_assignment[0].1 += F::ONE
+    with LigeroProver(inst) as prover:
+        assert prover.verify(prover.prove(idx, good))                    # assert!(proof_and_verify(circuit.clone(), vars))
+        assert not prover.verify(prover.prove(idx, bad))                 # assert!(!proof_and_verify(circuit, invalid_assignment))
+
+
+def test_reference_multioutput_1(oracle):
+    """x^2 = 9, y^3 = 64, x + y = 7 as three outputs (src/ligero/tests.rs:245-362); x = 3, y = 4"""
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    c = hp.ArithmeticCircuit()
+    x, y = c.new_variable(), c.new_variable()
+    c1, c2, c3 = (c.constant(_mont(oracle, v)) for v in (-9 + 1, -64 + 1, -7 + 1))
+    x2 = c.mul(x, x)
+    y3 = c.pow(y, 3)
+    s = c.add(x, y)
+    outs = [c.add(x2, c1), c.add(y3, c2), c.add(s, c3)]
+    inst = hp.LigeroInstance(c, outputs=outs)
+    with LigeroProver(inst) as prover:
+        assert prover.verify(prover.prove([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 4)])))
+        assert not prover.verify(prover.prove([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 5)])))
