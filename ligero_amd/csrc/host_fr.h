@@ -35,30 +35,29 @@ inline Fr sub_raw(const Fr& a, const Fr& b) {
     }
     return r;
 }
-// Montgomery product a*b/R mod p
+// Montgomery product a*b/R mod p (CIOS, unrolled: half the latency of the looped form, and the prover's
+// transcript spends most of its host time here)
 inline Fr mul(const Fr& a, const Fr& b) {
-    uint64_t t[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) {
-            c += (u128)a.l[j] * b.l[i] + t[j];
-            t[j] = (uint64_t)c;
-            c >>= 64;
-        }
-        uint64_t t4 = t[4] + (uint64_t)c;  // p has two spare bits: no overflow
-        uint64_t m = t[0] * kInv64;
-        c = ((u128)m * kP.l[0] + t[0]) >> 64;
-        for (int j = 1; j < 4; j++) {
-            c += (u128)m * kP.l[j] + t[j];
-            t[j - 1] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t4;
-        t[3] = (uint64_t)c;
-        t[4] = (uint64_t)(c >> 64);
+    const uint64_t p0 = kP.l[0], p1 = kP.l[1], p2 = kP.l[2], p3 = kP.l[3];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#define LG_HOST_MUL_ROUND(bi)                                                 \
+    {                                                                         \
+        u128 c = (u128)a.l[0] * (bi) + t0; t0 = (uint64_t)c; c >>= 64;        \
+        c += (u128)a.l[1] * (bi) + t1; t1 = (uint64_t)c; c >>= 64;            \
+        c += (u128)a.l[2] * (bi) + t2; t2 = (uint64_t)c; c >>= 64;            \
+        c += (u128)a.l[3] * (bi) + t3; t3 = (uint64_t)c; c >>= 64;            \
+        t4 += (uint64_t)c;             /* p has two spare bits: no overflow */ \
+        const uint64_t m = t0 * kInv64;                                       \
+        c = ((u128)m * p0 + t0) >> 64;                                        \
+        c += (u128)m * p1 + t1; t0 = (uint64_t)c; c >>= 64;                   \
+        c += (u128)m * p2 + t2; t1 = (uint64_t)c; c >>= 64;                   \
+        c += (u128)m * p3 + t3; t2 = (uint64_t)c; c >>= 64;                   \
+        c += t4; t3 = (uint64_t)c; t4 = (uint64_t)(c >> 64);                  \
     }
-    Fr r = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || geq(r, kP)) r = sub_raw(r, kP);
+    LG_HOST_MUL_ROUND(b.l[0]) LG_HOST_MUL_ROUND(b.l[1]) LG_HOST_MUL_ROUND(b.l[2]) LG_HOST_MUL_ROUND(b.l[3])
+#undef LG_HOST_MUL_ROUND
+    Fr r = {{t0, t1, t2, t3}};
+    if (t4 || geq(r, kP)) r = sub_raw(r, kP);
     return r;
 }
 inline Fr to_mont(const Fr& a) { return mul(a, kR2); }
