@@ -121,10 +121,10 @@ def full_prover_rate(device: int, steps: int = 5):
             v = (int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") << 256) % p      # Montgomery form
             vals[i, j - 1] = [(v >> (64 * l)) & mask for l in range(4)]
     idx = list(range(1, 265))
-    # three batch provers in flight: the host phases of one (transcript on host threads) overlap the device phases of the
-    # others; measured on the GPU box (16 usable CPUs): 1 prover 1 800 proofs/s, 3 provers 3 080 proofs/s
+    # four batch provers in flight: the host phases of one (transcript on host threads) overlap the device phases of the
+    # others; measured on the GPU box (16 usable CPUs): 1 prover 2 600 proofs/s, 4 provers 4 500 proofs/s
     import threading
-    nprov, threads = 3, max(1, usable_cpus() // 2)
+    nprov, threads = 4, max(1, usable_cpus() // 2)
     provers = [LigeroBatchProver(inst, 64, device=device, threads=threads) for _ in range(nprov)]
     try:
         for bp in provers:

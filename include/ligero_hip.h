@@ -141,6 +141,21 @@ int lg_reed_solomon(lg_ctx* ctx, const uint64_t* msg, uint32_t nrows, uint64_t* 
  */
 int lg_interleaved_row_mul(lg_ctx* ctx, const uint64_t* r, uint64_t* out);
 int lg_linear_constraint_poly(lg_ctx* ctx, const uint64_t* r_a, uint64_t* coeffs_out);
+/*
+ * The linear test without the challenge vector ever leaving the device (mod.rs:719-736):
+ *   lg_upload_constraint_matrix            self.a (mod.rs:202, built by generate_matrices, mod.rs:296-433) as COO triplets
+ *                                          (row, column, Montgomery value); columns < rows * k; duplicates are summed, as
+ *                                          SparseMatrix::row_mul does (src/matrices/mod.rs:100-110).  Once per context.
+ *   lg_linear_constraint_poly_from_seeds   seeds: batch * 32 bytes, the value of sponge.squeeze_bytes(32) at mod.rs:719 for each
+ *                                          proof.  r_linear = get_field_elements_from_prng(4mk, seed) (src/utils.rs:23-29:
+ *                                          ChaCha20Rng + F::rand rejection sampling) is generated on the device, r_a =
+ *                                          A.row_mul(r_linear) too, then as lg_linear_constraint_poly.
+ * The PRNG restates rand_chacha / ark-ff behaviour that cannot be validated here against the Rust crates (see
+ * ligero_amd/host/transcript.hpp, PARITY UNPINNED); it is bit-identical to that host restatement.
+ */
+int lg_upload_constraint_matrix(lg_ctx* ctx, uint64_t num_rows, uint64_t nnz, const uint64_t* row_idx, const uint64_t* col_idx,
+                                const uint64_t* values);
+int lg_linear_constraint_poly_from_seeds(lg_ctx* ctx, const uint8_t* seeds, uint64_t* coeffs_out);
 int lg_quadratic_constraint_poly(lg_ctx* ctx, const uint64_t* r, uint64_t* coeffs_out);
 
 /*

@@ -21,6 +21,7 @@ SYMBOLS = [
     "lg_open_columns", "lg_open_columns_batch",
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
     "lg_interleaved_row_mul", "lg_linear_constraint_poly", "lg_quadratic_constraint_poly",
+    "lg_upload_constraint_matrix", "lg_linear_constraint_poly_from_seeds",
     "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_merkle", "lg_device_buffer",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
@@ -77,6 +78,8 @@ def lib():
     L.lg_ctx_destroy.argtypes = [_vp]
     L.lg_ctx_destroy.restype = None
     L.lg_encode_commit.argtypes = [_vp, _vp, _vp, _vp]
+    L.lg_upload_constraint_matrix.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp, _vp]
+    L.lg_linear_constraint_poly_from_seeds.argtypes = [_vp, _vp, _vp]
     L.lg_host_register.argtypes = [_vp, _vp, ctypes.c_size_t]
     L.lg_host_unregister.argtypes = [_vp, _vp]
     L.lg_upload_preenc.argtypes = [_vp, _vp]

@@ -16,6 +16,7 @@
 #include "host_fr.h"
 #include "ntt_kernels.h"
 #include "ntt_launch.h"
+#include "challenge_kernels.h"
 #include "subproof_kernels.h"
 
 using lg::fr;
@@ -45,6 +46,14 @@ struct lg_ctx {
     fr* d_sub_q = nullptr;                 // [2k] evaluations / coefficients
     fr* d_sub_r = nullptr; size_t sub_r_elems = 0;              // challenge vector
     fr r3;                                 // 2^768 mod p
+    // constraint matrix A in CSC form (lg_upload_constraint_matrix) and the device-side challenge generator
+    uint32_t* d_a_colptr = nullptr; uint32_t* d_a_row = nullptr; fr* d_a_val = nullptr;
+    uint32_t* d_a_heavy = nullptr; uint32_t a_nheavy = 0;   // columns with more than lg::kHeavyColumn entries
+    uint64_t a_rows = 0, a_nnz = 0; bool a_loaded = false;
+    uint32_t* d_seeds = nullptr;           // [batch][8]
+    uint32_t* d_cc_counts = nullptr; size_t cc_counts_cap = 0;
+    uint32_t* d_short_flag = nullptr;
+    fr* d_rlin = nullptr; size_t rlin_elems = 0;   // r_linear [batch][4mk]
     uint32_t force_chunks = 0;             // LG_FORCE_CHUNKS (testing knob): pipeline depth regardless of size
     // resident commitment
     fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
@@ -417,7 +426,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->stream_dn) hipStreamSynchronize(c->stream_dn);
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
-    void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r};
+    void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
     void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
@@ -1010,25 +1019,124 @@ int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
     return read_back(c, out, c->d_sub_q, (size_t)c->batch * c->k * sizeof(fr));
 }
 
+// buffers of the linear test: d_scratch_a = r_a rows | their coefficients, d_scratch_b = planes
+static int linear_buffers(lg_ctx* c, uint32_t* per_out, uint32_t* nch_out) {
+    const uint64_t R = c->total_rows;
+    const size_t mat = (size_t)R * c->k;
+    *nch_out = sub_chunks(c->rows, per_out);
+    int rc = sub_buffers(c, (size_t)c->batch * *nch_out * 2 * c->k, 1);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->d_scratch_a, &c->scratch_a_elems, 2 * mat);
+    if (rc != LG_OK) return rc;
+    return grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)c->nplanes * R * c->ki);
+}
+static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_out);
+
 int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_out) {
     if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     LG_HIP(c, hipSetDevice(c->device));
+    uint32_t per, nch;
+    int rc = linear_buffers(c, &per, &nch);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->d_scratch_a, r_a, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    return linear_core(c, per, nch, coeffs_out);
+}
+
+int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, const uint64_t* row_idx, const uint64_t* col_idx, const uint64_t* values) {
+    if (!c || (nnz && (!row_idx || !col_idx || !values))) return LG_ERR_BAD_ARG;
+    const uint64_t cols = (uint64_t)c->rows * c->k;   // 4 m k
+    if (num_rows > 0xffffffffull || nnz > 0xffffffffull) return LG_ERR_UNSUPPORTED;
+    for (uint64_t e = 0; e < nnz; e++)
+        if (row_idx[e] >= num_rows || col_idx[e] >= cols) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    // COO -> CSC (counting sort by column; duplicates stay duplicates, the product adds them up like row_mul does)
+    std::vector<uint32_t> colptr(cols + 1, 0), erow(nnz);
+    std::vector<fr> eval(nnz);
+    for (uint64_t e = 0; e < nnz; e++) colptr[col_idx[e] + 1]++;
+    for (uint64_t cc = 0; cc < cols; cc++) colptr[cc + 1] += colptr[cc];
+    std::vector<uint32_t> fill(colptr.begin(), colptr.end() - 1);
+    for (uint64_t e = 0; e < nnz; e++) {
+        const uint32_t pos = fill[col_idx[e]]++;
+        erow[pos] = (uint32_t)row_idx[e];
+        memcpy(eval[pos].v, values + 4 * e, sizeof(fr));
+    }
+    std::vector<uint32_t> heavy;
+    for (uint64_t cc = 0; cc < cols; cc++)
+        if (colptr[cc + 1] - colptr[cc] > lg::kHeavyColumn) heavy.push_back((uint32_t)cc);
+    for (void* b : {(void*)c->d_a_colptr, (void*)c->d_a_row, (void*)c->d_a_val, (void*)c->d_a_heavy})
+        if (b) LG_HIP(c, hipFree(b));
+    c->d_a_colptr = nullptr; c->d_a_row = nullptr; c->d_a_val = nullptr; c->d_a_heavy = nullptr; c->a_loaded = false;
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_heavy), (heavy.size() ? heavy.size() : 1) * 4));
+    if (!heavy.empty()) LG_HIP(c, hipMemcpy(c->d_a_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice));
+    c->a_nheavy = (uint32_t)heavy.size();
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_colptr), colptr.size() * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_row), (nnz ? nnz : 1) * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_val), (nnz ? nnz : 1) * sizeof(fr)));
+    LG_HIP(c, hipMemcpy(c->d_a_colptr, colptr.data(), colptr.size() * 4, hipMemcpyHostToDevice));
+    if (nnz) {
+        LG_HIP(c, hipMemcpy(c->d_a_row, erow.data(), nnz * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_a_val, eval.data(), nnz * sizeof(fr), hipMemcpyHostToDevice));
+    }
+    c->a_rows = num_rows; c->a_nnz = nnz; c->a_loaded = true;
+    return LG_OK;
+}
+
+int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* coeffs_out) {
+    if (!c || !seeds || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (!c->committed || !c->a_loaded) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    LG_HIP(c, hipSetDevice(c->device));
+    uint32_t per, nch;
+    int rc = linear_buffers(c, &per, &nch);
+    if (rc != LG_OK) return rc;
+    const uint64_t n = (uint64_t)c->rows * c->k;      // 4 m k challenges per proof
+    if (n > 0x7fffffffull) return LG_ERR_UNSUPPORTED;
+    // 75.6 % of the 32-byte chunks are accepted; 1.5 chunks per element leaves > 50 standard deviations of margin
+    const uint32_t blocks = (uint32_t)((n * 3 + 3) / 4 + 64), wgs = (blocks + 255) / 256;
+    if (!c->d_seeds) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_seeds), (size_t)c->batch * 32));
+    if (!c->d_short_flag) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_short_flag), 4));
+    if (c->cc_counts_cap < (size_t)c->batch * wgs) {
+        if (c->d_cc_counts) LG_HIP(c, hipFree(c->d_cc_counts));
+        c->d_cc_counts = nullptr;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_cc_counts), (size_t)c->batch * wgs * 4));
+        c->cc_counts_cap = (size_t)c->batch * wgs;
+    }
+    rc = grow(c, &c->d_rlin, &c->rlin_elems, (size_t)c->batch * n);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->d_seeds, seeds, (size_t)c->batch * 32, hipMemcpyHostToDevice, c->stream));
+    LG_HIP(c, hipMemsetAsync(c->d_short_flag, 0, 4, c->stream));
+    lg::ChaChaArgs a;
+    a.seeds = c->d_seeds; a.out = c->d_rlin; a.counts = c->d_cc_counts; a.short_flag = c->d_short_flag;
+    a.n = (uint32_t)n; a.blocks = blocks; a.wgs = wgs;
+    hipLaunchKernelGGL(lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
+    LG_HIP(c, hipGetLastError());
+    lg::SparseRowMulArgs m;
+    m.col_ptr = c->d_a_colptr; m.ent_row = c->d_a_row; m.ent_val = c->d_a_val;
+    m.r = c->d_rlin; m.out = c->d_scratch_a; m.heavy = c->d_a_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)n;
+    hipLaunchKernelGGL(lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->stream, m);
+    if (c->a_nheavy) hipLaunchKernelGGL(lg::sparse_row_mul_heavy_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, m);
+    LG_HIP(c, hipGetLastError());
+    rc = linear_core(c, per, nch, coeffs_out);   // synchronises on the stream when it reads the coefficients back
+    if (rc != LG_OK) return rc;
+    uint32_t flag = 0;
+    LG_HIP(c, hipMemcpy(&flag, c->d_short_flag, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        snprintf(c->err, sizeof(c->err), "ChaCha candidate stream too short for %llu elements", (unsigned long long)n);
+        return LG_ERR_STATE;
+    }
+    return LG_OK;
+}
+
+static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_out) {
     const uint32_t rows = c->rows, O = 1u << c->logo;
     const uint64_t R = c->total_rows;
     const size_t mat = (size_t)R * c->k;
-    uint32_t per;
-    const uint32_t nch = sub_chunks(rows, &per);
-    int rc = sub_buffers(c, (size_t)c->batch * nch * 2 * c->k, 1);
-    if (rc != LG_OK) return rc;
-    rc = grow(c, &c->d_scratch_a, &c->scratch_a_elems, 2 * mat);   // r_a rows | their coefficients
-    if (rc != LG_OK) return rc;
-    rc = grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)c->nplanes * R * c->ki);
-    if (rc != LG_OK) return rc;
+    int rc = LG_OK;
     fr* d_ra = c->d_scratch_a;
     fr* d_rc = c->d_scratch_a + mat;
-    LG_HIP(c, hipMemcpyAsync(d_ra, r_a, mat * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     // r_polys = small_domain.ifft(row) (mod.rs:726-729), then their values on the odd points of the
     // size-2k domain = planes s = 4 (mod 8) of their encoding
     const uint64_t plane = R * c->ki;

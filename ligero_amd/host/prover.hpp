@@ -112,6 +112,20 @@ inline Digest column_hash(const std::vector<Fr>& col) {
     return h.finalize();
 }
 
+// self.a -> lg_upload_constraint_matrix (COO triplets)
+inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
+    std::vector<uint64_t> rows, cols;
+    std::vector<Fr> vals;
+    for (size_t r = 0; r < a.rows.size(); r++)
+        for (const auto& e : a.rows[r]) {
+            rows.push_back(r);
+            cols.push_back(e.second);
+            vals.push_back(e.first);
+        }
+    const int st = lg_upload_constraint_matrix(ctx, a.rows.size(), rows.size(), rows.data(), cols.data(), vals.empty() ? nullptr : vals[0].l);
+    if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
+}
+
 class HipLigero {
 public:
     HipLigero(const LigeroInstance& inst, int device = 0) : inst_(inst), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t) {
@@ -119,6 +133,7 @@ public:
         if (st != LG_OK) throw DeviceError(st, "lg_ctx_create");
         logn_ = 0;
         while ((size_t{1} << logn_) < n_) logn_++;
+        upload_constraint_matrix(ctx_, inst.a);
     }
     ~HipLigero() { lg_ctx_destroy(ctx_); }
     HipLigero(const HipLigero&) = delete;
@@ -142,10 +157,10 @@ public:
             proof.interleaved_proof.open = open_columns(sponge);
         }
         {   // prove_linear_constraints, mod.rs:712-747
-            const std::vector<Fr> r_linear = get_field_elements_from_prng(4 * m_ * k_, sponge.squeeze_seed());
-            const std::vector<Fr> r_a = inst_.a.row_mul(r_linear);
+            // r_linear (ChaCha20 + F::rand) and r_a = A.row_mul(r_linear) are produced on the device from the seed
+            const std::array<uint8_t, 32> seed = sponge.squeeze_seed();
             std::vector<Fr> poly(2 * k_);
-            check(lg_linear_constraint_poly(ctx_, r_a[0].l, poly[0].l), "lg_linear_constraint_poly");
+            check(lg_linear_constraint_poly_from_seeds(ctx_, seed.data(), poly[0].l), "lg_linear_constraint_poly_from_seeds");
             trim_zeros(poly);
             proof.linear_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
@@ -420,6 +435,7 @@ public:
         const int st = lg_ctx_create_batched(&ctx_, device, (uint32_t)(4 * m_), (uint32_t)k_, (uint32_t)n_, batch);
         if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_batched");
         while ((size_t{1} << logn_) < n_) logn_++;
+        upload_constraint_matrix(ctx_, inst.a);
         threads_ = threads ? threads : std::max(1u, std::min(usable_cpus(), batch));
         pool_.reset(new WorkerPool(threads_));
         mat_.resize((size_t)batch_ * 4 * m_ * k_);
@@ -445,7 +461,7 @@ public:
         PhaseTimer tm;
         std::vector<LigeroProof>& proofs = proofs_;
         proofs.resize(B);
-        scratch_.resize(B * mat);
+
         std::vector<PoseidonSponge> sponge(B, PoseidonSponge::test_sponge());
         parallel_for(B, [&](size_t b) {                                  // x / y / z / w assembly, mod.rs:476-516
             const auto r = inst_.build_preenc_u(assignments[b]);
@@ -472,14 +488,15 @@ public:
         });
         open_all(sponge, [&](size_t b) -> OpenedColumns& { return proofs[b].interleaved_proof.open; });
         tm.mark("absorb + open interleaved");
-        // linear test: r_a rows go into the (page-locked) matrix staging buffer
+        // linear test: only the 32-byte seeds go to the device; r_linear and r_a = A.row_mul(r_linear) are made there
         std::vector<Fr> poly(B * 2 * k_);
+        std::vector<uint8_t> seeds(B * 32);
         parallel_for(B, [&](size_t b) {
-            fill_field_elements_from_prng(&scratch_[b * mat], mat, sponge[b].squeeze_seed());   // r_linear
-            inst_.a.row_mul_into(&scratch_[b * mat], mat, &mat_[b * mat]);                        // r_a
+            const auto sd = sponge[b].squeeze_seed();
+            memcpy(&seeds[32 * b], sd.data(), 32);
         });
-        tm.mark("r_linear, A.row_mul (host)");
-        check(lg_linear_constraint_poly(ctx_, mat_[0].l, poly[0].l), "lg_linear_constraint_poly");
+        tm.mark("linear seeds (host)");
+        check(lg_linear_constraint_poly_from_seeds(ctx_, seeds.data(), poly[0].l), "lg_linear_constraint_poly_from_seeds");
         tm.mark("linear poly (device)");
         finish_poly(sponge, poly, [&](size_t b) -> ConstraintsProof& { return proofs[b].linear_constraints_proof; });
         tm.mark("absorb + open linear");
@@ -549,8 +566,7 @@ private:
     unsigned threads_ = 1;
     bool pinned_ = false;
     lg_ctx* ctx_ = nullptr;
-    std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u, later r_a
-    std::vector<Fr> scratch_;  // [batch][4m k]: r_linear
+    std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u
     std::vector<LigeroProof> proofs_;
     std::unique_ptr<WorkerPool> pool_;
     std::vector<Fr> cols_;  // [batch][t][4m]: opened columns

@@ -233,6 +233,25 @@ class LigeroCommitter:
         self._chk(self._L.lg_linear_constraint_poly(self._ctx, _ptr(r_a), _ptr(out)), "lg_linear_constraint_poly")
         return out
 
+    def upload_constraint_matrix(self, num_rows: int, row_idx, col_idx, values_mont):
+        """self.a of LigeroCircuit as COO triplets (host_pipeline.LigeroInstance.a_entries()), kept on the device"""
+        r = np.ascontiguousarray(row_idx, dtype=np.uint64)
+        c = np.ascontiguousarray(col_idx, dtype=np.uint64)
+        v = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(-1, 4)
+        if not (r.shape[0] == c.shape[0] == v.shape[0]):
+            raise ValueError("row, column and value arrays differ in length")
+        self._chk(self._L.lg_upload_constraint_matrix(self._ctx, num_rows, r.shape[0], _ptr(r), _ptr(c), _ptr(v)), "lg_upload_constraint_matrix")
+
+    def linear_constraint_poly_from_seeds(self, seeds: bytes) -> np.ndarray:
+        """prove_linear_constraints from the squeezed ChaCha seeds (32 bytes per proof): challenges, A.row_mul and the
+        polynomial all on the device.  Returns (batch, 2k, 4)."""
+        s = np.frombuffer(bytes(seeds), dtype=np.uint8).copy()
+        if s.size != 32 * self.batch:
+            raise ValueError("one 32-byte seed per proof")
+        out = np.empty((self.batch, 2 * self.k, 4), dtype=np.uint64)
+        self._chk(self._L.lg_linear_constraint_poly_from_seeds(self._ctx, _ptr(s), _ptr(out)), "lg_linear_constraint_poly_from_seeds")
+        return out
+
     def quadratic_constraint_poly(self, r) -> np.ndarray:
         """prove_quadratic_constraints (mod.rs:842-848): r: (batch*rows/4, 4) -> (batch, 2k, 4) coefficients"""
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * (self.rows // 4), 4)

@@ -198,3 +198,29 @@ def test_reference_multioutput_1(oracle):
     with LigeroProver(inst) as prover:
         assert prover.verify(prover.prove([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 4)])))
         assert not prover.verify(prover.prove([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 5)])))
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_device_side_linear_challenges(poseidon, oracle, batch):
+    """lg_linear_constraint_poly_from_seeds: ChaCha20 + F::rand rejection sampling (a stream compaction) and the sparse
+    A.row_mul on the device give the same polynomial as the host restatement of both feeding lg_linear_constraint_poly"""
+    import ligero_amd
+    from ligero_amd import host_pipeline as hp
+    inst, _, idx, vals = poseidon
+    pre, _ = inst.build_preenc_u(idx, vals)
+    rows_a, cols_a, vals_a = inst.a_entries()
+    seeds = [bytes([7 * b + i for i in range(32)]) for b in range(batch)] if batch > 1 else [bytes(32)]
+    with ligero_amd.LigeroCommitter(rows=inst.rows, k=inst.k, batch=batch) as c:
+        with pytest.raises(ligero_amd.LigeroHipError):                       # no commitment / no matrix yet
+            c.linear_constraint_poly_from_seeds(b"".join(seeds))
+        c.encode_commit(np.concatenate([pre] * batch), want_coeffs=False)
+        c.upload_constraint_matrix(4 * inst.m * inst.k, rows_a, cols_a, vals_a)
+        got = c.linear_constraint_poly_from_seeds(b"".join(seeds))
+        r_a = np.stack([inst.a_row_mul(hp.field_elements_from_seed(s, inst.rows * inst.k)) for s in seeds])
+        want = c.linear_constraint_poly(r_a.reshape(batch * inst.rows, inst.k, 4))
+        assert np.array_equal(got, want)
+        # seeds with extreme rejection patterns are still exact: all-ones key, and a repeat call (buffers reused)
+        s2 = [bytes([0xFF] * 32)] * batch
+        got2 = c.linear_constraint_poly_from_seeds(b"".join(s2))
+        r_a2 = np.stack([inst.a_row_mul(hp.field_elements_from_seed(s, inst.rows * inst.k)) for s in s2])
+        assert np.array_equal(got2, c.linear_constraint_poly(r_a2.reshape(batch * inst.rows, inst.k, 4)))
