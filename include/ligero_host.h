@@ -63,6 +63,11 @@ int lgh_a_row_mul(const lgh_instance* inst, const uint64_t* r, uint64_t* out);
 /* COO dump of A (nnz entries each), row-major order */
 int lgh_a_entries(const lgh_instance* inst, uint64_t* row_idx, uint64_t* col_idx, uint64_t* values);
 
+/* Witness file -> wire values (wire 0 first), Montgomery form: circom's witness.json (array of decimal strings, what
+ * src/ligero/tests.rs:384-390 reads) or snarkjs' binary .wtns.  *count_out = number of values in the file; at most
+ * `capacity` of them are stored (call with capacity 0 to size the buffer). */
+int lgh_read_witness(const char* path, uint64_t* values_out, uint64_t capacity, uint64_t* count_out);
+
 /*
  * Fiat-Shamir pieces (ligero_amd/host/transcript.hpp): restated from the published algorithms of
  * un-vendored crates -- PARITY UNPINNED except the ChaCha block function (RFC 8439 vector).

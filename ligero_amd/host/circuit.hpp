@@ -310,6 +310,91 @@ struct SparseMatrix {
     }
 };
 
+// ---------------------------------------------------------------- witness files
+// The reference's test reads circom/poseidon/witness.json with serde (src/ligero/tests.rs:384-390: a JSON array of
+// decimal strings, wire 0 first); snarkjs' binary .wtns holds the same values ("wtns", version 2, section 1 =
+// field size + prime + count, section 2 = count x 32-byte little-endian values).  Both give the wire
+// values in order, Montgomery form.
+inline std::vector<uint8_t> read_file_bytes(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<uint8_t> d;
+    uint8_t buf[65536];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + got);
+    std::fclose(f);
+    return d;
+}
+inline Fr fr_from_le_bytes_canonical(const uint8_t* p) {
+    Fr c;
+    for (int i = 0; i < 4; i++) {
+        c.l[i] = 0;
+        for (int j = 0; j < 8; j++) c.l[i] |= (uint64_t)p[8 * i + j] << (8 * j);
+    }
+    if (lg_host::geq(c, lg_host::kP)) throw std::runtime_error("witness value is not below the field modulus");
+    return lg_host::to_mont(c);
+}
+inline std::vector<Fr> read_witness(const std::string& path) {
+    const std::vector<uint8_t> d = read_file_bytes(path);
+    std::vector<Fr> out;
+    if (d.size() >= 12 && std::memcmp(d.data(), "wtns", 4) == 0) {
+        auto u32 = [&](size_t o) { if (o + 4 > d.size()) throw std::runtime_error("truncated .wtns"); uint32_t v; std::memcpy(&v, &d[o], 4); return v; };
+        auto u64 = [&](size_t o) { if (o + 8 > d.size()) throw std::runtime_error("truncated .wtns"); uint64_t v; std::memcpy(&v, &d[o], 8); return v; };
+        if (u32(4) != 2) throw std::runtime_error("unsupported .wtns version");
+        const uint32_t nsec = u32(8);
+        size_t off = 12;
+        uint64_t count = 0;
+        bool have_header = false;
+        for (uint32_t s = 0; s < nsec; s++) {
+            const uint32_t type = u32(off);
+            const uint64_t len = u64(off + 4);
+            off += 12;
+            if (off + len > d.size()) throw std::runtime_error("truncated .wtns section");
+            if (type == 1) {
+                if (u32(off) != 32) throw std::runtime_error(".wtns field size is not 32 bytes");
+                static const uint8_t prime[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+                                                  0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+                if (std::memcmp(&d[off + 4], prime, 32) != 0) throw std::runtime_error(".wtns prime is not BN254's scalar field");
+                count = u32(off + 36);
+                have_header = true;
+            } else if (type == 2) {
+                if (!have_header || len != count * 32) throw std::runtime_error(".wtns value section does not match its header");
+                for (uint64_t i = 0; i < count; i++) out.push_back(fr_from_le_bytes_canonical(&d[off + 32 * i]));
+            }
+            off += len;
+        }
+        return out;
+    }
+    // JSON: ["1", "1234...", ...]
+    size_t i = 0;
+    auto skip = [&] { while (i < d.size() && (d[i] == ' ' || d[i] == '\n' || d[i] == '\r' || d[i] == '\t' || d[i] == ',')) i++; };
+    skip();
+    if (i >= d.size() || d[i] != '[') throw std::runtime_error("witness file is neither .wtns nor a JSON array");
+    i++;
+    const Fr ten = fr_from_u64(10);
+    for (;;) {
+        skip();
+        if (i >= d.size()) throw std::runtime_error("unterminated JSON array");
+        if (d[i] == ']') break;
+        const bool quoted = d[i] == '"';
+        if (quoted) i++;
+        Fr v = fr_zero();
+        size_t digits = 0;
+        while (i < d.size() && d[i] >= '0' && d[i] <= '9') {
+            v = fr_add(fr_mul(v, ten), fr_from_u64((uint64_t)(d[i] - '0')));   // values are reduced mod p like F::from_str of a canonical string
+            i++;
+            digits++;
+        }
+        if (digits == 0 || digits > 78) throw std::runtime_error("bad number in witness JSON");
+        if (quoted) {
+            if (i >= d.size() || d[i] != '"') throw std::runtime_error("bad string in witness JSON");
+            i++;
+        }
+        out.push_back(v);
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------- LigeroCircuit::new and the x/y/z/w assembly
 // calculate_t of ark-poly-commit's linear_codes::utils (called at mod.rs:287-292), f64 arithmetic
 inline size_t calculate_t(size_t sec_param, size_t d_num, size_t d_den, size_t codeword_len, int field_bits = 254) {

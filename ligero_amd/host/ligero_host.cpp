@@ -150,6 +150,16 @@ int lgh_a_entries(const lgh_instance* i, uint64_t* row_idx, uint64_t* col_idx, u
     return LGH_OK;
 }
 
+int lgh_read_witness(const char* path, uint64_t* values_out, uint64_t capacity, uint64_t* count_out) {
+    if (!path || !count_out || (!values_out && capacity)) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const std::vector<Fr> w = read_witness(path);
+        *count_out = w.size();
+        for (size_t i = 0; i < w.size() && i < capacity; i++) store_fr(values_out + 4 * i, w[i]);
+        return LGH_OK;
+    });
+}
+
 // ---- Fiat-Shamir pieces (transcript.hpp; PARITY UNPINNED, see there) exposed for tests and FFI callers
 struct lgh_sponge {
     PoseidonSponge s = PoseidonSponge::test_sponge();

@@ -21,7 +21,7 @@ SYMBOLS = [
     "lgh_last_error", "lgh_circuit_new", "lgh_circuit_destroy", "lgh_circuit_num_nodes", "lgh_constant", "lgh_new_variable",
     "lgh_add", "lgh_mul", "lgh_pow", "lgh_minus", "lgh_circuit_from_r1cs", "lgh_circuit_num_outputs", "lgh_circuit_outputs",
     "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_a_row_mul", "lgh_a_entries",
-    "lgh_chacha_block", "lgh_field_elements_from_seed", "lgh_distinct_indices_from_seed", "lgh_sponge_new", "lgh_sponge_destroy",
+    "lgh_read_witness", "lgh_chacha_block", "lgh_field_elements_from_seed", "lgh_distinct_indices_from_seed", "lgh_sponge_new", "lgh_sponge_destroy",
     "lgh_sponge_absorb_bytes", "lgh_sponge_absorb_elements", "lgh_sponge_squeeze_bytes", "lgh_sponge_squeeze_elements",
 ]
 
@@ -57,6 +57,7 @@ def lib():
         L.lgh_build_preenc.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_a_row_mul.argtypes = [_vp, _vp, _vp]
         L.lgh_a_entries.argtypes = [_vp, _vp, _vp, _vp]
+        L.lgh_read_witness.argtypes = [ctypes.c_char_p, _vp, _u64, _vp]
         L.lgh_chacha_block.argtypes = [_u32, _vp, _vp, _vp]
         L.lgh_chacha_block.restype = None
         L.lgh_field_elements_from_seed.argtypes = [_vp, _u64, _vp]
@@ -174,6 +175,15 @@ class LigeroInstance:
         vals = np.empty((self.a_nnz, 4), dtype=np.uint64)
         _check(self._L.lgh_a_entries(self._h, _p(rows), _p(cols), _p(vals)), "a_entries")
         return rows, cols, vals
+
+
+def read_witness(path: str) -> np.ndarray:
+    """witness.json (decimal strings) or .wtns -> (wires, 4) Montgomery limbs, wire 0 first"""
+    cnt = ctypes.c_uint64(0)
+    _check(lib().lgh_read_witness(path.encode(), None, 0, ctypes.cast(ctypes.byref(cnt), _vp)), "read_witness")
+    out = np.empty((cnt.value, 4), dtype=np.uint64)
+    _check(lib().lgh_read_witness(path.encode(), _p(out), cnt.value, ctypes.cast(ctypes.byref(cnt), _vp)), "read_witness")
+    return out
 
 
 # ---- Fiat-Shamir pieces (ligero_amd/host/transcript.hpp; PARITY UNPINNED, see there)

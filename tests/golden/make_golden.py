@@ -5,7 +5,7 @@
     python tests/golden/make_golden.py
 
 What it writes
-  cube.r1cs, poseidon.r1cs, poseidon_witness.json
+  cube.r1cs, multiplication.r1cs, poseidon.r1cs, poseidon_witness.json, poseidon_witness.wtns
       DATA files copied from the reference's own test fixtures (circom/cube.r1cs,
       circom/poseidon/poseidon.r1cs, circom/poseidon/witness.json; used by
       src/arithmetic_circuit/tests.rs:189-241 and src/ligero/tests.rs:364-415).
@@ -56,6 +56,8 @@ def main():
     shutil.copy(f"{REF}/circom/cube.r1cs", f"{HERE}/cube.r1cs")
     shutil.copy(f"{REF}/circom/poseidon/poseidon.r1cs", f"{HERE}/poseidon.r1cs")
     shutil.copy(f"{REF}/circom/poseidon/witness.json", f"{HERE}/poseidon_witness.json")
+    shutil.copy(f"{REF}/circom/poseidon/witness.wtns", f"{HERE}/poseidon_witness.wtns")   # the same witness, snarkjs binary format
+    shutil.copy(f"{REF}/circom/multiplication.r1cs", f"{HERE}/multiplication.r1cs")
 
     # ---- batch of 64 Poseidon witnesses via the reference's wasm witness calculator
     blob = bytearray()

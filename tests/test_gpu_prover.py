@@ -4,6 +4,7 @@ fixtures, with every device sub-proof checked by the verifier's algebra and ever
 its Merkle path.  Mirrors the reference's test_poseidon (src/ligero/tests.rs:380-416: prove, then
 assert verify) and adds the negative cases that test does not have.  The transcript is UNPINNED
 against the Rust crates (transcript.hpp); the commitment root IS the golden one."""
+import json
 import os
 
 import numpy as np
@@ -224,3 +225,19 @@ def test_device_side_linear_challenges(poseidon, oracle, batch):
         got2 = c.linear_constraint_poly_from_seeds(b"".join(s2))
         r_a2 = np.stack([inst.a_row_mul(hp.field_elements_from_seed(s, inst.rows * inst.k)) for s in s2])
         assert np.array_equal(got2, c.linear_constraint_poly(r_a2.reshape(batch * inst.rows, inst.k, 4)))
+
+
+def test_cpp_example_program_from_files():
+    """the C++-only flow: .r1cs + witness file -> prove -> verify, as a program (ligero_amd/host/example_prove.cpp);
+    both witness formats; a circuit LigeroCircuit::new panics on reports the panic"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ligero_amd", "host", "example_prove")
+    assert os.path.exists(exe), "run `make -C ligero_amd/host`"
+    for wit in ("poseidon_witness.json", "poseidon_witness.wtns"):
+        out = subprocess.run([exe, os.path.join(GOLDEN, "poseidon.r1cs"), os.path.join(GOLDEN, wit)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert "m = 86  k = 128  n = 1024  t = 156" in out.stdout and "accepted = true" in out.stdout
+        assert "u_root = " + json.load(open(os.path.join(GOLDEN, "vectors.json")))["poseidon"]["root"] in out.stdout
+    bad = subprocess.run([exe, os.path.join(GOLDEN, "cube.r1cs"), os.path.join(GOLDEN, "poseidon_witness.json")], capture_output=True, text=True)
+    assert bad.returncode == 3 and "error:" in bad.stderr

@@ -166,3 +166,25 @@ def test_prover_library_exports():
         assert getattr(L, name) is not None
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "include", "ligero_prover.h")])
+
+
+def test_witness_readers(hp, oracle, model):
+    """witness.json and the .wtns of the same witness (both from the reference's circom/poseidon/) give the same wires,
+    equal to the test loader's; malformed files are refused"""
+    import tempfile
+    from conftest import GOLDEN
+    want = oracle.to_mont(oracle.ints_to_limbs(model.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))))
+    got_json = hp.read_witness(os.path.join(GOLDEN, "poseidon_witness.json"))
+    got_wtns = hp.read_witness(os.path.join(GOLDEN, "poseidon_witness.wtns"))
+    assert got_json.shape == (265, 4) and np.array_equal(got_json, want) and np.array_equal(got_wtns, want)
+    with tempfile.TemporaryDirectory() as d:
+        blob = open(os.path.join(GOLDEN, "poseidon_witness.wtns"), "rb").read()
+        for name, data in (("short.wtns", blob[:100]), ("prime.wtns", blob[:31] + b"\x00" + blob[32:]), ("junk.json", b'{"a": 1}'), ("open.json", b'["1", "2"')):
+            path = os.path.join(d, name)
+            open(path, "wb").write(data)
+            with pytest.raises(hp.HostPanic):
+                hp.read_witness(path)
+        path = os.path.join(d, "plain.json")
+        open(path, "wb").write(b'[ "0", 7 ,"21888242871839275222246405745257275088548364400416034343698204186575808495618" ]')
+        got = hp.read_witness(path)                                     # p + 1 reduces to 1
+        assert np.array_equal(got, oracle.to_mont(oracle.ints_to_limbs([0, 7, 1])))
