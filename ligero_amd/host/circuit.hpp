@@ -76,7 +76,7 @@ inline R1cs read_r1cs(const std::string& path) {
     size_t got;
     while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + got);
     std::fclose(f);
-    auto need = [&](size_t o, size_t len) { if (o + len > d.size()) throw std::runtime_error("r1cs: truncated file"); };
+    auto need = [&](size_t o, size_t len) { if (o > d.size() || len > d.size() - o) throw std::runtime_error("r1cs: truncated file"); };
     auto u32 = [&](size_t o) { need(o, 4); uint32_t v; std::memcpy(&v, d.data() + o, 4); return v; };
     auto u64 = [&](size_t o) { need(o, 8); uint64_t v; std::memcpy(&v, d.data() + o, 8); return v; };
     if (d.size() < 12 || std::memcmp(d.data(), "r1cs", 4) != 0 || u32(4) != 1) throw std::runtime_error("not a circom r1cs v1 file");
@@ -88,6 +88,7 @@ inline R1cs read_r1cs(const std::string& path) {
         off += 12;
         if (typ == 1) hdr = off;
         if (typ == 2) cons = off;
+        need(off, len);   // also keeps off from wrapping around
         off += len;
     }
     if (!hdr || !cons) throw std::runtime_error("r1cs: missing header or constraint section");
@@ -102,6 +103,9 @@ inline R1cs read_r1cs(const std::string& path) {
     size_t o = hdr + 4 + fs;
     r.n_wires = u32(o); r.n_pub_out = u32(o + 4); r.n_pub_in = u32(o + 8); r.n_prv_in = u32(o + 12);
     const uint32_t ncons = u32(o + 24);
+    // every wire has an 8-byte label in the wire map and every constraint at least three 4-byte counts: a header that
+    // claims more than the file can hold is corrupt (and would otherwise make the compiler allocate gigabytes)
+    if ((uint64_t)r.n_wires * 8 > d.size() || (uint64_t)ncons * 12 > d.size()) throw std::runtime_error("r1cs: header counts exceed the file size");
     o = cons;
     auto read_lc = [&]() {
         R1cs::Lc lc;
@@ -109,6 +113,7 @@ inline R1cs read_r1cs(const std::string& path) {
         o += 4;
         for (uint32_t i = 0; i < nnz; i++) {
             const uint32_t wire = u32(o);
+            if (wire >= r.n_wires) throw std::runtime_error("r1cs: wire index out of range");
             Fr v;
             need(o + 4, 32);
             std::memcpy(v.l, d.data() + o + 4, 32);
@@ -338,8 +343,8 @@ inline std::vector<Fr> read_witness(const std::string& path) {
     const std::vector<uint8_t> d = read_file_bytes(path);
     std::vector<Fr> out;
     if (d.size() >= 12 && std::memcmp(d.data(), "wtns", 4) == 0) {
-        auto u32 = [&](size_t o) { if (o + 4 > d.size()) throw std::runtime_error("truncated .wtns"); uint32_t v; std::memcpy(&v, &d[o], 4); return v; };
-        auto u64 = [&](size_t o) { if (o + 8 > d.size()) throw std::runtime_error("truncated .wtns"); uint64_t v; std::memcpy(&v, &d[o], 8); return v; };
+        auto u32 = [&](size_t o) { if (o > d.size() || d.size() - o < 4) throw std::runtime_error("truncated .wtns"); uint32_t v; std::memcpy(&v, &d[o], 4); return v; };
+        auto u64 = [&](size_t o) { if (o > d.size() || d.size() - o < 8) throw std::runtime_error("truncated .wtns"); uint64_t v; std::memcpy(&v, &d[o], 8); return v; };
         if (u32(4) != 2) throw std::runtime_error("unsupported .wtns version");
         const uint32_t nsec = u32(8);
         size_t off = 12;
@@ -349,8 +354,9 @@ inline std::vector<Fr> read_witness(const std::string& path) {
             const uint32_t type = u32(off);
             const uint64_t len = u64(off + 4);
             off += 12;
-            if (off + len > d.size()) throw std::runtime_error("truncated .wtns section");
+            if (off > d.size() || len > d.size() - off) throw std::runtime_error("truncated .wtns section");
             if (type == 1) {
+                if (len < 40) throw std::runtime_error("truncated .wtns header");
                 if (u32(off) != 32) throw std::runtime_error(".wtns field size is not 32 bytes");
                 static const uint8_t prime[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
                                                   0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};

@@ -188,3 +188,24 @@ def test_witness_readers(hp, oracle, model):
         open(path, "wb").write(b'[ "0", 7 ,"21888242871839275222246405745257275088548364400416034343698204186575808495618" ]')
         got = hp.read_witness(path)                                     # p + 1 reduces to 1
         assert np.array_equal(got, oracle.to_mont(oracle.ints_to_limbs([0, 7, 1])))
+
+
+def test_r1cs_reader_refuses_corrupt_files(hp):
+    """truncations, section lengths that run past the file (or wrap around), header counts the file cannot hold and
+    wire indices out of range are refused with an error, never read out of bounds or turned into huge allocations
+    (the same mutations pass an AddressSanitizer + UBSan build of the library, tools/fuzz_readers.py)"""
+    import tempfile
+    from conftest import GOLDEN
+    good = open(os.path.join(GOLDEN, "poseidon.r1cs"), "rb").read()
+    cases = [good[:n] for n in (0, 3, 11, 12, 23, 24, 60, 100, 5000, len(good) - 1)]
+    cases.append(good[:16] + (2 ** 64 - 8).to_bytes(8, "little") + good[24:])          # first section length wraps the offset
+    cases.append(good[:16] + (1 << 40).to_bytes(8, "little") + good[24:])              # ... or just runs past the end
+    hdr = good.index(bytes.fromhex("20000000010000f093f5e143"))                         # field size 32 + start of the prime
+    cases.append(good[:hdr + 36] + (0x7FFFFFFF).to_bytes(4, "little") + good[hdr + 40:])   # n_wires far beyond the file
+    cases.append(good[:hdr + 60] + (0x7FFFFFFF).to_bytes(4, "little") + good[hdr + 64:])   # n_constraints likewise
+    with tempfile.TemporaryDirectory() as d:
+        for i, data in enumerate(cases):
+            path = os.path.join(d, f"c{i}.r1cs")
+            open(path, "wb").write(data)
+            with pytest.raises(hp.HostPanic):
+                hp.ArithmeticCircuit.from_r1cs(path)
