@@ -40,6 +40,9 @@ struct lg_ctx {
     hipEvent_t ev_up[kMaxChunks] = {};     // "rows of chunk c have arrived from the host"
     hipEvent_t ev_coef[kMaxChunks] = {};   // "rows of chunk c are interpolated"
     hipEvent_t ev_done = nullptr;          // "tree of this commit is complete"
+    hipEvent_t ev_hashed = nullptr, ev_tree = nullptr;   // single-chunk commits: leaves complete / tree complete (on stream_h)
+    bool async_tree = true;                // LG_ASYNC_TREE=0 turns the overlap below off (A/B knob)
+    bool tree_pending = false;             // the tree of the last commit is still being built on stream_h
     uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
     lg_ctx* aux2k = nullptr;               // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
     fr* d_sub_partial = nullptr; size_t sub_partial_elems = 0;  // row-sum partials of the sub-proof polynomials
@@ -443,6 +446,8 @@ void lg_ctx_destroy(lg_ctx* c) {
     for (auto& e : c->ev_coef)
         if (e) hipEventDestroy(e);
     if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->ev_hashed) hipEventDestroy(c->ev_hashed);
+    if (c->ev_tree) hipEventDestroy(c->ev_tree);
     if (c->stream_up) hipStreamDestroy(c->stream_up);
     if (c->stream_dn) hipStreamDestroy(c->stream_dn);
     if (c->stream_h) hipStreamDestroy(c->stream_h);
@@ -483,6 +488,9 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         for (auto& e : c->ev_up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->ev_coef) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_done, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->ev_hashed, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->ev_tree, lg_event_flags()));
+        if (const char* e = getenv("LG_ASYNC_TREE")) c->async_tree = atoi(e) != 0;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
         const size_t mat = (size_t)c->total_rows * k;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
@@ -653,6 +661,18 @@ int lg_profile_enable(lg_ctx* c, int on) {
     return LG_OK;
 }
 
+// Single-chunk commits build their Merkle tree on the second stream and do NOT make the encode stream wait for
+// it: the tree is latency bound (a few workgroups, ten dependent SHA-256 levels, 0.075 ms on the Poseidon batch)
+// and the next commit's interpolation and evaluation do not touch the leaves, so in a stream of commits the tree
+// hides behind them.  Everything that reads or rewrites leaves / nodes calls settle_tree() first.
+static int settle_tree(lg_ctx* c) {
+    if (c->tree_pending) {
+        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tree, 0));
+        c->tree_pending = false;
+    }
+    return LG_OK;
+}
+
 // The commit (mod.rs:521-551).  host_pre == nullptr: the matrix is resident in d_preenc.  Otherwise the
 // rows are streamed from host memory chunk by chunk (same row range of every proof: one strided copy),
 // so that the PCIe transfer of chunk c+1 overlaps the encoding of chunk c; host_coeffs (optional)
@@ -722,6 +742,11 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
             LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
             LG_HIP(c, hipStreamWaitEvent(hs, c->ev_chunk[i], 0));
         }
+        if (i == 0) {   // the previous commit's tree may still be reading the leaves this hash is about to rewrite
+            const int rc = settle_tree(c);
+            if (rc != LG_OK) return rc;
+            if (nchunks > 1) LG_HIP(c, hipStreamWaitEvent(hs, c->ev_tree, 0));   // (ev_tree: completed or never recorded = no-op)
+        }
         if (prof && i == 0) LG_HIP(c, hipEventRecord(ev[3], hs));
         lg::ColHashArgs h;
         memset(&h, 0, sizeof(h));
@@ -753,6 +778,12 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         }
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
+    const bool async_tree = c->async_tree && nchunks == 1;
+    hipStream_t ms = async_tree ? c->stream_h : hs;
+    if (async_tree) {
+        LG_HIP(c, hipEventRecord(c->ev_hashed, c->stream));
+        LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_hashed, 0));
+    }
     // Merkle tree (mod.rs:544-551): nine levels per launch
     {
         lg::MerkleArgs m;
@@ -764,17 +795,21 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
             m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
             const dim3 grid(c->batch * m.chunks);
             if (leaf)
-                hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, hs, m);
+                hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, ms, m);
             else
-                hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, hs, m);
+                hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, ms, m);
             leaf = false;
             depth = depth > 9 ? depth - 9 : 0;
         }
         LG_HIP(c, hipGetLastError());
     }
     if (prof) {
-        LG_HIP(c, hipEventRecord(ev[5], hs));
+        LG_HIP(c, hipEventRecord(ev[5], ms));
         c->prof_commits++;
+    }
+    if (async_tree) {
+        LG_HIP(c, hipEventRecord(c->ev_tree, c->stream_h));
+        c->tree_pending = true;
     }
     // everything issued later on the encode stream (read-backs, the next commit) sees the tree
     if (nchunks > 1) {
@@ -829,6 +864,7 @@ int lg_profile_read(lg_ctx* c, float ms_out[LG_STAGE_COUNT], uint32_t* samples_o
 int lg_sync(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipStreamSynchronize(c->stream));
     return LG_OK;
 }
@@ -844,6 +880,7 @@ int lg_read_root(lg_ctx* c, uint8_t* root_out) {
     if (!c || !root_out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
     LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipMemcpy2DAsync(root_out, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, c->batch, hipMemcpyDeviceToHost, c->stream));
     LG_HIP(c, hipStreamSynchronize(c->stream));
     return LG_OK;
@@ -856,11 +893,13 @@ int lg_read_coeffs(lg_ctx* c, uint64_t* out) {
 int lg_read_leaves(lg_ctx* c, uint8_t* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     return read_back(c, out, c->d_leaves, (size_t)c->batch * c->n * 32);
 }
 int lg_read_nodes(lg_ctx* c, uint8_t* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     return read_back(c, out, c->d_nodes, (size_t)c->batch * (c->n - 1) * 32);
 }
 
@@ -911,6 +950,7 @@ static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const
         if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
     if (nidx == 0) return LG_OK;
     LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     const uint32_t plen = (uint32_t)c->logn - 1;
     if (c->idx_cap < nidx) {
         if (c->d_idx) LG_HIP(c, hipFree(c->d_idx));
@@ -1220,6 +1260,7 @@ int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
     if (c->batch != 1) return LG_ERR_STATE;
     if (c->nplanes < 32 && (plane_mask >> c->nplanes) != 0) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     const uint64_t plane = c->total_rows * c->ki;
     // every owned plane -- including the ones that coincide with the message -- is produced by
     // the evaluation kernel from the gathered coefficients, so no second exchange is needed
@@ -1256,6 +1297,7 @@ int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
 int lg_stage_merkle(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     lg::MerkleArgs m;
     m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
     uint32_t depth = (uint32_t)c->logn;
@@ -1278,6 +1320,11 @@ int lg_stage_merkle(lg_ctx* c) {
 
 int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
     if (!c || !dptr_out || !bytes_out) return LG_ERR_BAD_ARG;
+    if (which == LG_BUF_LEAVES || which == LG_BUF_NODES) {   // the caller will touch them outside our streams' order
+        LG_HIP(c, hipSetDevice(c->device));
+        const int rc_ = settle_tree(c);
+        if (rc_ != LG_OK) return rc_;
+    }
     switch (which) {
         case LG_BUF_PREENC: *dptr_out = c->d_preenc; *bytes_out = (size_t)c->total_rows * c->k * sizeof(fr); break;
         case LG_BUF_COEFFS: *dptr_out = c->d_coeffs; *bytes_out = (size_t)c->total_rows * c->k * sizeof(fr); break;
