@@ -235,6 +235,49 @@ __device__ __forceinline__ void ntt_sync() {
     }
 }
 
+// Radix-2 first pass of a coset evaluation (log2 k = 1 mod 3): pre-scale, butterfly and twiddle collapse into
+//     y0 = x0 c00 + x1 c01,   y1 = x0 c10 + x1 c11
+// -- two dot products (3 multiply-equivalents) instead of two pre-scales, the reduction of y0 and the twiddle of
+// y1 (4).  Every thread owns exactly four butterflies (K/2 units over K/8 threads); the operands of butterfly
+// i+1 are fetched while butterfly i is being multiplied (this pass is the only one whose operands all come from
+// global memory, and with two waves per SIMD an exposed fetch per butterfly cost ~5 % of the kernel).
+template <int LOGK>
+__device__ __forceinline__ void first2_pass(const LdsPlanes& row, int slot_base, int t, bool active, const Tw29& first2,
+                                            const fr* __restrict__ gin, uint32_t sel) {
+    constexpr int K = 1 << LOGK, LOGSUB = LOGK - 1, SUB = 1 << LOGSUB;
+    constexpr int T = NttPlan<LOGK>::kThreadsPerNtt;
+    static_assert((K >> 1) == 4 * T, "four butterflies per thread");
+    if (!active) return;
+    struct Operands {
+        fr x0, x1;
+        f29 c[4];
+    };
+    const size_t t0 = ((size_t)sel * 4) << LOGSUB;
+    auto fetch = [&](int i0) {
+        Operands o;
+        o.x0 = fr_load(gin + i0);
+        o.x1 = fr_load(gin + i0 + SUB);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o.c[j] = tw29_load(first2, t0 + (size_t)j * SUB + i0);
+        return o;
+    };
+    Operands cur = fetch(t);
+    static_for<0, 4>([&](auto itc) {
+        constexpr int it = decltype(itc)::value;
+        const int i0 = t + it * T;
+        Operands nxt;
+        if constexpr (it < 3) nxt = fetch(i0 + T);
+        f29 x[2] = {unpack29(cur.x0), unpack29(cur.x1)};
+        f29 c0[2] = {cur.c[0], cur.c[1]}, c1[2] = {cur.c[2], cur.c[3]}, y0, y1;
+        mul29_dot<2>(y0, x, c0);
+        mul29_dot<2>(y1, x, c1);
+        const int sbase = lds_swz<LOGK>(slot_base + i0);
+        row.put(sbase, y0);
+        row.put(sbase ^ lds_swz<LOGK>(SUB), y1);
+        if constexpr (it < 3) cur = nxt;
+    });
+}
+
 // One DIF pass over an LDS-resident row.  LOGS = log2 of the current sub-transform size.
 // LOGK = log2 of the LDS-resident transform size ki, LOGO = log2 of the outer radix; `sel` is the
 // plane id (evaluate) or the outer output index h (interpolate).
@@ -256,29 +299,7 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
         const int base = (blk << LOGS) + i0;
         const int sbase = lds_swz<LOGK>(slot_base + base);  // element q of this butterfly: sbase ^ sigma(q << LOGSUB)
         f29 e[R];
-        if constexpr (FIRST && EVALUATE && LOGO == 0 && LOGR == 1 && (LOGSUB > 0)) {
-            // radix-2 first pass of a coset evaluation: pre-scale, butterfly and twiddle collapse into
-            // y0 = x0 c00 + x1 c01, y1 = x0 c10 + x1 c11 -- two dot products (3 multiply-equivalents)
-            // instead of two pre-scales, the normalising product of y0 and the twiddle of y1 (4)
-            f29 x[2], c0[2], c1[2];
-#ifdef LG_ABL_NO_IN  // ablation builds only: inputs from registers
-            x[0] = a.one; x[0].v[0] += base;
-            x[1] = a.oneq; x[1].v[0] += base;
-#else
-            x[0] = unpack29(fr_load(gin + base));
-            x[1] = unpack29(fr_load(gin + base + SUB));
-#endif
-            const size_t t0 = ((size_t)sel * 4) << LOGSUB;
-            c0[0] = tw29_load(a.first2, t0 + i0);
-            c0[1] = tw29_load(a.first2, t0 + SUB + i0);
-            c1[0] = tw29_load(a.first2, t0 + 2 * SUB + i0);
-            c1[1] = tw29_load(a.first2, t0 + 3 * SUB + i0);
-            mul29_dot<2>(e[0], x, c0);
-            mul29_dot<2>(e[1], x, c1);
-            row.put(sbase, e[0]);
-            row.put(sbase ^ lds_swz<LOGK>(SUB), e[1]);
-            continue;
-        }
+        // (the radix-2 first pass of a coset evaluation has its own software-pipelined routine: first2_pass)
         if constexpr (FIRST && LOGO == 0) {
             fr raw[R];
             static_for<0, R>([&](auto qc) {
@@ -434,7 +455,10 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
     cs.invk = a.invk;
     cs.invkq = a.invkq;
     fr* canon = (!EVALUATE && LOGO == 0 && a.canon_out != nullptr) ? a.canon_out + row_in : nullptr;
-    dif_pass<LOGK, LOGO, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, slot_base, t, active, cs, a.in + row_in, a.coset_tw, sel, canon);
+    if constexpr (EVALUATE && LOGO == 0 && Plan::kFirstLogR == 1 && LOGK > 1)
+        first2_pass<LOGK>(row, slot_base, t, active, cs.first2, a.in + row_in, sel);
+    else
+        dif_pass<LOGK, LOGO, LOGK, Plan::kFirstLogR, true, EVALUATE>(row, slot_base, t, active, cs, a.in + row_in, a.coset_tw, sel, canon);
     dif_rest<LOGK, LOGO, LOGK - Plan::kFirstLogR, EVALUATE>(row, slot_base, t, active, cs);
     ntt_sync<LOGK>();
     if (!active) return;
