@@ -185,8 +185,8 @@ def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="poseidon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="timed workload only: no CPU baseline, no single-commit latency, no full-prover leg (profiler runs)")
