@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential sweep (GPU library vs the oracle) over shapes the fixed test cases do not name:
 random rows / k / batch, random data incl. field corners, both commit entry points, openings, sub-proof polynomials.
-    python tools/parity_sweep.py [seconds]"""
+    python tests/parity_sweep.py [seconds]
+(a checker script, not collected by pytest: lives under tests/ because it uses the oracle)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa
 import ligero_amd
-from oracle import binding as oracle            # tool only: the checker
+from oracle import binding as oracle            # the checker
 from conftest import random_mont
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0

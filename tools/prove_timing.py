@@ -7,15 +7,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa
 from ligero_amd import host_pipeline as hp
 from ligero_amd.prover import LigeroProver
-from oracle import model, binding as oracle      # tool only: loads the witness fixture
 
 G = os.path.join(ROOT, "tests", "golden")
 t0 = time.perf_counter()
 circ = hp.ArithmeticCircuit.from_r1cs(os.path.join(G, "poseidon.r1cs"))
 inst = hp.LigeroInstance(circ)
 t1 = time.perf_counter()
-w = model.load_witness_json(os.path.join(G, "poseidon_witness.json"))
-vals = oracle.to_mont(oracle.ints_to_limbs(w[1:]))
+w = hp.read_witness(os.path.join(G, "poseidon_witness.json"))
+vals = w[1:]
 idx = list(range(1, len(w)))
 prover = LigeroProver(inst)
 t2 = time.perf_counter()

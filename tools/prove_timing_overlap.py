@@ -7,12 +7,15 @@ sys.path.insert(0, ROOT)
 import torch  # noqa
 from ligero_amd import host_pipeline as hp
 from ligero_amd.prover import LigeroBatchProver
-from oracle import binding as oracle      # tool only
 G = os.path.join(ROOT, "tests", "golden")
 inst = hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(os.path.join(G, "poseidon.r1cs")))
 blob = open(os.path.join(G, "poseidon_witness_batch64.bin"), "rb").read()
-ws = [[int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") for j in range(265)] for i in range(64)]
-allv = np.stack([oracle.to_mont(oracle.ints_to_limbs(w[1:])) for w in ws])
+P, MASK = 21888242871839275222246405745257275088548364400416034343698204186575808495617, (1 << 64) - 1
+allv = np.empty((64, 264, 4), dtype=np.uint64)
+for i in range(64):
+    for j in range(1, 265):
+        v = (int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") << 256) % P      # Montgomery form
+        allv[i, j - 1] = [(v >> (64 * l)) & MASK for l in range(4)]
 idx = list(range(1, 265))
 for nprov, batch, threads in ((2, 64, 16), (3, 64, 16), (4, 64, 16), (2, 128, 16), (3, 64, 8), (4, 64, 8)):
     provers = [LigeroBatchProver(inst, batch, threads=threads) for _ in range(nprov)]
