@@ -391,10 +391,20 @@ static int plan_chunks(const lg_ctx* c, Chunk* out, bool from_host = false) {
         out[0] = Chunk{0, c->batch, 0, c->rows};
         return 1;
     }
+    // The hash of the LAST chunk has nothing left to hide behind, so the chunks taper: weights 4, 4, ..., 4, 3, 1
+    // (the exposed tail is 1/(4 parts - 4) of the hash instead of 1/parts).  LG_CHUNK_TAPER=0: equal chunks.
+    static const bool taper = [] { const char* e = getenv("LG_CHUNK_TAPER"); return !e || atoi(e) != 0; }();
+    std::vector<uint32_t> w(parts, 4);
+    if (taper && parts >= 4 && pairs >= 8 * parts) { w[parts - 2] = 3; w[parts - 1] = 1; }   // (3,2,1 / 2,1 tails measured the same)
+    uint64_t total = 0, acc = 0;
+    for (uint32_t x : w) total += x;
+    uint32_t r0 = 0;
     for (uint32_t i = 0; i < parts; i++) {
-        const uint32_t r0 = 2 * (uint32_t)((uint64_t)pairs * i / parts);
-        const uint32_t r1 = (i + 1 == parts) ? c->rows : 2 * (uint32_t)((uint64_t)pairs * (i + 1) / parts);
+        acc += w[i];
+        uint32_t r1 = (i + 1 == parts) ? c->rows : 2 * (uint32_t)((uint64_t)pairs * acc / total);
+        if (r1 <= r0) r1 = r0 + 2;
         out[n++] = Chunk{0, c->batch, r0, r1};
+        r0 = r1;
     }
     return n;
 }
