@@ -71,13 +71,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // LDS index swizzle: element `pos` of NTT slot `slot` lives at sigma(slot * K + pos) in each of
-// the three planes.  sigma XORs a 5-bit constant into the low index bits for every set upper
-// bit (table found by tools/lds_swizzle.py so that every pass and the digit-reversed read-back
-// are bank-conflict free or nearly so).  It is GF(2)-linear: sigma(a ^ b) = sigma(a) ^ sigma(b).
+// the three planes.  sigma XORs a constant (< 2^min(j, 5)) into the low index bits for every set bit
+// j >= 3 of the index (table found by tools/lds_swizzle.py: every pass and the digit-reversed read-back are
+// bank-conflict free in the guide's bank model).  It is GF(2)-linear and unit upper triangular, hence a
+// bijection with sigma(a ^ b) = sigma(a) ^ sigma(b).
 template <int LOGK>
 __host__ __device__ __forceinline__ constexpr int lds_swz(int i) {
     int x = i;
-    for (int j = 5; j < 24; j++)
+    for (int j = 3; j < 24; j++)
         if (kLdsSwz[LOGK][j] != 0) x ^= (0 - ((i >> j) & 1)) & kLdsSwz[LOGK][j];
     return x;
 }
