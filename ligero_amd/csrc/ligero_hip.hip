@@ -275,21 +275,6 @@ __global__ void __launch_bounds__(256) planes_to_rows_kernel(const fr* u, uint64
     fr_store(out + ((i * (uint64_t)k) << lognp) + ((uint64_t)q << lognp) + s, z);
 }
 
-// message rows (Montgomery) -> canonical integers in the planes that hold the systematic part of
-// the codeword: message index d = O j + c sits at codeword index 8 d = (8 O) j + 8 c, i.e. plane 8c,
-// slot j.  (With O = 1 the interpolation kernel writes this copy itself.)
-__global__ void __launch_bounds__(256) canon_planes_kernel(const fr* msg, fr* u, uint64_t plane_stride, uint64_t total_rows,
-                                                          uint32_t logk, uint32_t logo) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (total_rows << logk)) return;
-    const uint64_t row = gid >> logk;
-    const uint32_t d = (uint32_t)(gid & ((1u << logk) - 1));
-    const uint32_t c = d & ((1u << logo) - 1), j = d >> logo;
-    fr x = fr_load(msg + gid), y;
-    fr_from_mont(y, x);
-    fr_store(u + (uint64_t)(8 * c) * plane_stride + (row << (logk - logo)) + j, y);
-}
-
 }  // namespace lg
 
 // ----------------------------------------------------------------------------- launches
@@ -706,14 +691,11 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         LG_HIP(c, hipStreamWaitEvent(c->stream_up, c->ev_done, 0));
     } else {
         // rows -> coefficients (mod.rs:521-526) in one launch; also emits the canonical message = coset plane 0
-        lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->logo == 0 ? c->d_u : nullptr, 0, (uint32_t)c->total_rows);
+        // (with an outer fold the canonical message planes 8c are written by the same kernel: every input is loaded by
+        // the O workgroups of its row anyway, and a separate pass over the matrix cost 3.5 ms of S22's 94)
+        lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, 0, (uint32_t)c->total_rows);
+        a.plane_stride = plane;
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
-        if (c->logo > 0) {
-            const uint64_t threads = c->total_rows << c->logk;
-            hipLaunchKernelGGL(lg::canon_planes_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_preenc, c->d_u,
-                               plane, c->total_rows, (uint32_t)c->logk, (uint32_t)c->logo);
-            LG_HIP(c, hipGetLastError());
-        }
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[1], c->stream));
     auto upload_chunk = [&](int i) -> int {

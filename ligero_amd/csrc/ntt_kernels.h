@@ -36,7 +36,9 @@ constexpr int kMaxLdsLogK = 12;  // 4096 elements * 36 B = 144 KiB of the 160 Ki
 struct NttArgs {
     const fr* in;        // interpolate: message rows [rows][k]; evaluate: coefficient rows [rows][k]  (ABI words)
     fr* out;             // interpolate: coefficient rows [rows][k]; evaluate: base of the planes [8 O][rows][ki]
-    fr* canon_out;       // interpolate, O = 1 only: canonical (non-Montgomery) copy of the message = plane 0 (may be null)
+    fr* canon_out;       // interpolate: base of the codeword planes for the canonical (non-Montgomery) copy of the message
+                         // (may be null).  O = 1: plane 0.  O > 1: message index d sits in plane 8 (d mod O), slot d / O;
+                         // workgroup h of a row writes the inputs d = i + h ki it loads anyway (needs plane_stride)
     Tw29q tw;            // butterfly twiddles of the size-ki transform in pass order (pass_tw_offset below), plain
                          // value + Barrett quotient (shoup29); root = omega_ki^-1 (interpolate) or omega_ki (evaluate)
     Tw29q coset_tw;      // evaluate, O = 1: [plane s][d < k] = omega_n^(s d), the pre-scale of coefficient d (plain +
@@ -217,6 +219,7 @@ struct NttConsts {
     f29 w8[3];
     f29 w8q[3];
     f29 one, oneq;
+    uint64_t plane_stride;  // elements between codeword planes (canonical copy of a folded interpolation)
     f29 last;         // interpolate, single pass: Montgomery multiplier 2^261 / k of every output
     f29 invk, invkq;  // interpolate, O = 1, several passes: 1 / k for output 0 of the first pass
 };
@@ -453,9 +456,25 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
     cs.one = a.one;
     cs.oneq = a.oneq;
     cs.last = a.scale;
+    cs.plane_stride = a.plane_stride;
     cs.invk = a.invk;
     cs.invkq = a.invkq;
-    fr* canon = (!EVALUATE && LOGO == 0 && a.canon_out != nullptr) ? a.canon_out + row_in : nullptr;
+    // O = 1: this row of plane 0; O > 1: this row's offset inside every plane (the pass adds plane and slot)
+    fr* canon = (!EVALUATE && a.canon_out != nullptr) ? a.canon_out + (LOGO == 0 ? row_in : ((size_t)rg << LOGK)) : nullptr;
+    if constexpr (!EVALUATE && LOGO > 0) {
+        // canonical copy of the message for a folded interpolation: workgroup h of a row converts the segment
+        // [h ki, (h + 1) ki) of it (a second, cache-resident read of values the dot products load as well; inside the
+        // dot-product loop the extra live values spilled to scratch)
+        if (active && canon != nullptr) {
+            constexpr int O = 1 << LOGO;
+            for (int j = t; j < K; j += Plan::kThreadsPerNtt) {
+                const uint32_t dd = (uint32_t)j + (sel << LOGK);
+                f29 cv;
+                mul29_small(cv, unpack29(fr_load(a.in + row_in + dd)), 32u);
+                fr_store_stream(canon + (size_t)(8u * (dd & (O - 1))) * a.plane_stride + (dd >> LOGO), pack29_reduced(cv));
+            }
+        }
+    }
     if constexpr (EVALUATE && LOGO == 0 && Plan::kFirstLogR == 1 && LOGK > 1)
         first2_pass<LOGK>(row, slot_base, t, active, cs.first2, a.in + row_in, sel);
     else
