@@ -75,8 +75,7 @@ void lg_ctx_destroy(lg_ctx* ctx);
 int lg_encode_commit(lg_ctx* ctx, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out);
 /*
  * lg_encode_commit streams its host buffers: the rows travel over PCIe in chunks while earlier
- * chunks are being encoded, and the coefficient rows travel back the same way (k <= 4096; larger k
- * copy first).  The overlap needs page-locked host memory -- copies from/to pageable memory
+ * chunks are being encoded, and the coefficient rows travel back the same way.  The overlap needs page-locked host memory -- copies from/to pageable memory
  * block the calling thread, so only the upload overlaps there.  These two pin / unpin a buffer
  * the caller already owns (e.g. the Vec behind preenc_u); they wrap hipHostRegister so that the
  * caller does not have to link the HIP runtime.

@@ -721,6 +721,7 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
             lg::NttArgs ia = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, row0, nrows);
             ia.chunk_rows = ch.row_end - ch.row_begin;
             ia.proof_stride = c->rows;
+            ia.plane_stride = plane;
             LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, ia));
             if (host_coeffs) LG_HIP(c, hipEventRecord(c->ev_coef[i], c->stream));
         }
@@ -897,21 +898,9 @@ int lg_read_nodes(lg_ctx* c, uint8_t* out) {
 
 int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out) {
     if (!c || !preenc || !root_out) return LG_ERR_BAD_ARG;
-    int rc;
-    if (c->logo == 0) {
-        // rows stream in (and coefficients out) while earlier rows are being encoded
-        rc = commit_core(c, preenc, coeffs_out);
-        if (rc != LG_OK) return rc;
-    } else {  // k > 4096: the message planes are written by a separate pass over the whole matrix
-        rc = lg_upload_preenc(c, preenc);
-        if (rc != LG_OK) return rc;
-        rc = lg_commit_resident(c);
-        if (rc != LG_OK) return rc;
-        if (coeffs_out) {
-            rc = lg_read_coeffs(c, coeffs_out);
-            if (rc != LG_OK) return rc;
-        }
-    }
+    // rows stream in (and coefficients out) while earlier rows are being encoded
+    const int rc = commit_core(c, preenc, coeffs_out);
+    if (rc != LG_OK) return rc;
     return lg_read_root(c, root_out);
 }
 

@@ -148,7 +148,7 @@ def test_small_batches_match_oracle(lg, oracle, batch):
             assert np.array_equal(c.codeword_rows(proof=b), ref["u"])
 
 
-@pytest.mark.parametrize("batch,rows,k", [(3, 70, 32), (1, 300, 1024)])
+@pytest.mark.parametrize("batch,rows,k", [(3, 70, 32), (1, 300, 1024), (1, 24, 8192)])
 def test_streamed_commit_from_registered_host_buffers(lg, oracle, batch, rows, k, monkeypatch):
     """lg_encode_commit streams its host buffers in row chunks (input in, coefficients out) while
     earlier chunks are encoded; forced to 4 chunks here so that small shapes take that path, with
