@@ -280,6 +280,16 @@ def main():
                          "launches_per_step": dom_launches, "samples": stage["samples"] * dom_launches},
             "root0": root[:32].hex(),
         }
+        # the same roofline arithmetic for every stage (the contract's `roofline` object is the dominant one)
+        per_stage_bytes = {"evaluate": b_eval, "interpolate": batch * rows * 96 * k,
+                           "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}
+        tall = json.load(open(tfile)).get(args.workload, {}) if os.path.exists(tfile) else {}
+        line["stage_rooflines"] = {}
+        for sname in names:
+            nl = launches if sname in ("evaluate", "colhash") else 1
+            gbs = per_stage_bytes[sname] / nl / (stage[sname] / nl * 1e-3) / 1e9
+            line["stage_rooflines"][sname] = {"algorithmic_bytes_per_launch": per_stage_bytes[sname] / nl, "launches_per_step": nl,
+                                              "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname)}
         if copy_gbs:
             line["roofline"]["measured_copy_GBs"] = copy_gbs
             line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
