@@ -435,3 +435,30 @@ def test_poseidon_end_to_end_from_fixtures(lg, oracle, model, vectors):
         bad[zr, zc] = random_mont(9, 1)[0]                                 # a z entry of a multiplication gate
         c.encode_commit(bad, want_coeffs=False)
         assert oracle.fft(c.quadratic_constraint_poly(random_mont(322, inst.m))[0])[0::2].any()
+
+
+@pytest.mark.parametrize("async_tree", ["0", "1"])
+def test_back_to_back_commits_with_and_without_async_tree(lg, oracle, async_tree, monkeypatch):
+    """single-chunk commits build the tree on the second stream while the next commit is already encoding; every
+    reader of leaves / nodes must still see ITS commit's tree (settle_tree), with the overlap switched off as well"""
+    monkeypatch.setenv("LG_ASYNC_TREE", async_tree)
+    rows, k, batch = 36, 64, 4
+    pres = [random_mont(900 + i, batch * rows * k).reshape(batch * rows, k, 4) for i in range(3)]
+    refs = [[oracle.encode_commit(p[b * rows:(b + 1) * rows], k, 8 * k) for b in range(batch)] for p in pres]
+    with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+        assert c.pipeline_chunks() == 1
+        for rep in range(2):
+            for i, p in enumerate(pres):                      # a burst of commits, only the last one is read
+                c.upload(p)
+                c.commit_resident()
+            last = refs[-1]
+            assert c.root() == b"".join(r["root"] for r in last)
+            assert np.array_equal(c.nodes(), np.stack([r["nodes"] for r in last]))
+            assert np.array_equal(c.leaves(), np.stack([r["leaves"] for r in last]))
+            cols, sib, paths = c.open_columns([0, 7, 8 * k - 1], proof=batch - 1)
+            ecols, esib, epaths = oracle.open_columns(last[-1]["u"], last[-1]["leaves"], last[-1]["nodes"], [0, 7, 8 * k - 1])
+            assert np.array_equal(cols, ecols) and np.array_equal(sib, esib) and np.array_equal(paths, epaths)
+            # and a commit whose tree is read immediately
+            c.upload(pres[0])
+            c.commit_resident()
+            assert c.root() == b"".join(r["root"] for r in refs[0])
