@@ -205,11 +205,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
+    # LIGERO_BENCH_BACKEND=gloo: dry run of the multi-rank control flow on a box with fewer GPUs than ranks (ranks then
+    # share devices; RCCL needs one GPU per rank).  The driver's runs use the default, RCCL.
+    backend = os.environ.get("LIGERO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     rows, k, batch = WORKLOADS[args.workload]
     n = 8 * k
@@ -236,7 +244,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage = c.stage_ms()
