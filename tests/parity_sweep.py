@@ -19,9 +19,9 @@ t_end = time.time() + budget
 n_cases = 0
 P_LIMBS = np.array([0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)
 while time.time() < t_end:
-    logk = int(rng.integers(1, 13))
+    logk = int(rng.integers(1, 15))       # 13, 14: folded transforms (k = 8192, 16384)
     k = 1 << logk
-    max_rows = max(2, min(400, (1 << 21) // (8 * k)))
+    max_rows = max(4, min(400, (1 << 21) // (8 * k)))
     rows = int(rng.integers(1, max_rows // 4 + 1)) * 4
     batch = int(rng.choice([1, 1, 2, 3, 5]))
     if batch * rows * k * 8 > (1 << 22):
@@ -51,7 +51,7 @@ while time.time() < t_end:
             cols, sib, paths = c.open_columns(idx, proof=b)
             ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], idx)
             assert np.array_equal(cols, ecols) and np.array_equal(sib, esib) and np.array_equal(paths, epaths), ("open", rows, k, batch, b, seed)
-        if k <= 4096 and rows % 4 == 0:
+        if k <= 8192 and rows % 4 == 0:
             r = random_mont(seed + 1, batch * rows // 4).reshape(batch, rows // 4, 4)
             got = c.quadratic_constraint_poly(r)
             for b in range(batch):
