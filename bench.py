@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark of the MI355X Ligero encode-and-commit hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload poseidon|s20|s18]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload poseidon|s20|s18|s22]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 one rank per GPU.  A "step" is one pass of the hot path (src/ligero/mod.rs:521-551 of the
 reference: RS-encode every row, Blake2s every column, SHA-256 Merkle tree) over one batch of
-synthetic input that is already resident in HBM.  The path shards by independent proofs
-(BASELINE.json configs[4]): every rank commits its own batch, there is no data-path
-collective, scaling is weak.
+synthetic input that is already resident in HBM.
+
+Multi-GPU (N > 1), two modes:
+  * poseidon (default): the path shards by independent proofs (BASELINE.json configs[4]): every rank
+    commits its own batch, no data-path collective, "scaling": "weak".  The same run then also times
+    the coset-sharded single-proof commit below on the s22 shape (a few steps, reported under
+    "sharded_commit"), so that the driver's scaling run exercises RCCL over xGMI.
+  * s20 / s22 / s18: ONE proof coset-sharded over the N GPUs (BASELINE.json configs[3];
+    ligero_amd/sharded.py CosetShardedCommitter over RCCL): row-sharded interpolation, in-place
+    all-gather of the coefficient rows, each rank evaluates + hashes its coset planes, all-gather of
+    the column digests, replicated Merkle tree; "scaling": "strong", per-stage ms incl. both all-gathers.
 
 Workloads
   poseidon  (default; BASELINE.json configs[1], the shape the metric is quoted on)
@@ -45,6 +53,9 @@ WORKLOADS = {
     "s18": (2509, 4096, 1),
     "s22": (20068, 8192, 1),      # BASELINE configs[3] shape on ONE GPU (53 GB resident)
 }
+
+
+LARGE_SEED = 2022       # input of the s20 / s22 legs whose roots are pinned in tests/golden/large_roots.json
 
 
 def synthetic_preenc(seed: int, count: int) -> np.ndarray:
@@ -175,11 +186,197 @@ def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
     # all-cores variant of the same restatement, reported beside it
     nthr = min(orc.lib().orc_max_threads(), usable_cpus())
     if nthr > 1:
+        reps = max(1, min(sample_commits, 16))
         t0 = time.perf_counter()
-        orc.encode_commit(pre[:sample_rows], k, n, threads=nthr, want_u=False)
+        for _ in range(reps):
+            orc.encode_commit(pre[:sample_rows], k, n, threads=nthr, want_u=False)
         dt2 = time.perf_counter() - t0
-        out["all_cores"] = {"value": sample_rows * n / dt2, "cores": nthr}
+        out["all_cores"] = {"value": reps * sample_rows * n / dt2, "cores": nthr,
+                            "sample": f"{reps} x ({sample_rows} rows x {k} -> {n}), rows / columns over OpenMP threads, {dt2:.1f} s"}
     return out
+
+
+def shard_rows_of_seeded_matrix(seed: int, k: int, r0: int, r1: int) -> np.ndarray:
+    """rows [r0, r1) of synthetic_preenc(seed, rows * k) without generating the rest: PCG64.advance skips the 4 k
+    64-bit draws of each earlier row (full-range uint64 draws consume one output each)"""
+    bg = np.random.PCG64(seed)
+    bg.advance(r0 * k * 4)
+    out = np.random.Generator(bg).integers(0, 2**64, size=((r1 - r0) * k, 4), dtype=np.uint64)
+    out[:, 3] &= np.uint64((1 << 61) - 1)
+    return out.reshape(r1 - r0, k, 4)
+
+
+def golden_large(workload: str):
+    path = os.path.join(ROOT, "tests", "golden", "large_roots.json")
+    if os.path.exists(path):
+        return json.load(open(path)).get(workload)
+    return None
+
+
+def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, rank: int, local_rank: int, steps: int, warmup: int):
+    """ONE proof of the `workload` shape coset-sharded over `world` ranks (BASELINE configs[3]); returns the result dict on
+    every rank.  Timed region: barrier + sync, `steps` commits with the message rows resident, barrier + sync, max over ranks."""
+    from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
+    rows, k, _ = WORKLOADS[workload]
+    n = 8 * k
+    be = HipStageBackend(rows, k, device=local_rank, world=world, rank=rank)
+    try:
+        sc = CosetShardedCommitter(be, dist if world > 1 else None)
+        r0, r1 = sc.row_range()
+        pre = shard_rows_of_seeded_matrix(LARGE_SEED, k, r0, r1)
+
+        def fence():
+            be.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        root = sc.commit(pre)                      # uploads this rank's rows; later commits find them resident
+        for _ in range(max(0, warmup - 1)):
+            sc.commit(None)
+        names = ("interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle")
+        acc = {s: 0.0 for s in names}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            root = sc.commit(None)
+            for s in names:
+                acc[s] += sc.stage_ms[s]
+        fence()
+        elapsed = time.perf_counter() - t0
+        stage = torch.tensor([elapsed] + [acc[s] / steps for s in names], dtype=torch.float64,
+                             device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(stage, op=dist.ReduceOp.MAX)
+        stage = [float(x) for x in stage.tolist()]
+        elapsed = stage[0]
+        gold = golden_large(workload)
+        coeff_bytes = rows * k * 32
+        ag_ms = stage[2]
+        out = {
+            "workload": f"{workload}: 1 x ({rows} x {k} -> {n}) coset-sharded over {world} GPU(s)",
+            "value": steps * rows * n / elapsed, "unit": "field-elems/s", "ms_per_commit": 1e3 * elapsed / steps,
+            "steps": steps, "scaling": "strong", "n_gpus": world, "collective_backend": backend if world > 1 else None,
+            "stage_ms_max_over_ranks": dict(zip(names, stage[1:])),
+            "row_shard": [r0, r1], "rows_per_shard_padded": sc.shard_rows, "planes_per_rank": len(sc.planes),
+            "u_bytes_per_rank": len(sc.planes) * rows * (k if k <= 4096 else 4096) * 32,
+            "allgather_coeffs_GBs_per_rank_ingress": (coeff_bytes * (world - 1) / world) / (ag_ms * 1e-3) / 1e9 if world > 1 and ag_ms > 0 else None,
+            "root": root.hex(), "root_matches_golden": (root.hex() == gold["root"]) if gold else None,
+        }
+        return out
+    finally:
+        be.close()
+
+
+def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps):
+    """what a drop-in caller gets: lg_encode_commit from host buffers (PCIe inclusive), root read back; with and without the
+    coefficient rows coming home, pageable and page-locked (lg_host_register)"""
+    out = {}
+    c = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch, device=device)
+    try:
+        coeffs = np.empty_like(pre)
+        coeffs[:] = 0                                  # touch: page faults are not what is being measured
+
+        def run(want):
+            c.encode_commit(pre, want_coeffs=want, coeffs_out=coeffs if want else None)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                _, root = c.encode_commit(pre, want_coeffs=want, coeffs_out=coeffs if want else None)
+            return (time.perf_counter() - t0) / reps * 1e3, root
+        out["pageable_root_only"], root = run(False)
+        out["pageable_with_coeffs"], _ = run(True)
+        c.host_register(pre)
+        c.host_register(coeffs)
+        try:
+            out["page_locked_root_only"], root2 = run(False)
+            out["page_locked_with_coeffs"], _ = run(True)
+        finally:
+            c.host_unregister(coeffs)
+            c.host_unregister(pre)
+        out["root0"] = root[:32].hex()
+        assert root == root2
+        out["bytes_in"] = int(pre.nbytes)
+        out["note"] = "lg_encode_commit(host preenc_u -> root [+ host coefficient rows]); PCIe-inclusive, never `value`"
+    finally:
+        c.close()
+    return out
+
+
+def resident_run(ligero_amd, torch, dist, backend, workload, pre, device, steps, warmup, world):
+    """K commits of the resident matrix; returns (elapsed seconds [max over ranks], stage ms, launches per commit, roots)"""
+    rows, k, batch = WORKLOADS[workload]
+    c = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch, device=device)
+    try:
+        c.upload(pre)                           # inputs resident in HBM before the timed region
+        for _ in range(warmup):
+            c.commit_resident()
+        c.sync()
+        c.profile(True)                         # HIP events around each stage, on the stream the kernels run on
+
+        def fence():
+            c.sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.commit_resident()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, c.stage_ms(), c.pipeline_chunks(), c.root()
+    finally:
+        c.close()
+
+
+def roofline_of(workload, stage, launches, traffic_file):
+    """`roofline` (dominant kernel) and `stage_rooflines` from per-stage HIP-event times.  With more than one row chunk
+    the column hash runs on its own stream BESIDE the evaluation: its event span includes waiting for chunks to be
+    encoded, so it is reported as an overlapped span and left out of the dominant-kernel choice."""
+    rows, k, batch = WORKLOADS[workload]
+    n = 8 * k
+    _, b_eval = algorithmic_bytes(rows, k, n, batch)
+    names = ("interpolate", "evaluate", "colhash", "merkle")
+    per_stage_bytes = {"evaluate": b_eval, "interpolate": batch * rows * 96 * k,      # msg in, coeffs out, canonical copy out
+                       "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}
+    overlapped = {"colhash": launches > 1, "merkle": launches == 1}     # single-chunk commits build the tree beside the next commit
+    eligible = [s for s in names if not (s == "colhash" and launches > 1)]
+    dom = max(eligible, key=lambda s: stage[s])
+    tall = json.load(open(traffic_file)).get(workload, {}) if os.path.exists(traffic_file) else {}
+    rl, dom_rl = {}, None
+    for sname in names:
+        nl = launches if sname in ("evaluate", "colhash") else 1
+        ms = stage[sname] / nl
+        gbs = per_stage_bytes[sname] / nl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rl[sname] = {"algorithmic_bytes_per_launch": per_stage_bytes[sname] / nl, "launches_per_step": nl, "ms_per_launch": ms,
+                     "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname),
+                     "overlapped_span": bool(overlapped.get(sname, False))}
+        if sname == dom:
+            dom_rl = {"bound": "hbm", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
+                                                 "colhash": "blake2s_columns_kernel", "merkle": "merkle_subtree_kernel"}[dom],
+                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname),
+                      "algorithmic_bytes_per_launch": per_stage_bytes[sname] / nl, "ms_per_launch": ms, "launches_per_step": nl,
+                      "samples": stage["samples"] * nl}
+    return dom_rl, rl
+
+
+def valu_roofline_of(workload, stage):
+    rows, k, batch = WORKLOADS[workload]
+    mi = multiplier_instr_per_element(k)
+    if mi is None:
+        return None
+    rate = batch * rows * 7 * k * mi / (stage["evaluate"] * 1e-3) / 1e12
+    return {"unit": "T multiplier lane-instr/s", "kernel": "ntt_rows_kernel<evaluate>",
+            "multiplier_instr_per_element": mi, "achieved": rate, "peak": MAD_PEAK_T, "frac": rate / MAD_PEAK_T,
+            "peak_source": "measured v_mad_u64_u32 issue rate, whole chip (tools/microbench2.hip)",
+            "note": "the remaining issue slots go to carries, butterflies, packing and LDS traffic (DESIGN.md 4.2)"}
 
 
 def main():
@@ -189,7 +386,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="poseidon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true",
-                    help="timed workload only: no CPU baseline, no single-commit latency, no full-prover leg (profiler runs)")
+                    help="timed workload only: no CPU baseline, no latency / host-buffer / s20 / full-prover / sharded legs (profiler runs)")
+    ap.add_argument("--sharded-leg", default="s22", choices=["s22", "s20", "s18", "none"],
+                    help="multi-GPU poseidon run: shape of the extra coset-sharded single-proof leg (RCCL all-gathers)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,51 +420,47 @@ def main():
 
     rows, k, batch = WORKLOADS[args.workload]
     n = 8 * k
-    pre = synthetic_preenc(1000 + rank, batch * rows * k).reshape(batch * rows, k, 4)
-    c = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch, device=local_rank)
-    c.upload(pre)                           # inputs resident in HBM before the timed region
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    extras = world == 1 and not args.no_cpu_baseline
+    large = args.workload != "poseidon"
 
-    for _ in range(args.warmup):
-        c.commit_resident()
-    c.sync()
-    c.profile(True)                         # HIP events around each stage, on the stream the kernels run on
+    if large and world > 1:
+        # ---- ONE proof coset-sharded over the ranks (BASELINE configs[3]): strong scaling, RCCL all-gathers
+        steps = min(args.steps, 20)
+        res = sharded_commit_leg(torch, dist, backend, args.workload, world, rank, local_rank, steps, min(args.warmup, 3))
+        if rank == 0:
+            line = {
+                "metric": "RS-encoded field-elems/sec (Ligero encode+commit, one proof coset-sharded over the GPUs)",
+                "value": res["value"], "unit": "field-elems/s", "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 3),
+                "ms_per_step": res["ms_per_commit"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u32 limbs (BN254 Fr, 254-bit Montgomery) + u32 ARX hashes", "data": "synthetic",
+                "config": {"workload": res["workload"], "rows": rows, "k": k, "n": n,
+                           "parallelism": f"row-sharded interpolation + all-gather + coset-sharded evaluate/hash x{world}"},
+                "sharded_commit": res,
+            }
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
-    def fence():
-        c.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    # ---- independent commitments per rank (BASELINE configs[1] / [4]); one GPU: also configs[2] / the s22 shape
+    seed = LARGE_SEED if large else 1000 + rank
+    pre = synthetic_preenc(seed, batch * rows * k).reshape(batch * rows, k, 4)
+    elapsed, stage, launches, root = resident_run(ligero_amd, torch, dist, backend, args.workload, pre, local_rank, args.steps, args.warmup, world)
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        c.commit_resident()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stage = c.stage_ms()
-    launches = c.pipeline_chunks()          # evaluate / column-hash kernel launches per commit
-    root = c.root()
+    sharded = None
+    if world > 1 and args.sharded_leg != "none" and not args.no_cpu_baseline:
+        # the same ranks, one large proof over all of them: the driver's scaling run thereby measures the RCCL path too
+        try:
+            sharded = sharded_commit_leg(torch, dist, backend, args.sharded_leg, world, rank, local_rank, 5, 2)
+        except Exception as e:  # the headline line must survive a failure of the extra leg
+            sharded = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         commits = args.steps * batch * world
         elems = commits * rows * n
-        b_commit, b_eval = algorithmic_bytes(rows, k, n, batch)
-        names = ("interpolate", "evaluate", "colhash", "merkle")
-        dom = max(names, key=lambda s: stage[s])
-        dom_launches = launches if dom in ("evaluate", "colhash") else 1
-        dom_bytes = {"evaluate": b_eval, "interpolate": batch * rows * 96 * k,      # msg in, coeffs out, canonical copy out
-                     "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}[dom] / dom_launches
-        dom_ms = stage[dom] / dom_launches
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None          # HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json), if collected
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+        b_commit, _ = algorithmic_bytes(rows, k, n, batch)
+        dom_rl, stage_rl = roofline_of(args.workload, stage, launches, tfile)
         copy_gbs = device_copy_gbs(torch) if world == 1 else None
         line = {
             "metric": "RS-encoded field-elems/sec (Ligero encode+commit, Poseidon R1CS shape)" if args.workload == "poseidon"
@@ -280,40 +475,26 @@ def main():
             "commitments_per_sec": commits / elapsed,
             "encoded_rows_per_sec": commits * rows / elapsed,
             "commit_algorithmic_GBs": world * b_commit * args.steps / elapsed / 1e9,
-            "stage_ms": {s: stage[s] for s in names},
-            "roofline": {"bound": "hbm", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
-                                                    "colhash": "blake2s_columns_kernel", "merkle": "merkle_level_kernel"}[dom],
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
-                         "launches_per_step": dom_launches, "samples": stage["samples"] * dom_launches},
+            "commit_roofline_frac": world * b_commit * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+            "stage_ms": {s: stage[s] for s in ("interpolate", "evaluate", "colhash", "merkle")},
+            "roofline": dom_rl,
             "root0": root[:32].hex(),
+            "stage_rooflines": stage_rl,
         }
-        # the same roofline arithmetic for every stage (the contract's `roofline` object is the dominant one)
-        per_stage_bytes = {"evaluate": b_eval, "interpolate": batch * rows * 96 * k,
-                           "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}
-        tall = json.load(open(tfile)).get(args.workload, {}) if os.path.exists(tfile) else {}
-        line["stage_rooflines"] = {}
-        for sname in names:
-            nl = launches if sname in ("evaluate", "colhash") else 1
-            gbs = per_stage_bytes[sname] / nl / (stage[sname] / nl * 1e-3) / 1e9
-            line["stage_rooflines"][sname] = {"algorithmic_bytes_per_launch": per_stage_bytes[sname] / nl, "launches_per_step": nl,
-                                              "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname)}
+        if large:
+            gold = golden_large(args.workload)
+            line["root_matches_golden"] = (root[:32].hex() == gold["root"]) if gold else None
         if copy_gbs:
             line["roofline"]["measured_copy_GBs"] = copy_gbs
-            line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / copy_gbs
         # secondary roof: the path is integer-multiply bound, not HBM bound
-        mi = multiplier_instr_per_element(k)
-        if mi is not None:
-            rate = batch * rows * 7 * k * mi / (stage["evaluate"] * 1e-3) / 1e12
-            line["valu_roofline"] = {
-                "unit": "T multiplier lane-instr/s", "kernel": "ntt_rows_kernel<evaluate>",
-                "multiplier_instr_per_element": mi, "achieved": rate, "peak": MAD_PEAK_T, "frac": rate / MAD_PEAK_T,
-                "peak_source": "measured v_mad_u64_u32 issue rate, whole chip (tools/microbench2.hip)",
-                "note": "the remaining issue slots go to carries, butterflies, packing and LDS traffic (DESIGN.md 4.2)",
-            }
-        if world == 1 and args.workload == "poseidon" and not args.no_cpu_baseline:
-            # (skipped with --no-cpu-baseline, i.e. in profiler runs, so that every launch a profile sees belongs to the
-            # timed workload)  BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
+        vr = valu_roofline_of(args.workload, stage)
+        if vr:
+            line["valu_roofline"] = vr
+        if sharded is not None:
+            line["sharded_commit"] = sharded
+        if extras and args.workload == "poseidon":
+            # BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
             one = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=1, device=local_rank)
             one.upload(pre[:rows])
             for _ in range(5):
@@ -325,11 +506,30 @@ def main():
             one.sync()
             line["single_commit_ms"] = (time.perf_counter() - t1) / 50 * 1e3
             one.close()
+            # what a drop-in caller gets (host buffers in, root [+ coefficients] out): PCIe inclusive, never `value`
+            line["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, local_rank, 10)
+            # BASELINE configs[2] (the HBM-roofline report shape) under the same clock: 5 commits, root pinned by a golden
+            try:
+                pre20 = synthetic_preenc(LARGE_SEED, WORKLOADS["s20"][0] * WORKLOADS["s20"][1]).reshape(-1, WORKLOADS["s20"][1], 4)
+                e20, st20, l20, root20 = resident_run(ligero_amd, torch, None, backend, "s20", pre20, local_rank, 5, 2, 1)
+                r20, k20, _ = WORKLOADS["s20"]
+                d20, srl20 = roofline_of("s20", st20, l20, tfile)
+                gold = golden_large("s20")
+                line["s20"] = {"workload": f"s20: 1 x ({r20} x {k20} -> {8 * k20})", "steps": 5, "ms_per_step": e20 / 5 * 1e3,
+                               "value": 5 * r20 * 8 * k20 / e20, "unit": "field-elems/s", "roofline": d20, "stage_rooflines": srl20,
+                               "valu_roofline": valu_roofline_of("s20", st20), "root": root20[:32].hex(),
+                               "root_matches_golden": (root20[:32].hex() == gold["root"]) if gold else None}
+                hb = host_buffer_commit_ms(ligero_amd, pre20, r20, k20, 1, local_rank, 2)
+                line["s20"]["host_buffer_commit_ms"] = hb
+                del pre20
+            except Exception as e:
+                line["s20"] = {"error": f"{type(e).__name__}: {e}"}
             line["full_prover"] = full_prover_rate(local_rank)
-        if world == 1 and not args.no_cpu_baseline:
+        if extras:
             line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
+            line["vs_cpu_baseline"] = {"ratio": line["value"] / line["cpu_baseline"]["value"],
+                                       "of": "cpu_baseline.value (1-core port of the reference-shaped path); a reported ratio, not the target"}
         print(json.dumps(line), flush=True)
-    c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

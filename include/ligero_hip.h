@@ -52,7 +52,7 @@ const char* lg_status_string(int status);
 const char* lg_last_error(const lg_ctx* ctx);
 /* ABI version of this header: bumped on any incompatible change. */
 uint32_t lg_abi_version(void);
-#define LG_ABI_VERSION 1u
+#define LG_ABI_VERSION 2u
 
 /*
  * Context for `batch` independent commitments of identical shape (batch = 1 for
@@ -62,6 +62,20 @@ uint32_t lg_abi_version(void);
  */
 int lg_ctx_create(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n);
 int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch);
+/*
+ * Context of ONE rank of a single proof that is coset-sharded over several GPUs (the staged calls further
+ * down).  The codeword lives in np = 8 * max(1, k / 4096) coset planes (lg_ctx_planes);
+ * this context allocates only planes [plane_begin, plane_begin + plane_count) of U (1/8 of 42 GB per rank for the
+ * 2^22-constraint shape on 8 GPUs), receives its message rows through lg_stage_interpolate (only the range handed
+ * over is kept), and sizes LG_BUF_COEFFS for coeff_rows_alloc >= rows rows (0 = rows) so that world * ceil(rows /
+ * world) equal row shards fit and the caller can use ONE in-place all-gather even when world does not divide rows;
+ * the padding rows are never read.  lg_upload_preenc / lg_commit_resident / lg_encode_commit return LG_ERR_STATE on
+ * such a context, lg_stage_evaluate_hash refuses planes outside the owned run with LG_ERR_BAD_ARG.
+ */
+int lg_ctx_create_sharded(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t plane_begin, uint32_t plane_count,
+                          uint32_t coeff_rows_alloc);
+/* number of coset planes of this shape, and the run of them this context holds (all of them unless sharded) */
+int lg_ctx_planes(const lg_ctx* ctx, uint32_t* nplanes, uint32_t* plane_begin, uint32_t* plane_count);
 void lg_ctx_destroy(lg_ctx* ctx);
 
 /*
@@ -168,8 +182,18 @@ int lg_quadratic_constraint_poly(lg_ctx* ctx, const uint64_t* r, uint64_t* coeff
  *                             planes for k <= 4096): evaluate all rows, hash the columns ->
  *                             LG_BUF_LEAVES entries j
  *   4. (caller) all-gather the leaf digests
- *   5. lg_stage_merkle        tree over LG_BUF_LEAVES; afterwards lg_read_root / lg_open_columns
- *                             (columns of owned planes only) work as after lg_encode_commit
+ *   5. lg_stage_merkle        tree over LG_BUF_LEAVES; afterwards lg_read_root / lg_read_leaves / lg_read_nodes /
+ *                             lg_read_coeffs work as after lg_encode_commit
+ * What a staged commitment holds on THIS device is only what the stages put there: the planes passed to
+ * lg_stage_evaluate_hash since the last lg_stage_interpolate and the message rows passed to lg_stage_interpolate.  The
+ * library tracks both, and every entry point that would read anything else returns LG_ERR_STATE (lg_last_error names the
+ * planes / rows) instead of foreign or stale data:
+ *   lg_open_columns[_batch]                     every index j must lie in a held plane (j mod np)
+ *   lg_read_codeword_rows                       needs all planes
+ *   lg_linear_constraint_poly[_from_seeds],
+ *   lg_quadratic_constraint_poly                need the planes s = 0 (mod 4) (the size-2k domain)
+ *   lg_interleaved_row_mul, lg_commit_resident  need every message row
+ * A single rank that stages all planes and all rows ends up with a full commitment and no restriction.
  */
 int lg_stage_interpolate(lg_ctx* ctx, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows);
 int lg_stage_evaluate_hash(lg_ctx* ctx, uint32_t plane_mask);

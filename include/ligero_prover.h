@@ -52,10 +52,7 @@ const lgp_proof* lgp_batch_proof(const lgp_batch_prover* p, uint32_t index);
 /* inspection: info_out = { len(preenc_u_lc), len(linear poly), len(quadratic poly), opened columns per sub-proof,
  * column length, auth path length }; root_out = u_root */
 int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_out[32]);
-/* test hook: corrupt one item.  what: 0 u_root byte, 1 preenc_u_lc element, 2 linear polynomial coefficient,
- * 3 quadratic polynomial coefficient, 4 an element of an opened column (interleaved), 5 same (linear), 6 same
- * (quadratic), 7 an auth-path digest (interleaved), 8 leaf index of an opening (linear); index selects the item */
-int lgp_proof_tamper(lgp_proof* proof, int what, uint64_t index);
+/* (the proof-corruption hook the tamper tests use lives in a separate test-only library: ligero_amd/host/ligero_prover_testhooks.cpp) */
 
 #ifdef __cplusplus
 }

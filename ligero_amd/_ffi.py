@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LIGERO_HIP_LIB") or os.path.join(_HERE, "lib", "libli
 # every symbol include/ligero_hip.h declares (tests check the export list against this)
 SYMBOLS = [
     "lg_status_string", "lg_last_error", "lg_abi_version",
-    "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_destroy",
+    "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_create_sharded", "lg_ctx_planes", "lg_ctx_destroy",
     "lg_encode_commit", "lg_host_register", "lg_host_unregister", "lg_upload_preenc", "lg_commit_resident", "lg_sync",
     "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
     "lg_open_columns", "lg_open_columns_batch",
@@ -75,6 +75,8 @@ def lib():
     L.lg_abi_version.restype = _u32
     L.lg_ctx_create.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32]
     L.lg_ctx_create_batched.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32, _u32]
+    L.lg_ctx_create_sharded.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32, _u32, _u32, _u32]
+    L.lg_ctx_planes.argtypes = [_vp, _vp, _vp, _vp]
     L.lg_ctx_destroy.argtypes = [_vp]
     L.lg_ctx_destroy.restype = None
     L.lg_encode_commit.argtypes = [_vp, _vp, _vp, _vp]

@@ -61,7 +61,19 @@ struct lg_ctx {
     // resident commitment
     fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
     fr* d_coeffs = nullptr;   // [total_rows][k]  Montgomery
-    fr* d_u = nullptr;        // [8 O][total_rows][ki] canonical integers; planes 8c hold the message
+    fr* d_u = nullptr;        // [8 O][total_rows][ki] canonical integers; planes 8c hold the message.  In a sharded
+                              // context only planes [own_plane0, own_plane0 + own_planes) exist and this is the VIRTUAL
+                              // base d_u_alloc - own_plane0 * plane, so kernels keep indexing by absolute plane id
+    fr* d_u_alloc = nullptr;      // what hipMalloc returned for d_u
+    fr* d_preenc_alloc = nullptr; // sharded context: allocation behind the rows [pre_row0, pre_row0 + pre_rows) of d_preenc
+    // sharded (lg_ctx_create_sharded) single-proof context: one rank of a proof that is split over several GPUs
+    bool sharded = false;
+    uint32_t own_plane0 = 0, own_planes = 0;   // planes this context can hold (all of them unless sharded)
+    uint32_t coeff_rows_alloc = 0;             // rows of LG_BUF_COEFFS (>= rows: padding for equal all-gather shards)
+    uint32_t pre_row0 = 0, pre_rows = 0;       // sharded: rows of d_preenc that are allocated
+    // what the resident commitment covers (a staged commit may hold only some planes / message rows)
+    uint32_t have_planes = 0;                  // mask of the planes of d_u that belong to the current commitment
+    uint32_t have_row0 = 0, have_row1 = 0;     // message rows [have_row0, have_row1) of d_preenc that belong to it
     uint8_t* d_leaves = nullptr;  // [batch][n][32]
     uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
     // domain tables: 29-bit limbs, value * 2^261 mod p, three planes each (limbs 0-3 | 4-7 | 8)
@@ -80,6 +92,7 @@ struct lg_ctx {
     uint32_t* d_idx = nullptr; size_t idx_cap = 0;
     uint8_t* d_path_out = nullptr; size_t path_cap = 0;
     bool committed = false;
+    bool staging = false;                  // between lg_stage_interpolate and lg_stage_merkle
     bool profiling = false;
     static constexpr int kProfRing = 64;                 // commits remembered by the profiler
     hipEvent_t ev[kProfRing][6] = {};  // 0 start, 1 interpolate done, 2 evaluate done | hash stream: 3 first hash start, 4 last hash done, 5 tree done
@@ -97,6 +110,26 @@ static int fail_hip(lg_ctx* c, hipError_t e, const char* what) {
         hipError_t e_ = (call);                           \
         if (e_ != hipSuccess) return fail_hip(c, e_, #call); \
     } while (0)
+
+static uint32_t all_planes_mask(const lg_ctx* c) { return c->nplanes >= 32 ? 0xffffffffu : ((1u << c->nplanes) - 1u); }
+static uint32_t own_planes_mask(const lg_ctx* c) {
+    const uint32_t hi = c->own_plane0 + c->own_planes;   // <= 32
+    const uint32_t upto = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u);
+    return upto & ~((1u << c->own_plane0) - 1u);
+}
+// A staged (coset-sharded) commit leaves only some planes of U and some message rows on this device: entry points
+// that would read the others fail with LG_ERR_STATE instead of returning stale or foreign data.
+static int need_planes(lg_ctx* c, uint32_t mask, const char* what) {
+    if ((c->have_planes & mask) == mask) return LG_OK;
+    snprintf(c->err, sizeof(c->err), "%s needs coset planes 0x%x of the commitment, this context holds 0x%x (staged / sharded commit)", what, mask,
+             c->have_planes);
+    return LG_ERR_STATE;
+}
+static int need_all_message_rows(lg_ctx* c, const char* what) {
+    if (c->have_row0 == 0 && c->have_row1 == c->rows) return LG_OK;
+    snprintf(c->err, sizeof(c->err), "%s needs every row of preenc_u, this context holds rows [%u, %u) of %u", what, c->have_row0, c->have_row1, c->rows);
+    return LG_ERR_STATE;
+}
 
 // Montgomery-form (2^256) host element -> 29-bit limbs of value * 2^261 mod p
 static lg::f29 to_f29(const lg_host::Fr& a_mont) {
@@ -427,7 +460,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
-    void* bufs[] = {c->d_preenc, c->d_coeffs, c->d_u, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
+    void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
                     c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -450,7 +483,12 @@ void lg_ctx_destroy(lg_ctx* c) {
     delete c;
 }
 
-int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+}  // extern "C"
+
+struct ShardSpec {
+    uint32_t plane_begin, plane_count, coeff_rows_alloc;
+};
+static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch, const ShardSpec* shard) {
     if (!out) return LG_ERR_BAD_ARG;
     *out = nullptr;
     const int logk = ilog2_exact(k), logn = ilog2_exact(n);
@@ -472,6 +510,16 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     c->nplanes = 8u << c->logo;
     c->lognp = 3 + c->logo;
     if (const char* fc = getenv("LG_FORCE_CHUNKS")) c->force_chunks = (uint32_t)atoi(fc);
+    c->own_plane0 = 0; c->own_planes = c->nplanes; c->coeff_rows_alloc = (uint32_t)c->total_rows;
+    if (shard) {
+        if (batch != 1 || shard->plane_count == 0 || (uint64_t)shard->plane_begin + shard->plane_count > c->nplanes ||
+            shard->coeff_rows_alloc < rows) {
+            delete c;
+            return LG_ERR_BAD_ARG;
+        }
+        c->sharded = true;
+        c->own_plane0 = shard->plane_begin; c->own_planes = shard->plane_count; c->coeff_rows_alloc = shard->coeff_rows_alloc;
+    }
     int rc = LG_OK;
     auto body = [&]() -> int {
         LG_HIP(c, hipSetDevice(device));
@@ -488,9 +536,15 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
         if (const char* e = getenv("LG_ASYNC_TREE")) c->async_tree = atoi(e) != 0;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
         const size_t mat = (size_t)c->total_rows * k;
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coeffs), mat * sizeof(fr)));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u), 8 * mat * sizeof(fr)));
+        // sharded: the message rows arrive shard by shard (lg_stage_interpolate allocates what it is given), the
+        // coefficient buffer is padded so that equal all-gather shards fit, and only the owned planes of U exist
+        if (!c->sharded) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coeffs), (size_t)c->coeff_rows_alloc * k * sizeof(fr)));
+        {
+            const size_t plane = (size_t)c->total_rows * c->ki;
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_alloc), (size_t)c->own_planes * plane * sizeof(fr)));
+            c->d_u = c->d_u_alloc - (size_t)c->own_plane0 * plane;   // never dereferenced outside the owned planes
+        }
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
         // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
@@ -616,8 +670,25 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     return LG_OK;
 }
 
+extern "C" {
+
+int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+    return ctx_create_impl(out, device, rows, k, n, batch, nullptr);
+}
 int lg_ctx_create(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n) {
-    return lg_ctx_create_batched(out, device, rows, k, n, 1);
+    return ctx_create_impl(out, device, rows, k, n, 1, nullptr);
+}
+int lg_ctx_create_sharded(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t plane_begin, uint32_t plane_count,
+                          uint32_t coeff_rows_alloc) {
+    const ShardSpec sp = {plane_begin, plane_count, coeff_rows_alloc ? coeff_rows_alloc : rows};
+    return ctx_create_impl(out, device, rows, k, n, 1, &sp);
+}
+int lg_ctx_planes(const lg_ctx* c, uint32_t* nplanes, uint32_t* plane_begin, uint32_t* plane_count) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (nplanes) *nplanes = c->nplanes;
+    if (plane_begin) *plane_begin = c->own_plane0;
+    if (plane_count) *plane_count = c->own_planes;
+    return LG_OK;
 }
 
 int lg_ctx_dims(const lg_ctx* c, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch) {
@@ -638,7 +709,9 @@ int lg_ctx_pipeline_chunks(const lg_ctx* c, uint32_t* chunks_out) {
 
 int lg_upload_preenc(lg_ctx* c, const uint64_t* preenc) {
     if (!c || !preenc) return LG_ERR_BAD_ARG;
+    if (c->sharded) return LG_ERR_STATE;   // a sharded context takes its row shard through lg_stage_interpolate
     LG_HIP(c, hipSetDevice(c->device));
+    c->have_row0 = 0; c->have_row1 = c->rows;
     LG_HIP(c, hipMemcpyAsync(c->d_preenc, preenc, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     return LG_OK;
 }
@@ -673,6 +746,14 @@ static int settle_tree(lg_ctx* c) {
 // so that the PCIe transfer of chunk c+1 overlaps the encoding of chunk c; host_coeffs (optional)
 // receives the coefficient rows the same way in the other direction.
 static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeffs) {
+    if (c->sharded) {
+        snprintf(c->err, sizeof(c->err), "a sharded context holds planes [%u, %u) only: use the lg_stage_* calls", c->own_plane0, c->own_plane0 + c->own_planes);
+        return LG_ERR_STATE;
+    }
+    if (!host_pre) {
+        const int rc_ = need_all_message_rows(c, "lg_commit_resident");
+        if (rc_ != LG_OK) return rc_;
+    }
     LG_HIP(c, hipSetDevice(c->device));
     const uint64_t plane = c->total_rows * c->ki;
     const bool streamed = host_pre != nullptr;
@@ -810,6 +891,9 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
     }
     c->committed = true;
+    c->staging = false;
+    c->have_planes = all_planes_mask(c);
+    c->have_row0 = 0; c->have_row1 = c->rows;
     if (streamed && host_coeffs) LG_HIP(c, hipStreamSynchronize(c->stream_dn));
     return LG_OK;
 }
@@ -909,6 +993,7 @@ int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nro
     if (!c->committed) return LG_ERR_STATE;
     if (proof >= c->batch || (uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
     if (nrows == 0) return LG_OK;
+    { const int rc_ = need_planes(c, all_planes_mask(c), "lg_read_codeword_rows"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     const size_t elems = (size_t)nrows * c->n;
     int rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, elems);
@@ -927,9 +1012,13 @@ static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const
     if (!c->committed) return LG_ERR_STATE;
     if ((uint64_t)proof0 + nproofs > c->batch) return LG_ERR_BAD_ARG;
     const size_t nidx = (size_t)nproofs * t;
-    for (size_t i = 0; i < nidx; i++)
+    uint32_t touched = 0;
+    for (size_t i = 0; i < nidx; i++) {
         if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
+        touched |= 1u << (idx[i] & (c->nplanes - 1));
+    }
     if (nidx == 0) return LG_OK;
+    { const int rc_ = need_planes(c, touched, "lg_open_columns"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     const uint32_t plen = (uint32_t)c->logn - 1;
@@ -1020,6 +1109,7 @@ static int sub_interpolate_2k(lg_ctx* c, uint64_t* coeffs_out) {
 
 int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
     if (!c || !r || !out) return LG_ERR_BAD_ARG;
+    { const int rc_ = need_all_message_rows(c, "lg_interleaved_row_mul"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     uint32_t per;
     const uint32_t nch = sub_chunks(c->rows, &per);
@@ -1057,6 +1147,7 @@ int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_o
     if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
     if (!c->committed) return LG_ERR_STATE;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     uint32_t per, nch;
     int rc = linear_buffers(c, &per, &nch);
@@ -1108,6 +1199,7 @@ int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64
     if (!c || !seeds || !coeffs_out) return LG_ERR_BAD_ARG;
     if (!c->committed || !c->a_loaded) return LG_ERR_STATE;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly_from_seeds"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     uint32_t per, nch;
     int rc = linear_buffers(c, &per, &nch);
@@ -1194,6 +1286,7 @@ int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_
     if (!c->committed) return LG_ERR_STATE;
     if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_quadratic_constraint_poly"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     const uint32_t m = c->rows / 4;
     uint32_t per;
@@ -1228,10 +1321,29 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
     if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
     if (nrows == 0) return LG_OK;
     LG_HIP(c, hipSetDevice(c->device));
+    if (c->sharded) {
+        // the message rows of a sharded proof exist only shard by shard: hold exactly the range handed over
+        const bool inside = c->d_preenc_alloc && row0 >= c->pre_row0 && (uint64_t)row0 + nrows <= (uint64_t)c->pre_row0 + c->pre_rows;
+        if (!inside) {
+            if (!preenc_rows) return LG_ERR_STATE;   // "already resident" rows that were never uploaded
+            LG_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_preenc_alloc) LG_HIP(c, hipFree(c->d_preenc_alloc));
+            c->d_preenc_alloc = nullptr; c->pre_rows = 0;
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc_alloc), (size_t)nrows * c->k * sizeof(fr)));
+            c->pre_row0 = row0; c->pre_rows = nrows;
+            c->d_preenc = c->d_preenc_alloc - (size_t)row0 * c->k;   // virtual base: indexed by absolute row
+        }
+    }
     if (preenc_rows)
         LG_HIP(c, hipMemcpyAsync(c->d_preenc + (size_t)row0 * c->k, preenc_rows, (size_t)nrows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, nullptr, row0, nrows);
     LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+    // a staged commit starts (or grows by an adjacent row range); what an earlier commitment left in U is void
+    if (c->staging && row0 == c->have_row1) c->have_row1 = row0 + nrows;
+    else if (c->staging && row0 + nrows == c->have_row0) c->have_row0 = row0;
+    else if (!(c->staging && row0 >= c->have_row0 && row0 + nrows <= c->have_row1)) { c->have_row0 = row0; c->have_row1 = row0 + nrows; }
+    c->staging = true;
+    c->have_planes = 0;
     c->committed = false;
     return LG_OK;
 }
@@ -1240,6 +1352,12 @@ int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
     if (!c) return LG_ERR_BAD_ARG;
     if (c->batch != 1) return LG_ERR_STATE;
     if (c->nplanes < 32 && (plane_mask >> c->nplanes) != 0) return LG_ERR_BAD_ARG;
+    if (plane_mask & ~own_planes_mask(c)) {
+        snprintf(c->err, sizeof(c->err), "plane mask 0x%x reaches outside the planes [%u, %u) this sharded context holds", plane_mask, c->own_plane0,
+                 c->own_plane0 + c->own_planes);
+        return LG_ERR_BAD_ARG;
+    }
+    if (c->committed) { c->committed = false; c->have_planes = 0; }   // re-evaluating over a finished commitment voids it
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     const uint64_t plane = c->total_rows * c->ki;
@@ -1272,6 +1390,7 @@ int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
         LG_HIP(c, hipGetLastError());
         s = e + 1;
     }
+    c->have_planes |= plane_mask;
     return LG_OK;
 }
 
@@ -1296,6 +1415,7 @@ int lg_stage_merkle(lg_ctx* c) {
     }
     LG_HIP(c, hipGetLastError());
     c->committed = true;
+    c->staging = false;
     return LG_OK;
 }
 
@@ -1307,8 +1427,11 @@ int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
         if (rc_ != LG_OK) return rc_;
     }
     switch (which) {
-        case LG_BUF_PREENC: *dptr_out = c->d_preenc; *bytes_out = (size_t)c->total_rows * c->k * sizeof(fr); break;
-        case LG_BUF_COEFFS: *dptr_out = c->d_coeffs; *bytes_out = (size_t)c->total_rows * c->k * sizeof(fr); break;
+        case LG_BUF_PREENC:   // sharded: the allocated row range [pre_row0, pre_row0 + pre_rows) only
+            *dptr_out = c->sharded ? c->d_preenc_alloc : c->d_preenc;
+            *bytes_out = (size_t)(c->sharded ? c->pre_rows : c->total_rows) * c->k * sizeof(fr);
+            break;
+        case LG_BUF_COEFFS: *dptr_out = c->d_coeffs; *bytes_out = (size_t)c->coeff_rows_alloc * c->k * sizeof(fr); break;
         case LG_BUF_LEAVES: *dptr_out = c->d_leaves; *bytes_out = (size_t)c->batch * c->n * 32; break;
         case LG_BUF_NODES: *dptr_out = c->d_nodes; *bytes_out = (size_t)c->batch * (c->n - 1) * 32; break;
         default: return LG_ERR_BAD_ARG;

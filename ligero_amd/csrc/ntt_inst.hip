@@ -2,6 +2,8 @@
 // the size instantiations of the row-NTT kernel build in parallel.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "ntt_kernels.h"
 #include "ntt_launch.h"
 
@@ -14,12 +16,19 @@ namespace lg {
 template <int LOGK, int LOGO, bool EVAL>
 static hipError_t launch_t(hipStream_t st, const NttArgs& a) {
     using Plan = NttPlan<LOGK>;
-    static bool attr_set = false;
+    // The dynamic-LDS limit is a property of the (function, device) pair and contexts on different
+    // devices -- or several host threads -- may launch the same instantiation: one flag per device,
+    // set after the attribute is (setting it twice is harmless, so a race only repeats the call).
+    static std::atomic<uint64_t> attr_set[4] = {};   // bit d % 64 of word d / 64: up to 256 devices
     auto kern = ntt_rows_kernel<LOGK, LOGO, EVAL>;
-    if (!attr_set) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 256;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!tracked || !(attr_set[(dev >> 6) & 3].load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Plan::kLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (tracked) attr_set[dev >> 6].fetch_or(bit, std::memory_order_release);
     }
     const uint64_t work = EVAL ? (uint64_t)a.rows * a.ncos : ((uint64_t)a.rows << LOGO);
     if (work == 0) return hipSuccess;

@@ -7,29 +7,9 @@
 #include "../../include/ligero_prover.h"
 #include "host_handles.hpp"
 #include "prover.hpp"
+#include "prover_handles.hpp"
 
 using namespace ligero;
-
-struct lgp_prover {
-    HipLigero hip;
-    lgp_prover(const LigeroInstance& inst, int device) : hip(inst, device) {}
-};
-struct lgp_proof {
-    LigeroProof own;                 // storage of a proof this handle owns (lgp_prove, lgp_prove_batch)
-    const LigeroProof* view = &own;  // what the handle shows: its own proof, or one inside a batch prover (lgp_batch_proof)
-    lgp_proof() = default;
-    lgp_proof(const lgp_proof& o) : own(o.own), view(o.view == &o.own ? &own : o.view) {}
-    lgp_proof& operator=(const lgp_proof& o) {
-        own = o.own;
-        view = (o.view == &o.own) ? &own : o.view;
-        return *this;
-    }
-};
-struct lgp_batch_prover {
-    HipLigeroBatch hip;
-    std::vector<lgp_proof> views;   // borrowed views of the proofs of the last lgp_prove_batch
-    lgp_batch_prover(const LigeroInstance& inst, uint32_t batch, int device, unsigned threads) : hip(inst, batch, device, threads) {}
-};
 
 static thread_local std::string g_err;
 template <class F>
@@ -139,41 +119,6 @@ int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_ou
     info_out[5] = p.interleaved_proof.open.paths.empty() ? 0 : p.interleaved_proof.open.paths[0].auth_path.size();
     std::memcpy(root_out, p.u_root.data(), 32);
     return LGP_OK;
-}
-
-int lgp_proof_tamper(lgp_proof* proof, int what, uint64_t index) {
-    if (!proof || proof->view != &proof->own) return LGP_ERR_BAD_ARG;   // borrowed views are read-only
-    LigeroProof& p = proof->own;
-    auto bump = [](Fr& x) { x = fr_add(x, fr_one()); };
-    auto col_elem = [&](OpenedColumns& o) -> int {
-        if (o.columns.empty()) return LGP_ERR_BAD_ARG;
-        auto& c = o.columns[index % o.columns.size()];
-        bump(c[(index / o.columns.size()) % c.size()]);
-        return LGP_OK;
-    };
-    switch (what) {
-        case 0: p.u_root[index % 32] ^= 1; return LGP_OK;
-        case 1: if (p.interleaved_proof.preenc_u_lc.empty()) return LGP_ERR_BAD_ARG; bump(p.interleaved_proof.preenc_u_lc[index % p.interleaved_proof.preenc_u_lc.size()]); return LGP_OK;
-        case 2: if (p.linear_constraints_proof.polynomial.empty()) return LGP_ERR_BAD_ARG; bump(p.linear_constraints_proof.polynomial[index % p.linear_constraints_proof.polynomial.size()]); return LGP_OK;
-        case 3: if (p.quadratic_constraints_proof.polynomial.empty()) return LGP_ERR_BAD_ARG; bump(p.quadratic_constraints_proof.polynomial[index % p.quadratic_constraints_proof.polynomial.size()]); return LGP_OK;
-        case 4: return col_elem(p.interleaved_proof.open);
-        case 5: return col_elem(p.linear_constraints_proof.open);
-        case 6: return col_elem(p.quadratic_constraints_proof.open);
-        case 7: {
-            auto& paths = p.interleaved_proof.open.paths;
-            if (paths.empty() || paths[0].auth_path.empty()) return LGP_ERR_BAD_ARG;
-            auto& ph = paths[index % paths.size()];
-            ph.auth_path[(index / paths.size()) % ph.auth_path.size()][0] ^= 1;
-            return LGP_OK;
-        }
-        case 8: {
-            auto& paths = p.linear_constraints_proof.open.paths;
-            if (paths.empty()) return LGP_ERR_BAD_ARG;
-            paths[index % paths.size()].leaf_index ^= 1;
-            return LGP_OK;
-        }
-        default: return LGP_ERR_BAD_ARG;
-    }
 }
 
 }  // extern "C"

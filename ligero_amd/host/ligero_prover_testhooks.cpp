@@ -1,0 +1,53 @@
+// Test hooks for the prover ABI -- NOT part of the production library (libligero_prover.so does not export them):
+// built into ligero_amd/lib/libligero_prover_testhooks.so, which only tests/ load (tests/prover_hooks.py).
+#include <cstdint>
+
+#include "../../include/ligero_prover.h"
+#include "host_handles.hpp"
+#include "prover.hpp"
+#include "prover_handles.hpp"
+
+using namespace ligero;
+
+extern "C" {
+
+/* corrupt one item of a proof this handle owns.  what: 0 u_root byte, 1 preenc_u_lc element, 2 linear polynomial
+ * coefficient, 3 quadratic polynomial coefficient, 4 an element of an opened column (interleaved), 5 same (linear),
+ * 6 same (quadratic), 7 an auth-path digest (interleaved), 8 leaf index of an opening (linear); index selects the item */
+int lgp_proof_tamper(lgp_proof* proof, int what, uint64_t index) {
+    if (!proof || proof->view != &proof->own) return LGP_ERR_BAD_ARG;   // borrowed views are read-only
+    LigeroProof& p = proof->own;
+    auto bump = [](Fr& x) { x = fr_add(x, fr_one()); };
+    auto col_elem = [&](OpenedColumns& o) -> int {
+        if (o.columns.empty()) return LGP_ERR_BAD_ARG;
+        auto& c = o.columns[index % o.columns.size()];
+        bump(c[(index / o.columns.size()) % c.size()]);
+        return LGP_OK;
+    };
+    switch (what) {
+        case 0: p.u_root[index % 32] ^= 1; return LGP_OK;
+        case 1: if (p.interleaved_proof.preenc_u_lc.empty()) return LGP_ERR_BAD_ARG; bump(p.interleaved_proof.preenc_u_lc[index % p.interleaved_proof.preenc_u_lc.size()]); return LGP_OK;
+        case 2: if (p.linear_constraints_proof.polynomial.empty()) return LGP_ERR_BAD_ARG; bump(p.linear_constraints_proof.polynomial[index % p.linear_constraints_proof.polynomial.size()]); return LGP_OK;
+        case 3: if (p.quadratic_constraints_proof.polynomial.empty()) return LGP_ERR_BAD_ARG; bump(p.quadratic_constraints_proof.polynomial[index % p.quadratic_constraints_proof.polynomial.size()]); return LGP_OK;
+        case 4: return col_elem(p.interleaved_proof.open);
+        case 5: return col_elem(p.linear_constraints_proof.open);
+        case 6: return col_elem(p.quadratic_constraints_proof.open);
+        case 7: {
+            auto& paths = p.interleaved_proof.open.paths;
+            if (paths.empty() || paths[0].auth_path.empty()) return LGP_ERR_BAD_ARG;
+            auto& ph = paths[index % paths.size()];
+            ph.auth_path[(index / paths.size()) % ph.auth_path.size()][0] ^= 1;
+            return LGP_OK;
+        }
+        case 8: {
+            auto& paths = p.linear_constraints_proof.open.paths;
+            if (paths.empty()) return LGP_ERR_BAD_ARG;
+            paths[index % paths.size()].leaf_index ^= 1;
+            return LGP_OK;
+        }
+        default: return LGP_ERR_BAD_ARG;
+    }
+}
+
+
+}  // extern "C"

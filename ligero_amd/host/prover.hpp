@@ -441,11 +441,13 @@ public:
         mat_.resize((size_t)batch_ * 4 * m_ * k_);
         cols_.resize((size_t)batch_ * t_ * 4 * m_);
         // page-lock the two big staging buffers so the PCIe copies overlap the kernels (lg_encode_commit streams)
-        pinned_ = lg_host_register(ctx_, mat_.data(), mat_.size() * sizeof(Fr)) == LG_OK &&
-                  lg_host_register(ctx_, cols_.data(), cols_.size() * sizeof(Fr)) == LG_OK;
+        // (each registration is tracked on its own: a buffer must never be freed while still page-locked)
+        pinned_mat_ = lg_host_register(ctx_, mat_.data(), mat_.size() * sizeof(Fr)) == LG_OK;
+        pinned_cols_ = lg_host_register(ctx_, cols_.data(), cols_.size() * sizeof(Fr)) == LG_OK;
     }
     ~HipLigeroBatch() {
-        if (pinned_) { lg_host_unregister(ctx_, mat_.data()); lg_host_unregister(ctx_, cols_.data()); }
+        if (pinned_mat_) lg_host_unregister(ctx_, mat_.data());
+        if (pinned_cols_) lg_host_unregister(ctx_, cols_.data());
         lg_ctx_destroy(ctx_);
     }
     HipLigeroBatch(const HipLigeroBatch&) = delete;
@@ -564,7 +566,7 @@ private:
     size_t m_, k_, n_, t_;
     int logn_ = 0;
     unsigned threads_ = 1;
-    bool pinned_ = false;
+    bool pinned_mat_ = false, pinned_cols_ = false;
     lg_ctx* ctx_ = nullptr;
     std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u
     std::vector<LigeroProof> proofs_;

@@ -1,0 +1,31 @@
+// Handle types behind include/ligero_prover.h (internal: shared by ligero_prover.cpp and the test-hook library).
+#pragma once
+#include <vector>
+
+#include "prover.hpp"
+
+using ligero::HipLigero;
+using ligero::HipLigeroBatch;
+using ligero::LigeroInstance;
+using ligero::LigeroProof;
+
+struct lgp_prover {
+    HipLigero hip;
+    lgp_prover(const LigeroInstance& inst, int device) : hip(inst, device) {}
+};
+struct lgp_proof {
+    LigeroProof own;                 // storage of a proof this handle owns (lgp_prove, lgp_prove_batch)
+    const LigeroProof* view = &own;  // what the handle shows: its own proof, or one inside a batch prover (lgp_batch_proof)
+    lgp_proof() = default;
+    lgp_proof(const lgp_proof& o) : own(o.own), view(o.view == &o.own ? &own : o.view) {}
+    lgp_proof& operator=(const lgp_proof& o) {
+        own = o.own;
+        view = (o.view == &o.own) ? &own : o.view;
+        return *this;
+    }
+};
+struct lgp_batch_prover {
+    HipLigeroBatch hip;
+    std::vector<lgp_proof> views;   // borrowed views of the proofs of the last lgp_prove_batch
+    lgp_batch_prover(const LigeroInstance& inst, uint32_t batch, int device, unsigned threads) : hip(inst, batch, device, threads) {}
+};

@@ -62,15 +62,32 @@ class LigeroCommitter:
     (mod.rs:80-90) as far as the hot path needs them.
     """
 
-    def __init__(self, rows: int, k: int, n: Optional[int] = None, batch: int = 1, device: int = 0):
+    def __init__(self, rows: int, k: int, n: Optional[int] = None, batch: int = 1, device: int = 0,
+                 shard: Optional[Tuple[int, int, int]] = None):
+        """shard = (plane_begin, plane_count, coeff_rows_alloc): one rank of a proof that is coset-sharded over
+        several GPUs (lg_ctx_create_sharded): only those planes of U are allocated, the staged calls only."""
         n = 8 * k if n is None else n
         self._L = _ffi.lib()
         self._ctx = _vp()
         self.rows, self.k, self.n, self.batch, self.device = rows, k, n, batch, device
-        st = self._L.lg_ctx_create_batched(ctypes.byref(self._ctx), device, rows, k, n, batch)
+        if shard is None:
+            st = self._L.lg_ctx_create_batched(ctypes.byref(self._ctx), device, rows, k, n, batch)
+            what = f"lg_ctx_create_batched(rows={rows}, k={k}, n={n}, batch={batch})"
+        else:
+            if batch != 1:
+                raise ValueError("a sharded context holds one proof")
+            st = self._L.lg_ctx_create_sharded(ctypes.byref(self._ctx), device, rows, k, n, int(shard[0]), int(shard[1]), int(shard[2]))
+            what = f"lg_ctx_create_sharded(rows={rows}, k={k}, n={n}, planes=[{shard[0]}, +{shard[1]}), coeff_rows={shard[2]})"
         if st != _ffi.LG_OK:
             self._ctx = None
-            _ffi.check(st, f"lg_ctx_create_batched(rows={rows}, k={k}, n={n}, batch={batch})")
+            _ffi.check(st, what)
+
+    def planes(self) -> Tuple[int, int, int]:
+        """(number of coset planes of this shape, first held plane, held planes)"""
+        a, b, c = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self._chk(self._L.lg_ctx_planes(self._ctx, ctypes.cast(ctypes.byref(a), _vp), ctypes.cast(ctypes.byref(b), _vp),
+                                        ctypes.cast(ctypes.byref(c), _vp)), "lg_ctx_planes")
+        return int(a.value), int(b.value), int(c.value)
 
     # -- lifetime
     def close(self):

@@ -16,7 +16,7 @@ from .host_pipeline import LigeroInstance
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
-           "lgp_proof_info", "lgp_proof_tamper", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
+           "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
            "lgp_prove_batch", "lgp_batch_proof"]
 _vp = ctypes.c_void_p
 _lib = None
@@ -38,7 +38,6 @@ def lib():
         L.lgp_proof_destroy.argtypes = [_vp]
         L.lgp_proof_destroy.restype = None
         L.lgp_proof_info.argtypes = [_vp, _vp, _vp]
-        L.lgp_proof_tamper.argtypes = [_vp, ctypes.c_int, ctypes.c_uint64]
         L.lgp_batch_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.lgp_batch_prover_destroy.argtypes = [_vp]
         L.lgp_batch_prover_destroy.restype = None
@@ -75,9 +74,6 @@ class Proof:
         d = {k: int(v) for k, v in zip(keys, info)}
         d["u_root"] = root.tobytes()
         return d
-
-    def tamper(self, what: int, index: int = 0):
-        _check(self._L.lgp_proof_tamper(self._h, what, index), "lgp_proof_tamper")
 
 
 class LigeroProver:

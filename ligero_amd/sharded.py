@@ -6,7 +6,10 @@ xGMI on ROCm; "gloo" in the CPU tests).  Two modes:
 * `CosetShardedCommitter` -- ONE large proof on G GPUs (BASELINE configs[3]).  A column's Blake2s
   chain spans all rows, so rows cannot be sharded end to end; instead
     1. rank g interpolates its row shard                                   (mod.rs:521-526)
-    2. all-gather of the coefficient rows (bulk: 4m*k*32 bytes)            RCCL
+    2. ONE in-place all-gather of the coefficient rows (bulk: 4m*k*32 B)   RCCL
+       (row shards are ceil(rows/G) rows each, the coefficient buffer is padded to G such
+       shards, so the shapes BASELINE names -- 20 068 and 10 036 rows on 8 GPUs -- need no
+       ragged fallback; the last rank's shard is short and its padding rows are never read)
     3. rank g evaluates + hashes the coset planes it owns, for ALL rows    (mod.rs:528-542)
     4. all-gather of the n 32-byte leaf digests (tiny)                     RCCL
     5. every rank builds the (replicated) tree                             (mod.rs:544-551)
@@ -20,7 +23,8 @@ gloo at world_size 2 without a GPU.
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Sequence, Tuple
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -30,8 +34,19 @@ _vp = ctypes.c_void_p
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
-    """contiguous, balanced [begin, end) of `total` items for `rank`"""
+    """contiguous, balanced [begin, end) of `total` items for `rank` (proofs in throughput mode)"""
     return (total * rank) // world, (total * (rank + 1)) // world
+
+
+def padded_shard_rows(total: int, world: int) -> int:
+    """rows per rank when `total` rows are dealt in `world` EQUAL shards (the last one padded)"""
+    return -(-total // world)
+
+
+def padded_shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """real rows [begin, end) of `rank`'s shard of ceil(total / world) rows (empty for trailing ranks of tiny inputs)"""
+    per = padded_shard_rows(total, world)
+    return min(total, rank * per), min(total, (rank + 1) * per)
 
 
 def owned_planes(nplanes: int, world: int, rank: int) -> List[int]:
@@ -53,11 +68,16 @@ class HipStageBackend:
     """Staged single-proof commit on this rank's GPU through the C ABI (include/ligero_hip.h:
     lg_stage_interpolate / lg_stage_evaluate_hash / lg_stage_merkle / lg_device_buffer)."""
 
-    def __init__(self, rows: int, k: int, device: int = 0):
+    def __init__(self, rows: int, k: int, device: int = 0, world: int = 1, rank: int = 0):
+        """One rank of `world`: the context allocates only this rank's coset planes of U and a coefficient buffer
+        padded to `world` equal row shards (lg_ctx_create_sharded)."""
         from .ligero import LigeroCommitter
-        self.c = LigeroCommitter(rows=rows, k=k, batch=1, device=device)
         self.rows, self.k, self.n, self.device = rows, k, 8 * k, device
         self.nplanes = 8 if k <= 4096 else 8 * (k // 4096)
+        planes = owned_planes(self.nplanes, world, rank)
+        self.coeff_rows = world * padded_shard_rows(rows, world)
+        self.c = LigeroCommitter(rows=rows, k=k, batch=1, device=device, shard=(planes[0], len(planes), self.coeff_rows))
+        assert self.c.planes() == (self.nplanes, planes[0], len(planes))
         self._L = _ffi.lib()
 
     def _buffer(self, which: int):
@@ -88,8 +108,9 @@ class HipStageBackend:
         self.c.sync()
 
     def coeffs_bytes(self):
-        """[rows, k*32] uint8 view of the resident coefficient rows"""
-        return self._buffer(_ffi.LG_BUF_COEFFS).view(self.rows, self.k * 32)
+        """[coeff_rows, k*32] uint8 view of the resident coefficient rows (coeff_rows = world * ceil(rows / world):
+        rows past `rows` are all-gather padding)"""
+        return self._buffer(_ffi.LG_BUF_COEFFS).view(self.coeff_rows, self.k * 32)
 
     def leaves_bytes(self):
         """[n, 32] uint8 view of the resident leaf digests"""
@@ -116,42 +137,54 @@ class CosetShardedCommitter:
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
         self.planes = owned_planes(backend.nplanes, self.world, self.rank)
+        self.shard_rows = padded_shard_rows(backend.rows, self.world)
+        self.stage_ms: Dict[str, float] = {}      # wall time of each stage of the last commit() (each ends in a device sync)
+        self._digest_buf = None
 
     def row_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
-        return shard_range(self.be.rows, self.world, self.rank if rank is None else rank)
+        return padded_shard_range(self.be.rows, self.world, self.rank if rank is None else rank)
 
-    def commit(self, preenc_rows_local: np.ndarray) -> bytes:
-        """preenc_rows_local: this rank's rows [row_range()) of preenc_u.  Returns u_root."""
+    def commit(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
+        """preenc_rows_local: this rank's rows [row_range()) of preenc_u (None: they are resident from an earlier
+        commit).  Returns u_root."""
         be, dist = self.be, self.dist
+        ms = self.stage_ms = {}
         r0, r1 = self.row_range()
+        t = time.perf_counter()
+
+        def lap(name):
+            nonlocal t
+            now = time.perf_counter()
+            ms[name] = (now - t) * 1e3
+            t = now
+
         be.stage_interpolate(preenc_rows_local, r0, r1 - r0)
         be.sync()
+        lap("interpolate")
         if self.world > 1:
+            # equal (padded) shards: ONE in-place all-gather whatever rows % world is
             coeffs = be.coeffs_bytes()
-            if be.rows % self.world == 0:   # equal shards: one in-place all-gather
-                dist.all_gather_into_tensor(coeffs, coeffs[r0:r1], group=self.group)
-            else:                           # ragged shards: one broadcast per owner
-                for g in range(self.world):
-                    g0, g1 = self.row_range(g)
-                    if g1 > g0:
-                        dist.broadcast(coeffs[g0:g1], src=g, group=self.group)
+            p0 = self.rank * self.shard_rows
+            dist.all_gather_into_tensor(coeffs.view(-1), coeffs[p0:p0 + self.shard_rows].view(-1), group=self.group)
             self._device_sync(coeffs)
+        lap("allgather_coeffs")
         be.stage_evaluate_hash(self.planes)
         be.sync()
+        lap("evaluate_hash")
         if self.world > 1:
             import torch
-            np_ = be.nplanes
-            leaves = be.leaves_bytes().view(be.n // np_, np_, 32)          # [q][plane][32]
-            mine = leaves[:, self.planes[0]:self.planes[-1] + 1, :].contiguous()
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(parts, mine, group=self.group)
-            per = np_ // self.world
-            for g in range(self.world):
-                if g != self.rank:
-                    leaves[:, g * per:(g + 1) * per, :] = parts[g]
+            np_, per = be.nplanes, len(self.planes)
+            leaves = be.leaves_bytes().view(be.n // np_, self.world, per, 32)   # [q][owner][plane of owner][32]
+            mine = leaves[:, self.rank].contiguous()
+            if self._digest_buf is None or self._digest_buf.device != mine.device:
+                self._digest_buf = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(self._digest_buf.view(-1), mine.view(-1), group=self.group)   # flat: gloo insists on 1-D shapes
+            leaves.copy_(self._digest_buf.permute(1, 0, 2, 3))                  # one strided copy back into leaf order
             self._device_sync(leaves)
+        lap("allgather_digests")
         be.stage_merkle()
         be.sync()
+        lap("merkle")
         return be.root()
 
     @staticmethod

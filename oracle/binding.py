@@ -48,6 +48,7 @@ def lib():
         L.orc_col_hash.argtypes = [_vp, _u32, _vp]
         L.orc_merkle_tree.argtypes = [_u32, _vp, _vp]
         L.orc_encode_commit.argtypes = [_u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]
+        L.orc_encode_commit_streamed.argtypes = [_u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, ctypes.c_int]
         L.orc_open_columns.argtypes = [_u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]
         L.orc_dense_row_mul.argtypes = [_u32, _u32, _vp, _vp, _vp]
         L.orc_linear_constraint_poly.argtypes = [_u32, _u32, _vp, _vp, _vp]
@@ -157,6 +158,18 @@ def encode_commit(preenc: np.ndarray, k: int, n: int, threads: int = 1, want_u: 
     rc = lib().orc_encode_commit(rows, k, n, _p(preenc), _p(coeffs), _p(u), _p(leaves), _p(nodes), _p(root), threads)
     assert rc == 0, rc
     return dict(coeffs=coeffs, u=u, leaves=leaves, nodes=nodes, root=root.tobytes())
+
+
+def encode_commit_streamed(preenc: np.ndarray, k: int, n: int, threads: int = 1, block_rows: int = 64):
+    """the same commitment without materialising U (rows encoded and absorbed block by block); returns dict(leaves, nodes, root)"""
+    preenc = np.ascontiguousarray(preenc, dtype=np.uint64).reshape(-1, k, 4)
+    rows = preenc.shape[0]
+    leaves = np.empty((n, 32), dtype=np.uint8)
+    nodes = np.empty((n - 1, 32), dtype=np.uint8)
+    root = np.empty(32, dtype=np.uint8)
+    rc = lib().orc_encode_commit_streamed(rows, k, n, _p(preenc), block_rows, _p(leaves), _p(nodes), _p(root), threads)
+    assert rc == 0, rc
+    return dict(leaves=leaves, nodes=nodes, root=root.tobytes())
 
 
 def open_columns(u: np.ndarray, leaves: np.ndarray, nodes: np.ndarray, idx):

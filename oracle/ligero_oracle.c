@@ -438,6 +438,58 @@ int orc_encode_commit(uint32_t rows, uint32_t k, uint32_t n, const uint64_t *pre
     return 0;
 }
 
+/* The same commitment for matrices whose encoding U does not fit host memory (the 2^22-constraint
+ * shape: 42 GB): rows are encoded in blocks of `block_rows` and every column's Blake2s state absorbs
+ * the block before the next one is encoded -- the byte string each column hashes is exactly the one
+ * of orc_encode_commit (LE64(rows) || row 0 || row 1 || ...), only the transposition of mod.rs:536
+ * is never materialised.  Used to generate the full-size golden roots (tests/golden/make_golden_large.py);
+ * checked against orc_encode_commit on small shapes in tests/test_oracle.py. */
+int orc_encode_commit_streamed(uint32_t rows, uint32_t k, uint32_t n, const uint64_t *preenc, uint32_t block_rows,
+                               uint8_t *leaves_out, uint8_t *nodes_out, uint8_t *root_out, int threads) {
+    if (log2_exact(k) < 0 || log2_exact(n) < 0 || n < k || n < 2 || rows == 0 || block_rows == 0) return -1;
+    fr_t *coeffs = (fr_t *)malloc(sizeof(fr_t) * (size_t)block_rows * k);
+    fr_t *u = (fr_t *)malloc(sizeof(fr_t) * (size_t)block_rows * n);
+    b2s_t *st = (b2s_t *)malloc(sizeof(b2s_t) * (size_t)n);
+    uint8_t *leaves = leaves_out ? leaves_out : (uint8_t *)malloc((size_t)n * 32);
+    uint8_t *nodes = nodes_out ? nodes_out : (uint8_t *)malloc((size_t)(n - 1) * 32);
+    if (!coeffs || !u || !st || !leaves || !nodes) return -2;
+    (void)threads;
+    uint8_t pre[8];
+    for (int i = 0; i < 8; i++) pre[i] = (uint8_t)((uint64_t)rows >> (8 * i));
+    for (uint32_t j = 0; j < n; j++) {
+        b2s_init(&st[j]);
+        b2s_update(&st[j], pre, 8);
+    }
+    for (uint32_t r0 = 0; r0 < rows; r0 += block_rows) {
+        const uint32_t nb = rows - r0 < block_rows ? rows - r0 : block_rows;
+#pragma omp parallel for schedule(static) if (threads > 1) num_threads(threads > 1 ? threads : 1)
+        for (long i = 0; i < (long)nb; i++) {
+            orc_reed_solomon_interpolate(k, preenc + 4 * (size_t)(r0 + i) * k, k, (uint64_t *)(coeffs + (size_t)i * k));
+            orc_reed_solomon_evaluate(n, (const uint64_t *)(coeffs + (size_t)i * k), k, (uint64_t *)(u + (size_t)i * n));
+        }
+#pragma omp parallel for schedule(static) if (threads > 1) num_threads(threads > 1 ? threads : 1)
+        for (long j = 0; j < (long)n; j++) {
+            for (uint32_t i = 0; i < nb; i++) {
+                fr_t c;
+                uint8_t bytes[32];
+                fr_from_mont(&c, u + (size_t)i * n + j);
+                for (int w = 0; w < 4; w++)
+                    for (int b = 0; b < 8; b++) bytes[8 * w + b] = (uint8_t)(c.l[w] >> (8 * b));
+                b2s_update(&st[j], bytes, 32);
+            }
+        }
+    }
+    for (uint32_t j = 0; j < n; j++) b2s_final(&st[j], leaves + 32 * (size_t)j);
+    orc_merkle_tree(n, leaves, nodes);
+    memcpy(root_out, nodes, 32);
+    free(coeffs);
+    free(u);
+    free(st);
+    if (!leaves_out) free(leaves);
+    if (!nodes_out) free(nodes);
+    return 0;
+}
+
 /* ---- open_columns, mod.rs:944-952 (indices come from the host-side Fiat-Shamir PRNG) ----
  * cols_out: t x rows (Montgomery); sib_out: t x 32 (leaf_sibling_hash);
  * paths_out: t x (log2 n - 1) x 32, root-side first (MerkleTree::generate_proof). */

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential sweep (GPU library vs the oracle) over shapes the fixed test cases do not name:
 random rows / k / batch, random data incl. field corners, both commit entry points, openings, sub-proof polynomials.
-    python tests/parity_sweep.py [seconds]
-(a checker script, not collected by pytest: lives under tests/ because it uses the oracle)"""
+    python tests/parity_sweep.py [seconds] [seed]
+Collected by pytest through tests/test_gpu_parity_sweep.py (fixed seed, bounded time); as a script it sweeps for as long
+as asked with a time-derived seed.  Lives under tests/ because it uses the oracle."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,49 +14,57 @@ import ligero_amd
 from oracle import binding as oracle            # the checker
 from conftest import random_mont
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(time.time()))
-t_end = time.time() + budget
-n_cases = 0
-P_LIMBS = np.array([0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)
-while time.time() < t_end:
-    logk = int(rng.integers(1, 15))       # 13, 14: folded transforms (k = 8192, 16384)
-    k = 1 << logk
-    max_rows = max(4, min(400, (1 << 21) // (8 * k)))
-    rows = int(rng.integers(1, max_rows // 4 + 1)) * 4
-    batch = int(rng.choice([1, 1, 2, 3, 5]))
-    if batch * rows * k * 8 > (1 << 22):
-        batch = 1
-    seed = int(rng.integers(1 << 30))
-    pre = random_mont(seed, batch * rows * k).reshape(batch * rows, k, 4)
-    # sprinkle corner values: 0, 1 (Montgomery one is in random_mont's range anyway), p - 1
-    for _ in range(8):
-        i, j = int(rng.integers(batch * rows)), int(rng.integers(k))
-        pre[i, j] = [0, 0, 0, 0] if rng.integers(2) else P_LIMBS - np.array([1, 0, 0, 0], dtype=np.uint64)
-    force = int(rng.choice([0, 0, 2, 3]))
-    if force:
-        os.environ["LG_FORCE_CHUNKS"] = str(force)
-    else:
-        os.environ.pop("LG_FORCE_CHUNKS", None)
-    with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
-        if rng.integers(2):
-            coeffs, roots = c.encode_commit(pre)
+def sweep(budget: float, seed: int) -> int:
+    """random cases until `budget` seconds have passed; returns how many ran (every one asserted bit-exact)"""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n_cases = 0
+    P_LIMBS = np.array([0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)
+    while time.time() < t_end:
+        logk = int(rng.integers(1, 15))       # 13, 14: folded transforms (k = 8192, 16384)
+        k = 1 << logk
+        max_rows = max(4, min(400, (1 << 21) // (8 * k)))
+        rows = int(rng.integers(1, max_rows // 4 + 1)) * 4
+        batch = int(rng.choice([1, 1, 2, 3, 5]))
+        if batch * rows * k * 8 > (1 << 22):
+            batch = 1
+        seed = int(rng.integers(1 << 30))
+        pre = random_mont(seed, batch * rows * k).reshape(batch * rows, k, 4)
+        # sprinkle corner values: 0, 1 (Montgomery one is in random_mont's range anyway), p - 1
+        for _ in range(8):
+            i, j = int(rng.integers(batch * rows)), int(rng.integers(k))
+            pre[i, j] = [0, 0, 0, 0] if rng.integers(2) else P_LIMBS - np.array([1, 0, 0, 0], dtype=np.uint64)
+        force = int(rng.choice([0, 0, 2, 3]))
+        if force:
+            os.environ["LG_FORCE_CHUNKS"] = str(force)
         else:
-            c.upload(pre); c.commit_resident(); coeffs, roots = c.coeffs(), c.root()
-        t = min(8 * k, 5)
-        idx = np.sort(rng.choice(8 * k, size=t, replace=False)).astype(np.uint32)
-        for b in range(batch):
-            ref = oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, 8 * k)
-            assert np.array_equal(coeffs[b * rows:(b + 1) * rows], ref["coeffs"]), ("coeffs", rows, k, batch, b, seed)
-            assert roots[32 * b:32 * b + 32] == ref["root"], ("root", rows, k, batch, b, seed, force)
-            cols, sib, paths = c.open_columns(idx, proof=b)
-            ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], idx)
-            assert np.array_equal(cols, ecols) and np.array_equal(sib, esib) and np.array_equal(paths, epaths), ("open", rows, k, batch, b, seed)
-        if k <= 8192 and rows % 4 == 0:
-            r = random_mont(seed + 1, batch * rows // 4).reshape(batch, rows // 4, 4)
-            got = c.quadratic_constraint_poly(r)
+            os.environ.pop("LG_FORCE_CHUNKS", None)
+        with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+            if rng.integers(2):
+                coeffs, roots = c.encode_commit(pre)
+            else:
+                c.upload(pre); c.commit_resident(); coeffs, roots = c.coeffs(), c.root()
+            t = min(8 * k, 5)
+            idx = np.sort(rng.choice(8 * k, size=t, replace=False)).astype(np.uint32)
             for b in range(batch):
-                want = oracle.quadratic_constraint_poly(coeffs[b * rows:(b + 1) * rows], r[b])
-                assert np.array_equal(got[b], want), ("quad", rows, k, batch, b, seed)
-    n_cases += 1
-print(f"parity sweep: {n_cases} random cases, all bit-exact")
+                ref = oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, 8 * k)
+                assert np.array_equal(coeffs[b * rows:(b + 1) * rows], ref["coeffs"]), ("coeffs", rows, k, batch, b, seed)
+                assert roots[32 * b:32 * b + 32] == ref["root"], ("root", rows, k, batch, b, seed, force)
+                cols, sib, paths = c.open_columns(idx, proof=b)
+                ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], idx)
+                assert np.array_equal(cols, ecols) and np.array_equal(sib, esib) and np.array_equal(paths, epaths), ("open", rows, k, batch, b, seed)
+            if k <= 8192 and rows % 4 == 0:
+                r = random_mont(seed + 1, batch * rows // 4).reshape(batch, rows // 4, 4)
+                got = c.quadratic_constraint_poly(r)
+                for b in range(batch):
+                    want = oracle.quadratic_constraint_poly(coeffs[b * rows:(b + 1) * rows], r[b])
+                    assert np.array_equal(got[b], want), ("quad", rows, k, batch, b, seed)
+        n_cases += 1
+    os.environ.pop("LG_FORCE_CHUNKS", None)
+    return n_cases
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    print(f"parity sweep (seed {seed}): {sweep(budget, seed)} random cases, all bit-exact")

@@ -462,3 +462,64 @@ def test_back_to_back_commits_with_and_without_async_tree(lg, oracle, async_tree
             c.upload(pres[0])
             c.commit_resident()
             assert c.root() == b"".join(r["root"] for r in refs[0])
+
+
+def test_full_size_s22_properties(lg, oracle, model):
+    """BASELINE config 4 shape on ONE GPU (20 068 x 8192 -> 65 536: U = 42 GB, 53 GB resident; folded interpolation and
+    evaluation, 16 coset planes, 8-chunk commit pipeline) -- far too big for the oracle's in-memory commit, so: the root,
+    the leaf digests and the inner nodes against the golden the oracle's STREAMED restatement produced for the same seeded
+    input (tests/golden/large_roots.json, tests/golden/make_golden_large.py), plus the size-independent properties of the
+    S20 test: spot rows against the oracle, systematic code, column hashes of opened columns, Merkle paths, whole tree
+    recomputed from the GPU's leaves."""
+    import hashlib
+    import json
+    from bench import LARGE_SEED, synthetic_preenc
+    rows, k = 20068, 8192
+    n = 8 * k
+    gold = json.load(open(os.path.join(GOLDEN, "large_roots.json")))["s22"]
+    assert (gold["rows"], gold["k"], gold["seed"]) == (rows, k, LARGE_SEED)
+    pre = synthetic_preenc(LARGE_SEED, rows * k).reshape(rows, k, 4)
+    with lg.LigeroCommitter(rows=rows, k=k) as c:
+        assert c.pipeline_chunks() == 8
+        c.upload(pre)
+        c.commit_resident()
+        root = c.root()
+        assert root.hex() == gold["root"]
+        leaves = c.leaves()[0]
+        nodes = c.nodes()[0]
+        assert hashlib.sha256(leaves.tobytes()).hexdigest() == gold["leaves_sha256"]
+        assert hashlib.sha256(nodes.tobytes()).hexdigest() == gold["nodes_sha256"]
+        coeffs = c.coeffs()
+        for r in (0, 1, rows // 2, rows - 1):
+            eco = oracle.reed_solomon_interpolate(pre[r], k)
+            assert np.array_equal(coeffs[r], eco)
+            assert np.array_equal(c.codeword_rows(row0=r, nrows=1)[0], oracle.reed_solomon_evaluate(eco, n))
+        del coeffs
+        idx = [0, 1, 8, 15, 16, 8191, 12345, n - 2, n - 1]
+        cols, sib, paths = c.open_columns(idx)
+        assert nodes[0].tobytes() == root
+        for i, j in enumerate(idx):
+            if j % 8 == 0:
+                assert np.array_equal(cols[i], pre[:, j // 8])        # systematic
+            leaf = oracle.col_hash(cols[i])
+            assert leaf == leaves[j].tobytes()
+            assert model.merkle_verify(root, leaf, j, sib[i].tobytes(), [x.tobytes() for x in paths[i]])
+        assert np.array_equal(oracle.merkle_tree(leaves), nodes)      # whole tree from the GPU's leaves
+        # the host-buffer entry point (streamed over PCIe in 8 chunks) reaches the same root
+        _, root2 = c.encode_commit(pre, want_coeffs=False)
+        assert root2 == root
+
+
+def test_full_size_s20_golden_root(lg):
+    """BASELINE config 3 shape against the golden of the oracle's streamed restatement (same seeded input as bench.py's s20 leg)"""
+    import hashlib
+    import json
+    from bench import LARGE_SEED, synthetic_preenc
+    rows, k = 10036, 4096
+    gold = json.load(open(os.path.join(GOLDEN, "large_roots.json")))["s20"]
+    pre = synthetic_preenc(LARGE_SEED, rows * k).reshape(rows, k, 4)
+    with lg.LigeroCommitter(rows=rows, k=k) as c:
+        _, root = c.encode_commit(pre, want_coeffs=False)
+        assert root.hex() == gold["root"]
+        assert hashlib.sha256(c.leaves()[0].tobytes()).hexdigest() == gold["leaves_sha256"]
+        assert hashlib.sha256(c.nodes()[0].tobytes()).hexdigest() == gold["nodes_sha256"]

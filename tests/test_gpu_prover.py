@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
+from prover_hooks import tamper
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +49,7 @@ def test_tampered_proofs_are_rejected(poseidon, what, index):
     digest, a leaf index -- and verify() must say no"""
     _, prover, idx, vals = poseidon
     proof = prover.prove(idx, vals)
-    proof.tamper(what, index)
+    tamper(proof, what, index)
     assert not prover.verify(proof)
 
 
@@ -107,7 +108,7 @@ def test_batch_prover_matches_single_prover(poseidon, oracle, vectors):
             single = prover.prove(idx, allv[b])
             assert single.info() == proofs[b].info()
         # tampering one proof of the batch does not go unnoticed
-        proofs[5].tamper(6, 99)
+        tamper(proofs[5], 6, 99)
         assert not prover.verify(proofs[5])
     with LigeroBatchProver(inst, 3, threads=1) as bp3:           # odd batch, single-threaded host side
         for p in bp3.prove(idx, allv[:3]):
@@ -117,7 +118,7 @@ def test_batch_prover_matches_single_prover(poseidon, oracle, vectors):
         assert [v.info()["u_root"].hex() for v in views] == vectors["poseidon_batch64_roots"][3:6]
         assert all(prover.verify(v) for v in views)
         with pytest.raises(RuntimeError):
-            views[0].tamper(1, 0)
+            tamper(views[0], 1, 0)
         views2 = bp3.prove(idx, allv[:3], copy=False)               # storage is reused: the earlier views now show these
         assert [v.info()["u_root"].hex() for v in views2] == vectors["poseidon_batch64_roots"][:3]
 

@@ -33,18 +33,26 @@ def _worker(rank, world, port, rows, k, out):
     try:
         from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
         pre = random_mont(515, rows * k).reshape(rows, k, 4)               # same seed on every rank
-        be = HipStageBackend(rows, k, device=0)
+        be = HipStageBackend(rows, k, device=0, world=world, rank=rank)     # only this rank's planes of U are allocated
         sc = CosetShardedCommitter(be, dist)
         r0, r1 = sc.row_range()
         root = sc.commit(pre[r0:r1])
         opened = sc.open_columns([0, 5, 8 * k - 1])
-        out[rank] = (root, {j: (c.tobytes(), s.tobytes(), p.tobytes()) for j, (c, s, p) in opened.items()})
+        # a column of a plane the OTHER rank owns must be refused by the C ABI itself, not served from foreign memory
+        foreign = (1 - rank) * (be.nplanes // world)
+        try:
+            be.open_columns([foreign])
+            refused = False
+        except Exception as e:                                              # LigeroHipError(status = LG_ERR_STATE)
+            refused = getattr(e, "status", None) == -6
+        out[rank] = (root, {j: (c.tobytes(), s.tobytes(), p.tobytes()) for j, (c, s, p) in opened.items()}, refused, dict(sc.stage_ms))
         be.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows,k", [(20, 128), (21, 128), (6, 4096), (4, 8192)])   # even / ragged shards, one row per wg, folded k
+# even / ragged row shards (ragged = the padded single all-gather), one row per workgroup at k = 4096, folded k = 8192
+@pytest.mark.parametrize("rows,k", [(20, 128), (21, 128), (6, 4096), (7, 4096), (4, 8192), (5, 8192)])
 def test_world2_on_one_gpu_matches_oracle(oracle, rows, k):
     import torch.multiprocessing as mp
     world = 2
@@ -58,7 +66,138 @@ def test_world2_on_one_gpu_matches_oracle(oracle, rows, k):
     assert set(out.keys()) == {0, 1}
     got = {}
     for rank in range(world):
-        root, opened = out[rank]
+        root, opened, refused, stage_ms = out[rank]
         assert root == ref["root"], rank
+        assert refused, "a column of an unowned plane was served"
+        assert set(stage_ms) == {"interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle"}
         got.update(opened)
     assert got == want                                                    # every opened column came from its owner, bit-exact
+
+
+def test_partial_commitments_refuse_foreign_data(oracle):
+    """after a staged commit a context holds only the planes / message rows the stages put there; the C ABI
+    must answer LG_ERR_STATE (-6) for everything else instead of returning stale or foreign data with LG_OK."""
+    import ctypes
+    import ligero_amd
+    from ligero_amd import _ffi
+    L = _ffi.lib()
+    rows, k = 8, 64
+    n = 8 * k
+    pre = random_mont(99, rows * k).reshape(rows, k, 4)
+    vp = ctypes.c_void_p
+
+    def status(fn, *a):
+        return fn(*a)
+
+    with ligero_amd.LigeroCommitter(rows=rows, k=k) as c:                    # an ordinary context, staged by hand
+        half = rows // 2
+        first = np.ascontiguousarray(pre[:half])
+        assert L.lg_stage_interpolate(c._ctx, first.ctypes.data_as(vp), 0, half) == 0
+        assert L.lg_stage_evaluate_hash(c._ctx, 0x0f) == 0                     # planes 0..3 only
+        assert L.lg_stage_merkle(c._ctx) == 0
+        cols, sib, paths = c.open_columns([0, 8, 3])                           # planes 0, 0, 3: held
+        idx = np.array([4], dtype=np.uint32)
+        o1 = np.empty((1, rows, 4), dtype=np.uint64); o2 = np.empty((1, 32), dtype=np.uint8); o3 = np.empty((1, 16, 32), dtype=np.uint8)
+        assert L.lg_open_columns(c._ctx, 0, idx.ctypes.data_as(vp), 1, o1.ctypes.data_as(vp), o2.ctypes.data_as(vp), o3.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE
+        assert b"planes" in L.lg_last_error(c._ctx)
+        buf = np.empty((rows, n, 4), dtype=np.uint64)
+        assert L.lg_read_codeword_rows(c._ctx, 0, 0, rows, buf.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE
+        r = random_mont(5, rows).reshape(rows, 4)
+        out = np.empty((2 * k, 4), dtype=np.uint64)
+        assert L.lg_quadratic_constraint_poly(c._ctx, r.ctypes.data_as(vp), out.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE   # needs plane 4
+        ra = random_mont(6, rows * k).reshape(rows, k, 4)
+        assert L.lg_linear_constraint_poly(c._ctx, ra.ctypes.data_as(vp), out.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE
+        assert L.lg_interleaved_row_mul(c._ctx, r.ctypes.data_as(vp), out.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE          # rows [0, half) only
+        assert L.lg_commit_resident(c._ctx) == _ffi.LG_ERR_STATE
+        # a full commit on the same context lifts every restriction
+        coeffs, root = c.encode_commit(pre)
+        ref = oracle.encode_commit(pre, k, n)
+        assert root == ref["root"] and np.array_equal(c.codeword_rows(), ref["u"])
+        c.quadratic_constraint_poly(r[: rows // 4])
+        c.interleaved_row_mul(r)
+
+    with ligero_amd.LigeroCommitter(rows=rows, k=k, shard=(2, 2, rows)) as c:   # one rank of four: planes 2, 3
+        assert c.planes() == (8, 2, 2)
+        flat = np.ascontiguousarray(pre)
+        assert L.lg_upload_preenc(c._ctx, flat.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE
+        assert L.lg_commit_resident(c._ctx) == _ffi.LG_ERR_STATE
+        root = np.empty(32, dtype=np.uint8)
+        assert L.lg_encode_commit(c._ctx, flat.ctypes.data_as(vp), None, root.ctypes.data_as(vp)) == _ffi.LG_ERR_STATE
+        assert L.lg_stage_interpolate(c._ctx, flat.ctypes.data_as(vp), 0, rows) == 0
+        assert L.lg_stage_evaluate_hash(c._ctx, 0x10) == _ffi.LG_ERR_BAD_ARG     # plane 4 does not exist on this rank
+        assert L.lg_stage_evaluate_hash(c._ctx, 0x0c) == 0
+        assert L.lg_stage_merkle(c._ctx) == 0
+        ref = oracle.encode_commit(pre, k, n)
+        cols, sib, paths = c.open_columns([2, 11])                              # planes 2 and 3
+        ecols, _, _ = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], [2, 11])
+        assert np.array_equal(cols, ecols)
+        lv = c.leaves()[0]
+        for j in range(n):
+            if j % 8 in (2, 3):
+                assert lv[j].tobytes() == ref["leaves"][j].tobytes()
+    with pytest.raises(Exception):
+        ligero_amd.LigeroCommitter(rows=rows, k=k, shard=(6, 3, rows))          # planes 6..8 of 8
+
+
+def _rccl_worker(rows, k, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from ligero_amd.sharded import HipStageBackend
+        pre = random_mont(616, rows * k).reshape(rows, k, 4)
+        be = HipStageBackend(rows, k, device=0, world=1, rank=0)
+        be.stage_interpolate(pre, 0, rows)
+        be.sync()
+        # the two exchanges of CosetShardedCommitter.commit, verbatim, on the library's own device buffers
+        coeffs = be.coeffs_bytes()
+        before = coeffs.clone()
+        dist.all_gather_into_tensor(coeffs.view(-1), coeffs[0:rows].view(-1))
+        torch.cuda.synchronize()
+        same = bool(torch.equal(coeffs, before))
+        be.stage_evaluate_hash(list(range(be.nplanes)))
+        be.sync()
+        leaves = be.leaves_bytes().view(be.n // be.nplanes, 1, be.nplanes, 32)
+        mine = leaves[:, 0].contiguous()
+        buf = torch.empty((1,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(buf.view(-1), mine.view(-1))
+        leaves.copy_(buf.permute(1, 0, 2, 3))
+        torch.cuda.synchronize()
+        be.stage_merkle()
+        out["root"] = be.root()
+        out["same"] = same
+        be.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_on_the_library_buffers(oracle):
+    """RCCL itself (backend "nccl"), world_size 1 on the one GPU of the test box: the in-place all-gather on the aliased
+    coefficient buffer and the digest all-gather run through librccl on the device pointers the C ABI hands out."""
+    import torch.multiprocessing as mp
+    rows, k = 12, 256
+    mgr = mp.Manager()
+    out = mgr.dict()
+    p = mp.get_context("spawn").Process(target=_rccl_worker, args=(rows, k, out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    pre = random_mont(616, rows * k).reshape(rows, k, 4)
+    assert out["same"] and out["root"] == oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
+
+
+def test_contexts_on_two_devices_in_one_process(oracle):
+    """the dynamic-LDS attribute of the row-NTT kernels is per device; k = 4096 needs 144 KiB"""
+    import torch
+    import ligero_amd
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    rows, k = 3, 4096
+    pre = random_mont(7, rows * k).reshape(rows, k, 4)
+    want = oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
+    for dev in (0, 1):
+        with ligero_amd.LigeroCommitter(rows=rows, k=k, device=dev) as c:
+            assert c.encode_commit(pre, want_coeffs=False)[1] == want

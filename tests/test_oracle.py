@@ -199,3 +199,23 @@ def test_subproof_polynomials_model_vs_c(oracle, model):
     P = model.P
     mat = to_m([1, 2, 8, 3, 4, 5]).reshape(2, 3, 4)
     assert from_m(oracle.dense_row_mul(mat, to_m([P - 5, 17]))) == [46, 58, 45]
+
+
+@pytest.mark.parametrize("rows,k,block", [(5, 8, 2), (13, 64, 4), (70, 16, 64)])
+def test_streamed_commit_equals_in_memory_commit(oracle, rows, k, block):
+    """the blocked-row variant that produces the full-size goldens (tests/golden/large_roots.json) hashes exactly the
+    same byte string per column as the reference-shaped commit (mod.rs:521-551)"""
+    pre = random_mont(rows * 7 + k, rows * k).reshape(rows, k, 4)
+    a = oracle.encode_commit(pre, k, 8 * k)
+    for threads in (1, 3):
+        b = oracle.encode_commit_streamed(pre, k, 8 * k, threads=threads, block_rows=block)
+        assert a["root"] == b["root"] and np.array_equal(a["leaves"], b["leaves"]) and np.array_equal(a["nodes"], b["nodes"])
+
+
+def test_large_goldens_are_committed():
+    import json
+    from bench import LARGE_SEED, WORKLOADS
+    g = json.load(open(os.path.join(GOLDEN, "large_roots.json")))
+    for name in ("s20", "s22"):
+        assert (g[name]["rows"], g[name]["k"]) == WORKLOADS[name][:2] and g[name]["seed"] == LARGE_SEED
+        assert len(bytes.fromhex(g[name]["root"])) == 32

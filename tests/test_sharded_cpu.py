@@ -21,12 +21,14 @@ sys.path.insert(0, ROOT)
 class OracleStageBackend:
     """test double for ligero_amd.sharded.HipStageBackend (same methods), CPU + oracle"""
 
-    def __init__(self, rows, k):
+    def __init__(self, rows, k, world=1):
         from oracle import binding as orc
+        from ligero_amd.sharded import padded_shard_rows
         self.orc = orc
         self.rows, self.k, self.n, self.nplanes = rows, k, 8 * k, 8
+        self.coeff_rows = world * padded_shard_rows(rows, world)          # equal all-gather shards (padding rows stay 0xff)
         self.preenc = np.zeros((rows, k, 4), dtype=np.uint64)
-        self.coeffs = np.zeros((rows, k, 4), dtype=np.uint64)
+        self.coeffs = np.full((self.coeff_rows, k, 4), np.uint64(2**64 - 1), dtype=np.uint64)
         self.leaves = np.zeros((self.n, 32), dtype=np.uint8)
         self.nodes = None
         self.u = {}
@@ -51,7 +53,7 @@ class OracleStageBackend:
         pass
 
     def coeffs_bytes(self):
-        return torch.from_numpy(self.coeffs.view(np.uint8).reshape(self.rows, self.k * 32))
+        return torch.from_numpy(self.coeffs.view(np.uint8).reshape(self.coeff_rows, self.k * 32))
 
     def leaves_bytes(self):
         return torch.from_numpy(self.leaves)
@@ -90,7 +92,7 @@ def _worker(rank, world, port, rows, k, batch, out):
     try:
         from ligero_amd.sharded import CosetShardedCommitter, ShardedBatchCommitter, shard_range
         pre = random_mont(4242, rows * k).reshape(rows, k, 4)           # same seed on every rank
-        sc = CosetShardedCommitter(OracleStageBackend(rows, k), dist)
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), dist)
         r0, r1 = sc.row_range()
         root = sc.commit(pre[r0:r1])
         opened = sc.open_columns([0, 1, 9, 8 * k - 1])
@@ -103,7 +105,7 @@ def _worker(rank, world, port, rows, k, batch, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows,k", [(6, 8), (7, 16)])     # even and ragged row shards
+@pytest.mark.parametrize("rows,k", [(6, 8), (7, 16), (1, 8)])     # even and ragged row shards; a rank with no rows at all
 def test_world2_gloo_matches_single_process(oracle, rows, k):
     world, batch = 2, 3
     mgr = mp.Manager()
@@ -121,15 +123,21 @@ def test_world2_gloo_matches_single_process(oracle, rows, k):
     # plane ownership: rank 0 owns planes 0-3 (columns 0, 1), rank 1 owns 4-7 (column 8k-1 = plane 7)
     assert out[0][1] == [0, 1, 9] and out[1][1] == [8 * k - 1]
     assert out[0][3][1] == out[1][3][0] and out[1][3][1] == rows
+    assert out[0][3] == (0, min(rows, (rows + 1) // 2))                  # padded equal shards: ceil(rows / 2) rows first
 
 
 def test_single_process_degenerate(oracle):
-    from ligero_amd.sharded import CosetShardedCommitter, owned_planes, shard_range
+    from ligero_amd.sharded import CosetShardedCommitter, owned_planes, padded_shard_range, padded_shard_rows, shard_range
     rows, k = 5, 8
     pre = random_mont(99, rows * k).reshape(rows, k, 4)
     sc = CosetShardedCommitter(OracleStageBackend(rows, k), None)
     assert sc.commit(pre) == oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
     assert owned_planes(8, 4, 3) == [6, 7] and owned_planes(16, 8, 1) == [2, 3]
     assert [shard_range(10, 4, r) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    # the shapes BASELINE configs[2] / [3] name, on 8 GPUs: equal shards of ceil(rows / 8), the last one short
+    assert padded_shard_rows(20068, 8) == 2509 and padded_shard_range(20068, 8, 7) == (17563, 20068)
+    assert padded_shard_rows(10036, 8) == 1255 and padded_shard_range(10036, 8, 7) == (8785, 10036)
+    assert [padded_shard_range(3, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert [padded_shard_range(5, 4, r) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
     with pytest.raises(ValueError):
         owned_planes(8, 3, 0)
