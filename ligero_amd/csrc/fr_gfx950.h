@@ -43,31 +43,53 @@ __device__ __forceinline__ uint64_t mad_wide(uint32_t a, uint32_t b, uint64_t c)
     return (uint64_t)a * b + c;  // v_mad_u64_u32
 }
 
+// Carry chains are written with the add/sub-with-carry builtins (v_add_co / v_addc_co / v_sub_co / v_subb_co, 1.75 ns per
+// wave-instruction) and selections with v_bitop3_b32 (a full-rate three-input boolean, 1.0 ns): expressed in 64-bit C
+// arithmetic the compiler produced v_lshl_add_u64 pairs plus v_cndmask_b32 ..., vcc, and the VCC form of v_cndmask
+// issues at ~10 ns per wave-instruction on gfx950 (tools/microbench5.hip, profiles/r02_microbench5_instruction_issue.log)
+// -- the eight selects of one conditional subtraction cost more than sixty multiplies.
+// select(mask, a, d) = (mask & a) | (~mask & d)
+__device__ __forceinline__ uint32_t fr_select(uint32_t mask, uint32_t a, uint32_t d) { return __builtin_amdgcn_bitop3_b32(mask, a, d, 0xca); }
+
 // r = a + b (no reduction; caller guarantees no wrap)
 __device__ __forceinline__ void fr_add_raw(fr& r, const fr& a, const fr& b) {
-    uint64_t c = 0;
+    uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
+        uint32_t co;
+        r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &co);
+        c = co;
     }
 }
 
 // r = a - m if a >= m else a, where m is the constant multiple of p selected by TWO_P
 template <bool TWO_P>
 __device__ __forceinline__ void fr_cond_sub(fr& r, const fr& a) {
-    uint32_t d[8];
-    int64_t c = 0;
+#ifdef LG_CONDSUB_C64   // the round-1 form (64-bit C arithmetic + ?:), kept for A/B builds
+    uint32_t dd[8];
+    int64_t cc = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (int64_t)a.v[i] - (int64_t)(TWO_P ? fr_2p(i) : fr_p(i));
-        d[i] = (uint32_t)c;
-        c >>= 32;
+        cc += (int64_t)a.v[i] - (int64_t)(TWO_P ? fr_2p(i) : fr_p(i));
+        dd[i] = (uint32_t)cc;
+        cc >>= 32;
     }
-    bool neg = c < 0;
+    const bool neg = cc < 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = neg ? a.v[i] : d[i];
+    for (int i = 0; i < 8; i++) r.v[i] = neg ? a.v[i] : dd[i];
+    return;
+#endif
+    uint32_t d[8];
+    uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t bo;
+        d[i] = __builtin_subc(a.v[i], TWO_P ? fr_2p(i) : fr_p(i), br, &bo);
+        br = bo;
+    }
+    const uint32_t keep = 0u - br;   // all ones when a < m
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = fr_select(keep, a.v[i], d[i]);
 }
 
 // lazy add: inputs < 2p, output < 2p
@@ -80,20 +102,20 @@ __device__ __forceinline__ void fr_add_lazy(fr& r, const fr& a, const fr& b) {
 // lazy sub: inputs < 2p, output < 2p  (a - b, +2p if negative)
 __device__ __forceinline__ void fr_sub_lazy(fr& r, const fr& a, const fr& b) {
     uint32_t d[8];
-    int64_t c = 0;
+    uint32_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (int64_t)a.v[i] - (int64_t)b.v[i];
-        d[i] = (uint32_t)c;
-        c >>= 32;
+        uint32_t bo;
+        d[i] = __builtin_subc(a.v[i], b.v[i], br, &bo);
+        br = bo;
     }
-    uint32_t mask = (c < 0) ? 0xffffffffu : 0u;
-    uint64_t cc = 0;
+    const uint32_t mask = 0u - br;
+    uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        cc += (uint64_t)d[i] + (fr_2p(i) & mask);
-        r.v[i] = (uint32_t)cc;
-        cc >>= 32;
+        uint32_t co;
+        r.v[i] = __builtin_addc(d[i], fr_2p(i) & mask, c, &co);
+        c = co;
     }
 }
 
