@@ -160,6 +160,49 @@ def full_prover_rate(device: int, steps: int = 5):
             "note": "full prove() incl. transcript on host threads; host bound; transcript unpinned vs the Rust crates"}
 
 
+def s20_prover_rate(device: int, proofs: int = 2):
+    """BASELINE configs[2] as a PROOF rate: the synthetic 2^20-constraint repeated-squaring R1CS (tools/gen_repeated_squaring_r1cs.py,
+    SURVEY 8d) -> C++ host pipeline (from_constraint_system, LigeroCircuit::new, evaluation trace, preenc_u) -> device prover
+    (commit + three sub-proofs + openings).  Setup (R1CS compile, constraint matrix A with 46.6 M entries, upload) is reported apart."""
+    import importlib.util
+    import tempfile
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    spec = importlib.util.spec_from_file_location("gen_rs", os.path.join(ROOT, "tools", "gen_repeated_squaring_r1cs.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with tempfile.TemporaryDirectory() as d:
+        t0 = time.perf_counter()
+        r1cs = os.path.join(d, "rs20.r1cs")
+        gen.write_r1cs(r1cs, 20)
+        wit = gen.witness(20, 1)
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        inst = hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(r1cs))
+        t_inst = time.perf_counter() - t0
+    dims = (inst.m, inst.k, inst.n, inst.t)
+    mask = (1 << 64) - 1
+    p = gen.P
+    vals = np.empty((len(wit) - 1, 4), dtype=np.uint64)
+    for j, v in enumerate(wit[1:]):
+        vm = (v << 256) % p                                   # Montgomery form
+        vals[j] = (vm & mask, (vm >> 64) & mask, (vm >> 128) & mask, vm >> 192)
+    idx = np.arange(1, len(wit), dtype=np.uint64)
+    t0 = time.perf_counter()
+    with LigeroProver(inst, device=device) as prover:
+        t_upload = time.perf_counter() - t0
+        proof = prover.prove(idx, vals)                       # first proof: buffers, tables
+        t0 = time.perf_counter()
+        for _ in range(proofs):
+            proof = prover.prove(idx, vals)
+        dt = (time.perf_counter() - t0) / proofs
+        root = proof.info()["u_root"].hex()
+    return {"value": 1.0 / dt, "unit": "proofs/s", "s_per_proof": dt, "proofs_timed": proofs, "dims_m_k_n_t": dims,
+            "dims_match_survey": dims == (2509, 4096, 32768, 156), "nodes": inst.num_nodes, "a_nnz": inst.a_nnz, "u_root": root,
+            "setup_s": {"generate_r1cs_and_witness": t_gen, "compile_and_ligero_new": t_inst, "prover_create_upload_A": t_upload},
+            "note": "one proof at a time (single HipLigero prover): host evaluation trace + preenc_u assembly, then device; transcript unpinned"}
+
+
 def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
     """The oracle (C restatement, reference-equivalent single-thread shape) timed on this
     host's cores on a bounded sample of the same workload."""
@@ -525,6 +568,10 @@ def main():
             except Exception as e:
                 line["s20"] = {"error": f"{type(e).__name__}: {e}"}
             line["full_prover"] = full_prover_rate(local_rank)
+            try:
+                line["s20"]["full_prover_from_r1cs"] = s20_prover_rate(local_rank)
+            except Exception as e:
+                line["s20"]["full_prover_from_r1cs"] = {"error": f"{type(e).__name__}: {e}"}
         if extras:
             line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
             line["vs_cpu_baseline"] = {"ratio": line["value"] / line["cpu_baseline"]["value"],

@@ -255,39 +255,74 @@ public:
 };
 
 // ---------------------------------------------------------------- sparse matrix (src/matrices/mod.rs:6-126)
+// The reference keeps a Vec of rows, each a Vec<(F, usize)>.  Same rows, same entry order, but stored compressed
+// (row_ptr + one entry array): the constraint matrix of the 2^20-constraint circuit has 41 M rows and 45 M entries, and
+// one heap allocation per row would cost more memory than the entries themselves.
 struct SparseMatrix {
+    struct Entry {            // (value, column) -- the reference's (F, usize); a plain struct so that rows move with memcpy
+        Fr first;
+        size_t second;
+    };
+    struct RowView {
+        const Entry* b;
+        const Entry* e;
+        const Entry* begin() const { return b; }
+        const Entry* end() const { return e; }
+        size_t size() const { return (size_t)(e - b); }
+        bool empty() const { return b == e; }
+        const Entry& operator[](size_t i) const { return b[i]; }
+    };
     size_t num_cols = 0;
-    std::vector<std::vector<std::pair<Fr, size_t>>> rows;
+    std::vector<uint64_t> row_ptr{0};
+    std::vector<Entry> ent;
     explicit SparseMatrix(size_t cols = 0) : num_cols(cols) {}
-    size_t num_rows() const { return rows.size(); }
-    void push_row(std::vector<std::pair<Fr, size_t>> r) { rows.push_back(std::move(r)); }
-    void push_empty_row() { rows.emplace_back(); }
-    void push_empty_rows(size_t n) { rows.resize(rows.size() + n); }
+    size_t num_rows() const { return row_ptr.size() - 1; }
+    RowView row(size_t i) const { return RowView{ent.data() + row_ptr[i], ent.data() + row_ptr[i + 1]}; }
+    void push_row(std::initializer_list<Entry> r) { ent.insert(ent.end(), r.begin(), r.end()); row_ptr.push_back(ent.size()); }
+    void push_row(const std::vector<Entry>& r) { ent.insert(ent.end(), r.begin(), r.end()); row_ptr.push_back(ent.size()); }
+    void push_row1(const Fr& v, size_t col) { ent.push_back(Entry{v, col}); row_ptr.push_back(ent.size()); }
+    void push_empty_row() { row_ptr.push_back(ent.size()); }
+    void push_empty_rows(size_t n) { row_ptr.resize(row_ptr.size() + n, ent.size()); }
     static SparseMatrix identity(size_t n) {
         SparseMatrix m(n);
-        for (size_t i = 0; i < n; i++) m.rows.push_back({{fr_one(), i}});
+        m.ent.reserve(n);
+        m.row_ptr.reserve(n + 1);
+        const Fr one = fr_one();
+        for (size_t i = 0; i < n; i++) m.push_row1(one, i);
         return m;
     }
     static SparseMatrix zero(size_t nr, size_t nc) {
         SparseMatrix m(nc);
-        m.rows.resize(nr);
+        m.push_empty_rows(nr);
         return m;
     }
     SparseMatrix h_stack(const SparseMatrix& o) && {
         if (num_rows() != o.num_rows()) throw std::runtime_error("Row number mismatch in when stacking matrices horizontally");
-        for (size_t i = 0; i < rows.size(); i++)
-            for (const auto& e : o.rows[i]) rows[i].emplace_back(e.first, e.second + num_cols);
-        num_cols += o.num_cols;
-        return std::move(*this);
+        SparseMatrix out(num_cols + o.num_cols);
+        out.ent.resize(ent.size() + o.ent.size());
+        out.row_ptr.resize(row_ptr.size());
+        Entry* w = out.ent.data();
+        for (size_t i = 0; i < num_rows(); i++) {
+            const size_t na = row_ptr[i + 1] - row_ptr[i], nb = o.row_ptr[i + 1] - o.row_ptr[i];
+            if (na) std::memcpy(w, ent.data() + row_ptr[i], na * sizeof(Entry));
+            w += na;
+            const Entry* src = o.ent.data() + o.row_ptr[i];
+            for (size_t j = 0; j < nb; j++) { w[j].first = src[j].first; w[j].second = src[j].second + num_cols; }
+            w += nb;
+            out.row_ptr[i + 1] = (uint64_t)(w - out.ent.data());
+        }
+        return out;
     }
-    SparseMatrix v_stack(SparseMatrix o) && {
+    SparseMatrix v_stack(const SparseMatrix& o) && {
         if (num_cols != o.num_cols) throw std::runtime_error("Column number mismatch in when stacking matrices vertically");
-        for (auto& r : o.rows) rows.push_back(std::move(r));
+        const uint64_t base = ent.size();
+        ent.insert(ent.end(), o.ent.begin(), o.ent.end());
+        row_ptr.reserve(row_ptr.size() + o.num_rows());
+        for (size_t i = 1; i < o.row_ptr.size(); i++) row_ptr.push_back(base + o.row_ptr[i]);
         return std::move(*this);
     }
     SparseMatrix neg() && {
-        for (auto& r : rows)
-            for (auto& e : r) e.first = fr_neg(e.first);
+        for (auto& e : ent) e.first = fr_neg(e.first);
         return std::move(*this);
     }
     // mod.rs:100-110: result[col] += row[i] * value for every entry of row i
@@ -297,22 +332,18 @@ struct SparseMatrix {
         return out;
     }
     // the same into caller-owned storage of num_cols elements
-    void row_mul_into(const Fr* row, size_t row_len, Fr* out) const {
+    void row_mul_into(const Fr* rowv, size_t row_len, Fr* out) const {
         for (size_t c = 0; c < num_cols; c++) out[c] = fr_zero();
-        const size_t n = row_len < rows.size() ? row_len : rows.size();
+        const size_t n = row_len < num_rows() ? row_len : num_rows();
         const Fr one = fr_one(), minus_one = fr_neg(fr_one());
         for (size_t i = 0; i < n; i++)
-            for (const auto& e : rows[i]) {  // almost every entry of A is +-1: add / subtract instead of multiplying
-                if (fr_eq(e.first, one)) out[e.second] = fr_add(out[e.second], row[i]);
-                else if (fr_eq(e.first, minus_one)) out[e.second] = fr_sub(out[e.second], row[i]);
-                else out[e.second] = fr_add(out[e.second], fr_mul(row[i], e.first));
+            for (const auto& e : row(i)) {  // almost every entry of A is +-1: add / subtract instead of multiplying
+                if (fr_eq(e.first, one)) out[e.second] = fr_add(out[e.second], rowv[i]);
+                else if (fr_eq(e.first, minus_one)) out[e.second] = fr_sub(out[e.second], rowv[i]);
+                else out[e.second] = fr_add(out[e.second], fr_mul(rowv[i], e.first));
             }
     }
-    size_t nnz() const {
-        size_t n = 0;
-        for (const auto& r : rows) n += r.size();
-        return n;
-    }
+    size_t nnz() const { return ent.size(); }
 };
 
 // ---------------------------------------------------------------- witness files
@@ -433,7 +464,7 @@ public:
         while (k < m) k <<= 1;
         n = 8 * k;                                                       // reed_solomon_parameters, mod.rs:283-294
         t = calculate_t(lambda, n - k + 1, n, n);
-        std::unordered_map<size_t, size_t> index_map;                    // mod.rs:179-194
+        std::vector<size_t> index_map(circuit.nodes.size(), kNoIndex);   // mod.rs:179-194 (a HashMap there; dense here)
         index_map[0] = 0;
         size_t seen = 0;
         for (size_t i = 1; i < circuit.nodes.size(); i++) {
@@ -449,9 +480,13 @@ public:
         return index + 1;
     }
 
-    // prove (mod.rs:449-452) + prove_inner (mod.rs:476-516): assignment by ORIGINAL node index
-    std::vector<std::vector<Fr>> build_preenc_u(const std::vector<std::pair<size_t, Fr>>& var_assignment, bool* all_outputs_one = nullptr) const {
+    // prove (mod.rs:449-452) + prove_inner (mod.rs:476-516): assignment by ORIGINAL node index.  Writes preenc_u as the
+    // flat row-major 4m x k matrix the C ABI takes -- x, y, z, w each padded to m k (mod.rs:506-509), cut into rows of k
+    // (as_matrix, mod.rs:1014-1017) and stacked [X; Y; Z; W] (mod.rs:511-516) is exactly the concatenation of the four
+    // padded vectors -- without the intermediate Vecs (at 2^20 constraints they are 1.3 GB each way).
+    void build_preenc_into(const std::vector<std::pair<size_t, Fr>>& var_assignment, Fr* out, bool* all_outputs_one = nullptr) const {
         std::vector<std::pair<size_t, Fr>> bumped;
+        bumped.reserve(var_assignment.size());
         for (const auto& v : var_assignment) bumped.emplace_back(bump_index(v.first), v.second);
         const std::vector<Fr> sol = circuit.evaluation_trace(bumped);
         if (all_outputs_one) {
@@ -459,20 +494,25 @@ public:
             for (size_t o : outputs)
                 if (!fr_eq(sol[o], fr_one())) *all_outputs_one = false;
         }
-        std::vector<Fr> x, y, z, w;
+        const size_t mk = m * k;
+        std::memset(static_cast<void*>(out), 0, 4 * mk * sizeof(Fr));      // the all-zero limbs are the field's zero
+        Fr *x = out, *y = out + mk, *z = out + 2 * mk, *w = out + 3 * mk;
+        size_t pos = 0;
         for (size_t i = 0; i < circuit.nodes.size(); i++) {
             const Node& nd = circuit.nodes[i];
             if (nd.kind == Node::Constant && i != 0) continue;
-            w.push_back(sol[i]);
-            if (nd.kind == Node::Mul) { x.push_back(sol[nd.l]); y.push_back(sol[nd.r]); z.push_back(sol[i]); }
-            else { x.push_back(fr_zero()); y.push_back(fr_zero()); z.push_back(fr_zero()); }
+            if (pos >= mk) throw std::runtime_error("solution vector longer than m * k");
+            w[pos] = sol[i];
+            if (nd.kind == Node::Mul) { x[pos] = sol[nd.l]; y[pos] = sol[nd.r]; z[pos] = sol[i]; }
+            pos++;
         }
-        if (w.size() > m * k) throw std::runtime_error("solution vector longer than m * k");
+    }
+    std::vector<std::vector<Fr>> build_preenc_u(const std::vector<std::pair<size_t, Fr>>& var_assignment, bool* all_outputs_one = nullptr) const {
+        std::vector<Fr> flat(4 * m * k);
+        build_preenc_into(var_assignment, flat.data(), all_outputs_one);
         std::vector<std::vector<Fr>> rows;
-        for (auto* vec : {&x, &y, &z, &w}) {
-            vec->resize(m * k, fr_zero());
-            for (size_t i = 0; i < m; i++) rows.emplace_back(vec->begin() + i * k, vec->begin() + (i + 1) * k);   // as_matrix, mod.rs:1014-1017
-        }
+        rows.reserve(4 * m);
+        for (size_t i = 0; i < 4 * m; i++) rows.emplace_back(flat.begin() + i * k, flat.begin() + (i + 1) * k);
         return rows;
     }
 
@@ -487,19 +527,19 @@ private:
         for (auto& kv : circuit.variables) kv.second = bump_index(kv.second);
     }
 
-    static size_t at(const std::unordered_map<size_t, size_t>& m, size_t key) {
-        auto it = m.find(key);
+    static constexpr size_t kNoIndex = ~size_t{0};
+    static size_t at(const std::vector<size_t>& m, size_t key) {
         // the reference unwraps here (mod.rs:345 etc.): a gate whose operands are both constants panics
-        if (it == m.end()) throw std::runtime_error("called `Option::unwrap()` on a `None` value: gate operand is a constant without an index (mul/add of two constants)");
-        return it->second;
+        if (key >= m.size() || m[key] == kNoIndex) throw std::runtime_error("called `Option::unwrap()` on a `None` value: gate operand is a constant without an index (mul/add of two constants)");
+        return m[key];
     }
 
-    SparseMatrix generate_matrices(const std::unordered_map<size_t, size_t>& index_map, size_t num_cols) const {   // mod.rs:296-433
+    SparseMatrix generate_matrices(const std::vector<size_t>& index_map, size_t num_cols) const {   // mod.rs:296-433
         const auto& nodes = circuit.nodes;
         SparseMatrix p_x(num_cols), p_y(num_cols), p_z(num_cols), p_add(num_cols);
         const Fr one = fr_one(), minus_one = fr_neg(fr_one());
         auto add_row = [&](size_t l, size_t r) {
-            std::vector<std::pair<Fr, size_t>> row;
+            std::vector<SparseMatrix::Entry> row;
             if (nodes[l].kind == Node::Constant) row = {{nodes[l].value, 0}, {one, at(index_map, r)}};
             else if (nodes[r].kind == Node::Constant) row = {{one, at(index_map, l)}, {nodes[r].value, 0}};
             else row = {{one, at(index_map, l)}, {one, at(index_map, r)}};
@@ -519,7 +559,7 @@ private:
                 case Node::Add: {
                     p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row();
                     auto row = add_row(nd.l, nd.r);
-                    row.emplace_back(minus_one, at(index_map, i));
+                    row.push_back(SparseMatrix::Entry{minus_one, at(index_map, i)});
                     p_add.push_row(std::move(row));
                     break;
                 }
@@ -538,7 +578,7 @@ private:
             if (nd.kind == Node::Add) {
                 p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row();
                 auto row = add_row(nd.l, nd.r);
-                row.emplace_back(minus_one, 0);
+                row.push_back(SparseMatrix::Entry{minus_one, 0});
                 p_add.push_row(std::move(row));
             } else if (nd.kind == Node::Mul) {
                 p_add.push_empty_row();
@@ -551,10 +591,30 @@ private:
         if (p_x.num_rows() > num_cols) throw std::runtime_error("attempt to subtract with overflow (more rows than m * k)");
         const size_t padding = num_cols - p_x.num_rows();
         p_x.push_empty_rows(padding); p_y.push_empty_rows(padding); p_z.push_empty_rows(padding); p_add.push_empty_rows(padding);
-        SparseMatrix upper_right = std::move(p_x).v_stack(std::move(p_y)).v_stack(std::move(p_z)).neg();
-        SparseMatrix upper = SparseMatrix::identity(3 * num_cols).h_stack(upper_right);
-        SparseMatrix lower = SparseMatrix::zero(num_cols, 3 * num_cols).h_stack(p_add);
-        return std::move(upper).v_stack(std::move(lower));
+        // mod.rs:418-432:  upper = identity(3 m k).h_stack( -(P_x.v_stack(P_y).v_stack(P_z)) ),
+        //                  lower = zero(m k, 3 m k).h_stack(P_add),   A = upper.v_stack(lower)
+        // assembled in one pass into exactly-sized storage: through the stacking helpers the 2^20-constraint instance
+        // (41 M rows, 46.6 M entries of 40 bytes) was copied four times, and first-touch page faults of those copies
+        // were most of LigeroCircuit::new's 15 s.  Row r < 3 m k is (1, r) followed by the negated entries of its P row
+        // shifted by 3 m k columns; row 3 m k + r is P_add's row r shifted likewise.
+        const size_t mk = num_cols;
+        SparseMatrix a(4 * mk);
+        a.row_ptr.resize(4 * mk + 1);
+        a.ent.resize(3 * mk + p_x.nnz() + p_y.nnz() + p_z.nnz() + p_add.nnz());
+        SparseMatrix::Entry* w = a.ent.data();
+        size_t r_out = 0;
+        const SparseMatrix* upper_blocks[3] = {&p_x, &p_y, &p_z};
+        for (const SparseMatrix* blk : upper_blocks)
+            for (size_t r = 0; r < mk; r++, r_out++) {
+                *w++ = SparseMatrix::Entry{one, r_out};
+                for (const auto& e : blk->row(r)) *w++ = SparseMatrix::Entry{fr_neg(e.first), e.second + 3 * mk};
+                a.row_ptr[r_out + 1] = (uint64_t)(w - a.ent.data());
+            }
+        for (size_t r = 0; r < mk; r++, r_out++) {
+            for (const auto& e : p_add.row(r)) *w++ = SparseMatrix::Entry{e.first, e.second + 3 * mk};
+            a.row_ptr[r_out + 1] = (uint64_t)(w - a.ent.data());
+        }
+        return a;
     }
 };
 

@@ -115,13 +115,12 @@ int lgh_build_preenc(const lgh_instance* i, const uint64_t* node_idx, const uint
     if (!i || (count && (!node_idx || !values)) || !preenc_out) return LGH_ERR_BAD_ARG;
     return guarded([&] {
         std::vector<std::pair<size_t, Fr>> vars;
+        vars.reserve(count);
         for (uint64_t j = 0; j < count; j++) vars.emplace_back((size_t)node_idx[j], load_fr(values + 4 * j));
         bool ok = false;
-        const auto rows = i->inst.build_preenc_u(vars, &ok);
+        static_assert(sizeof(Fr) == 32, "Fr is four u64 limbs");
+        i->inst.build_preenc_into(vars, reinterpret_cast<Fr*>(preenc_out), &ok);
         if (all_outputs_one) *all_outputs_one = ok ? 1 : 0;
-        size_t o = 0;
-        for (const auto& r : rows)
-            for (const auto& v : r) { store_fr(preenc_out + 4 * o, v); o++; }
         return LGH_OK;
     });
 }
@@ -141,8 +140,8 @@ int lgh_a_row_mul(const lgh_instance* i, const uint64_t* r, uint64_t* out) {
 int lgh_a_entries(const lgh_instance* i, uint64_t* row_idx, uint64_t* col_idx, uint64_t* values) {
     if (!i || !row_idx || !col_idx || !values) return LGH_ERR_BAD_ARG;
     size_t o = 0;
-    for (size_t r = 0; r < i->inst.a.rows.size(); r++)
-        for (const auto& e : i->inst.a.rows[r]) {
+    for (size_t r = 0; r < i->inst.a.num_rows(); r++)
+        for (const auto& e : i->inst.a.row(r)) {
             row_idx[o] = r; col_idx[o] = e.second;
             store_fr(values + 4 * o, e.first);
             o++;

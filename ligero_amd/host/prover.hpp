@@ -116,13 +116,16 @@ inline Digest column_hash(const std::vector<Fr>& col) {
 inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
     std::vector<uint64_t> rows, cols;
     std::vector<Fr> vals;
-    for (size_t r = 0; r < a.rows.size(); r++)
-        for (const auto& e : a.rows[r]) {
+    rows.reserve(a.nnz());
+    cols.reserve(a.nnz());
+    vals.reserve(a.nnz());
+    for (size_t r = 0; r < a.num_rows(); r++)
+        for (const auto& e : a.row(r)) {
             rows.push_back(r);
             cols.push_back(e.second);
             vals.push_back(e.first);
         }
-    const int st = lg_upload_constraint_matrix(ctx, a.rows.size(), rows.size(), rows.data(), cols.data(), vals.empty() ? nullptr : vals[0].l);
+    const int st = lg_upload_constraint_matrix(ctx, a.num_rows(), rows.size(), rows.data(), cols.data(), vals.empty() ? nullptr : vals[0].l);
     if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
 }
 
@@ -135,18 +138,24 @@ public:
         while ((size_t{1} << logn_) < n_) logn_++;
         upload_constraint_matrix(ctx_, inst.a);
     }
-    ~HipLigero() { lg_ctx_destroy(ctx_); }
+    ~HipLigero() {
+        if (pinned_) lg_host_unregister(ctx_, flat_.data());
+        lg_ctx_destroy(ctx_);
+    }
     HipLigero(const HipLigero&) = delete;
     HipLigero& operator=(const HipLigero&) = delete;
 
     // ---------------------------------------------------------------- prove (mod.rs:435-578)
     LigeroProof prove(const std::vector<std::pair<size_t, Fr>>& var_assignment, PoseidonSponge& sponge) {
-        const std::vector<std::vector<Fr>> rows = inst_.build_preenc_u(var_assignment);
-        std::vector<Fr> flat;
-        flat.reserve(4 * m_ * k_);
-        for (const auto& r : rows) flat.insert(flat.end(), r.begin(), r.end());
+        // preenc_u straight into a buffer this prover keeps (and page-locks, so that lg_encode_commit's PCIe chunks overlap
+        // the encoding): at 2^20 constraints the matrix is 1.3 GB and fresh memory for it costs more than the commitment
+        if (flat_.empty()) {
+            flat_.resize(4 * m_ * k_);
+            pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
+        }
+        inst_.build_preenc_into(var_assignment, flat_.data());
         LigeroProof proof;
-        check(lg_encode_commit(ctx_, flat[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
+        check(lg_encode_commit(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
 
         {   // prove_interleaved, mod.rs:646-669
@@ -319,6 +328,8 @@ private:
     size_t m_, k_, n_, t_;
     int logn_ = 0;
     lg_ctx* ctx_ = nullptr;
+    std::vector<Fr> flat_;      // preenc_u of the proof being made (reused between proofs)
+    bool pinned_ = false;
 };
 
 // ---------------------------------------------------------------- throughput mode (BASELINE configs[4])

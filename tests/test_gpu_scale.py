@@ -1,0 +1,78 @@
+"""BASELINE.json configs[2] from an ACTUAL R1CS: tools/gen_repeated_squaring_r1cs.py writes the synthetic
+2^20-constraint repeated-squaring system as a circom .r1cs + .wtns, the C++ host pipeline compiles it the
+way ArithmeticCircuit::from_constraint_system does (src/arithmetic_circuit/mod.rs:455-520), LigeroCircuit::new derives
+(m, k, n, t) = (2509, 4096, 32 768, 156) (src/ligero/mod.rs:171-175, 275-294), the witness goes through the evaluation trace into
+preenc_u (mod.rs:476-516: x / y / z non-zero at Mul nodes only, w dense, zero tail), the GPU commits to it -- root against the
+oracle's streamed restatement on the same matrix -- and prove() / verify() run end to end on the device prover."""
+import importlib.util
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from prover_hooks import tamper
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_rs", os.path.join(ROOT, "tools", "gen_repeated_squaring_r1cs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_s20_from_r1cs_commit_prove_verify(oracle, tmp_path):
+    import ligero_amd
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    gen = _gen()
+    r1cs, wtns = str(tmp_path / "rs20.r1cs"), str(tmp_path / "rs20.wtns")
+    gen.write_r1cs(r1cs, 20)
+    wit = gen.witness(20, 1)
+    gen.write_wtns(wtns, wit)
+    t0 = time.time()
+    circ = hp.ArithmeticCircuit.from_r1cs(r1cs)
+    assert circ.num_nodes() == 5 * (1 << 20) + 3 == 5242883 and len(circ.outputs) == 1 << 20
+    inst = hp.LigeroInstance(circ)
+    assert (inst.m, inst.k, inst.n, inst.t) == (2509, 4096, 32768, 156)
+    assert inst.num_constants == 2
+    t_setup = time.time() - t0
+    w = hp.read_witness(wtns)
+    assert w.shape[0] == (1 << 20) + 2
+    idx = np.arange(1, w.shape[0], dtype=np.uint64)
+    pre, ok = inst.build_preenc_u(idx, w[1:])
+    assert ok, "every output Az * Bz - Cz + 1 must evaluate to 1"
+    # structure of preenc_u: the Mul-node positions of X / Y / Z, dense W, zero tail
+    rows, k = 4 * inst.m, inst.k
+    flat = pre.reshape(4, inst.m * k, 4)
+    nz = [(flat[b] != 0).any(axis=1) for b in range(4)]
+    sol_len = 1 + 5242883 - 2                                     # nodes kept in w: all but the non-leading constant
+    assert int(nz[3].sum()) == sol_len and not nz[3][sol_len:].any()
+    assert int(nz[0].sum()) == int(nz[1].sum()) == int(nz[2].sum()) == 2 * (1 << 20)   # two Mul gates per constraint
+    with ligero_amd.LigeroCommitter(rows=rows, k=k) as c:
+        _, root = c.encode_commit(pre, want_coeffs=False)
+        want = oracle.encode_commit_streamed(pre, k, 8 * k, threads=min(16, os.cpu_count() or 1))
+        assert root == want["root"]
+        assert np.array_equal(c.leaves()[0], want["leaves"])
+    with LigeroProver(inst) as prover:
+        t1 = time.time()
+        proof = prover.prove(idx, w[1:])
+        t_first = time.time() - t1
+        t1 = time.time()
+        proof = prover.prove(idx, w[1:])
+        t_prove = time.time() - t1
+        info = proof.info()
+        assert info["u_root"] == root
+        assert info["opened_columns"] == 156 and info["column_len"] == rows and info["auth_path_len"] == 14
+        t1 = time.time()
+        assert prover.verify(proof)
+        t_verify = time.time() - t1
+        print(f"s20 from r1cs: setup {t_setup:.1f} s, first prove {t_first:.2f} s, prove {t_prove:.2f} s, verify {t_verify:.1f} s")
+        tamper(proof, 5, 12345)                                    # one element of an opened column of the linear test
+        assert not prover.verify(proof)
+        bad = w[1:].copy()
+        bad[777] = bad[778]                                        # break one squaring
+        assert not prover.verify(prover.prove(idx, bad))

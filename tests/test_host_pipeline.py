@@ -209,3 +209,51 @@ def test_r1cs_reader_refuses_corrupt_files(hp):
             open(path, "wb").write(data)
             with pytest.raises(hp.HostPanic):
                 hp.ArithmeticCircuit.from_r1cs(path)
+
+
+def _gen_rs():
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gen_rs", os.path.join(ROOT, "tools", "gen_repeated_squaring_r1cs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("log_n", [3, 10])
+def test_repeated_squaring_generator_and_pipeline(hp, model, tmp_path, log_n):
+    """the synthetic R1CS of BASELINE configs[2] / [3] at small N: file layout (parsed by the model's reader AND the C++ one),
+    node count 5 N + 3, dimensions by mod.rs:171-175 / 275-294, all outputs one, preenc_u equal to the model's"""
+    gen = _gen_rs()
+    n = 1 << log_n
+    r1cs, wtns = str(tmp_path / "rs.r1cs"), str(tmp_path / "rs.wtns")
+    gen.write_r1cs(r1cs, log_n)
+    wit = gen.witness(log_n, 7)
+    gen.write_wtns(wtns, wit)
+    assert all(wit[i + 2] == wit[i + 1] ** 2 % model.P for i in range(n))
+    circ = hp.ArithmeticCircuit.from_r1cs(r1cs)
+    assert circ.num_nodes() == 5 * n + 3 and len(circ.outputs) == n
+    inst = hp.LigeroInstance(circ)
+    sol = 1 + (5 * n + 3) - 2 + n
+    m, k = model.compute_dimensions(sol)
+    assert (inst.m, inst.k, inst.n) == (m, k, 8 * k)
+    w = hp.read_witness(wtns)
+    assert w.shape[0] == n + 2
+    pre, ok = inst.build_preenc_u(np.arange(1, n + 2, dtype=np.uint64), w[1:])
+    assert ok
+    mm, kk, nn, tt, mpre, _, outs = model.preenc_from_r1cs(r1cs, wit)        # (asserts itself that every output evaluates to 1)
+    assert (mm, kk, nn, tt) == (inst.m, inst.k, inst.n, inst.t) and len(outs) == n
+    from oracle import binding as orc
+    want = orc.to_mont(orc.ints_to_limbs([v for row in mpre for v in row])).reshape(4 * mm, kk, 4)
+    assert np.array_equal(pre, want)
+
+
+def test_repeated_squaring_dimensions_at_baseline_sizes():
+    """LigeroCircuit dimensions of configs[2] / [3] from the node counts alone (mod.rs:171-175, 275-294), as SURVEY 8(d) lists them"""
+    from ligero_amd.ligero import compute_dimensions, reed_solomon_parameters
+    for log_n, want in ((20, (2509, 4096, 32768, 156)), (22, (5017, 8192, 65536, 156))):
+        n = 1 << log_n
+        sol = 1 + (5 * n + 3) - 2 + n
+        m, k = compute_dimensions(sol)
+        nn, t = reed_solomon_parameters(m, k, 128)
+        assert (m, k, nn, t) == want
