@@ -1,0 +1,218 @@
+//! Dumps what the reference's own prover does at every third-party boundary of the hot path and of the transcript, so
+//! that this repository's restatements can be compared byte for byte (tests/golden/compare_rust_dump.py).
+//!
+//! NOT compiled in this repository's image (no Rust toolchain there): written against the public arkworks 0.5.0-alpha
+//! APIs the reference itself uses.  If a signature has drifted, the fix is local to the wrapper impls below -- the
+//! recorded quantities are what matters.
+//!
+//! Cases: `multiplication` (circom/multiplication.r1cs, a 4-wire circuit) and `poseidon` (the reference's
+//! test_poseidon, src/ligero/tests.rs:364-415).
+use std::borrow::Borrow;
+use std::str::FromStr;
+use std::sync::Mutex;
+
+use ark_bn254::Fr;
+use ark_crypto_primitives::{
+    crh::{sha256::Sha256, CRHScheme, TwoToOneCRHScheme},
+    merkle_tree::{ByteDigestConverter, Config},
+    sponge::{poseidon::PoseidonConfig, poseidon::PoseidonSponge, Absorb, CryptographicSponge, FieldElementSize},
+    Error,
+};
+use ark_ff::{BigInteger, PrimeField};
+use ark_poly_commit::{
+    test_sponge,
+    test_types::{FieldToBytesColHasher, LeafIdentityHasher},
+};
+use ark_relations::r1cs::ConstraintSystem;
+use ark_std::rand::Rng;
+use blake2::Blake2s256;
+use itertools::Itertools;
+use ligero::{
+    arithmetic_circuit::ArithmeticCircuit,
+    ligero::{LigeroCircuit, LigeroMTParams},
+    reader::read_constraint_system,
+    DEFAULT_SECURITY_LEVEL,
+};
+use serde::Serialize;
+use sha2::{Digest, Sha256 as Sha2};
+
+// ------------------------------------------------------------------------------------------------ the log
+#[derive(Default, Serialize, Clone)]
+struct Log {
+    /// column hash: one entry per H::evaluate call, in call order (the reference hashes columns 0..n serially,
+    /// mod.rs:536-542; later calls come from verify_column_openings, mod.rs:976-983)
+    col_hash_input_sha256: Vec<String>, // sha256 of the exact bytes Blake2s absorbed is not observable; this is sha256 of
+    // serialize_compressed(column) as recomputed here -- see col_hash_input_prefix for the observable framing
+    col_hash_input_len: Vec<usize>,      // number of field elements
+    col_hash_first_elems: Vec<Vec<String>>, // first two elements of each column, canonical little-endian hex
+    col_hash_output: Vec<String>,
+    /// two-to-one hash: (kind, left bytes, right bytes, output), in call order
+    two_to_one: Vec<(String, String, String, String)>,
+    /// sponge: ("absorb", bytes as the sponge sees them (to_sponge_bytes), field elements (to_sponge_field_elements))
+    /// or ("squeeze_bytes", n, output)
+    sponge: Vec<SpongeEvent>,
+}
+#[derive(Serialize, Clone)]
+struct SpongeEvent {
+    op: String,
+    bytes: String,
+    field_elements: Vec<String>,
+}
+static LOG: Mutex<Option<Log>> = Mutex::new(None);
+fn with_log<R>(f: impl FnOnce(&mut Log) -> R) -> R {
+    let mut g = LOG.lock().unwrap();
+    f(g.get_or_insert_with(Log::default))
+}
+fn fr_hex(x: &Fr) -> String {
+    hex::encode(x.into_bigint().to_bytes_le())
+}
+
+// ------------------------------------------------------------------------------------------------ column hash
+pub struct RecColHasher;
+impl CRHScheme for RecColHasher {
+    type Input = Vec<Fr>;
+    type Output = Vec<u8>;
+    type Parameters = ();
+    fn setup<R: Rng>(_: &mut R) -> Result<(), Error> {
+        Ok(())
+    }
+    fn evaluate<T: Borrow<Vec<Fr>>>(p: &(), input: T) -> Result<Vec<u8>, Error> {
+        let col: &Vec<Fr> = input.borrow();
+        let out = <FieldToBytesColHasher<Fr, Blake2s256> as CRHScheme>::evaluate(p, col.clone())?;
+        // the byte string the hasher is documented to absorb: CanonicalSerialize::serialize_compressed(Vec<F>)
+        let mut ser = Vec::new();
+        ark_serialize::CanonicalSerialize::serialize_compressed(col, &mut ser).unwrap();
+        // ... and the proof that it is that string: Blake2s256 of it must be the hasher's output
+        let direct = <Blake2s256 as blake2::Digest>::digest(&ser).to_vec();
+        assert_eq!(direct, out, "FieldToBytesColHasher != Blake2s256(serialize_compressed(column))");
+        with_log(|l| {
+            l.col_hash_input_sha256.push(hex::encode(Sha2::digest(&ser)));
+            l.col_hash_input_len.push(col.len());
+            l.col_hash_first_elems.push(col.iter().take(2).map(fr_hex).collect());
+            l.col_hash_output.push(hex::encode(&out));
+        });
+        Ok(out)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Merkle tree
+pub struct RecSha256;
+impl TwoToOneCRHScheme for RecSha256 {
+    type Input = [u8];
+    type Output = Vec<u8>;
+    type Parameters = ();
+    fn setup<R: Rng>(_: &mut R) -> Result<(), Error> {
+        Ok(())
+    }
+    fn evaluate<T: Borrow<[u8]>>(p: &(), l: T, r: T) -> Result<Vec<u8>, Error> {
+        let out = <Sha256 as TwoToOneCRHScheme>::evaluate(p, l.borrow(), r.borrow())?;
+        with_log(|g| g.two_to_one.push(("evaluate".into(), hex::encode(l.borrow()), hex::encode(r.borrow()), hex::encode(&out))));
+        Ok(out)
+    }
+    fn compress<T: Borrow<Vec<u8>>>(p: &(), l: T, r: T) -> Result<Vec<u8>, Error> {
+        let out = <Sha256 as TwoToOneCRHScheme>::compress(p, l.borrow(), r.borrow())?;
+        with_log(|g| g.two_to_one.push(("compress".into(), hex::encode(l.borrow()), hex::encode(r.borrow()), hex::encode(&out))));
+        Ok(out)
+    }
+}
+/// TestMerkleTreeParams (ark-poly-commit test_types; src/ligero/types.rs:6-8) with the recording two-to-one hash
+#[derive(Clone)]
+pub struct RecMerkleParams;
+impl Config for RecMerkleParams {
+    type Leaf = Vec<u8>;
+    type LeafDigest = <LeafIdentityHasher as CRHScheme>::Output;
+    type LeafInnerDigestConverter = ByteDigestConverter<Self::LeafDigest>;
+    type InnerDigest = <RecSha256 as TwoToOneCRHScheme>::Output;
+    type LeafHash = LeafIdentityHasher;
+    type TwoToOneHash = RecSha256;
+}
+/// LigeroMTTestParams (src/ligero/types.rs:15-46) over the recording types: all three parameter sets are ()
+pub struct RecParams;
+impl LigeroMTParams<RecMerkleParams, RecColHasher> for RecParams {
+    fn leaf_hash_param(&self) -> &() {
+        &()
+    }
+    fn two_to_one_hash_param(&self) -> &() {
+        &()
+    }
+    fn col_hash_params(&self) -> &() {
+        &()
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sponge
+#[derive(Clone)]
+pub struct RecSponge {
+    inner: PoseidonSponge<Fr>,
+}
+impl CryptographicSponge for RecSponge {
+    type Config = PoseidonConfig<Fr>;
+    fn new(params: &Self::Config) -> Self {
+        RecSponge { inner: PoseidonSponge::new(params) }
+    }
+    fn absorb(&mut self, input: &impl Absorb) {
+        let bytes = input.to_sponge_bytes_as_vec();
+        let elems: Vec<Fr> = input.to_sponge_field_elements_as_vec();
+        with_log(|l| l.sponge.push(SpongeEvent { op: "absorb".into(), bytes: hex::encode(&bytes), field_elements: elems.iter().map(fr_hex).collect() }));
+        self.inner.absorb(input)
+    }
+    fn squeeze_bytes(&mut self, num_bytes: usize) -> Vec<u8> {
+        let out = self.inner.squeeze_bytes(num_bytes);
+        with_log(|l| l.sponge.push(SpongeEvent { op: format!("squeeze_bytes({num_bytes})"), bytes: hex::encode(&out), field_elements: vec![] }));
+        out
+    }
+    fn squeeze_bits(&mut self, num_bits: usize) -> Vec<bool> {
+        self.inner.squeeze_bits(num_bits)
+    }
+    fn squeeze_field_elements_with_sizes<F: PrimeField>(&mut self, sizes: &[FieldElementSize]) -> Vec<F> {
+        self.inner.squeeze_field_elements_with_sizes(sizes)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cases
+#[derive(Serialize)]
+struct Case {
+    name: String,
+    witness: Vec<String>, // canonical LE hex, wire 0 first
+    num_nodes: usize,
+    prove: Log,  // everything logged during prove()
+    verify: Log, // everything logged during verify() (the re-hashed opened columns, the path checks)
+    verified: bool,
+}
+
+fn run_case(name: &str, r1cs: &str, wasm: &str, witness: Vec<Fr>) -> Case {
+    let cs: ConstraintSystem<Fr> = read_constraint_system(r1cs, wasm);
+    let (circuit, outputs) = ArithmeticCircuit::from_constraint_system(&cs);
+    let num_nodes = circuit.num_nodes();
+    let var_assignment = witness.clone().into_iter().enumerate().skip(1).collect_vec();
+    let ligero = LigeroCircuit::new(circuit, outputs, DEFAULT_SECURITY_LEVEL);
+    let sponge = RecSponge { inner: test_sponge() };
+    *LOG.lock().unwrap() = Some(Log::default());
+    let proof = ligero.prove::<RecMerkleParams, RecColHasher, RecParams>(var_assignment, &RecParams, &mut sponge.clone());
+    let prove_log = LOG.lock().unwrap().replace(Log::default()).unwrap();
+    let verified = ligero.verify::<RecMerkleParams, RecColHasher, RecParams>(proof, &RecParams, &mut sponge.clone());
+    let verify_log = LOG.lock().unwrap().take().unwrap();
+    Case { name: name.into(), witness: witness.iter().map(fr_hex).collect(), num_nodes, prove: prove_log, verify: verify_log, verified }
+}
+
+#[test]
+fn pin_dump() {
+    // src/ligero/tests.rs:375-381
+    let poseidon_witness: Vec<Fr> = serde_json::from_str::<Vec<String>>(&std::fs::read_to_string("circom/poseidon/witness.json").unwrap())
+        .unwrap()
+        .iter()
+        .map(|s| Fr::from_str(s).unwrap())
+        .collect();
+    // multiplication.circom: c <== a * b with a = 3, b = 11: wires [1, c, a, b]
+    let mult_witness: Vec<Fr> = [1u64, 33, 3, 11].iter().map(|v| Fr::from(*v)).collect();
+    let cases = vec![
+        run_case("multiplication", "circom/multiplication.r1cs", "circom/multiplication.wasm", mult_witness),
+        run_case("poseidon", "circom/poseidon/poseidon.r1cs", "circom/poseidon/poseidon_js/poseidon.wasm", poseidon_witness),
+    ];
+    for c in &cases {
+        assert!(c.verified, "{}: the reference rejected its own proof", c.name);
+    }
+    let out = std::env::var("LIGERO_PIN_OUT").unwrap_or_else(|_| "rust_dump.json".into());
+    std::fs::write(&out, serde_json::to_string(&cases).unwrap()).unwrap();
+    println!("wrote {out}");
+}
