@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace lg {
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
@@ -145,6 +147,169 @@ __global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const ColHashAr
     uint4* out = reinterpret_cast<uint4*>(a.leaves + 32 * ((((uint64_t)b * a.k + q) << a.lognp) + s));
     out[0] = make_uint4(h[0], h[1], h[2], h[3]);
     out[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// ---------------------------------------------------------------- Blake2s, four lanes per column
+// For FEW columns (one Poseidon proof: 1024 columns = 16 waves on 1024 SIMDs) the one-lane-per-column kernel above is
+// a pure latency chain: 173 blocks x 996 dependent-ish instructions at one wave per SIMD, 0.33 of the 0.39 ms of a single
+// commitment.  Here a QUAD of lanes shares one column: lane l holds column l of the 4 x 4 state (v[l], v[4+l], v[8+l],
+// v[12+l]), so the four G functions of a half-round run side by side.  The diagonal half-round mixes the columns:
+// rotations inside the quad, done as DPP quad_perm operands of the instructions that consume them (and the rotation back
+// rides on the first uses of the next column half-round), so no lane exchange is a separate instruction.  The 64-byte block is staged through LDS (each lane loads 16 bytes of the two rows it covers) and
+// every lane fetches the two message words of its G with ds_read_b32 from per-lane addresses that are loop invariant
+// (sigma is applied once, when the 40 addresses are built): 240 VALU + 40 LDS reads per lane and block instead of 996 VALU.
+// Throughput per column is lower than the one-lane kernel's (four lanes do 1.7x the instructions of one), so the host
+// picks this kernel only when the one-lane form cannot fill the machine.
+struct B2sQuadSigma {
+    uint8_t w[10][4][4];   // [round][lane][column x, column y, diagonal x, diagonal y] -> message word index
+};
+__host__ __device__ constexpr B2sQuadSigma b2s_quad_sigma() {
+    B2sQuadSigma t{};
+    for (int r = 0; r < 10; r++)
+        for (int l = 0; l < 4; l++) {
+            t.w[r][l][0] = (uint8_t)b2s_sigma(r, 2 * l);
+            t.w[r][l][1] = (uint8_t)b2s_sigma(r, 2 * l + 1);
+            t.w[r][l][2] = (uint8_t)b2s_sigma(r, 8 + 2 * ((l + 3) % 4));   // lane l works on diagonal l - 1 (see the kernel)
+            t.w[r][l][3] = (uint8_t)b2s_sigma(r, 9 + 2 * ((l + 3) % 4));
+        }
+    return t;
+}
+__constant__ const B2sQuadSigma kB2sQuadSigma = b2s_quad_sigma();
+__constant__ const uint32_t kB2sIv[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+
+// quad_perm:[1,2,3,0] / [2,3,0,1] / [3,0,1,2]: lane l reads lane (l + 1, 2, 3) % 4 of its quad
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_rot(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+constexpr int kQuadRot1 = 0x39, kQuadRot2 = 0x4E, kQuadRot3 = 0x93;
+
+// a wave's LDS operations execute in order; this only stops the compiler from moving reads across the writes
+__device__ __forceinline__ void quad_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+constexpr int kQuadSlotWords = 20;    // per slot: 2 pad | 2 carried words | 16 words of two rows; the block is words 2..17
+constexpr int kQuadStrideWords = 44;  // two slots + pad: 44 c mod 32 is distinct for the 8 quads of a 32-lane group
+
+struct ColHashQuadArgs {
+    const uint4* u;         // coset planes, canonical integers, 2 x uint4 per element
+    uint8_t* leaves;        // [batch][n][32]
+    uint32_t rows, k, lognp;
+    uint32_t proof_begin, proof_count;
+    uint32_t plane_begin, plane_count;
+    uint64_t plane_stride;  // elements
+};
+
+__global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const ColHashQuadArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[64 * kQuadStrideWords];
+    const uint32_t lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
+    const uint64_t col = (uint64_t)blockIdx.x * 64 + quad;
+    const uint64_t total = (uint64_t)a.proof_count * a.plane_count * a.k;
+    const bool active = col < total;                       // whole quads are active or not
+    const uint64_t cc = active ? col : 0;
+    const uint32_t q = (uint32_t)(cc % a.k);
+    const uint32_t s = a.plane_begin + (uint32_t)((cc / a.k) % a.plane_count);
+    const uint32_t b = a.proof_begin + (uint32_t)((cc / a.k) / a.plane_count);
+    // lane l fetches 16 bytes: rows (2 blk + l / 2), half (l % 2)
+    const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + (lane >> 1)) * a.k + q) + (lane & 1);
+    const uint64_t step = 4 * (uint64_t)a.k;               // two rows, in uint4
+    uint32_t* slot0 = lds + quad * kQuadStrideWords;
+    // loop-invariant LDS addresses of this lane's message words (slot 0; slot 1 = + kQuadSlotWords words)
+    const uint32_t* mw[10][4];
+#pragma unroll
+    for (int r = 0; r < 10; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) mw[r][j] = slot0 + 2 + kB2sQuadSigma.w[r][lane][j];
+    const uint32_t iv_lo = kB2sIv[lane], iv_hi = kB2sIv[4 + lane];
+    uint32_t h_lo = iv_lo ^ (lane == 0 ? 0x01010020u : 0u), h_hi = iv_hi;
+
+    const uint32_t rows = a.rows;
+    const uint32_t nblk = (rows & 1) ? (rows + 1) / 2 : rows / 2 + 1;   // rows even: the last block holds only the 8 carried bytes
+    const uint64_t total_len = 8 + 32 * (uint64_t)rows;
+    auto fetch = [&](uint32_t blk) -> uint4 {
+        const uint32_t row = 2 * blk + (lane >> 1);
+        return (active && row < rows) ? p[(uint64_t)blk * step] : make_uint4(0, 0, 0, 0);
+    };
+    // store the rows of block blk into slot blk & 1 and the 8 bytes they carry over into the other slot
+    auto stage = [&](uint32_t blk, const uint4& v) {
+        uint32_t* sl = slot0 + (blk & 1) * kQuadSlotWords;
+        *reinterpret_cast<uint4*>(sl + 4 + 4 * lane) = v;
+        if (lane == 3) {
+            uint32_t* other = slot0 + ((blk & 1) ^ 1) * kQuadSlotWords;
+            other[2] = v.z;
+            other[3] = v.w;
+        }
+    };
+    if (lane == 0) { slot0[2] = rows; slot0[3] = 0; }      // LE64(rows): serialize_compressed length prefix of Vec<F>
+    uint4 cur = fetch(0);
+    stage(0, cur);
+    uint4 nxt = fetch(1);
+    auto block = [&](uint32_t blk, auto slot_c) {
+        constexpr int so = decltype(slot_c)::value * kQuadSlotWords;   // compile-time slot: the 40 reads use immediate offsets
+        const bool last = blk + 1 == nblk;
+        const uint64_t t = last ? total_len : 64 * (uint64_t)(blk + 1);
+        uint32_t va = h_lo, vb = h_hi, vc = iv_lo;
+        const uint32_t tw = lane == 0 ? (uint32_t)t : (lane == 1 ? (uint32_t)(t >> 32) : ((lane == 2 && last) ? 0xffffffffu : 0u));
+        uint32_t vd = iv_hi ^ tw;
+        quad_lds_order();
+        // all 40 message words of this lane up front: the reads are independent of the chain below, so their latency
+        // hides behind the first rounds instead of being paid four words at a time in every round
+        uint32_t mr[10][4];
+#pragma unroll
+        for (int r = 0; r < 10; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) mr[r][j] = mw[r][j][so];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            const uint32_t x0 = mr[r][0], y0 = mr[r][1], x1 = mr[r][2], y1 = mr[r][3];
+            // column half-round.  Between the half-rounds a, c, d travel and b stays: lane l then works on diagonal l - 1,
+            // G(v[l-1], v[4+l], v[8+l+1], v[12+l+2]) -- b is the LAST value a G produces and a, d, c the oldest, so the DPP
+            // operands below are never the result of the instruction just before them (a DPP read of a fresh VALU result costs
+            // two wait states).  From the second round on va, vc, vd arrive rotated by the previous diagonal half-round and are
+            // rotated back on their first use.
+            if (r > 0) {
+                va = quad_rot<kQuadRot1>(va) + x0 + vb;              // v[l] sits in lane l + 1
+                vd = rotr32(quad_rot<kQuadRot2>(vd) ^ va, 16);       // v[12 + l] in lane l - 2
+                vc = quad_rot<kQuadRot3>(vc) + vd;                   // v[8 + l] in lane l - 1
+            } else {
+                va = va + x0 + vb;
+                vd = rotr32(vd ^ va, 16);
+                vc = vc + vd;
+            }
+            vb = rotr32(vb ^ vc, 12);
+            va = va + vb + y0;
+            vd = rotr32(vd ^ va, 8);
+            vc = vc + vd;
+            vb = rotr32(vb ^ vc, 7);
+            // diagonal half-round: lane l takes a from lane l - 1, c from lane l + 1, d from lane l + 2
+            va = quad_rot<kQuadRot3>(va) + x1 + vb;
+            vd = rotr32(quad_rot<kQuadRot2>(vd) ^ va, 16);
+            vc = quad_rot<kQuadRot1>(vc) + vd;
+            vb = rotr32(vb ^ vc, 12);
+            va = va + vb + y1;
+            vd = rotr32(vd ^ va, 8);
+            vc = vc + vd;
+            vb = rotr32(vb ^ vc, 7);
+        }
+        // undo the last diagonal rotation and feed forward: h[l] ^= v[l] ^ v[8 + l], h[4 + l] ^= v[4 + l] ^ v[12 + l]
+        h_lo ^= quad_rot<kQuadRot1>(va) ^ quad_rot<kQuadRot3>(vc);
+        h_hi ^= vb ^ quad_rot<kQuadRot2>(vd);
+        if (!last) {
+            quad_lds_order();
+            stage(blk + 1, nxt);
+            nxt = fetch(blk + 2);
+        }
+    };
+    for (uint32_t blk = 0; blk < nblk; blk += 2) {
+        block(blk, std::integral_constant<int, 0>{});
+        if (blk + 1 < nblk) block(blk + 1, std::integral_constant<int, 1>{});
+    }
+    if (!active) return;
+    uint32_t* out = reinterpret_cast<uint32_t*>(a.leaves + 32 * ((((uint64_t)b * a.k + q) << a.lognp) + s));
+    out[lane] = h_lo;
+    out[4 + lane] = h_hi;
 }
 
 // ---------------------------------------------------------------- SHA-256

@@ -58,6 +58,8 @@ struct lg_ctx {
     uint32_t* d_short_flag = nullptr;
     fr* d_rlin = nullptr; size_t rlin_elems = 0;   // r_linear [batch][4mk]
     uint32_t force_chunks = 0;             // LG_FORCE_CHUNKS (testing knob): pipeline depth regardless of size
+    uint64_t quad_hash_max_columns = 32768; // single-chunk commits with at most this many columns use the four-lanes-per-column
+                                           // Blake2s (LG_HASH_QUAD_MAX_COLUMNS overrides; 0 = never)
     // resident commitment
     fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
     fr* d_coeffs = nullptr;   // [total_rows][k]  Montgomery
@@ -510,6 +512,7 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
     c->nplanes = 8u << c->logo;
     c->lognp = 3 + c->logo;
     if (const char* fc = getenv("LG_FORCE_CHUNKS")) c->force_chunks = (uint32_t)atoi(fc);
+    if (const char* qm = getenv("LG_HASH_QUAD_MAX_COLUMNS")) c->quad_hash_max_columns = strtoull(qm, nullptr, 0);
     c->own_plane0 = 0; c->own_planes = c->nplanes; c->coeff_rows_alloc = (uint32_t)c->total_rows;
     if (shard) {
         if (batch != 1 || shard->plane_count == 0 || (uint64_t)shard->plane_begin + shard->plane_count > c->nplanes ||
@@ -835,7 +838,18 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         h.plane_begin = 0; h.plane_count = c->nplanes;
         h.plane_stride = plane;
         const uint64_t threads = (uint64_t)ch.proof_count * c->n;
-        hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+        if (h.first && h.last && threads <= c->quad_hash_max_columns) {
+            // few columns (a single small proof): the one-lane-per-column kernel would be one latency chain per SIMD;
+            // four lanes per column shorten the chain (hash_kernels.h)
+            lg::ColHashQuadArgs qa;
+            memset(&qa, 0, sizeof(qa));
+            qa.u = h.u; qa.leaves = h.leaves; qa.rows = h.rows; qa.k = h.k; qa.lognp = h.lognp;
+            qa.proof_begin = h.proof_begin; qa.proof_count = h.proof_count; qa.plane_begin = 0; qa.plane_count = c->nplanes;
+            qa.plane_stride = plane;
+            hipLaunchKernelGGL(lg::blake2s_columns_quad_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(256), 0, hs, qa);
+        } else {
+            hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+        }
         LG_HIP(c, hipGetLastError());
         if (streamed && i + 1 < nchunks) {
             const int rc = upload_chunk(i + 1);
