@@ -74,6 +74,21 @@ int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
  */
 int lg_ctx_create_sharded(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t plane_begin, uint32_t plane_count,
                           uint32_t coeff_rows_alloc);
+/*
+ * The reference is generic over `F: PrimeField` (mod.rs:146) and its tests instantiate two fields: ark_bn254::Fr (every
+ * circom fixture, every BASELINE config) and ark_bls12_377::Fq (tests.rs:23, 186-193: 377 bits, 6 x u64, 48-byte serialization).
+ * lg_ctx_create_field selects the element type of a context; elements then cross the ABI as lg_ctx_element_words() u64 limbs
+ * each (4 / 6), little endian, Montgomery form with R = 2^(64 limbs) -- the in-memory ark_ff::Fp of that field.
+ *   LG_FIELD_BN254_FR           the tuned path (what lg_ctx_create / _batched give)
+ *   LG_FIELD_BLS12_377_FQ       portable kernels (generic_kernels.h): the hot path -- lg_encode_commit, lg_upload_preenc /
+ *                               lg_commit_resident / lg_sync, lg_read_*, lg_open_columns[_batch], lg_reed_solomon* -- for
+ *                               k <= 2048; the sub-proof, staged, streaming-registration and profiling calls return LG_ERR_UNSUPPORTED
+ *   LG_FIELD_BN254_FR_GENERIC   BN254 Fr through the same portable kernels (k <= 4096): a cross-check, not a product mode
+ */
+typedef enum lg_field { LG_FIELD_BN254_FR = 0, LG_FIELD_BLS12_377_FQ = 1, LG_FIELD_BN254_FR_GENERIC = 2 } lg_field;
+int lg_ctx_create_field(lg_ctx** out, int device, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch);
+/* u64 limbs per field element of this context (4 for BN254 Fr, 6 for BLS12-377 Fq) */
+uint32_t lg_ctx_element_words(const lg_ctx* ctx);
 /* number of coset planes of this shape, and the run of them this context holds (all of them unless sharded) */
 int lg_ctx_planes(const lg_ctx* ctx, uint32_t* nplanes, uint32_t* plane_begin, uint32_t* plane_count);
 void lg_ctx_destroy(lg_ctx* ctx);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LIGERO_HIP_LIB") or os.path.join(_HERE, "lib", "libli
 # every symbol include/ligero_hip.h declares (tests check the export list against this)
 SYMBOLS = [
     "lg_status_string", "lg_last_error", "lg_abi_version",
-    "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_create_sharded", "lg_ctx_planes", "lg_ctx_destroy",
+    "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_create_sharded", "lg_ctx_create_field", "lg_ctx_element_words", "lg_ctx_planes", "lg_ctx_destroy",
     "lg_encode_commit", "lg_host_register", "lg_host_unregister", "lg_upload_preenc", "lg_commit_resident", "lg_sync",
     "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
     "lg_open_columns", "lg_open_columns_batch",
@@ -36,6 +36,7 @@ LG_ERR_STATE = -6
 LG_ERR_UNSUPPORTED = -7
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
 LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES = 0, 1, 2, 3
+LG_FIELD_BN254_FR, LG_FIELD_BLS12_377_FQ, LG_FIELD_BN254_FR_GENERIC = 0, 1, 2
 
 _vp = ctypes.c_void_p
 _u32 = ctypes.c_uint32
@@ -76,6 +77,9 @@ def lib():
     L.lg_ctx_create.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32]
     L.lg_ctx_create_batched.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32, _u32]
     L.lg_ctx_create_sharded.argtypes = [ctypes.POINTER(_vp), _int, _u32, _u32, _u32, _u32, _u32, _u32]
+    L.lg_ctx_create_field.argtypes = [ctypes.POINTER(_vp), _int, _int, _u32, _u32, _u32, _u32]
+    L.lg_ctx_element_words.argtypes = [_vp]
+    L.lg_ctx_element_words.restype = _u32
     L.lg_ctx_planes.argtypes = [_vp, _vp, _vp, _vp]
     L.lg_ctx_destroy.argtypes = [_vp]
     L.lg_ctx_destroy.restype = None
@@ -110,7 +114,7 @@ def lib():
     L.lg_profile_read.argtypes = [_vp, _vp, _vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is ctypes.c_int and name not in ("lg_abi_version",):
+        if fn.restype is ctypes.c_int and name not in ("lg_abi_version", "lg_ctx_element_words"):
             fn.restype = _int
     _lib = L
     return L

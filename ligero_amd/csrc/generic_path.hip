@@ -1,0 +1,448 @@
+// Generic-field encode-and-commit path: host side (tables, buffers, launches) for generic_kernels.h.  Serves the second
+// element type the reference instantiates, ark_bls12_377::Fq (src/ligero/tests.rs:23, 186-193), and -- as a
+// cross-check of these kernels -- BN254 Fr again.  gfx950 only, no CPU fallback.
+#include "generic_path.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ligero_hip.h"
+#include "generic_kernels.h"
+
+namespace {
+
+typedef unsigned __int128 u128;
+
+// ---- host modular arithmetic for table generation: N <= 6 limbs of 64 bits, Montgomery form with R = 2^(64 N)
+struct HostField {
+    int n = 0;             // 64-bit limbs
+    uint64_t p[6] = {0};
+    uint64_t inv64 = 0;    // -p^-1 mod 2^64
+    uint64_t r1[6] = {0};  // R mod p   (Montgomery one)
+    uint64_t r2[6] = {0};  // R^2 mod p
+    int two_adicity = 0;
+    uint64_t root[6] = {0};  // 2^two_adicity-th primitive root of unity, Montgomery form
+
+    bool geq(const uint64_t* a, const uint64_t* b) const {
+        for (int i = n - 1; i >= 0; i--)
+            if (a[i] != b[i]) return a[i] > b[i];
+        return true;
+    }
+    void sub_raw(uint64_t* r, const uint64_t* a, const uint64_t* b) const {
+        uint64_t borrow = 0;
+        for (int i = 0; i < n; i++) {
+            const u128 d = (u128)a[i] - b[i] - borrow;
+            r[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+    }
+    void mul(uint64_t* r, const uint64_t* a, const uint64_t* b) const {   // a b R^-1 mod p
+        uint64_t t[8] = {0};
+        for (int i = 0; i < n; i++) {
+            u128 c = 0;
+            for (int j = 0; j < n; j++) {
+                c += (u128)a[j] * b[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[n];
+            t[n] = (uint64_t)c;
+            t[n + 1] = (uint64_t)(c >> 64);
+            const uint64_t m = t[0] * inv64;
+            c = ((u128)m * p[0] + t[0]) >> 64;
+            for (int j = 1; j < n; j++) {
+                c += (u128)m * p[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[n];
+            t[n - 1] = (uint64_t)c;
+            t[n] = t[n + 1] + (uint64_t)(c >> 64);
+            t[n + 1] = 0;
+        }
+        if (t[n] || geq(t, p)) sub_raw(t, t, p);
+        memcpy(r, t, 8 * n);
+    }
+    void pow(uint64_t* r, const uint64_t* base, const uint64_t* e, int elimbs) const {
+        uint64_t acc[6], b[6];
+        memcpy(acc, r1, 8 * n);
+        memcpy(b, base, 8 * n);
+        for (int i = 0; i < elimbs; i++)
+            for (int bit = 0; bit < 64; bit++) {
+                if ((e[i] >> bit) & 1) mul(acc, acc, b);
+                mul(b, b, b);
+            }
+        memcpy(r, acc, 8 * n);
+    }
+    void inverse(uint64_t* r, const uint64_t* a) const {   // a^(p-2)
+        uint64_t e[6];
+        memcpy(e, p, 8 * n);
+        e[0] -= 2;                                          // p is odd and > 2: no borrow
+        pow(r, a, e, n);
+    }
+    void from_u64(uint64_t* r, uint64_t v) const {
+        uint64_t x[6] = {v, 0, 0, 0, 0, 0};
+        mul(r, x, r2);
+    }
+    // generator of the order-2^logsize subgroup: GeneralEvaluationDomain::new(size).group_gen (Radix2 domain)
+    void domain_generator(uint64_t* r, int logsize) const {
+        uint64_t e[1] = {1ull << (two_adicity - logsize)};
+        pow(r, root, e, 1);
+    }
+};
+
+static void hex_to_limbs(const char* hex, uint64_t* out, int n) {
+    memset(out, 0, 8 * n);
+    const size_t len = strlen(hex);
+    for (size_t i = 0; i < len; i++) {
+        const char ch = hex[len - 1 - i];
+        const uint64_t d = (ch >= '0' && ch <= '9') ? ch - '0' : (ch >= 'a' && ch <= 'f') ? ch - 'a' + 10 : ch - 'A' + 10;
+        out[i / 16] |= d << (4 * (i % 16));
+    }
+}
+
+// modulus, Montgomery constants and the 2-adic root (canonical, = GENERATOR^((p-1)/2^TWO_ADICITY)), recomputed by
+// tests/test_oracle.py::test_generic_field_constants from p and the multiplicative generator alone
+static bool make_field(int field, HostField* f) {
+    const char *p, *root;
+    if (field == LG_FIELD_BLS12_377_FQ) {
+        // ark_bls12_377::Fq: modulus and GENERATOR = 15 as in the crate's field definition (restated: the crate is not vendored)
+        f->n = 6; f->two_adicity = 46;
+        p = "01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001";
+        root = "36a92e05198a8030f152488aeffc9b40fbe05b4512a3d4b44d994a0ddff8c606df0a4306fe0bc37eca603cc563b9a1";
+    } else if (field == LG_FIELD_BN254_FR_GENERIC) {
+        f->n = 4; f->two_adicity = 28;
+        p = "30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001";
+        root = "2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0";
+    } else {
+        return false;
+    }
+    hex_to_limbs(p, f->p, f->n);
+    uint64_t inv = 1;                                        // Newton: p^-1 mod 2^64
+    for (int i = 0; i < 6; i++) inv *= 2 - f->p[0] * inv;
+    f->inv64 = 0 - inv;
+    // R mod p and R^2 mod p by doubling 1 up 64 n (resp. 128 n) times
+    uint64_t x[6] = {1, 0, 0, 0, 0, 0};
+    for (int step = 0; step < 128 * f->n; step++) {
+        uint64_t carry = 0;
+        for (int i = 0; i < f->n; i++) {
+            const uint64_t nc = x[i] >> 63;
+            x[i] = (x[i] << 1) | carry;
+            carry = nc;
+        }
+        if (carry || f->geq(x, f->p)) f->sub_raw(x, x, f->p);
+        if (step == 64 * f->n - 1) memcpy(f->r1, x, 8 * f->n);
+    }
+    memcpy(f->r2, x, 8 * f->n);
+    uint64_t rc[6];
+    hex_to_limbs(root, rc, f->n);
+    f->mul(f->root, rc, f->r2);
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- state
+struct gf_state {
+    int field = 0;
+    int nw = 0;                 // 32-bit words per element
+    uint32_t rows = 0, k = 0, n = 0, batch = 1;
+    int logk = 0, logn = 0;
+    uint64_t total_rows = 0;
+    hipStream_t stream = nullptr;
+    HostField hf;
+    void *d_pre = nullptr, *d_coeffs = nullptr, *d_u = nullptr, *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_wn = nullptr;
+    uint8_t *d_leaves = nullptr, *d_nodes = nullptr;
+    void *d_sa = nullptr, *d_sb = nullptr, *d_sc = nullptr;   // scratch of the row operators / openings
+    size_t sa_bytes = 0, sb_bytes = 0, sc_bytes = 0;
+    uint32_t* d_idx = nullptr; size_t idx_cap = 0;
+    uint8_t* d_path = nullptr; size_t path_cap = 0;
+    bool committed = false;
+    char* err = nullptr; size_t errlen = 0;
+};
+
+#define GF_HIP(g, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            if ((g) && (g)->err) snprintf((g)->err, (g)->errlen, "%s: %s", #call, hipGetErrorString(e_)); \
+            return e_ == hipErrorOutOfMemory ? LG_ERR_OOM : LG_ERR_HIP;                        \
+        }                                                                                      \
+    } while (0)
+
+template <int NW>
+static lg::GfConsts<NW> consts_of(const HostField& f) {
+    lg::GfConsts<NW> c;
+    for (int i = 0; i < NW; i++) {
+        c.p[i] = (uint32_t)(f.p[i / 2] >> (32 * (i & 1)));
+        c.r2[i] = (uint32_t)(f.r2[i / 2] >> (32 * (i & 1)));
+    }
+    c.inv32 = (uint32_t)f.inv64;
+    return c;
+}
+template <int NW>
+static lg::gfe<NW> elem_of(const uint64_t* x) {
+    lg::gfe<NW> e;
+    for (int i = 0; i < NW; i++) e.v[i] = (uint32_t)(x[i / 2] >> (32 * (i & 1)));
+    return e;
+}
+
+static int grow(gf_state* g, void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return LG_OK;
+    if (*p) GF_HIP(g, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    GF_HIP(g, hipMalloc(p, need));
+    *cap = need;
+    return LG_OK;
+}
+
+void gf_destroy(gf_state* g) {
+    if (!g) return;
+    if (g->stream) hipStreamSynchronize(g->stream);
+    void* bufs[] = {g->d_pre, g->d_coeffs, g->d_u, g->d_tw_fwd, g->d_tw_inv, g->d_wn, g->d_leaves, g->d_nodes, g->d_sa, g->d_sb, g->d_sc, g->d_idx, g->d_path};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    delete g;
+}
+uint32_t gf_element_words64(const gf_state* g) { return (uint32_t)g->hf.n; }
+bool gf_committed(const gf_state* g) { return g->committed; }
+
+int gf_create(gf_state** out, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch, hipStream_t stream, char* err, size_t errlen) {
+    *out = nullptr;
+    gf_state* g = new (std::nothrow) gf_state();
+    if (!g) return LG_ERR_OOM;
+    g->err = err; g->errlen = errlen;
+    if (!make_field(field, &g->hf)) { delete g; return LG_ERR_BAD_ARG; }
+    g->field = field; g->nw = 2 * g->hf.n;
+    g->rows = rows; g->k = k; g->n = n; g->batch = batch; g->stream = stream;
+    g->total_rows = (uint64_t)rows * batch;
+    while ((1u << g->logk) < k) g->logk++;
+    while ((1u << g->logn) < n) g->logn++;
+    // one row per workgroup in LDS: k * 4 NW bytes of the 160 KiB
+    if ((size_t)k * 4 * g->nw > 128 * 1024 || g->logn > g->hf.two_adicity) { delete g; return LG_ERR_UNSUPPORTED; }
+    const size_t eb = 4 * (size_t)g->nw, mat = (size_t)g->total_rows * k;
+    auto body = [&]() -> int {
+        GF_HIP(g, hipMalloc(&g->d_pre, mat * eb));
+        GF_HIP(g, hipMalloc(&g->d_coeffs, mat * eb));
+        GF_HIP(g, hipMalloc(&g->d_u, 8 * mat * eb));
+        GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_leaves), (size_t)batch * n * 32));
+        GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_nodes), (size_t)batch * (n - 1) * 32));
+        // tables: powers of omega_k, omega_k^-1 (k/2 each) and omega_n (n), Montgomery form
+        const HostField& f = g->hf;
+        const int L = f.n;
+        uint64_t wn[6], wk[6], wki[6];
+        f.domain_generator(wn, g->logn);
+        f.domain_generator(wk, g->logk);
+        f.inverse(wki, wk);
+        const size_t half = k / 2 ? k / 2 : 1;
+        std::vector<uint64_t> tf(half * L), ti(half * L), tn((size_t)n * L);
+        uint64_t a[6], b[6];
+        memcpy(a, f.r1, 8 * L); memcpy(b, f.r1, 8 * L);
+        for (size_t e = 0; e < half; e++) {
+            memcpy(&tf[e * L], a, 8 * L); memcpy(&ti[e * L], b, 8 * L);
+            f.mul(a, a, wk); f.mul(b, b, wki);
+        }
+        memcpy(a, f.r1, 8 * L);
+        for (size_t e = 0; e < n; e++) { memcpy(&tn[e * L], a, 8 * L); f.mul(a, a, wn); }
+        GF_HIP(g, hipMalloc(&g->d_tw_fwd, tf.size() * 8));
+        GF_HIP(g, hipMalloc(&g->d_tw_inv, ti.size() * 8));
+        GF_HIP(g, hipMalloc(&g->d_wn, tn.size() * 8));
+        GF_HIP(g, hipMemcpy(g->d_tw_fwd, tf.data(), tf.size() * 8, hipMemcpyHostToDevice));
+        GF_HIP(g, hipMemcpy(g->d_tw_inv, ti.data(), ti.size() * 8, hipMemcpyHostToDevice));
+        GF_HIP(g, hipMemcpy(g->d_wn, tn.data(), tn.size() * 8, hipMemcpyHostToDevice));
+        return LG_OK;
+    };
+    const int rc = body();
+    if (rc != LG_OK) { gf_destroy(g); return rc; }
+    *out = g;
+    return LG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- launches
+template <int NW>
+static int launch_ntt(gf_state* g, const void* in, void* out, uint32_t nrows, bool evaluate, uint64_t plane_stride) {
+    if (nrows == 0) return LG_OK;
+    lg::GfNttArgs<NW> a;
+    memset(&a, 0, sizeof(a));
+    a.in = static_cast<const lg::gfe<NW>*>(in);
+    a.out = static_cast<lg::gfe<NW>*>(out);
+    a.tw = static_cast<const lg::gfe<NW>*>(evaluate ? g->d_tw_fwd : g->d_tw_inv);
+    a.wn = static_cast<const lg::gfe<NW>*>(g->d_wn);
+    a.F = consts_of<NW>(g->hf);
+    if (evaluate) {
+        uint64_t one[6] = {1, 0, 0, 0, 0, 0};
+        a.scale = elem_of<NW>(one);                   // x R * 1 * R^-1 = x: the codeword is stored canonical
+    } else {
+        uint64_t kk[6], kinv[6];
+        g->hf.from_u64(kk, g->k);
+        g->hf.inverse(kinv, kk);
+        a.scale = elem_of<NW>(kinv);
+    }
+    a.rows = nrows; a.k = g->k; a.logk = (uint32_t)g->logk; a.n = g->n;
+    a.evaluate = evaluate ? 1 : 0;
+    a.ncos = evaluate ? 8 : 0;
+    for (int s = 0; s < 8; s++) a.cosets[s] = (uint8_t)s;
+    a.plane_stride = plane_stride;
+    auto kern = lg::gf_ntt_rows_kernel<NW>;
+    const size_t lds = (size_t)g->k * 4 * NW;
+    GF_HIP(g, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(nrows * (evaluate ? 8u : 1u)), dim3(256), lds, g->stream, a);
+    GF_HIP(g, hipGetLastError());
+    return LG_OK;
+}
+
+static int merkle(gf_state* g) {
+    lg::MerkleArgs m;
+    m.leaves = g->d_leaves; m.nodes = g->d_nodes; m.n = g->n; m.logn = (uint32_t)g->logn; m.batch = g->batch;
+    uint32_t depth = (uint32_t)g->logn;
+    bool leaf = true;
+    while (depth > 0) {
+        m.in_depth = depth;
+        m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
+        const dim3 grid(g->batch * m.chunks);
+        if (leaf) hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, g->stream, m);
+        else hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, g->stream, m);
+        leaf = false;
+        depth = depth > 9 ? depth - 9 : 0;
+    }
+    GF_HIP(g, hipGetLastError());
+    return LG_OK;
+}
+
+template <int NW>
+static int commit_t(gf_state* g, const uint64_t* host_pre, uint64_t* host_coeffs) {
+    const size_t eb = 4 * NW, mat = (size_t)g->total_rows * g->k;
+    if (host_pre) GF_HIP(g, hipMemcpyAsync(g->d_pre, host_pre, mat * eb, hipMemcpyHostToDevice, g->stream));
+    int rc = launch_ntt<NW>(g, g->d_pre, g->d_coeffs, (uint32_t)g->total_rows, false, 0);          // mod.rs:521-526
+    if (rc != LG_OK) return rc;
+    // every plane, the message's included, comes out of the evaluation kernel (mod.rs:528-533)
+    rc = launch_ntt<NW>(g, g->d_coeffs, g->d_u, (uint32_t)g->total_rows, true, g->total_rows * g->k);
+    if (rc != LG_OK) return rc;
+    lg::GfHashArgs<NW> h;
+    h.u = static_cast<const lg::gfe<NW>*>(g->d_u); h.leaves = g->d_leaves; h.rows = g->rows; h.k = g->k; h.proofs = g->batch;
+    h.plane_stride = g->total_rows * g->k;
+    const uint64_t threads = (uint64_t)g->batch * g->n;
+    hipLaunchKernelGGL(lg::gf_blake2s_columns_kernel<NW>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, g->stream, h);   // mod.rs:536-542
+    GF_HIP(g, hipGetLastError());
+    rc = merkle(g);                                                                                 // mod.rs:544-551
+    if (rc != LG_OK) return rc;
+    g->committed = true;
+    if (host_coeffs) {
+        GF_HIP(g, hipMemcpyAsync(host_coeffs, g->d_coeffs, mat * eb, hipMemcpyDeviceToHost, g->stream));
+        GF_HIP(g, hipStreamSynchronize(g->stream));
+    }
+    return LG_OK;
+}
+
+int gf_upload(gf_state* g, const uint64_t* preenc) {
+    GF_HIP(g, hipMemcpyAsync(g->d_pre, preenc, (size_t)g->total_rows * g->k * 4 * g->nw, hipMemcpyHostToDevice, g->stream));
+    return LG_OK;
+}
+int gf_commit(gf_state* g, const uint64_t* host_pre, uint64_t* host_coeffs) {
+    return g->nw == 12 ? commit_t<12>(g, host_pre, host_coeffs) : commit_t<8>(g, host_pre, host_coeffs);
+}
+int gf_sync(gf_state* g) {
+    GF_HIP(g, hipStreamSynchronize(g->stream));
+    return LG_OK;
+}
+static int read_back(gf_state* g, void* dst, const void* src, size_t bytes) {
+    GF_HIP(g, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g->stream));
+    GF_HIP(g, hipStreamSynchronize(g->stream));
+    return LG_OK;
+}
+int gf_read_root(gf_state* g, uint8_t* out) {
+    GF_HIP(g, hipMemcpy2DAsync(out, 32, g->d_nodes, (size_t)(g->n - 1) * 32, 32, g->batch, hipMemcpyDeviceToHost, g->stream));
+    GF_HIP(g, hipStreamSynchronize(g->stream));
+    return LG_OK;
+}
+int gf_read_coeffs(gf_state* g, uint64_t* out) { return read_back(g, out, g->d_coeffs, (size_t)g->total_rows * g->k * 4 * g->nw); }
+int gf_read_leaves(gf_state* g, uint8_t* out) { return read_back(g, out, g->d_leaves, (size_t)g->batch * g->n * 32); }
+int gf_read_nodes(gf_state* g, uint8_t* out) { return read_back(g, out, g->d_nodes, (size_t)g->batch * (g->n - 1) * 32); }
+
+template <int NW>
+static int codeword_rows_t(gf_state* g, const void* planes, uint64_t plane_stride, uint64_t row_base, uint32_t nrows, uint64_t* out) {
+    const size_t bytes = (size_t)nrows * g->n * 4 * NW;
+    int rc = grow(g, &g->d_sc, &g->sc_bytes, bytes);
+    if (rc != LG_OK) return rc;
+    const uint64_t threads = (uint64_t)nrows * g->n;
+    hipLaunchKernelGGL(lg::gf_planes_to_rows_kernel<NW>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, g->stream,
+                       static_cast<const lg::gfe<NW>*>(planes), plane_stride, row_base, nrows, g->k, elem_of<NW>(g->hf.r2), consts_of<NW>(g->hf),
+                       static_cast<lg::gfe<NW>*>(g->d_sc));
+    GF_HIP(g, hipGetLastError());
+    return read_back(g, out, g->d_sc, bytes);
+}
+int gf_read_codeword_rows(gf_state* g, uint32_t proof, uint32_t row0, uint32_t nrows, uint64_t* out) {
+    if (nrows == 0) return LG_OK;
+    const uint64_t base = (uint64_t)proof * g->rows + row0, ps = g->total_rows * g->k;
+    return g->nw == 12 ? codeword_rows_t<12>(g, g->d_u, ps, base, nrows, out) : codeword_rows_t<8>(g, g->d_u, ps, base, nrows, out);
+}
+
+template <int NW>
+static int open_t(gf_state* g, uint32_t proof0, uint32_t nproofs, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths) {
+    const size_t nidx = (size_t)nproofs * t;
+    const uint32_t plen = (uint32_t)g->logn - 1;
+    if (g->idx_cap < nidx) {
+        if (g->d_idx) GF_HIP(g, hipFree(g->d_idx));
+        g->d_idx = nullptr; g->idx_cap = 0;
+        GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_idx), nidx * 4));
+        g->idx_cap = nidx;
+    }
+    const size_t path_bytes = nidx * (plen + 1) * 32;
+    if (g->path_cap < path_bytes) {
+        if (g->d_path) GF_HIP(g, hipFree(g->d_path));
+        g->d_path = nullptr; g->path_cap = 0;
+        GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_path), path_bytes));
+        g->path_cap = path_bytes;
+    }
+    const size_t col_bytes = nidx * g->rows * 4 * NW;
+    int rc = grow(g, &g->d_sc, &g->sc_bytes, col_bytes);
+    if (rc != LG_OK) return rc;
+    GF_HIP(g, hipMemcpyAsync(g->d_idx, idx, nidx * 4, hipMemcpyHostToDevice, g->stream));
+    const uint64_t threads = (uint64_t)t * g->rows;
+    hipLaunchKernelGGL(lg::gf_gather_columns_kernel<NW>, dim3((uint32_t)((threads + 255) / 256), nproofs), dim3(256), 0, g->stream,
+                       static_cast<const lg::gfe<NW>*>(g->d_u), g->total_rows * g->k, g->d_idx, t, g->rows, g->k, proof0, elem_of<NW>(g->hf.r2),
+                       consts_of<NW>(g->hf), static_cast<lg::gfe<NW>*>(g->d_sc));
+    // sibling leaves and authentication paths: the BN254 path's kernel with zero column elements (digests do not depend on the field)
+    lg::GatherPathArgs pa;
+    pa.leaves = g->d_leaves; pa.nodes = g->d_nodes; pa.idx = g->d_idx; pa.sib = g->d_path; pa.paths = g->d_path + nidx * 32;
+    pa.n = g->n; pa.logn = (uint32_t)g->logn; pa.t = t; pa.proof0 = proof0;
+    const uint64_t pthreads = (uint64_t)t * (plen + 1);
+    hipLaunchKernelGGL(lg::gather_paths_kernel, dim3((uint32_t)((pthreads + 255) / 256), nproofs), dim3(256), 0, g->stream, pa);
+    GF_HIP(g, hipGetLastError());
+    GF_HIP(g, hipMemcpyAsync(cols, g->d_sc, col_bytes, hipMemcpyDeviceToHost, g->stream));
+    GF_HIP(g, hipMemcpyAsync(sib, pa.sib, nidx * 32, hipMemcpyDeviceToHost, g->stream));
+    if (plen) GF_HIP(g, hipMemcpyAsync(paths, pa.paths, nidx * plen * 32, hipMemcpyDeviceToHost, g->stream));
+    GF_HIP(g, hipStreamSynchronize(g->stream));
+    return LG_OK;
+}
+int gf_open_columns(gf_state* g, uint32_t proof0, uint32_t nproofs, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths) {
+    return g->nw == 12 ? open_t<12>(g, proof0, nproofs, idx, t, cols, sib, paths) : open_t<8>(g, proof0, nproofs, idx, t, cols, sib, paths);
+}
+
+template <int NW>
+static int rs_t(gf_state* g, const uint64_t* in, uint32_t nrows, uint64_t* out, bool interp, bool eval) {
+    const size_t eb = 4 * NW, mat = (size_t)nrows * g->k;
+    int rc = grow(g, &g->d_sa, &g->sa_bytes, 2 * mat * eb);
+    if (rc != LG_OK) return rc;
+    uint8_t* d_in = static_cast<uint8_t*>(g->d_sa);
+    uint8_t* d_co = d_in + mat * eb;
+    GF_HIP(g, hipMemcpyAsync(d_in, in, mat * eb, hipMemcpyHostToDevice, g->stream));
+    const void* coeffs = d_in;
+    if (interp) {
+        rc = launch_ntt<NW>(g, d_in, d_co, nrows, false, 0);
+        if (rc != LG_OK) return rc;
+        coeffs = d_co;
+    }
+    if (!eval) return read_back(g, out, coeffs, mat * eb);
+    rc = grow(g, &g->d_sb, &g->sb_bytes, 8 * mat * eb);
+    if (rc != LG_OK) return rc;
+    rc = launch_ntt<NW>(g, coeffs, g->d_sb, nrows, true, (uint64_t)nrows * g->k);
+    if (rc != LG_OK) return rc;
+    return codeword_rows_t<NW>(g, g->d_sb, (uint64_t)nrows * g->k, 0, nrows, out);
+}
+int gf_reed_solomon(gf_state* g, const uint64_t* in, uint32_t nrows, uint64_t* out, bool interp, bool eval) {
+    if (nrows == 0) return LG_OK;
+    return g->nw == 12 ? rs_t<12>(g, in, nrows, out, interp, eval) : rs_t<8>(g, in, nrows, out, interp, eval);
+}

@@ -86,7 +86,7 @@ struct ColHashArgs {
 // several launches over consecutive row ranges (the commit pipeline hashes a chunk of rows
 // while the next chunk is still being encoded): the chaining value and the 8 bytes that
 // straddle the 64-byte block boundary are parked in `state` in between.
-__global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const ColHashArgs a) {
+static __global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const ColHashArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = (uint64_t)a.proof_count * a.plane_count * a.k;
     if (gid >= total) return;
@@ -202,7 +202,7 @@ struct ColHashQuadArgs {
     uint64_t plane_stride;  // elements
 };
 
-__global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const ColHashQuadArgs a) {
+static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const ColHashQuadArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[64 * kQuadStrideWords];
     const uint32_t lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
     const uint64_t col = (uint64_t)blockIdx.x * 64 + quad;
@@ -386,6 +386,40 @@ __device__ __forceinline__ void sha256_two_to_one(const uint4* left, const uint4
     }
     out[0] = make_uint4(bswap32(st[0]), bswap32(st[1]), bswap32(st[2]), bswap32(st[3]));
     out[1] = make_uint4(bswap32(st[4]), bswap32(st[5]), bswap32(st[6]), bswap32(st[7]));
+}
+
+// sibling leaf + authentication path (root side first) of opened columns: MerkleTree::generate_proof pieces (mod.rs:951);
+// one thread per 32-byte digest, blockIdx.y = proof within the call
+struct GatherPathArgs {
+    const uint8_t* leaves;   // [batch][n][32]
+    const uint8_t* nodes;    // [batch][n-1][32]
+    const uint32_t* idx;     // [proofs][t]
+    uint8_t* sib;            // [proofs][t][32]
+    uint8_t* paths;          // [proofs][t][logn-1][32]
+    uint32_t n, logn, t, proof0;
+};
+static __global__ void __launch_bounds__(256) gather_paths_kernel(GatherPathArgs a) {
+    const uint32_t p = blockIdx.y, plen = a.logn - 1;
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= (uint64_t)a.t * (plen + 1)) return;
+    const uint8_t* leaves = a.leaves + 32 * (uint64_t)(a.proof0 + p) * a.n;
+    const uint8_t* nodes = a.nodes + 32 * (uint64_t)(a.proof0 + p) * (a.n - 1);
+    const uint32_t c = (uint32_t)(h / (plen + 1)), lvl = (uint32_t)(h % (plen + 1));
+    const uint32_t j = a.idx[(uint64_t)p * a.t + c];
+    const uint4* src;
+    uint4* dst;
+    if (lvl == plen) {  // leaf sibling
+        src = reinterpret_cast<const uint4*>(leaves + 32 * (uint64_t)(j ^ 1));
+        dst = reinterpret_cast<uint4*>(a.sib + 32 * ((uint64_t)p * a.t + c));
+    } else {            // auth_path[lvl]: sibling of the ancestor at depth lvl + 1
+        const uint32_t depth = lvl + 1;
+        const uint32_t anc = j >> (a.logn - depth);
+        const uint32_t node = ((1u << depth) - 1) + (anc ^ 1);
+        src = reinterpret_cast<const uint4*>(nodes + 32 * (uint64_t)node);
+        dst = reinterpret_cast<uint4*>(a.paths + 32 * (((uint64_t)p * a.t + c) * plen + lvl));
+    }
+    dst[0] = src[0];
+    dst[1] = src[1];
 }
 
 struct MerkleArgs {

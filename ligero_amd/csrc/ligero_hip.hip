@@ -17,6 +17,7 @@
 #include "ntt_kernels.h"
 #include "ntt_launch.h"
 #include "challenge_kernels.h"
+#include "generic_path.h"
 #include "subproof_kernels.h"
 
 using lg::fr;
@@ -44,6 +45,8 @@ struct lg_ctx {
     bool async_tree = true;                // LG_ASYNC_TREE=0 turns the overlap below off (A/B knob)
     bool tree_pending = false;             // the tree of the last commit is still being built on stream_h
     uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
+    gf_state* gf = nullptr;                // set for contexts over a generic field (lg_ctx_create_field): every supported
+                                           // entry point forwards to generic_path.hip, the others return LG_ERR_UNSUPPORTED
     lg_ctx* aux2k = nullptr;               // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
     fr* d_sub_partial = nullptr; size_t sub_partial_elems = 0;  // row-sum partials of the sub-proof polynomials
     fr* d_sub_q = nullptr;                 // [2k] evaluations / coefficients
@@ -459,6 +462,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->stream_dn) hipStreamSynchronize(c->stream_dn);
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
+    if (c->gf) gf_destroy(c->gf);
     void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
@@ -686,6 +690,36 @@ int lg_ctx_create_sharded(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
     const ShardSpec sp = {plane_begin, plane_count, coeff_rows_alloc ? coeff_rows_alloc : rows};
     return ctx_create_impl(out, device, rows, k, n, 1, &sp);
 }
+int lg_ctx_create_field(lg_ctx** out, int device, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+    if (field == LG_FIELD_BN254_FR) return ctx_create_impl(out, device, rows, k, n, batch, nullptr);
+    if (!out) return LG_ERR_BAD_ARG;
+    *out = nullptr;
+    if (field != LG_FIELD_BLS12_377_FQ && field != LG_FIELD_BN254_FR_GENERIC) return LG_ERR_BAD_ARG;
+    const int logk = ilog2_exact(k), logn = ilog2_exact(n);
+    if (rows == 0 || batch == 0 || logk < 1 || logn < 0 || n != 8 * (uint64_t)k) return LG_ERR_BAD_DIMS;
+    if ((uint64_t)rows * batch > 0xffffffffull / 8) return LG_ERR_BAD_DIMS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LG_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return LG_ERR_NO_DEVICE;
+    lg_ctx* c = new (std::nothrow) lg_ctx();
+    if (!c) return LG_ERR_OOM;
+    c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
+    c->total_rows = (uint64_t)rows * batch;
+    c->ki = k; c->logki = logk; c->nplanes = 8; c->own_planes = 8; c->coeff_rows_alloc = (uint32_t)c->total_rows;
+    auto body = [&]() -> int {
+        LG_HIP(c, hipSetDevice(device));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        return gf_create(&c->gf, field, rows, k, n, batch, c->stream, c->err, sizeof(c->err));
+    };
+    const int rc = body();
+    if (rc != LG_OK) {
+        lg_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LG_OK;
+}
+uint32_t lg_ctx_element_words(const lg_ctx* c) { return c ? (c->gf ? gf_element_words64(c->gf) : 4u) : 0u; }
 int lg_ctx_planes(const lg_ctx* c, uint32_t* nplanes, uint32_t* plane_begin, uint32_t* plane_count) {
     if (!c) return LG_ERR_BAD_ARG;
     if (nplanes) *nplanes = c->nplanes;
@@ -705,6 +739,7 @@ int lg_ctx_dims(const lg_ctx* c, uint32_t* rows, uint32_t* k, uint32_t* n, uint3
 
 int lg_ctx_pipeline_chunks(const lg_ctx* c, uint32_t* chunks_out) {
     if (!c || !chunks_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { *chunks_out = 1; return LG_OK; }
     Chunk chunks[lg_ctx::kMaxChunks];
     *chunks_out = (uint32_t)plan_chunks(c, chunks);
     return LG_OK;
@@ -712,6 +747,7 @@ int lg_ctx_pipeline_chunks(const lg_ctx* c, uint32_t* chunks_out) {
 
 int lg_upload_preenc(lg_ctx* c, const uint64_t* preenc) {
     if (!c || !preenc) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_upload(c->gf, preenc); }
     if (c->sharded) return LG_ERR_STATE;   // a sharded context takes its row shard through lg_stage_interpolate
     LG_HIP(c, hipSetDevice(c->device));
     c->have_row0 = 0; c->have_row1 = c->rows;
@@ -721,6 +757,7 @@ int lg_upload_preenc(lg_ctx* c, const uint64_t* preenc) {
 
 int lg_profile_enable(lg_ctx* c, int on) {
     if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     LG_HIP(c, hipSetDevice(c->device));
     if (on && !c->ev_valid) {
         for (auto& set : c->ev)
@@ -914,6 +951,7 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
 
 int lg_commit_resident(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_commit(c->gf, nullptr, nullptr); }
     return commit_core(c, nullptr, nullptr);
 }
 
@@ -932,6 +970,7 @@ int lg_host_unregister(lg_ctx* c, void* ptr) {
 
 int lg_profile_read(lg_ctx* c, float ms_out[LG_STAGE_COUNT], uint32_t* samples_out) {
     if (!c || !ms_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (!c->ev_valid || !c->profiling || c->prof_commits == 0) return LG_ERR_STATE;
     LG_HIP(c, hipSetDevice(c->device));
     const uint64_t have = c->prof_commits < lg_ctx::kProfRing ? c->prof_commits : lg_ctx::kProfRing;
@@ -954,6 +993,7 @@ int lg_profile_read(lg_ctx* c, float ms_out[LG_STAGE_COUNT], uint32_t* samples_o
 
 int lg_sync(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_sync(c->gf); }
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipStreamSynchronize(c->stream));
@@ -969,6 +1009,7 @@ static int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes) {
 
 int lg_read_root(lg_ctx* c, uint8_t* root_out) {
     if (!c || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_root(c->gf, root_out) : LG_ERR_STATE; }
     if (!c->committed) return LG_ERR_STATE;
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
@@ -978,17 +1019,20 @@ int lg_read_root(lg_ctx* c, uint8_t* root_out) {
 }
 int lg_read_coeffs(lg_ctx* c, uint64_t* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_coeffs(c->gf, out) : LG_ERR_STATE; }
     if (!c->committed) return LG_ERR_STATE;
     return read_back(c, out, c->d_coeffs, (size_t)c->total_rows * c->k * sizeof(fr));
 }
 int lg_read_leaves(lg_ctx* c, uint8_t* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_leaves(c->gf, out) : LG_ERR_STATE; }
     if (!c->committed) return LG_ERR_STATE;
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     return read_back(c, out, c->d_leaves, (size_t)c->batch * c->n * 32);
 }
 int lg_read_nodes(lg_ctx* c, uint8_t* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_nodes(c->gf, out) : LG_ERR_STATE; }
     if (!c->committed) return LG_ERR_STATE;
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     return read_back(c, out, c->d_nodes, (size_t)c->batch * (c->n - 1) * 32);
@@ -996,6 +1040,7 @@ int lg_read_nodes(lg_ctx* c, uint8_t* out) {
 
 int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out) {
     if (!c || !preenc || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); const int rc_ = gf_commit(c->gf, preenc, coeffs_out); return rc_ != LG_OK ? rc_ : gf_read_root(c->gf, root_out); }
     // rows stream in (and coefficients out) while earlier rows are being encoded
     const int rc = commit_core(c, preenc, coeffs_out);
     if (rc != LG_OK) return rc;
@@ -1004,6 +1049,12 @@ int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, ui
 
 int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nrows, uint64_t* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) {
+        if (!gf_committed(c->gf)) return LG_ERR_STATE;
+        if (proof >= c->batch || (uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
+        LG_HIP(c, hipSetDevice(c->device));
+        return gf_read_codeword_rows(c->gf, proof, row0, nrows, out);
+    }
     if (!c->committed) return LG_ERR_STATE;
     if (proof >= c->batch || (uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
     if (nrows == 0) return LG_OK;
@@ -1023,6 +1074,15 @@ int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nro
 static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out,
                              uint8_t* paths_out) {
     if (!c || !idx || !cols_out || !sib_out || (!paths_out && c->logn > 1)) return LG_ERR_BAD_ARG;
+    if (c->gf) {
+        if (!gf_committed(c->gf)) return LG_ERR_STATE;
+        if ((uint64_t)proof0 + nproofs > c->batch) return LG_ERR_BAD_ARG;
+        for (size_t i = 0; i < (size_t)nproofs * t; i++)
+            if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
+        if ((size_t)nproofs * t == 0) return LG_OK;
+        LG_HIP(c, hipSetDevice(c->device));
+        return gf_open_columns(c->gf, proof0, nproofs, idx, t, cols_out, sib_out, paths_out);
+    }
     if (!c->committed) return LG_ERR_STATE;
     if ((uint64_t)proof0 + nproofs > c->batch) return LG_ERR_BAD_ARG;
     const size_t nidx = (size_t)nproofs * t;
@@ -1123,6 +1183,7 @@ static int sub_interpolate_2k(lg_ctx* c, uint64_t* coeffs_out) {
 
 int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
     if (!c || !r || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     { const int rc_ = need_all_message_rows(c, "lg_interleaved_row_mul"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     uint32_t per;
@@ -1159,6 +1220,7 @@ static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_o
 
 int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_out) {
     if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (!c->committed) return LG_ERR_STATE;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly"); if (rc_ != LG_OK) return rc_; }
@@ -1172,6 +1234,7 @@ int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_o
 
 int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, const uint64_t* row_idx, const uint64_t* col_idx, const uint64_t* values) {
     if (!c || (nnz && (!row_idx || !col_idx || !values))) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     const uint64_t cols = (uint64_t)c->rows * c->k;   // 4 m k
     if (num_rows > 0xffffffffull || nnz > 0xffffffffull) return LG_ERR_UNSUPPORTED;
     for (uint64_t e = 0; e < nnz; e++)
@@ -1211,6 +1274,7 @@ int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, cons
 
 int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* coeffs_out) {
     if (!c || !seeds || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (!c->committed || !c->a_loaded) return LG_ERR_STATE;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly_from_seeds"); if (rc_ != LG_OK) return rc_; }
@@ -1297,6 +1361,7 @@ static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_o
 
 int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_out) {
     if (!c || !r || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (!c->committed) return LG_ERR_STATE;
     if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
@@ -1331,6 +1396,7 @@ int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_
 // the leaf digests, and every rank builds the (replicated) tree.
 int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows) {
     if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (c->batch != 1) return LG_ERR_STATE;
     if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
     if (nrows == 0) return LG_OK;
@@ -1364,6 +1430,7 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
 
 int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
     if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (c->batch != 1) return LG_ERR_STATE;
     if (c->nplanes < 32 && (plane_mask >> c->nplanes) != 0) return LG_ERR_BAD_ARG;
     if (plane_mask & ~own_planes_mask(c)) {
@@ -1410,6 +1477,7 @@ int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
 
 int lg_stage_merkle(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     lg::MerkleArgs m;
@@ -1435,6 +1503,7 @@ int lg_stage_merkle(lg_ctx* c) {
 
 int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
     if (!c || !dptr_out || !bytes_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (which == LG_BUF_LEAVES || which == LG_BUF_NODES) {   // the caller will touch them outside our streams' order
         LG_HIP(c, hipSetDevice(c->device));
         const int rc_ = settle_tree(c);
@@ -1456,6 +1525,11 @@ int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
 // row operators on scratch buffers: a = input rows / coefficients, b = coset planes, c = natural-order output
 static int rs_common(lg_ctx* c, const uint64_t* in, uint32_t nrows, uint64_t* out, bool do_interp, bool do_eval) {
     if (!c || !in || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) {
+        if ((uint64_t)nrows > c->total_rows) return LG_ERR_BAD_ARG;
+        LG_HIP(c, hipSetDevice(c->device));
+        return gf_reed_solomon(c->gf, in, nrows, out, do_interp, do_eval);
+    }
     if (nrows == 0) return LG_OK;
     if ((uint64_t)nrows > c->total_rows) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));

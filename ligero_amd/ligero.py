@@ -63,13 +63,26 @@ class LigeroCommitter:
     """
 
     def __init__(self, rows: int, k: int, n: Optional[int] = None, batch: int = 1, device: int = 0,
-                 shard: Optional[Tuple[int, int, int]] = None):
+                 shard: Optional[Tuple[int, int, int]] = None, field: int = 0):
         """shard = (plane_begin, plane_count, coeff_rows_alloc): one rank of a proof that is coset-sharded over
-        several GPUs (lg_ctx_create_sharded): only those planes of U are allocated, the staged calls only."""
+        several GPUs (lg_ctx_create_sharded): only those planes of U are allocated, the staged calls only.
+        field: _ffi.LG_FIELD_* -- BN254 Fr (default, 4 u64 limbs per element), BLS12-377 Fq (6 limbs, the reference's second
+        test field; hot path only) or BN254 Fr through the portable kernels (cross-check).  Element arrays then have
+        `self.ew` limbs in their last axis."""
         n = 8 * k if n is None else n
         self._L = _ffi.lib()
         self._ctx = _vp()
         self.rows, self.k, self.n, self.batch, self.device = rows, k, n, batch, device
+        self.ew = 4
+        if field != 0:
+            if shard is not None:
+                raise ValueError("sharded contexts exist for BN254 Fr only")
+            st = self._L.lg_ctx_create_field(ctypes.byref(self._ctx), device, field, rows, k, n, batch)
+            if st != _ffi.LG_OK:
+                self._ctx = None
+                _ffi.check(st, f"lg_ctx_create_field(field={field}, rows={rows}, k={k}, n={n}, batch={batch})")
+            self.ew = int(self._L.lg_ctx_element_words(self._ctx))
+            return
         if shard is None:
             st = self._L.lg_ctx_create_batched(ctypes.byref(self._ctx), device, rows, k, n, batch)
             what = f"lg_ctx_create_batched(rows={rows}, k={k}, n={n}, batch={batch})"
@@ -112,9 +125,9 @@ class LigeroCommitter:
 
     def _mat(self, a, cols, what) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.uint64)
-        if a.size % (cols * 4) != 0:
+        if a.size % (cols * self.ew) != 0:
             raise ValueError(f"{what}: size {a.size} is not a multiple of {cols} elements")
-        return a.reshape(-1, cols, 4)
+        return a.reshape(-1, cols, self.ew)
 
     # -- the hot path, mod.rs:521-551
     def encode_commit(self, preenc_u, want_coeffs: bool = True, coeffs_out=None):
@@ -162,7 +175,7 @@ class LigeroCommitter:
         return out.tobytes()
 
     def coeffs(self) -> np.ndarray:
-        out = np.empty((self.batch * self.rows, self.k, 4), dtype=np.uint64)
+        out = np.empty((self.batch * self.rows, self.k, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_read_coeffs(self._ctx, _ptr(out)), "lg_read_coeffs")
         return out
 
@@ -179,7 +192,7 @@ class LigeroCommitter:
     def codeword_rows(self, row0: int = 0, nrows: Optional[int] = None, proof: int = 0) -> np.ndarray:
         """Rows of the encoded matrix U (mod.rs:528-533), natural column order, Montgomery."""
         nrows = self.rows - row0 if nrows is None else nrows
-        out = np.empty((nrows, self.n, 4), dtype=np.uint64)
+        out = np.empty((nrows, self.n, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_read_codeword_rows(self._ctx, proof, row0, nrows, _ptr(out)), "lg_read_codeword_rows")
         return out
 
@@ -190,7 +203,7 @@ class LigeroCommitter:
         idx = np.ascontiguousarray(indices, dtype=np.uint32)
         t = idx.shape[0]
         plen = self.n.bit_length() - 2
-        cols = np.empty((t, self.rows, 4), dtype=np.uint64)
+        cols = np.empty((t, self.rows, self.ew), dtype=np.uint64)
         sib = np.empty((t, 32), dtype=np.uint8)
         paths = np.empty((t, plen, 32), dtype=np.uint8)
         self._chk(self._L.lg_open_columns(self._ctx, proof, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns")
@@ -206,10 +219,10 @@ class LigeroCommitter:
         plen = self.n.bit_length() - 2
         if out is not None:
             cols, sib, paths = out
-            if cols.shape != (self.batch, t, self.rows, 4) or sib.shape != (self.batch, t, 32) or paths.shape != (self.batch, t, plen, 32):
+            if cols.shape != (self.batch, t, self.rows, self.ew) or sib.shape != (self.batch, t, 32) or paths.shape != (self.batch, t, plen, 32):
                 raise ValueError("out arrays do not match this opening")
         else:
-            cols = np.empty((self.batch, t, self.rows, 4), dtype=np.uint64)
+            cols = np.empty((self.batch, t, self.rows, self.ew), dtype=np.uint64)
             sib = np.empty((self.batch, t, 32), dtype=np.uint8)
             paths = np.empty((self.batch, t, plen, 32), dtype=np.uint8)
         self._chk(self._L.lg_open_columns_batch(self._ctx, _ptr(idx), t, _ptr(cols), _ptr(sib), _ptr(paths)), "lg_open_columns_batch")
@@ -224,13 +237,13 @@ class LigeroCommitter:
 
     def reed_solomon_evaluate(self, coeffs) -> np.ndarray:
         c = self._mat(coeffs, self.k, "coeffs")
-        out = np.empty((c.shape[0], self.n, 4), dtype=np.uint64)
+        out = np.empty((c.shape[0], self.n, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_reed_solomon_evaluate(self._ctx, _ptr(c), c.shape[0], _ptr(out)), "lg_reed_solomon_evaluate")
         return out
 
     def reed_solomon(self, msg) -> np.ndarray:
         m = self._mat(msg, self.k, "msg")
-        out = np.empty((m.shape[0], self.n, 4), dtype=np.uint64)
+        out = np.empty((m.shape[0], self.n, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_reed_solomon(self._ctx, _ptr(m), m.shape[0], _ptr(out)), "lg_reed_solomon")
         return out
 

@@ -219,3 +219,46 @@ def test_large_goldens_are_committed():
     for name in ("s20", "s22"):
         assert (g[name]["rows"], g[name]["k"]) == WORKLOADS[name][:2] and g[name]["seed"] == LARGE_SEED
         assert len(bytes.fromhex(g[name]["root"])) == 32
+
+
+def test_generic_field_constants():
+    """the constants the generic-field path embeds (ligero_amd/csrc/generic_path.hip make_field) recomputed from the moduli and
+    multiplicative generators alone; BN254's must equal what model.py derives from the modulus read out of the .r1cs fixtures"""
+    import re
+    from oracle import model_field as mf
+    src = open(os.path.join(os.path.dirname(GOLDEN), "..", "ligero_amd", "csrc", "generic_path.hip")).read()
+    consts = re.findall(r'(?:p|root) = "([0-9a-f]+)";', src)
+    assert len(consts) == 4
+    fq, fr = mf.BLS12_377_FQ, mf.BN254_FR
+    assert int(consts[0], 16) == fq.p and int(consts[1], 16) == fq.root
+    assert int(consts[2], 16) == fr.p == model_P() and int(consts[3], 16) == fr.root
+    assert fq.p.bit_length() == 377 and fq.two_adicity == 46 and fq.nbytes == 48
+    # the curve equation the reference's BLS12-377 test proves (tests.rs:186-193 / arithmetic_circuit/tests.rs: y^2 = x^3 + 1 over Fq)
+    # holds for the G1 generator's affine coordinates, which ties this modulus to that test's field
+    gx = 0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef
+    gy = 0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6
+    assert (gy * gy - gx * gx * gx - 1) % fq.p == 0
+
+
+def model_P():
+    from oracle import model
+    return model.P
+
+
+def test_generic_field_model_agrees_with_bn254_model():
+    from oracle import model, model_field as mf
+    import random
+    random.seed(5)
+    f = mf.BN254_FR
+    pre = [[random.randrange(f.p) for _ in range(8)] for _ in range(5)]
+    assert f.encode_commit(pre, 8, 64) == model.encode_commit(pre, 8, 64)
+    # 48-byte elements: framing against hashlib directly
+    q = mf.BLS12_377_FQ
+    col = [1, q.p - 1, 12345]
+    assert q.col_hash(col) == hashlib.blake2s(struct.pack("<Q", 3) + b"".join(v.to_bytes(48, "little") for v in col)).digest()
+    msg = [random.randrange(q.p) for _ in range(4)]
+    cw = q.reed_solomon_evaluate(q.reed_solomon_interpolate(msg, 4), 32)
+    assert cw[::8] == msg
+    w = q.domain_generator(32)
+    co = q.reed_solomon_interpolate(msg, 4)
+    assert cw == [sum(c * pow(w, j * d, q.p) for d, c in enumerate(co)) % q.p for j in range(32)]
