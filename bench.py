@@ -389,8 +389,10 @@ def roofline_of(workload, stage, launches, traffic_file):
     names = ("interpolate", "evaluate", "colhash", "merkle")
     per_stage_bytes = {"evaluate": b_eval, "interpolate": batch * rows * 96 * k,      # msg in, coeffs out, canonical copy out
                        "colhash": batch * (rows * n * 32 + n * 32), "merkle": batch * (64 * n - 32)}
-    overlapped = {"colhash": launches > 1, "merkle": launches == 1}     # single-chunk commits build the tree beside the next commit
-    eligible = [s for s in names if not (s == "colhash" and launches > 1)]
+    # single-chunk commits: the hash and the tree of commit i run on a second stream beside the interpolation of commit i + 1
+    # (LG_ASYNC_HASH / LG_ASYNC_TREE), so those three event spans include each other's slow-down; evaluate does not overlap them
+    overlapped = {"colhash": True, "merkle": launches == 1, "interpolate": launches == 1}
+    eligible = [s for s in names if not overlapped.get(s, False)] or ["evaluate"]
     dom = max(eligible, key=lambda s: stage[s])
     tall = json.load(open(traffic_file)).get(workload, {}) if os.path.exists(traffic_file) else {}
     rl, dom_rl = {}, None

@@ -44,6 +44,12 @@ struct lg_ctx {
     hipEvent_t ev_hashed = nullptr, ev_tree = nullptr;   // single-chunk commits: leaves complete / tree complete (on stream_h)
     bool async_tree = true;                // LG_ASYNC_TREE=0 turns the overlap below off (A/B knob)
     bool tree_pending = false;             // the tree of the last commit is still being built on stream_h
+    // single-chunk commits: the column hash of commit i runs on stream_h BESIDE the interpolation / evaluation of commit
+    // i + 1 (one wave per SIMD of a latency chain fills issue slots instead of holding the machine): U is double buffered
+    bool async_hash = true;                // LG_ASYNC_HASH=0: hash on the encode stream, one U buffer (A/B knob)
+    fr* d_u_pp[2] = {nullptr, nullptr};    // [0] = d_u_alloc, [1] allocated by the first overlapped commit
+    int u_parity = 0;
+    hipEvent_t ev_hash_free[2] = {nullptr, nullptr};   // "the hash that read U[p] is done" (on stream_h)
     uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
     gf_state* gf = nullptr;                // set for contexts over a generic field (lg_ctx_create_field): every supported
                                            // entry point forwards to generic_path.hip, the others return LG_ERR_UNSUPPORTED
@@ -480,6 +486,9 @@ void lg_ctx_destroy(lg_ctx* c) {
     for (auto& e : c->ev_coef)
         if (e) hipEventDestroy(e);
     if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->d_u_pp[1]) hipFree(c->d_u_pp[1]);
+    for (auto& e : c->ev_hash_free)
+        if (e) hipEventDestroy(e);
     if (c->ev_hashed) hipEventDestroy(c->ev_hashed);
     if (c->ev_tree) hipEventDestroy(c->ev_tree);
     if (c->stream_up) hipStreamDestroy(c->stream_up);
@@ -541,6 +550,8 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_hashed, lg_event_flags()));
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_tree, lg_event_flags()));
         if (const char* e = getenv("LG_ASYNC_TREE")) c->async_tree = atoi(e) != 0;
+        if (const char* e = getenv("LG_ASYNC_HASH")) c->async_hash = atoi(e) != 0;
+        for (auto& e : c->ev_hash_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
         const size_t mat = (size_t)c->total_rows * k;
         // sharded: the message rows arrive shard by shard (lg_stage_interpolate allocates what it is given), the
@@ -551,6 +562,7 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
             const size_t plane = (size_t)c->total_rows * c->ki;
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_alloc), (size_t)c->own_planes * plane * sizeof(fr)));
             c->d_u = c->d_u_alloc - (size_t)c->own_plane0 * plane;   // never dereferenced outside the owned planes
+            c->d_u_pp[0] = c->d_u_alloc;
         }
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
@@ -801,8 +813,17 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
     hipEvent_t* ev = c->ev[c->prof_commits % lg_ctx::kProfRing];
     Chunk chunks[lg_ctx::kMaxChunks];
     const int nchunks = plan_chunks(c, chunks, streamed);
-    // one chunk: nothing to overlap, so everything stays on the encode stream (no cross-stream waits)
-    hipStream_t hs = nchunks > 1 ? c->stream_h : c->stream;
+    // one chunk: the hash of THIS commit has nothing of its own to hide behind; it is put beside the NEXT commit's encoding
+    // (async_hash) -- or, with that off, everything stays on the encode stream (no cross-stream waits)
+    const bool async_hash = c->async_hash && c->async_tree && nchunks == 1;
+    hipStream_t hs = (nchunks > 1 || async_hash) ? c->stream_h : c->stream;
+    if (async_hash) {
+        // this commit encodes into the other U buffer; the hash that last read it (two commits ago) must be done
+        const int par = (c->u_parity ^= 1);
+        if (!c->d_u_pp[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_pp[par]), (size_t)c->nplanes * plane * sizeof(fr)));
+        c->d_u = c->d_u_pp[par];
+        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_hash_free[par], 0));   // (never recorded = no-op)
+    }
     if (prof) LG_HIP(c, hipEventRecord(ev[0], c->stream));
     if (streamed) {
         // copies go on their own stream and the encode stream picks the chunks up by event.  Copy c+1 is
@@ -856,7 +877,11 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
             LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
             LG_HIP(c, hipStreamWaitEvent(hs, c->ev_chunk[i], 0));
         }
-        if (i == 0) {   // the previous commit's tree may still be reading the leaves this hash is about to rewrite
+        if (async_hash) {
+            // the hash follows the previous commit's tree on stream_h by stream order; it only waits for this encoding
+            LG_HIP(c, hipEventRecord(c->ev_hashed, c->stream));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_hashed, 0));
+        } else if (i == 0) {   // the previous commit's tree may still be reading the leaves this hash is about to rewrite
             const int rc = settle_tree(c);
             if (rc != LG_OK) return rc;
             if (nchunks > 1) LG_HIP(c, hipStreamWaitEvent(hs, c->ev_tree, 0));   // (ev_tree: completed or never recorded = no-op)
@@ -903,9 +928,10 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         }
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
+    if (async_hash) LG_HIP(c, hipEventRecord(c->ev_hash_free[c->u_parity], hs));
     const bool async_tree = c->async_tree && nchunks == 1;
     hipStream_t ms = async_tree ? c->stream_h : hs;
-    if (async_tree) {
+    if (async_tree && !async_hash) {
         LG_HIP(c, hipEventRecord(c->ev_hashed, c->stream));
         LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_hashed, 0));
     }
