@@ -142,6 +142,13 @@ static int need_all_message_rows(lg_ctx* c, const char* what) {
     return LG_ERR_STATE;
 }
 
+// every kernel launch is followed by its own error check (a failed launch must not be reported against a later one)
+#define LG_LAUNCH(c, ...)                  \
+    do {                                   \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+        LG_HIP(c, hipGetLastError());      \
+    } while (0)
+
 // Montgomery-form (2^256) host element -> 29-bit limbs of value * 2^261 mod p
 static lg::f29 to_f29(const lg_host::Fr& a_mont) {
     static const lg_host::Fr m32 = lg_host::to_mont(lg_host::Fr{{32, 0, 0, 0}});
@@ -946,9 +953,9 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
             m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
             const dim3 grid(c->batch * m.chunks);
             if (leaf)
-                hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, ms, m);
+                LG_LAUNCH(c, lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, ms, m);
             else
-                hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, ms, m);
+                LG_LAUNCH(c, lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, ms, m);
             leaf = false;
             depth = depth > 9 ? depth - 9 : 0;
         }
@@ -1327,15 +1334,13 @@ int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64
     lg::ChaChaArgs a;
     a.seeds = c->d_seeds; a.out = c->d_rlin; a.counts = c->d_cc_counts; a.short_flag = c->d_short_flag;
     a.n = (uint32_t)n; a.blocks = blocks; a.wgs = wgs;
-    hipLaunchKernelGGL(lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
-    hipLaunchKernelGGL(lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
-    LG_HIP(c, hipGetLastError());
+    LG_LAUNCH(c, lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
+    LG_LAUNCH(c, lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
     lg::SparseRowMulArgs m;
     m.col_ptr = c->d_a_colptr; m.ent_row = c->d_a_row; m.ent_val = c->d_a_val;
     m.r = c->d_rlin; m.out = c->d_scratch_a; m.heavy = c->d_a_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)n;
-    hipLaunchKernelGGL(lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->stream, m);
-    if (c->a_nheavy) hipLaunchKernelGGL(lg::sparse_row_mul_heavy_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, m);
-    LG_HIP(c, hipGetLastError());
+    LG_LAUNCH(c, lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->stream, m);
+    if (c->a_nheavy) LG_LAUNCH(c, lg::sparse_row_mul_heavy_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, m);
     rc = linear_core(c, per, nch, coeffs_out);   // synchronises on the stream when it reads the coefficients back
     if (rc != LG_OK) return rc;
     uint32_t flag = 0;
@@ -1515,9 +1520,9 @@ int lg_stage_merkle(lg_ctx* c) {
         m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
         const dim3 grid(c->batch * m.chunks);
         if (leaf)
-            hipLaunchKernelGGL(lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, c->stream, m);
+            LG_LAUNCH(c, lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, c->stream, m);
         else
-            hipLaunchKernelGGL(lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, c->stream, m);
+            LG_LAUNCH(c, lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, c->stream, m);
         leaf = false;
         depth = depth > 9 ? depth - 9 : 0;
     }
