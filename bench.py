@@ -264,14 +264,14 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
     n = 8 * k
     be = HipStageBackend(rows, k, device=local_rank, world=world, rank=rank)
     try:
-        sc = CosetShardedCommitter(be, dist if world > 1 else None)
+        sc = CosetShardedCommitter(be, dist, collectives_at_world_1=True)     # dist is None in a plain one-GPU run
         r0, r1 = sc.row_range()
         pre = shard_rows_of_seeded_matrix(LARGE_SEED, k, r0, r1)
 
         def fence():
             be.sync()
             torch.cuda.synchronize()
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
                 torch.cuda.synchronize()
 
@@ -290,7 +290,7 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
         elapsed = time.perf_counter() - t0
         stage = torch.tensor([elapsed] + [acc[s] / steps for s in names], dtype=torch.float64,
                              device="cuda" if backend == "nccl" else "cpu")
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(stage, op=dist.ReduceOp.MAX)
         stage = [float(x) for x in stage.tolist()]
         elapsed = stage[0]
@@ -456,7 +456,10 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # LIGERO_BENCH_FORCE_DIST=1 (launched through torch.distributed.run with one process): initialise the process group -- RCCL by
+    # default -- at world size 1 as well, so that a one-GPU box runs the exact collective calls of the multi-GPU paths
+    force_dist = os.environ.get("LIGERO_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -466,10 +469,10 @@ def main():
     rows, k, batch = WORKLOADS[args.workload]
     n = 8 * k
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    extras = world == 1 and not args.no_cpu_baseline
+    extras = dist is None and not args.no_cpu_baseline
     large = args.workload != "poseidon"
 
-    if large and world > 1:
+    if large and dist is not None:
         # ---- ONE proof coset-sharded over the ranks (BASELINE configs[3]): strong scaling, RCCL all-gathers
         steps = min(args.steps, 20)
         res = sharded_commit_leg(torch, dist, backend, args.workload, world, rank, local_rank, steps, min(args.warmup, 3))
@@ -494,7 +497,7 @@ def main():
     elapsed, stage, launches, root = resident_run(ligero_amd, torch, dist, backend, args.workload, pre, local_rank, args.steps, args.warmup, world)
 
     sharded = None
-    if world > 1 and args.sharded_leg != "none" and not args.no_cpu_baseline:
+    if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
         # the same ranks, one large proof over all of them: the driver's scaling run thereby measures the RCCL path too
         try:
             sharded = sharded_commit_leg(torch, dist, backend, args.sharded_leg, world, rank, local_rank, 5, 2)

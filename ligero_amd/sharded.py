@@ -130,10 +130,13 @@ class CosetShardedCommitter:
     """One proof over `world` ranks.  `backend` does the device work; `dist` is torch.distributed
     (already initialised) or None for a single process."""
 
-    def __init__(self, backend, dist=None, group=None):
+    def __init__(self, backend, dist=None, group=None, collectives_at_world_1: bool = False):
+        """collectives_at_world_1: issue the two all-gathers even in a one-rank group (they are identities then) -- lets a
+        one-GPU box run the exact RCCL calls of the multi-GPU path (bench.py LIGERO_BENCH_FORCE_DIST, tests)."""
         self.be = backend
         self.dist = dist
         self.group = group
+        self.force = bool(collectives_at_world_1) and dist is not None
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
         self.planes = owned_planes(backend.nplanes, self.world, self.rank)
@@ -161,7 +164,7 @@ class CosetShardedCommitter:
         be.stage_interpolate(preenc_rows_local, r0, r1 - r0)
         be.sync()
         lap("interpolate")
-        if self.world > 1:
+        if self.world > 1 or self.force:
             # equal (padded) shards: ONE in-place all-gather whatever rows % world is
             coeffs = be.coeffs_bytes()
             p0 = self.rank * self.shard_rows
@@ -171,7 +174,7 @@ class CosetShardedCommitter:
         be.stage_evaluate_hash(self.planes)
         be.sync()
         lap("evaluate_hash")
-        if self.world > 1:
+        if self.world > 1 or self.force:
             import torch
             np_, per = be.nplanes, len(self.planes)
             leaves = be.leaves_bytes().view(be.n // np_, self.world, per, 32)   # [q][owner][plane of owner][32]

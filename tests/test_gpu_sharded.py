@@ -74,6 +74,22 @@ def test_world2_on_one_gpu_matches_oracle(oracle, rows, k):
     assert got == want                                                    # every opened column came from its owner, bit-exact
 
 
+@pytest.mark.parametrize("rows,k,chunks", [(22, 128, 3), (9, 4096, 2), (6, 8192, 3)])
+def test_world2_with_the_chunked_stage_pipeline(oracle, monkeypatch, rows, k, chunks):
+    """lg_stage_evaluate_hash pipelines row chunks over two streams at large sizes (hash of chunk i beside the evaluation of chunk
+    i + 1, Blake2s state parked between launches); forced here at small sizes, per rank and per owned plane run"""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("LG_FORCE_CHUNKS", str(chunks))
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), rows, k, out), nprocs=world, join=True)
+    pre = random_mont(515, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    for rank in range(world):
+        assert out[rank][0] == ref["root"], rank
+
+
 def test_partial_commitments_refuse_foreign_data(oracle):
     """after a staged commit a context holds only the planes / message rows the stages put there; the C ABI
     must answer LG_ERR_STATE (-6) for everything else instead of returning stale or foreign data with LG_OK."""
