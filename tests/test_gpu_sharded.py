@@ -39,7 +39,7 @@ def _worker(rank, world, port, rows, k, out):
         root = sc.commit(pre[r0:r1])
         opened = sc.open_columns([0, 5, 8 * k - 1])
         # a column of a plane the OTHER rank owns must be refused by the C ABI itself, not served from foreign memory
-        foreign = (1 - rank) * (be.nplanes // world)
+        foreign = ((rank + 1) % world) * (be.nplanes // world)                # first plane of the next rank
         try:
             be.open_columns([foreign])
             refused = False
@@ -88,6 +88,27 @@ def test_world2_with_the_chunked_stage_pipeline(oracle, monkeypatch, rows, k, ch
     ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
     for rank in range(world):
         assert out[rank][0] == ref["root"], rank
+
+
+@pytest.mark.parametrize("world,rows,k", [(4, 21, 128), (8, 12, 128), (8, 7, 8192)])
+def test_world4_and_world8_on_one_gpu(oracle, world, rows, k):
+    """the world sizes of the driver's scaling run with the real device backend (all ranks share this box's GPU, gloo collectives):
+    one or two planes per rank at k = 128, two of sixteen at the folded k = 8192; ragged and empty row shards"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), rows, k, out), nprocs=world, join=True)
+    pre = random_mont(515, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k)
+    ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], [0, 5, 8 * k - 1])
+    want = {j: (ecols[i].tobytes(), esib[i].tobytes(), epaths[i].tobytes()) for i, j in enumerate([0, 5, 8 * k - 1])}
+    got = {}
+    for rank in range(world):
+        root, opened, refused, _ = out[rank]
+        assert root == ref["root"], rank
+        assert refused
+        got.update(opened)
+    assert got == want
 
 
 def test_partial_commitments_refuse_foreign_data(oracle):

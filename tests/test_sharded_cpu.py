@@ -126,6 +126,44 @@ def test_world2_gloo_matches_single_process(oracle, rows, k):
     assert out[0][3] == (0, min(rows, (rows + 1) // 2))                  # padded equal shards: ceil(rows / 2) rows first
 
 
+def _worker_n(rank, world, port, rows, k, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ligero_amd.sharded import CosetShardedCommitter
+        pre = random_mont(99, rows * k).reshape(rows, k, 4)
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), dist)
+        r0, r1 = sc.row_range()
+        root = sc.commit(pre[r0:r1])
+        opened = sc.open_columns(list(range(8 * k)))
+        out[rank] = (root, sorted(opened), (r0, r1), list(sc.planes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rows,k", [(4, 10, 4), (8, 12, 4), (8, 5, 2)])   # the ranks the driver's scaling run uses; fewer rows than ranks
+def test_world4_and_world8_gloo(oracle, world, rows, k):
+    """the orchestration at the world sizes of the scaling run (1 / 2 / 4 / 8): padded row shards (some ranks may own no row at
+    all), one or two planes per rank, every column opened by exactly one rank"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_n, args=(world, _free_port(), rows, k, out), nprocs=world, join=True)
+    pre = random_mont(99, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    assert set(out.keys()) == set(range(world))
+    seen, covered = [], 0
+    for rank in range(world):
+        root, opened, (r0, r1), planes = out[rank]
+        assert root == ref["root"], rank
+        assert planes == list(range(rank * 8 // world, (rank + 1) * 8 // world))
+        assert all(j % 8 in planes for j in opened)
+        seen += opened
+        assert r0 == covered or r0 == r1 == rows
+        covered = max(covered, r1)
+    assert sorted(seen) == list(range(8 * k)) and covered == rows
+
+
 def test_single_process_degenerate(oracle):
     from ligero_amd.sharded import CosetShardedCommitter, owned_planes, padded_shard_range, padded_shard_rows, shard_range
     rows, k = 5, 8
