@@ -182,3 +182,73 @@ __global__ void __launch_bounds__(256) gf_planes_to_rows_kernel(const gfe<NW>* u
 }
 
 }  // namespace lg
+
+namespace lg {
+
+// ---- sub-proof reductions over a generic field (mod.rs:658, 723-736, 842-848), one thread per output point, a loop over rows.
+// Written for the reference's second test field, whose only circuit has ten nodes: correctness first.
+
+// prove_interleaved: out[c] = sum_i r[i] * preenc_u[i][c]   (Montgomery x Montgomery -> Montgomery)
+template <int NW>
+__global__ void __launch_bounds__(256) gf_row_mul_kernel(const gfe<NW>* pre, const gfe<NW>* r, uint32_t rows, uint32_t k, GfConsts<NW> F, gfe<NW>* out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= k) return;
+    gfe<NW> acc;
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc.v[w] = 0;
+    for (uint32_t i = 0; i < rows; i++) {
+        gfe<NW> t, s;
+        gf_mul<NW>(t, gf_load<NW>(pre + (size_t)i * k + c), gf_load<NW>(r + i), F);
+        gf_add<NW>(s, acc, t, F);
+        acc = s;
+    }
+    gf_store<NW>(out + c, acc);
+}
+
+// point j of the size-2k domain is codeword index 4 j: plane (j & 1) * 4, slot j >> 1
+// linear test: q[j] = sum_i u_i(eta_j) * r_i(eta_j), both canonical in their planes; out Montgomery (x R^3 after the sum of a b / R)
+template <int NW>
+__global__ void __launch_bounds__(256) gf_linear_points_kernel(const gfe<NW>* u, const gfe<NW>* rv, uint64_t plane_stride, uint32_t rows, uint32_t k,
+                                                               gfe<NW> r3, GfConsts<NW> F, gfe<NW>* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * k) return;
+    const uint64_t off = (uint64_t)((j & 1) * 4) * plane_stride + (j >> 1);
+    gfe<NW> acc;
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc.v[w] = 0;
+    for (uint32_t i = 0; i < rows; i++) {
+        gfe<NW> t, s;
+        gf_mul<NW>(t, gf_load<NW>(u + off + (uint64_t)i * k), gf_load<NW>(rv + off + (uint64_t)i * k), F);
+        gf_add<NW>(s, acc, t, F);
+        acc = s;
+    }
+    gfe<NW> y;
+    gf_mul<NW>(y, acc, r3, F);
+    gf_store<NW>(out + j, y);
+}
+
+// quadratic test: q[j] = sum_{i < m} r_i * (x_i(eta_j) * y_i(eta_j) - z_i(eta_j)); rows of U: x = [0, m), y = [m, 2m), z = [2m, 3m)
+template <int NW>
+__global__ void __launch_bounds__(256) gf_quadratic_points_kernel(const gfe<NW>* u, const gfe<NW>* r, uint64_t plane_stride, uint32_t m, uint32_t k,
+                                                                  gfe<NW> one_plain, gfe<NW> r3, GfConsts<NW> F, gfe<NW>* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * k) return;
+    const uint64_t off = (uint64_t)((j & 1) * 4) * plane_stride + (j >> 1);
+    gfe<NW> acc;
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc.v[w] = 0;
+    for (uint32_t i = 0; i < m; i++) {
+        gfe<NW> xy, z, d, t, s;
+        gf_mul<NW>(xy, gf_load<NW>(u + off + (uint64_t)i * k), gf_load<NW>(u + off + (uint64_t)(m + i) * k), F);   // x y / R
+        gf_mul<NW>(z, gf_load<NW>(u + off + (uint64_t)(2 * m + i) * k), one_plain, F);                                // z / R
+        gf_sub<NW>(d, xy, z, F);
+        gf_mul<NW>(t, d, gf_load<NW>(r + i), F);                                                                      // (x y - z) r / R
+        gf_add<NW>(s, acc, t, F);
+        acc = s;
+    }
+    gfe<NW> y;
+    gf_mul<NW>(y, acc, r3, F);
+    gf_store<NW>(out + j, y);
+}
+
+}  // namespace lg

@@ -21,3 +21,7 @@ int gf_read_codeword_rows(gf_state* g, uint32_t proof, uint32_t row0, uint32_t n
 int gf_open_columns(gf_state* g, uint32_t proof0, uint32_t nproofs, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths);
 int gf_reed_solomon(gf_state* g, const uint64_t* in, uint32_t nrows, uint64_t* out, bool interpolate, bool evaluate);
 bool gf_committed(const gf_state* g);
+// the arithmetic of the three sub-proofs on the resident commitment (batch 1), as the BN254 entry points of the same names
+int gf_interleaved_row_mul(gf_state* g, const uint64_t* r, uint64_t* out);
+int gf_linear_constraint_poly(gf_state* g, const uint64_t* r_a, uint64_t* coeffs_out);
+int gf_quadratic_constraint_poly(gf_state* g, const uint64_t* r, uint64_t* coeffs_out);

@@ -160,6 +160,7 @@ struct gf_state {
     uint32_t* d_idx = nullptr; size_t idx_cap = 0;
     uint8_t* d_path = nullptr; size_t path_cap = 0;
     bool committed = false;
+    gf_state* aux2k = nullptr;   // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
     char* err = nullptr; size_t errlen = 0;
 };
 
@@ -201,6 +202,7 @@ static int grow(gf_state* g, void** p, size_t* cap, size_t need) {
 void gf_destroy(gf_state* g) {
     if (!g) return;
     if (g->stream) hipStreamSynchronize(g->stream);
+    if (g->aux2k) gf_destroy(g->aux2k);
     void* bufs[] = {g->d_pre, g->d_coeffs, g->d_u, g->d_tw_fwd, g->d_tw_inv, g->d_wn, g->d_leaves, g->d_nodes, g->d_sa, g->d_sb, g->d_sc, g->d_idx, g->d_path};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -445,4 +447,94 @@ static int rs_t(gf_state* g, const uint64_t* in, uint32_t nrows, uint64_t* out, 
 int gf_reed_solomon(gf_state* g, const uint64_t* in, uint32_t nrows, uint64_t* out, bool interp, bool eval) {
     if (nrows == 0) return LG_OK;
     return g->nw == 12 ? rs_t<12>(g, in, nrows, out, interp, eval) : rs_t<8>(g, in, nrows, out, interp, eval);
+}
+
+// ---------------------------------------------------------------------------------------------- sub-proof polynomials
+template <int NW>
+static lg::gfe<NW> r3_of(const HostField& f) {
+    uint64_t r3[6];
+    f.mul(r3, f.r2, f.r2);   // R^2 * R^2 / R = R^3
+    return elem_of<NW>(r3);
+}
+
+template <int NW>
+static int row_mul_t(gf_state* g, const uint64_t* r, uint64_t* out) {
+    const size_t eb = 4 * NW;
+    int rc = grow(g, &g->d_sc, &g->sc_bytes, ((size_t)g->rows + g->k) * eb);
+    if (rc != LG_OK) return rc;
+    uint8_t* d_r = static_cast<uint8_t*>(g->d_sc);
+    uint8_t* d_out = d_r + (size_t)g->rows * eb;
+    GF_HIP(g, hipMemcpyAsync(d_r, r, (size_t)g->rows * eb, hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(lg::gf_row_mul_kernel<NW>, dim3((g->k + 255) / 256), dim3(256), 0, g->stream, static_cast<const lg::gfe<NW>*>(g->d_pre),
+                       reinterpret_cast<const lg::gfe<NW>*>(d_r), g->rows, g->k, consts_of<NW>(g->hf), reinterpret_cast<lg::gfe<NW>*>(d_out));
+    GF_HIP(g, hipGetLastError());
+    return read_back(g, out, d_out, (size_t)g->k * eb);
+}
+int gf_interleaved_row_mul(gf_state* g, const uint64_t* r, uint64_t* out) {
+    if (g->batch != 1) return LG_ERR_UNSUPPORTED;
+    return g->nw == 12 ? row_mul_t<12>(g, r, out) : row_mul_t<8>(g, r, out);
+}
+
+// size-2k inverse transform of the 2k point values in d_points (Montgomery) -> coefficients (Montgomery), copied out
+template <int NW>
+static int interpolate_2k(gf_state* g, const void* d_points, uint64_t* coeffs_out) {
+    if (!g->aux2k) {
+        const int rc = gf_create(&g->aux2k, g->field, 1, 2 * g->k, 16 * g->k, 1, g->stream, g->err, g->errlen);
+        if (rc != LG_OK) return rc;
+    }
+    gf_state* x = g->aux2k;
+    const int rc = launch_ntt<NW>(x, d_points, x->d_coeffs, 1, false, 0);
+    if (rc != LG_OK) return rc;
+    return read_back(g, coeffs_out, x->d_coeffs, (size_t)2 * g->k * 4 * NW);
+}
+
+template <int NW>
+static int linear_t(gf_state* g, const uint64_t* r_a, uint64_t* coeffs_out) {
+    const size_t eb = 4 * NW, mat = (size_t)g->rows * g->k;
+    const uint64_t plane = (uint64_t)g->rows * g->k;
+    int rc = grow(g, &g->d_sa, &g->sa_bytes, 2 * mat * eb);
+    if (rc != LG_OK) return rc;
+    rc = grow(g, &g->d_sb, &g->sb_bytes, 8 * mat * eb);
+    if (rc != LG_OK) return rc;
+    rc = grow(g, &g->d_sc, &g->sc_bytes, (size_t)2 * g->k * eb);
+    if (rc != LG_OK) return rc;
+    uint8_t* d_ra = static_cast<uint8_t*>(g->d_sa);
+    uint8_t* d_rc = d_ra + mat * eb;
+    GF_HIP(g, hipMemcpyAsync(d_ra, r_a, mat * eb, hipMemcpyHostToDevice, g->stream));
+    rc = launch_ntt<NW>(g, d_ra, d_rc, g->rows, false, 0);                  // r_polys = small_domain.ifft(row), mod.rs:726-729
+    if (rc != LG_OK) return rc;
+    rc = launch_ntt<NW>(g, d_rc, g->d_sb, g->rows, true, plane);            // their values on the large domain (planes 0 and 4 are used)
+    if (rc != LG_OK) return rc;
+    hipLaunchKernelGGL(lg::gf_linear_points_kernel<NW>, dim3((2 * g->k + 255) / 256), dim3(256), 0, g->stream, static_cast<const lg::gfe<NW>*>(g->d_u),
+                       static_cast<const lg::gfe<NW>*>(g->d_sb), plane, g->rows, g->k, r3_of<NW>(g->hf), consts_of<NW>(g->hf),
+                       static_cast<lg::gfe<NW>*>(g->d_sc));
+    GF_HIP(g, hipGetLastError());
+    return interpolate_2k<NW>(g, g->d_sc, coeffs_out);
+}
+int gf_linear_constraint_poly(gf_state* g, const uint64_t* r_a, uint64_t* coeffs_out) {
+    if (g->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (!g->committed) return LG_ERR_STATE;
+    return g->nw == 12 ? linear_t<12>(g, r_a, coeffs_out) : linear_t<8>(g, r_a, coeffs_out);
+}
+
+template <int NW>
+static int quadratic_t(gf_state* g, const uint64_t* r, uint64_t* coeffs_out) {
+    const size_t eb = 4 * NW;
+    const uint32_t m = g->rows / 4;
+    int rc = grow(g, &g->d_sc, &g->sc_bytes, ((size_t)2 * g->k + m) * eb);
+    if (rc != LG_OK) return rc;
+    uint8_t* d_q = static_cast<uint8_t*>(g->d_sc);
+    uint8_t* d_r = d_q + (size_t)2 * g->k * eb;
+    GF_HIP(g, hipMemcpyAsync(d_r, r, (size_t)m * eb, hipMemcpyHostToDevice, g->stream));
+    uint64_t one[6] = {1, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(lg::gf_quadratic_points_kernel<NW>, dim3((2 * g->k + 255) / 256), dim3(256), 0, g->stream, static_cast<const lg::gfe<NW>*>(g->d_u),
+                       reinterpret_cast<const lg::gfe<NW>*>(d_r), (uint64_t)g->rows * g->k, m, g->k, elem_of<NW>(one), r3_of<NW>(g->hf), consts_of<NW>(g->hf),
+                       reinterpret_cast<lg::gfe<NW>*>(d_q));
+    GF_HIP(g, hipGetLastError());
+    return interpolate_2k<NW>(g, d_q, coeffs_out);
+}
+int gf_quadratic_constraint_poly(gf_state* g, const uint64_t* r, uint64_t* coeffs_out) {
+    if (g->batch != 1 || (g->rows & 3)) return LG_ERR_UNSUPPORTED;
+    if (!g->committed) return LG_ERR_STATE;
+    return g->nw == 12 ? quadratic_t<12>(g, r, coeffs_out) : quadratic_t<8>(g, r, coeffs_out);
 }

@@ -1216,7 +1216,7 @@ static int sub_interpolate_2k(lg_ctx* c, uint64_t* coeffs_out) {
 
 int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
     if (!c || !r || !out) return LG_ERR_BAD_ARG;
-    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_interleaved_row_mul(c->gf, r, out); }
     { const int rc_ = need_all_message_rows(c, "lg_interleaved_row_mul"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     uint32_t per;
@@ -1253,7 +1253,7 @@ static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_o
 
 int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_out) {
     if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
-    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_linear_constraint_poly(c->gf, r_a, coeffs_out); }
     if (!c->committed) return LG_ERR_STATE;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly"); if (rc_ != LG_OK) return rc_; }
@@ -1392,7 +1392,7 @@ static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_o
 
 int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_out) {
     if (!c || !r || !coeffs_out) return LG_ERR_BAD_ARG;
-    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_quadratic_constraint_poly(c->gf, r, coeffs_out); }
     if (!c->committed) return LG_ERR_STATE;
     if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;

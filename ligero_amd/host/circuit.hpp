@@ -12,7 +12,9 @@
 //       reed_solomon_parameters, generate_matrices}                  src/ligero/mod.rs:147-433
 //   prove_inner's x/y/z/w assembly + as_matrix -> preenc_u           src/ligero/mod.rs:476-516, 1014-1017
 //
-// Field: ark_bn254::Fr, Montgomery form, same limbs as the C ABI.  Where the reference panics
+// The classes are templates over the element type E (field.hpp: ark_bn254::Fr, ark_bls12_377::Fq -- the two fields the
+// reference's tests instantiate); the plain names (ArithmeticCircuit, SparseMatrix, LigeroInstance) are the BN254 instances
+// every circom fixture and BASELINE config uses.  Elements are in Montgomery form, same limbs as the C ABI.  Where the reference panics
 // this layer throws std::runtime_error with the reference's message.  Product code: independent
 // of oracle/.
 #pragma once
@@ -23,42 +25,15 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <utility>
 #include <vector>
 
 #include "../csrc/host_fr.h"
+#include "field.hpp"
 
 namespace ligero {
-
-using lg_host::Fr;
-
-inline bool fr_is_zero(const Fr& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
-inline bool fr_eq(const Fr& a, const Fr& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
-inline Fr fr_zero() { return Fr{{0, 0, 0, 0}}; }
-inline Fr fr_one() { return lg_host::kOneMont; }
-inline Fr fr_neg(const Fr& a) { return fr_is_zero(a) ? a : lg_host::sub_raw(lg_host::kP, a); }
-inline Fr fr_add(const Fr& a, const Fr& b) {
-    Fr r;
-    unsigned __int128 c = 0;
-    for (int i = 0; i < 4; i++) {
-        c += (unsigned __int128)a.l[i] + b.l[i];
-        r.l[i] = (uint64_t)c;
-        c >>= 64;
-    }
-    if (c || lg_host::geq(r, lg_host::kP)) r = lg_host::sub_raw(r, lg_host::kP);
-    return r;
-}
-inline Fr fr_sub(const Fr& a, const Fr& b) { return fr_add(a, fr_neg(b)); }
-inline Fr fr_mul(const Fr& a, const Fr& b) { return lg_host::mul(a, b); }
-inline Fr fr_from_u64(uint64_t v) { return lg_host::to_mont(Fr{{v, 0, 0, 0}}); }
-struct FrLess {
-    bool operator()(const Fr& a, const Fr& b) const {
-        for (int i = 3; i >= 0; i--)
-            if (a.l[i] != b.l[i]) return a.l[i] < b.l[i];
-        return false;
-    }
-};
 
 // ---------------------------------------------------------------- .r1cs v1
 struct R1cs {
@@ -131,17 +106,25 @@ inline R1cs read_r1cs(const std::string& path) {
 }
 
 // ---------------------------------------------------------------- arithmetic circuit
-struct Node {
-    enum Kind : uint8_t { Variable, Constant, Add, Mul } kind;
+struct NodeBase {
+    enum Kind : uint8_t { Variable, Constant, Add, Mul };
+};
+template <class E>
+struct NodeT : NodeBase {
+    Kind kind;
     size_t l = 0, r = 0;   // Add / Mul operands
-    Fr value{};            // Constant
+    E value{};             // Constant
     std::string label;     // Variable
 };
+using Node = NodeT<Fr>;
 
-class ArithmeticCircuit {
+template <class E>
+class ArithmeticCircuitT {
 public:
+    using F = Field<E>;
+    using Node = NodeT<E>;
     std::vector<Node> nodes;
-    std::map<Fr, size_t, FrLess> constants;               // value -> index (mod.rs:31)
+    std::map<E, size_t, ElemLess<E>> constants;           // value -> index (mod.rs:31)
     std::unordered_map<std::string, size_t> variables;    // label -> index (mod.rs:33)
 
     size_t num_nodes() const { return nodes.size(); }
@@ -149,16 +132,16 @@ public:
     size_t num_variables() const { return variables.size(); }
     size_t last() const { return nodes.size() - 1; }
 
-    size_t constant(const Fr& v) {                         // mod.rs:76-84
+    size_t constant(const E& v) {                         // mod.rs:76-84
         auto it = constants.find(v);
         if (it != constants.end()) return it->second;
-        nodes.push_back(Node{Node::Constant, 0, 0, v, {}});
+        nodes.push_back(Node{{}, Node::Constant, 0, 0, v, {}});
         constants[v] = nodes.size() - 1;
         return nodes.size() - 1;
     }
     size_t new_variable_with_label(const std::string& label) {   // mod.rs:92-100
         if (variables.count(label)) throw std::runtime_error("Variable label already in use: " + label);
-        nodes.push_back(Node{Node::Variable, 0, 0, {}, label});
+        nodes.push_back(Node{{}, Node::Variable, 0, 0, {}, label});
         variables[label] = nodes.size() - 1;
         return nodes.size() - 1;
     }
@@ -166,13 +149,13 @@ public:
     size_t add(size_t l, size_t r) {                       // mod.rs:125-131
         if (l >= nodes.size()) throw std::runtime_error("Left operand to Add not in circuit:");
         if (r >= nodes.size()) throw std::runtime_error("Right operand to Add not in circuit:");
-        nodes.push_back(Node{Node::Add, l, r, {}, {}});
+        nodes.push_back(Node{{}, Node::Add, l, r, {}, {}});
         return nodes.size() - 1;
     }
     size_t mul(size_t l, size_t r) {                       // mod.rs:139-145
         if (l >= nodes.size()) throw std::runtime_error("Left operand to Mul not in circuit:");
         if (r >= nodes.size()) throw std::runtime_error("Right operand to Mul not in circuit:");
-        nodes.push_back(Node{Node::Mul, l, r, {}, {}});
+        nodes.push_back(Node{{}, Node::Mul, l, r, {}, {}});
         return nodes.size() - 1;
     }
     size_t add_nodes(const std::vector<size_t>& idx) {     // mod.rs:148-153
@@ -194,10 +177,11 @@ public:
         return cur;
     }
     size_t minus(size_t node) {                            // mod.rs:220-223
-        const size_t m1 = constant(fr_neg(fr_one()));
+        const size_t m1 = constant(F::neg(F::one()));
         return mul(m1, node);
     }
-    size_t compile_sparse_scalar_product(const R1cs::Lc& row) {   // mod.rs:501-520
+    size_t compile_sparse_scalar_product(const R1cs::Lc& row) {   // mod.rs:501-520 (circom fixtures: BN254 only)
+        static_assert(std::is_same<E, Fr>::value, "R1CS files carry BN254 Fr coefficients");
         std::vector<std::pair<size_t, size_t>> consts;
         for (const auto& t : row) consts.emplace_back(constant(t.first), (size_t)t.second);
         std::vector<size_t> products;
@@ -206,9 +190,10 @@ public:
         return add_nodes(products);
     }
     // mod.rs:455-495.  Zero coefficients are dropped, as ark-relations' to_matrices does.
-    static std::pair<ArithmeticCircuit, std::vector<size_t>> from_constraint_system(const R1cs& cs) {
-        ArithmeticCircuit c;
-        const size_t one = c.constant(fr_one());
+    static std::pair<ArithmeticCircuitT, std::vector<size_t>> from_constraint_system(const R1cs& cs) {
+        static_assert(std::is_same<E, Fr>::value, "R1CS files carry BN254 Fr coefficients");
+        ArithmeticCircuitT c;
+        const size_t one = c.constant(F::one());
         for (uint32_t i = 1; i < cs.n_wires; i++) c.new_variable();
         auto rows = [&](const std::vector<R1cs::Lc>& mat) {
             std::vector<size_t> out;
@@ -223,7 +208,7 @@ public:
         const auto a = rows(cs.a), b = rows(cs.b), cc = rows(cs.c);
         std::vector<size_t> ab, minus_c, outputs;
         for (size_t i = 0; i < a.size(); i++) ab.push_back(c.mul(a[i], b[i]));
-        const size_t m1 = c.constant(fr_neg(fr_one()));
+        const size_t m1 = c.constant(F::neg(F::one()));
         for (size_t i = 0; i < cc.size(); i++) minus_c.push_back(c.mul(cc[i], m1));
         for (size_t i = 0; i < ab.size(); i++) outputs.push_back(c.add_nodes({ab[i], minus_c[i], one}));
         return {std::move(c), std::move(outputs)};
@@ -231,8 +216,8 @@ public:
     // mod.rs:325-358 (values of every node the outputs depend on; nodes only reference earlier
     // nodes, so one forward sweep gives what the reference's recursion gives).  An unassigned
     // variable is the reference's "Uninitialised variable" panic.
-    std::vector<Fr> evaluation_trace(const std::vector<std::pair<size_t, Fr>>& vars) const {
-        std::vector<Fr> val(nodes.size(), fr_zero());
+    std::vector<E> evaluation_trace(const std::vector<std::pair<size_t, E>>& vars) const {
+        std::vector<E> val(nodes.size(), F::zero());
         std::vector<uint8_t> set(nodes.size(), 0);
         for (const auto& v : vars) {
             if (v.first >= nodes.size() || nodes[v.first].kind != Node::Variable) throw std::runtime_error("Value supplied for non-variable node");
@@ -246,21 +231,24 @@ public:
                 case Node::Variable:
                     if (!set[i]) throw std::runtime_error("Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
                     break;
-                case Node::Add: val[i] = fr_add(val[nd.l], val[nd.r]); break;
-                case Node::Mul: val[i] = fr_mul(val[nd.l], val[nd.r]); break;
+                case Node::Add: val[i] = F::add(val[nd.l], val[nd.r]); break;
+                case Node::Mul: val[i] = F::mul(val[nd.l], val[nd.r]); break;
             }
         }
         return val;
     }
 };
+using ArithmeticCircuit = ArithmeticCircuitT<Fr>;
 
 // ---------------------------------------------------------------- sparse matrix (src/matrices/mod.rs:6-126)
 // The reference keeps a Vec of rows, each a Vec<(F, usize)>.  Same rows, same entry order, but stored compressed
 // (row_ptr + one entry array): the constraint matrix of the 2^20-constraint circuit has 41 M rows and 45 M entries, and
 // one heap allocation per row would cost more memory than the entries themselves.
-struct SparseMatrix {
+template <class E>
+struct SparseMatrixT {
+    using F = Field<E>;
     struct Entry {            // (value, column) -- the reference's (F, usize); a plain struct so that rows move with memcpy
-        Fr first;
+        E first;
         size_t second;
     };
     struct RowView {
@@ -275,30 +263,30 @@ struct SparseMatrix {
     size_t num_cols = 0;
     std::vector<uint64_t> row_ptr{0};
     std::vector<Entry> ent;
-    explicit SparseMatrix(size_t cols = 0) : num_cols(cols) {}
+    explicit SparseMatrixT(size_t cols = 0) : num_cols(cols) {}
     size_t num_rows() const { return row_ptr.size() - 1; }
     RowView row(size_t i) const { return RowView{ent.data() + row_ptr[i], ent.data() + row_ptr[i + 1]}; }
     void push_row(std::initializer_list<Entry> r) { ent.insert(ent.end(), r.begin(), r.end()); row_ptr.push_back(ent.size()); }
     void push_row(const std::vector<Entry>& r) { ent.insert(ent.end(), r.begin(), r.end()); row_ptr.push_back(ent.size()); }
-    void push_row1(const Fr& v, size_t col) { ent.push_back(Entry{v, col}); row_ptr.push_back(ent.size()); }
+    void push_row1(const E& v, size_t col) { ent.push_back(Entry{v, col}); row_ptr.push_back(ent.size()); }
     void push_empty_row() { row_ptr.push_back(ent.size()); }
     void push_empty_rows(size_t n) { row_ptr.resize(row_ptr.size() + n, ent.size()); }
-    static SparseMatrix identity(size_t n) {
-        SparseMatrix m(n);
+    static SparseMatrixT identity(size_t n) {
+        SparseMatrixT m(n);
         m.ent.reserve(n);
         m.row_ptr.reserve(n + 1);
-        const Fr one = fr_one();
+        const E one = F::one();
         for (size_t i = 0; i < n; i++) m.push_row1(one, i);
         return m;
     }
-    static SparseMatrix zero(size_t nr, size_t nc) {
-        SparseMatrix m(nc);
+    static SparseMatrixT zero(size_t nr, size_t nc) {
+        SparseMatrixT m(nc);
         m.push_empty_rows(nr);
         return m;
     }
-    SparseMatrix h_stack(const SparseMatrix& o) && {
+    SparseMatrixT h_stack(const SparseMatrixT& o) && {
         if (num_rows() != o.num_rows()) throw std::runtime_error("Row number mismatch in when stacking matrices horizontally");
-        SparseMatrix out(num_cols + o.num_cols);
+        SparseMatrixT out(num_cols + o.num_cols);
         out.ent.resize(ent.size() + o.ent.size());
         out.row_ptr.resize(row_ptr.size());
         Entry* w = out.ent.data();
@@ -313,7 +301,7 @@ struct SparseMatrix {
         }
         return out;
     }
-    SparseMatrix v_stack(const SparseMatrix& o) && {
+    SparseMatrixT v_stack(const SparseMatrixT& o) && {
         if (num_cols != o.num_cols) throw std::runtime_error("Column number mismatch in when stacking matrices vertically");
         const uint64_t base = ent.size();
         ent.insert(ent.end(), o.ent.begin(), o.ent.end());
@@ -321,30 +309,31 @@ struct SparseMatrix {
         for (size_t i = 1; i < o.row_ptr.size(); i++) row_ptr.push_back(base + o.row_ptr[i]);
         return std::move(*this);
     }
-    SparseMatrix neg() && {
-        for (auto& e : ent) e.first = fr_neg(e.first);
+    SparseMatrixT neg() && {
+        for (auto& e : ent) e.first = F::neg(e.first);
         return std::move(*this);
     }
     // mod.rs:100-110: result[col] += row[i] * value for every entry of row i
-    std::vector<Fr> row_mul(const std::vector<Fr>& row) const {
-        std::vector<Fr> out(num_cols);
+    std::vector<E> row_mul(const std::vector<E>& row) const {
+        std::vector<E> out(num_cols);
         row_mul_into(row.data(), row.size(), out.data());
         return out;
     }
     // the same into caller-owned storage of num_cols elements
-    void row_mul_into(const Fr* rowv, size_t row_len, Fr* out) const {
-        for (size_t c = 0; c < num_cols; c++) out[c] = fr_zero();
+    void row_mul_into(const E* rowv, size_t row_len, E* out) const {
+        for (size_t c = 0; c < num_cols; c++) out[c] = F::zero();
         const size_t n = row_len < num_rows() ? row_len : num_rows();
-        const Fr one = fr_one(), minus_one = fr_neg(fr_one());
+        const E one = F::one(), minus_one = F::neg(F::one());
         for (size_t i = 0; i < n; i++)
             for (const auto& e : row(i)) {  // almost every entry of A is +-1: add / subtract instead of multiplying
-                if (fr_eq(e.first, one)) out[e.second] = fr_add(out[e.second], rowv[i]);
-                else if (fr_eq(e.first, minus_one)) out[e.second] = fr_sub(out[e.second], rowv[i]);
-                else out[e.second] = fr_add(out[e.second], fr_mul(rowv[i], e.first));
+                if (F::eq(e.first, one)) out[e.second] = F::add(out[e.second], rowv[i]);
+                else if (F::eq(e.first, minus_one)) out[e.second] = F::sub(out[e.second], rowv[i]);
+                else out[e.second] = F::add(out[e.second], F::mul(rowv[i], e.first));
             }
     }
     size_t nnz() const { return ent.size(); }
 };
+using SparseMatrix = SparseMatrixT<Fr>;
 
 // ---------------------------------------------------------------- witness files
 // The reference's test reads circom/poseidon/witness.json with serde (src/ligero/tests.rs:384-390: a JSON array of
@@ -444,9 +433,13 @@ inline size_t calculate_t(size_t sec_param, size_t d_num, size_t d_den, size_t c
     return t < codeword_len ? t : codeword_len;
 }
 
-class LigeroInstance {
+template <class E>
+class LigeroInstanceT {
 public:
-    ArithmeticCircuit circuit;
+    using F = Field<E>;
+    using Node = NodeT<E>;
+    using SparseMatrix = SparseMatrixT<E>;
+    ArithmeticCircuitT<E> circuit;
     std::vector<size_t> outputs;
     size_t one_index = 0;
     bool one_found = false;
@@ -454,8 +447,8 @@ public:
     SparseMatrix a;
 
     // mod.rs:147-228
-    LigeroInstance(ArithmeticCircuit c, std::vector<size_t> outs, size_t lambda) : circuit(std::move(c)) {
-        auto it = circuit.constants.find(fr_one());
+    LigeroInstanceT(ArithmeticCircuitT<E> c, std::vector<size_t> outs, size_t lambda) : circuit(std::move(c)) {
+        auto it = circuit.constants.find(F::one());
         if (it != circuit.constants.end()) { one_index = it->second; one_found = true; } else { one_index = 1; one_found = false; }
         if (one_index != 0) insert_one();
         const size_t sol_vec_length = 1 + circuit.num_nodes() - circuit.num_constants() + outs.size();
@@ -463,7 +456,7 @@ public:
         k = 1;
         while (k < m) k <<= 1;
         n = 8 * k;                                                       // reed_solomon_parameters, mod.rs:283-294
-        t = calculate_t(lambda, n - k + 1, n, n);
+        t = calculate_t(lambda, n - k + 1, n, n, F::kModulusBits);
         std::vector<size_t> index_map(circuit.nodes.size(), kNoIndex);   // mod.rs:179-194 (a HashMap there; dense here)
         index_map[0] = 0;
         size_t seen = 0;
@@ -484,19 +477,19 @@ public:
     // flat row-major 4m x k matrix the C ABI takes -- x, y, z, w each padded to m k (mod.rs:506-509), cut into rows of k
     // (as_matrix, mod.rs:1014-1017) and stacked [X; Y; Z; W] (mod.rs:511-516) is exactly the concatenation of the four
     // padded vectors -- without the intermediate Vecs (at 2^20 constraints they are 1.3 GB each way).
-    void build_preenc_into(const std::vector<std::pair<size_t, Fr>>& var_assignment, Fr* out, bool* all_outputs_one = nullptr) const {
-        std::vector<std::pair<size_t, Fr>> bumped;
+    void build_preenc_into(const std::vector<std::pair<size_t, E>>& var_assignment, E* out, bool* all_outputs_one = nullptr) const {
+        std::vector<std::pair<size_t, E>> bumped;
         bumped.reserve(var_assignment.size());
         for (const auto& v : var_assignment) bumped.emplace_back(bump_index(v.first), v.second);
-        const std::vector<Fr> sol = circuit.evaluation_trace(bumped);
+        const std::vector<E> sol = circuit.evaluation_trace(bumped);
         if (all_outputs_one) {
             *all_outputs_one = true;
             for (size_t o : outputs)
-                if (!fr_eq(sol[o], fr_one())) *all_outputs_one = false;
+                if (!F::eq(sol[o], F::one())) *all_outputs_one = false;
         }
         const size_t mk = m * k;
-        std::memset(static_cast<void*>(out), 0, 4 * mk * sizeof(Fr));      // the all-zero limbs are the field's zero
-        Fr *x = out, *y = out + mk, *z = out + 2 * mk, *w = out + 3 * mk;
+        std::memset(static_cast<void*>(out), 0, 4 * mk * sizeof(E));      // the all-zero limbs are the field's zero
+        E *x = out, *y = out + mk, *z = out + 2 * mk, *w = out + 3 * mk;
         size_t pos = 0;
         for (size_t i = 0; i < circuit.nodes.size(); i++) {
             const Node& nd = circuit.nodes[i];
@@ -507,10 +500,10 @@ public:
             pos++;
         }
     }
-    std::vector<std::vector<Fr>> build_preenc_u(const std::vector<std::pair<size_t, Fr>>& var_assignment, bool* all_outputs_one = nullptr) const {
-        std::vector<Fr> flat(4 * m * k);
+    std::vector<std::vector<E>> build_preenc_u(const std::vector<std::pair<size_t, E>>& var_assignment, bool* all_outputs_one = nullptr) const {
+        std::vector<E> flat(4 * m * k);
         build_preenc_into(var_assignment, flat.data(), all_outputs_one);
-        std::vector<std::vector<Fr>> rows;
+        std::vector<std::vector<E>> rows;
         rows.reserve(4 * m);
         for (size_t i = 0; i < 4 * m; i++) rows.emplace_back(flat.begin() + i * k, flat.begin() + (i + 1) * k);
         return rows;
@@ -519,11 +512,11 @@ public:
 private:
     void insert_one() {                                                  // mod.rs:244-271
         if (one_found) circuit.nodes.erase(circuit.nodes.begin() + one_index);
-        circuit.nodes.insert(circuit.nodes.begin(), Node{Node::Constant, 0, 0, fr_one(), {}});
+        circuit.nodes.insert(circuit.nodes.begin(), Node{{}, Node::Constant, 0, 0, F::one(), {}});
         for (auto& nd : circuit.nodes)
             if (nd.kind == Node::Add || nd.kind == Node::Mul) { nd.l = bump_index(nd.l); nd.r = bump_index(nd.r); }
         for (auto& kv : circuit.constants) kv.second = bump_index(kv.second);
-        circuit.constants[fr_one()] = 0;
+        circuit.constants[F::one()] = 0;
         for (auto& kv : circuit.variables) kv.second = bump_index(kv.second);
     }
 
@@ -537,9 +530,9 @@ private:
     SparseMatrix generate_matrices(const std::vector<size_t>& index_map, size_t num_cols) const {   // mod.rs:296-433
         const auto& nodes = circuit.nodes;
         SparseMatrix p_x(num_cols), p_y(num_cols), p_z(num_cols), p_add(num_cols);
-        const Fr one = fr_one(), minus_one = fr_neg(fr_one());
+        const E one = F::one(), minus_one = F::neg(F::one());
         auto add_row = [&](size_t l, size_t r) {
-            std::vector<SparseMatrix::Entry> row;
+            std::vector<typename SparseMatrix::Entry> row;
             if (nodes[l].kind == Node::Constant) row = {{nodes[l].value, 0}, {one, at(index_map, r)}};
             else if (nodes[r].kind == Node::Constant) row = {{one, at(index_map, l)}, {nodes[r].value, 0}};
             else row = {{one, at(index_map, l)}, {one, at(index_map, r)}};
@@ -559,7 +552,7 @@ private:
                 case Node::Add: {
                     p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row();
                     auto row = add_row(nd.l, nd.r);
-                    row.push_back(SparseMatrix::Entry{minus_one, at(index_map, i)});
+                    row.push_back(typename SparseMatrix::Entry{minus_one, at(index_map, i)});
                     p_add.push_row(std::move(row));
                     break;
                 }
@@ -578,7 +571,7 @@ private:
             if (nd.kind == Node::Add) {
                 p_x.push_empty_row(); p_y.push_empty_row(); p_z.push_empty_row();
                 auto row = add_row(nd.l, nd.r);
-                row.push_back(SparseMatrix::Entry{minus_one, 0});
+                row.push_back(typename SparseMatrix::Entry{minus_one, 0});
                 p_add.push_row(std::move(row));
             } else if (nd.kind == Node::Mul) {
                 p_add.push_empty_row();
@@ -601,21 +594,22 @@ private:
         SparseMatrix a(4 * mk);
         a.row_ptr.resize(4 * mk + 1);
         a.ent.resize(3 * mk + p_x.nnz() + p_y.nnz() + p_z.nnz() + p_add.nnz());
-        SparseMatrix::Entry* w = a.ent.data();
+        typename SparseMatrix::Entry* w = a.ent.data();
         size_t r_out = 0;
         const SparseMatrix* upper_blocks[3] = {&p_x, &p_y, &p_z};
         for (const SparseMatrix* blk : upper_blocks)
             for (size_t r = 0; r < mk; r++, r_out++) {
-                *w++ = SparseMatrix::Entry{one, r_out};
-                for (const auto& e : blk->row(r)) *w++ = SparseMatrix::Entry{fr_neg(e.first), e.second + 3 * mk};
+                *w++ = typename SparseMatrix::Entry{one, r_out};
+                for (const auto& e : blk->row(r)) *w++ = typename SparseMatrix::Entry{F::neg(e.first), e.second + 3 * mk};
                 a.row_ptr[r_out + 1] = (uint64_t)(w - a.ent.data());
             }
         for (size_t r = 0; r < mk; r++, r_out++) {
-            for (const auto& e : p_add.row(r)) *w++ = SparseMatrix::Entry{e.first, e.second + 3 * mk};
+            for (const auto& e : p_add.row(r)) *w++ = typename SparseMatrix::Entry{e.first, e.second + 3 * mk};
             a.row_ptr[r_out + 1] = (uint64_t)(w - a.ent.data());
         }
         return a;
     }
 };
+using LigeroInstance = LigeroInstanceT<Fr>;
 
 }  // namespace ligero

@@ -26,6 +26,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -36,24 +37,32 @@
 
 namespace ligero {
 
-struct OpenedColumns {
-    std::vector<std::vector<Fr>> columns;  // t columns of 4m elements
+template <class E>
+struct OpenedColumnsT {
+    std::vector<std::vector<E>> columns;  // t columns of 4m elements
     std::vector<MerklePath> paths;
 };
-struct InterleavedProof {       // src/ligero/types.rs InterleavedProof
-    std::vector<Fr> preenc_u_lc;
-    OpenedColumns open;
+template <class E>
+struct InterleavedProofT {      // src/ligero/types.rs InterleavedProof
+    std::vector<E> preenc_u_lc;
+    OpenedColumnsT<E> open;
 };
-struct ConstraintsProof {       // LinearConstraintsProof / QuadraticConstraintsProof
-    std::vector<Fr> polynomial;  // DensePolynomial coefficients, trailing zeros trimmed
-    OpenedColumns open;
+template <class E>
+struct ConstraintsProofT {      // LinearConstraintsProof / QuadraticConstraintsProof
+    std::vector<E> polynomial;  // DensePolynomial coefficients, trailing zeros trimmed
+    OpenedColumnsT<E> open;
 };
-struct LigeroProof {
+template <class E>
+struct LigeroProofT {
     Digest u_root;
-    InterleavedProof interleaved_proof;
-    ConstraintsProof linear_constraints_proof;
-    ConstraintsProof quadratic_constraints_proof;
+    InterleavedProofT<E> interleaved_proof;
+    ConstraintsProofT<E> linear_constraints_proof;
+    ConstraintsProofT<E> quadratic_constraints_proof;
 };
+using OpenedColumns = OpenedColumnsT<Fr>;
+using InterleavedProof = InterleavedProofT<Fr>;
+using ConstraintsProof = ConstraintsProofT<Fr>;
+using LigeroProof = LigeroProofT<Fr>;
 
 struct DeviceError : std::runtime_error {
     int status;
@@ -61,7 +70,9 @@ struct DeviceError : std::runtime_error {
 };
 
 // natural-order radix-2 NTT on the host (the verifier's intermediate_domain.fft of 2k points, mod.rs:786, 885)
-inline std::vector<Fr> host_fft(std::vector<Fr> a) {
+template <class E>
+inline std::vector<E> host_fft(std::vector<E> a) {
+    using F = Field<E>;
     const size_t n = a.size();
     int logn = 0;
     while ((size_t{1} << logn) < n) logn++;
@@ -74,11 +85,11 @@ inline std::vector<Fr> host_fft(std::vector<Fr> a) {
     }
     for (int s = 1; s <= logn; s++) {
         const size_t len = size_t{1} << s;
-        const Fr wlen = lg_host::domain_generator(s);
+        const E wlen = F::domain_generator(s);
         for (size_t i = 0; i < n; i += len) {
-            Fr w = fr_one();
+            E w = F::one();
             for (size_t j = 0; j < len / 2; j++) {
-                const Fr u = a[i + j], v = fr_mul(a[i + j + len / 2], w);
+                const E u = a[i + j], v = fr_mul(a[i + j + len / 2], w);
                 a[i + j] = fr_add(u, v);
                 a[i + j + len / 2] = fr_sub(u, v);
                 w = fr_mul(w, wlen);
@@ -88,26 +99,30 @@ inline std::vector<Fr> host_fft(std::vector<Fr> a) {
     return a;
 }
 
-inline Fr poly_evaluate(const std::vector<Fr>& coeffs, const Fr& x) {
-    Fr acc = fr_zero();
+template <class E>
+inline E poly_evaluate(const std::vector<E>& coeffs, const E& x) {
+    E acc = Field<E>::zero();
     for (size_t i = coeffs.size(); i-- > 0;) acc = fr_add(fr_mul(acc, x), coeffs[i]);
     return acc;
 }
-inline void trim_zeros(std::vector<Fr>& c) {  // DensePolynomial::from_coefficients_vec
+template <class E>
+inline void trim_zeros(std::vector<E>& c) {  // DensePolynomial::from_coefficients_vec
     while (!c.empty() && fr_is_zero(c.back())) c.pop_back();
 }
 
-// FieldToBytesColHasher<F, Blake2s256>::evaluate (types.rs:18): Blake2s(LE64(len) || 32-byte LE canonical elements)
-inline Digest column_hash(const std::vector<Fr>& col) {
+// FieldToBytesColHasher<F, Blake2s256>::evaluate (types.rs:18): Blake2s(LE64(len) || canonical elements, 8 bytes per limb LE)
+template <class E>
+inline Digest column_hash(const std::vector<E>& col) {
+    using F = Field<E>;
     Blake2s h;
     uint8_t len[8];
     for (int i = 0; i < 8; i++) len[i] = (uint8_t)((uint64_t)col.size() >> (8 * i));
     h.update(len, 8);
-    for (const Fr& e : col) {
-        const Fr c = lg_host::from_mont(e);
-        uint8_t b[32];
-        for (int i = 0; i < 32; i++) b[i] = (uint8_t)(c.l[i / 8] >> (8 * (i % 8)));
-        h.update(b, 32);
+    for (const E& e : col) {
+        const E c = F::from_mont(e);
+        uint8_t b[8 * F::kLimbs];
+        for (int i = 0; i < 8 * F::kLimbs; i++) b[i] = (uint8_t)(c.l[i / 8] >> (8 * (i % 8)));
+        h.update(b, sizeof(b));
     }
     return h.finalize();
 }
@@ -129,21 +144,36 @@ inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
     if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
 }
 
-class HipLigero {
+// E = Fr: the tuned BN254 device path, linear-test challenges generated on the device.  Any other element type (the
+// reference's second test field, ark_bls12_377::Fq): a generic-field context (lg_ctx_create_field), challenges and A.row_mul on
+// the host, the same device calls otherwise.
+template <class E>
+class HipLigeroT {
+    using F = Field<E>;
+    using Fr = E;   // (the body below was written for one field; within this class `Fr` is the element type)
+    using LigeroInstance = LigeroInstanceT<E>;
+    using LigeroProof = LigeroProofT<E>;
+    using InterleavedProof = InterleavedProofT<E>;
+    using ConstraintsProof = ConstraintsProofT<E>;
+    using OpenedColumns = OpenedColumnsT<E>;
+    using PoseidonSponge = PoseidonSpongeT<E>;
+    static constexpr bool kDeviceChallenges = std::is_same<E, lg_host::Fr>::value;
+    static Fr fr_zero() { return F::zero(); }
+
 public:
-    HipLigero(const LigeroInstance& inst, int device = 0) : inst_(inst), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t) {
-        const int st = lg_ctx_create(&ctx_, device, (uint32_t)(4 * m_), (uint32_t)k_, (uint32_t)n_);
-        if (st != LG_OK) throw DeviceError(st, "lg_ctx_create");
+    HipLigeroT(const LigeroInstance& inst, int device = 0) : inst_(inst), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t) {
+        const int st = lg_ctx_create_field(&ctx_, device, F::kLgField, (uint32_t)(4 * m_), (uint32_t)k_, (uint32_t)n_, 1);
+        if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_field");
         logn_ = 0;
         while ((size_t{1} << logn_) < n_) logn_++;
-        upload_constraint_matrix(ctx_, inst.a);
+        if constexpr (kDeviceChallenges) upload_constraint_matrix(ctx_, inst.a);
     }
-    ~HipLigero() {
+    ~HipLigeroT() {
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
         lg_ctx_destroy(ctx_);
     }
-    HipLigero(const HipLigero&) = delete;
-    HipLigero& operator=(const HipLigero&) = delete;
+    HipLigeroT(const HipLigeroT&) = delete;
+    HipLigeroT& operator=(const HipLigeroT&) = delete;
 
     // ---------------------------------------------------------------- prove (mod.rs:435-578)
     LigeroProof prove(const std::vector<std::pair<size_t, Fr>>& var_assignment, PoseidonSponge& sponge) {
@@ -159,7 +189,7 @@ public:
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
 
         {   // prove_interleaved, mod.rs:646-669
-            const std::vector<Fr> r = get_field_elements_from_prng(4 * m_, sponge.squeeze_seed());
+            const std::vector<Fr> r = get_field_elements_from_prng<E>(4 * m_, sponge.squeeze_seed());
             proof.interleaved_proof.preenc_u_lc.resize(k_);
             check(lg_interleaved_row_mul(ctx_, r[0].l, proof.interleaved_proof.preenc_u_lc[0].l), "lg_interleaved_row_mul");
             sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
@@ -169,14 +199,19 @@ public:
             // r_linear (ChaCha20 + F::rand) and r_a = A.row_mul(r_linear) are produced on the device from the seed
             const std::array<uint8_t, 32> seed = sponge.squeeze_seed();
             std::vector<Fr> poly(2 * k_);
-            check(lg_linear_constraint_poly_from_seeds(ctx_, seed.data(), poly[0].l), "lg_linear_constraint_poly_from_seeds");
+            if constexpr (kDeviceChallenges) {
+                check(lg_linear_constraint_poly_from_seeds(ctx_, seed.data(), poly[0].l), "lg_linear_constraint_poly_from_seeds");
+            } else {   // mod.rs:719-722 on the host, the polynomial on the device
+                const std::vector<Fr> r_a = inst_.a.row_mul(get_field_elements_from_prng<E>(4 * m_ * k_, seed));
+                check(lg_linear_constraint_poly(ctx_, r_a[0].l, poly[0].l), "lg_linear_constraint_poly");
+            }
             trim_zeros(poly);
             proof.linear_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
             proof.linear_constraints_proof.open = open_columns(sponge);
         }
         {   // prove_quadratic_constraints, mod.rs:832-859
-            const std::vector<Fr> r = get_field_elements_from_prng(m_, sponge.squeeze_seed());
+            const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
             std::vector<Fr> poly(2 * k_);
             check(lg_quadratic_constraint_poly(ctx_, r[0].l, poly[0].l), "lg_quadratic_constraint_poly");
             trim_zeros(poly);
@@ -243,7 +278,7 @@ private:
 
     // mod.rs:671-708
     bool verify_interleaved(const InterleavedProof& p, const Digest& root, PoseidonSponge& sponge) {
-        const std::vector<Fr> r = get_field_elements_from_prng(4 * m_, sponge.squeeze_seed());
+        const std::vector<Fr> r = get_field_elements_from_prng<E>(4 * m_, sponge.squeeze_seed());
         sponge.absorb_elements(p.preenc_u_lc);
         if (!verify_column_openings(p.open, root, sponge)) return false;
         if (p.preenc_u_lc.size() > k_) return false;
@@ -261,7 +296,7 @@ private:
 
     // mod.rs:748-830
     bool verify_linear(const ConstraintsProof& p, const Digest& root, PoseidonSponge& sponge) {
-        const std::vector<Fr> r_linear = get_field_elements_from_prng(4 * m_ * k_, sponge.squeeze_seed());
+        const std::vector<Fr> r_linear = get_field_elements_from_prng<E>(4 * m_ * k_, sponge.squeeze_seed());
         const std::vector<Fr> r_a = inst_.a.row_mul(r_linear);
         // r_polys = small_domain.ifft of every k-chunk of r_a (mod.rs:773-781)
         std::vector<Fr> r_polys(4 * m_ * k_);
@@ -290,10 +325,10 @@ private:
             }
         }
         const size_t cofactor = n_ / (2 * k_);
-        const Fr wn = lg_host::domain_generator(logn_);
+        const Fr wn = F::domain_generator(logn_);
         for (size_t c = 0; c < nopen; c++) {   // sum_i r_i(eta_j) * U_{i, j} = q(eta_j), mod.rs:820-829
             const size_t j = p.open.paths[c].leaf_index;
-            const Fr eval = (j % cofactor == 0) ? inter[j / cofactor] : poly_evaluate(p.polynomial, lg_host::pow_u64(wn, j));
+            const Fr eval = (j % cofactor == 0) ? inter[j / cofactor] : poly_evaluate(p.polynomial, F::pow_u64(wn, j));
             if (!fr_eq(acc[c], eval)) return false;
         }
         return true;
@@ -301,7 +336,7 @@ private:
 
     // mod.rs:861-933
     bool verify_quadratic_constraints(const ConstraintsProof& p, const Digest& root, PoseidonSponge& sponge) {
-        const std::vector<Fr> r = get_field_elements_from_prng(m_, sponge.squeeze_seed());
+        const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
         if (!p.polynomial.empty() && p.polynomial.size() - 1 >= 2 * k_ - 1) return false;
         std::vector<Fr> p0 = p.polynomial;
         p0.resize(2 * k_, fr_zero());
@@ -311,11 +346,11 @@ private:
         const size_t cofactor = n_ / (2 * k_);
         sponge.absorb_elements(p.polynomial);
         if (!verify_column_openings(p.open, root, sponge)) return false;
-        const Fr wn = lg_host::domain_generator(logn_);
+        const Fr wn = F::domain_generator(logn_);
         for (size_t c = 0; c < p.open.columns.size(); c++) {
             const size_t col = p.open.paths[c].leaf_index;
             const std::vector<Fr>& column = p.open.columns[c];
-            const Fr lhs = (col % cofactor == 0) ? inter[col / cofactor] : poly_evaluate(p.polynomial, lg_host::pow_u64(wn, col));
+            const Fr lhs = (col % cofactor == 0) ? inter[col / cofactor] : poly_evaluate(p.polynomial, F::pow_u64(wn, col));
             Fr rhs = fr_zero();
             for (size_t i = 0; i < m_; i++)
                 rhs = fr_add(rhs, fr_mul(r[i], fr_sub(fr_mul(column[i], column[i + m_]), column[i + 2 * m_])));
@@ -331,6 +366,7 @@ private:
     std::vector<Fr> flat_;      // preenc_u of the proof being made (reused between proofs)
     bool pinned_ = false;
 };
+using HipLigero = HipLigeroT<Fr>;
 
 // ---------------------------------------------------------------- throughput mode (BASELINE configs[4])
 // `batch` independent proofs of the same circuit per call: every device step is ONE batch-wide call of

@@ -120,24 +120,29 @@ private:
 using ChaCha20Rng = ChaChaRng<20>;
 using StdRng = ChaChaRng<12>;  // rand 0.8
 
-// F::rand: four u64 limbs, top two bits masked off (256 - 254), rejected while >= p; the limbs are the
-// element's internal (Montgomery) representation as they are
-template <class Rng>
-inline Fr fr_rand(Rng& rng) {
+// F::rand: N u64 limbs, the bits above MODULUS_BIT_SIZE masked off (two for BN254 Fr, seven for BLS12-377 Fq), rejected while
+// >= p; the limbs are the element's internal (Montgomery) representation as they are
+template <class E, class Rng>
+inline E field_rand(Rng& rng) {
+    using F = Field<E>;
     for (;;) {
-        Fr t;
-        for (int i = 0; i < 4; i++) t.l[i] = rng.next_u64();
-        t.l[3] &= ~0ull >> 2;
-        if (!lg_host::geq(t, lg_host::kP)) return t;
+        E t;
+        for (int i = 0; i < F::kLimbs; i++) t.l[i] = rng.next_u64();
+        t.l[F::kLimbs - 1] &= ~0ull >> (64 * F::kLimbs - F::kModulusBits);
+        if (!F::geq_modulus(t)) return t;
     }
 }
+template <class Rng>
+inline Fr fr_rand(Rng& rng) { return field_rand<Fr>(rng); }
 
-inline void fill_field_elements_from_prng(Fr* out, size_t n, const std::array<uint8_t, 32>& seed) {
+template <class E>
+inline void fill_field_elements_from_prng(E* out, size_t n, const std::array<uint8_t, 32>& seed) {
     ChaCha20Rng rng(seed);
-    for (size_t i = 0; i < n; i++) out[i] = fr_rand(rng);
+    for (size_t i = 0; i < n; i++) out[i] = field_rand<E>(rng);
 }
-inline std::vector<Fr> get_field_elements_from_prng(size_t n, const std::array<uint8_t, 32>& seed) {
-    std::vector<Fr> out(n);
+template <class E = Fr>
+inline std::vector<E> get_field_elements_from_prng(size_t n, const std::array<uint8_t, 32>& seed) {
+    std::vector<E> out(n);
     fill_field_elements_from_prng(out.data(), n, seed);
     return out;
 }
@@ -170,12 +175,21 @@ inline std::vector<uint64_t> get_distinct_indices_from_prng(uint64_t n, uint64_t
 // ---- Poseidon duplex sponge, width 3 (rate 2 + capacity 1)
 inline Fr fr_pow_u64(Fr base, uint64_t e) { return lg_host::pow_u64(base, e); }
 
-class PoseidonSponge {
+template <class E>
+class PoseidonSpongeT {
+    using F = Field<E>;
+    using Fr = E;   // (the body below was written for one field; within this class `Fr` is the element type)
+    static Fr fr_zero() { return F::zero(); }
+    static Fr fr_one() { return F::one(); }
+    static Fr fr_pow_u64(const Fr& b, uint64_t e) { return F::pow_u64(b, e); }
+    // bytes packed per field element by absorb(&Vec<u8>) and taken per element by squeeze_bytes: (MODULUS_BIT_SIZE - 1) / 8
+    static constexpr size_t kUsableBytes = (F::kModulusBits - 1) / 8;
+
 public:
     // test_sponge(): 8 full + 31 partial rounds, alpha = 17, mds [[1,0,1],[1,1,0],[0,1,1]], round constants
     // 39 x 3 draws of F::rand from ark_std::test_rng() (StdRng seeded with the bytes below)
-    static PoseidonSponge test_sponge() {
-        PoseidonSponge s;
+    static PoseidonSpongeT test_sponge() {
+        PoseidonSpongeT s;
         s.full_rounds_ = 8;
         s.partial_rounds_ = 31;
         s.alpha_ = 17;
@@ -187,24 +201,25 @@ public:
             StdRng rng(seed);
             std::vector<std::array<Fr, 3>> a(8 + 31);
             for (auto& row : a)
-                for (auto& x : row) x = fr_rand(rng);
+                for (auto& x : row) x = field_rand<E>(rng);
             return a;
         }();
         s.ark_ = ark;
         return s;
     }
 
-    // absorb(&Vec<u8>): LE64(len) || bytes, packed 31 bytes per field element, little endian
+    // absorb(&Vec<u8>): LE64(len) || bytes, packed (MODULUS_BIT_SIZE - 1) / 8 bytes per field element (31 for BN254 Fr, 47 for
+    // BLS12-377 Fq), little endian
     void absorb_bytes(const uint8_t* data, size_t len) {
         std::vector<uint8_t> bytes(8 + len);
         for (int i = 0; i < 8; i++) bytes[i] = (uint8_t)((uint64_t)len >> (8 * i));
         memcpy(bytes.data() + 8, data, len);
         std::vector<Fr> elems;
-        for (size_t off = 0; off < bytes.size(); off += 31) {
-            const size_t take = std::min<size_t>(31, bytes.size() - off);
-            Fr canon = {{0, 0, 0, 0}};
+        for (size_t off = 0; off < bytes.size(); off += kUsableBytes) {
+            const size_t take = std::min<size_t>(kUsableBytes, bytes.size() - off);
+            Fr canon = F::zero();
             for (size_t i = 0; i < take; i++) canon.l[i / 8] |= (uint64_t)bytes[off + i] << (8 * (i % 8));
-            elems.push_back(lg_host::to_mont(canon));
+            elems.push_back(F::to_mont(canon));
         }
         absorb_elements(elems);
     }
@@ -238,13 +253,13 @@ public:
         }
         return out;
     }
-    // squeeze_bytes: ceil(n / 31) elements, the low 31 little-endian bytes of each, truncated to n
+    // squeeze_bytes: ceil(n / usable) elements, the low `usable` little-endian bytes of each, truncated to n
     std::vector<uint8_t> squeeze_bytes(size_t n) {
-        const size_t usable = 31, nelem = (n + usable - 1) / usable;
+        const size_t usable = kUsableBytes, nelem = (n + usable - 1) / usable;
         const std::vector<Fr> src = squeeze_native_field_elements(nelem);
         std::vector<uint8_t> bytes;
         for (const Fr& e : src) {
-            const Fr c = lg_host::from_mont(e);
+            const Fr c = F::from_mont(e);
             for (size_t i = 0; i < usable; i++) bytes.push_back((uint8_t)(c.l[i / 8] >> (8 * (i % 8))));
         }
         bytes.resize(n);
@@ -336,5 +351,6 @@ private:
     bool squeezing_ = false;  // DuplexSpongeMode
     size_t next_index_ = 0;
 };
+using PoseidonSponge = PoseidonSpongeT<Fr>;
 
 }  // namespace ligero

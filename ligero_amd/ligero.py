@@ -250,16 +250,16 @@ class LigeroCommitter:
     # -- sub-proof polynomials on the resident commitment (mod.rs:658, 723-736, 842-848), whole batch per call
     def interleaved_row_mul(self, r) -> np.ndarray:
         """prove_interleaved: preenc_u.row_mul(r_interleaved) (mod.rs:658); r: (batch*rows, 4) -> (batch, k, 4)"""
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * self.rows, 4)
-        out = np.empty((self.batch, self.k, 4), dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * self.rows, self.ew)
+        out = np.empty((self.batch, self.k, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_interleaved_row_mul(self._ctx, _ptr(r), _ptr(out)), "lg_interleaved_row_mul")
         return out
 
     def linear_constraint_poly(self, r_a) -> np.ndarray:
         """prove_linear_constraints (mod.rs:723-736): r_a = A.row_mul(r_linear) as (batch*rows, k, 4) ->
         (batch, 2k, 4) coefficients of sum_i u_polys[i] * ifft(r_a_i) (zero padded)"""
-        r_a = np.ascontiguousarray(r_a, dtype=np.uint64).reshape(self.batch * self.rows, self.k, 4)
-        out = np.empty((self.batch, 2 * self.k, 4), dtype=np.uint64)
+        r_a = np.ascontiguousarray(r_a, dtype=np.uint64).reshape(self.batch * self.rows, self.k, self.ew)
+        out = np.empty((self.batch, 2 * self.k, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_linear_constraint_poly(self._ctx, _ptr(r_a), _ptr(out)), "lg_linear_constraint_poly")
         return out
 
@@ -284,8 +284,8 @@ class LigeroCommitter:
 
     def quadratic_constraint_poly(self, r) -> np.ndarray:
         """prove_quadratic_constraints (mod.rs:842-848): r: (batch*rows/4, 4) -> (batch, 2k, 4) coefficients"""
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * (self.rows // 4), 4)
-        out = np.empty((self.batch, 2 * self.k, 4), dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(self.batch * (self.rows // 4), self.ew)
+        out = np.empty((self.batch, 2 * self.k, self.ew), dtype=np.uint64)
         self._chk(self._L.lg_quadratic_constraint_poly(self._ctx, _ptr(r), _ptr(out)), "lg_quadratic_constraint_poly")
         return out
 

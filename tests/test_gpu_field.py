@@ -5,6 +5,8 @@
   * over BN254 Fr they must reproduce the C oracle AND the tuned path bit for bit (a cross-check of the kernels themselves);
   * over BLS12-377 Fq they must reproduce the Python big-int model (oracle/model_field.py) -- coefficients, codeword, the
     Blake2s leaves over 48-byte elements, tree, root, openings."""
+import os
+
 import numpy as np
 import pytest
 
@@ -105,5 +107,37 @@ def test_generic_context_limits_and_unsupported_calls(lg):
             c.root()                                                               # nothing committed yet
         assert e.value.status == _ffi.LG_ERR_STATE
         with pytest.raises(lg.LigeroHipError) as e:
-            c.quadratic_constraint_poly(np.zeros((1, 4), dtype=np.uint64))
+            c.quadratic_constraint_poly(np.zeros((1, 6), dtype=np.uint64))         # needs a commitment
+        assert e.value.status == _ffi.LG_ERR_STATE
+        with pytest.raises(lg.LigeroHipError) as e:
+            c.profile(True)                                                         # tuned-path-only call
         assert e.value.status == _ffi.LG_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("rows,k", [(12, 8), (16, 4), (344, 128), (8, 1024)])
+def test_generic_sub_proof_polynomials_on_bn254_match_oracle(lg, oracle, rows, k):
+    """the three sub-proof reductions of the portable path (mod.rs:658, 723-736, 842-848), instantiated for BN254, against the
+    oracle -- the same kernels serve ark_bls12_377::Fq in the prove / verify mirror below"""
+    from ligero_amd import _ffi
+    m = rows // 4
+    pre = random_mont(3 * rows + k, rows * k).reshape(rows, k, 4)
+    r_int = random_mont(21, rows).reshape(rows, 4)
+    r_a = random_mont(22, rows * k).reshape(rows, k, 4)
+    r_q = random_mont(23, m).reshape(m, 4)
+    with lg.LigeroCommitter(rows=rows, k=k, field=_ffi.LG_FIELD_BN254_FR_GENERIC) as c:
+        coeffs, _ = c.encode_commit(pre)
+        assert np.array_equal(c.interleaved_row_mul(r_int)[0], oracle.dense_row_mul(pre, r_int))
+        assert np.array_equal(c.linear_constraint_poly(r_a)[0], oracle.linear_constraint_poly(coeffs, r_a))
+        assert np.array_equal(c.quadratic_constraint_poly(r_q)[0], oracle.quadratic_constraint_poly(coeffs, r_q))
+
+
+def test_prove_and_verify_bls12_377():
+    """src/ligero/tests.rs:186-193 mirrored in C++ over the templated host classes and the generic-field device path
+    (ligero_amd/host/example_bls12_377.cpp): y^2 = x^3 + 1 over Fq, (m, k) = (4, 4), a curve point is accepted, x + 1 is rejected"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ligero_amd", "host", "example_bls12_377")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "test_prove_and_verify_bls12_377: ok" in r.stdout
+    assert r.stdout.count("valid assignment accepted, x + 1 rejected") == 2
