@@ -82,7 +82,9 @@ int lg_ctx_create_sharded(lg_ctx** out, int device, uint32_t rows, uint32_t k, u
  *   LG_FIELD_BN254_FR           the tuned path (what lg_ctx_create / _batched give)
  *   LG_FIELD_BLS12_377_FQ       portable kernels (generic_kernels.h): the hot path -- lg_encode_commit, lg_upload_preenc /
  *                               lg_commit_resident / lg_sync, lg_read_*, lg_open_columns[_batch], lg_reed_solomon* -- for
- *                               k <= 2048; the sub-proof, staged, streaming-registration and profiling calls return LG_ERR_UNSUPPORTED
+ *                               k <= 2048, and lg_interleaved_row_mul / lg_linear_constraint_poly / lg_quadratic_constraint_poly
+ *                               for batch 1 and k <= 1024; the device-side challenge generation, the staged and the profiling
+ *                               calls return LG_ERR_UNSUPPORTED
  *   LG_FIELD_BN254_FR_GENERIC   BN254 Fr through the same portable kernels (k <= 4096): a cross-check, not a product mode
  */
 typedef enum lg_field { LG_FIELD_BN254_FR = 0, LG_FIELD_BLS12_377_FQ = 1, LG_FIELD_BN254_FR_GENERIC = 2 } lg_field;

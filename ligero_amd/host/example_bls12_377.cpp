@@ -27,7 +27,16 @@ static bool proof_and_verify(const ArithmeticCircuitT<E>& circuit, const std::ve
     return prover.verify(proof, vs);
 }
 
+static int run();
 int main() {
+    try {
+        return run();
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 3;
+    }
+}
+static int run() {
     // generate_bls12_377_circuit
     ArithmeticCircuitT<E> circuit;
     const size_t one = circuit.constant(F::one());
@@ -60,6 +69,37 @@ int main() {
     const E Y2 = F::sub(F::mul(lam, F::sub(X, X2)), Y);
 
     int failures = 0;
+    {   // test_construction_bls12_377 (tests.rs:35-142): the induced matrices P_x, P_y, P_z, P_add inside A = [[I, -P_xyz], [0, P_add]]
+        LigeroInstanceT<E> lc(circuit, {circuit.last()}, 128);
+        const size_t mk = lc.m * lc.k;   // 16
+        const E one_e = F::one(), minus = F::neg(F::one());
+        struct Ent { int sign; size_t col; };
+        auto row_is = [&](size_t row, bool identity, std::initializer_list<Ent> want, int flip) {
+            const auto r = lc.a.row(row);
+            size_t pos = 0;
+            if (identity) { if (r.size() < 1 || !F::eq(r[0].first, one_e) || r[0].second != row) return false; pos = 1; }
+            if (r.size() != pos + want.size()) return false;
+            for (const Ent& w : want) {
+                const E v = (w.sign * flip > 0) ? one_e : minus;
+                if (!F::eq(r[pos].first, v) || r[pos].second != 3 * mk + w.col) return false;
+                pos++;
+            }
+            return true;
+        };
+        bool ok = lc.a.num_rows() == 4 * mk && lc.a.num_cols == 4 * mk;
+        // rows 3..6 of P_x, P_y, P_z (negated in A), rows 7..10 of P_add
+        const Ent px[4][1] = {{{1, 2}}, {{-1, 0}}, {{1, 1}}, {{1, 5}}}, py[4][1] = {{{1, 2}}, {{1, 3}}, {{1, 1}}, {{1, 1}}}, pz[4][1] = {{{1, 3}}, {{1, 4}}, {{1, 5}}, {{1, 6}}};
+        for (int i = 0; i < 4; i++) {
+            ok = ok && row_is(3 + i, true, {px[i][0]}, -1) && row_is(mk + 3 + i, true, {py[i][0]}, -1) && row_is(2 * mk + 3 + i, true, {pz[i][0]}, -1);
+            ok = ok && lc.a.row(3 * mk + 3 + i).empty();
+        }
+        ok = ok && row_is(3 * mk + 7, false, {{1, 6}, {1, 0}, {-1, 7}}, 1) && row_is(3 * mk + 8, false, {{1, 7}, {1, 4}, {-1, 8}}, 1) &&
+             row_is(3 * mk + 9, false, {{1, 8}, {1, 0}, {-1, 9}}, 1) && row_is(3 * mk + 10, false, {{1, 8}, {1, 0}, {-1, 0}}, 1);
+        for (size_t r0 : {size_t{0}, size_t{1}, size_t{2}, size_t{7}, size_t{11}, size_t{15}}) ok = ok && row_is(r0, true, {}, -1);
+        printf("test_construction_bls12_377 (A matrix tables): %s\n", ok ? "ok" : "MISMATCH");
+        fflush(stdout);
+        failures += ok ? 0 : 1;
+    }
     const std::pair<const char*, std::pair<E, E>> points[] = {{"G", {X, Y}}, {"2G", {X2, Y2}}};
     for (const auto& pt : points) {
         std::vector<std::pair<size_t, E>> vars = {{1, pt.second.first}, {2, pt.second.second}};
