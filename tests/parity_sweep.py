@@ -39,7 +39,17 @@ def sweep(budget: float, seed: int) -> int:
             os.environ["LG_FORCE_CHUNKS"] = str(force)
         else:
             os.environ.pop("LG_FORCE_CHUNKS", None)
+        # both column-hash kernels and both stream layouts of single-chunk commits (round 2), whatever the size
+        os.environ["LG_HASH_QUAD_MAX_COLUMNS"] = str(rng.choice([0, 32768, 1 << 40]))
+        os.environ["LG_ASYNC_HASH"] = str(int(rng.integers(2)))
         with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+            # other commitments first: the U double buffer, the parked Blake2s states and the asynchronous tree must not leak
+            for _ in range(int(rng.integers(3))):
+                other = random_mont(seed + 7, batch * rows * k).reshape(batch * rows, k, 4)
+                if rng.integers(2):
+                    c.encode_commit(other, want_coeffs=False)
+                else:
+                    c.upload(other); c.commit_resident()
             if rng.integers(2):
                 coeffs, roots = c.encode_commit(pre)
             else:
@@ -60,7 +70,8 @@ def sweep(budget: float, seed: int) -> int:
                     want = oracle.quadratic_constraint_poly(coeffs[b * rows:(b + 1) * rows], r[b])
                     assert np.array_equal(got[b], want), ("quad", rows, k, batch, b, seed)
         n_cases += 1
-    os.environ.pop("LG_FORCE_CHUNKS", None)
+    for var in ("LG_FORCE_CHUNKS", "LG_HASH_QUAD_MAX_COLUMNS", "LG_ASYNC_HASH"):
+        os.environ.pop(var, None)
     return n_cases
 
 
