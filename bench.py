@@ -552,7 +552,12 @@ def main():
             for _ in range(50):
                 one.commit_resident()
             one.sync()
-            line["single_commit_ms"] = (time.perf_counter() - t1) / 50 * 1e3
+            line["single_commit_ms"] = (time.perf_counter() - t1) / 50 * 1e3      # a stream of single commitments (pipelined)
+            t1 = time.perf_counter()
+            for _ in range(50):
+                one.commit_resident()
+                one.root()                                                        # waits for the tree: the latency of ONE commitment
+            line["single_commit_latency_ms"] = (time.perf_counter() - t1) / 50 * 1e3
             one.close()
             # what a drop-in caller gets (host buffers in, root [+ coefficients] out): PCIe inclusive, never `value`
             line["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, local_rank, 10)
