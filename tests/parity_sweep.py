@@ -63,6 +63,16 @@ def sweep(budget: float, seed: int) -> int:
                 cols, sib, paths = c.open_columns(idx, proof=b)
                 ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], idx)
                 assert np.array_equal(cols, ecols) and np.array_equal(sib, esib) and np.array_equal(paths, epaths), ("open", rows, k, batch, b, seed)
+            if k <= 4096 and rng.integers(4) == 0:
+                # the portable generic-field kernels instantiated for BN254 must agree with the tuned path on everything
+                from ligero_amd import _ffi
+                with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch, field=_ffi.LG_FIELD_BN254_FR_GENERIC) as g:
+                    gco, groots = g.encode_commit(pre)
+                    assert groots == roots and np.array_equal(gco, coeffs), ("generic", rows, k, batch, seed)
+                    assert np.array_equal(g.leaves(), c.leaves()), ("generic leaves", rows, k, batch, seed)
+                    gc, gs, gp = g.open_columns(idx, proof=batch - 1)
+                    tc, ts, tp = c.open_columns(idx, proof=batch - 1)
+                    assert np.array_equal(gc, tc) and np.array_equal(gs, ts) and np.array_equal(gp, tp), ("generic open", rows, k, batch, seed)
             if k <= 8192 and rows % 4 == 0:
                 r = random_mont(seed + 1, batch * rows // 4).reshape(batch, rows // 4, 4)
                 got = c.quadratic_constraint_poly(r)
