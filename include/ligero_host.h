@@ -37,10 +37,45 @@ void lgh_circuit_destroy(lgh_circuit* c);
 int64_t lgh_circuit_num_nodes(const lgh_circuit* c);
 int64_t lgh_constant(lgh_circuit* c, const uint64_t value[4]);
 int64_t lgh_new_variable(lgh_circuit* c);
+/* new_variable_with_label / get_variable (src/arithmetic_circuit/mod.rs:92-100, 115-117); a label in use, or one the
+ * circuit does not have, is the reference's panic (LGH_ERR_PANIC) */
+int64_t lgh_new_variable_with_label(lgh_circuit* c, const char* label);
+int64_t lgh_get_variable(const lgh_circuit* c, const char* label);
+int64_t lgh_circuit_num_gates(const lgh_circuit* c);
 int64_t lgh_add(lgh_circuit* c, uint64_t left, uint64_t right);
 int64_t lgh_mul(lgh_circuit* c, uint64_t left, uint64_t right);
 int64_t lgh_pow(lgh_circuit* c, uint64_t node, uint64_t exponent);
 int64_t lgh_minus(lgh_circuit* c, uint64_t node);
+/* pow_bigint (mod.rs:164-179; exponent = nlimbs little-endian u64), indicator x^(p-1) (mod.rs:203-217),
+ * scalar_product (mod.rs:228-239), mul_nodes (mod.rs:156-161) */
+int64_t lgh_pow_bigint(lgh_circuit* c, uint64_t node, const uint64_t* exponent_limbs, uint64_t nlimbs);
+int64_t lgh_indicator(lgh_circuit* c, uint64_t node);
+int64_t lgh_scalar_product(lgh_circuit* c, const uint64_t* left, const uint64_t* right, uint64_t count);
+int64_t lgh_mul_nodes(lgh_circuit* c, const uint64_t* nodes, uint64_t count);
+/* evaluate_multioutput (mod.rs:381-387): values of the output nodes in node order (each node once); values_out has
+ * room for n_outputs elements, *count_out says how many were written.  Only what the outputs depend on is evaluated. */
+int lgh_evaluate_multioutput(const lgh_circuit* c, const uint64_t* node_idx, const uint64_t* values, uint64_t count,
+                             const uint64_t* outputs, uint64_t n_outputs, uint64_t* values_out, uint64_t* count_out);
+
+/* one node of the circuit: kind 0 Variable / 1 Constant / 2 Add / 3 Mul (src/arithmetic_circuit/mod.rs:14-24); left/right
+ * for gates, value (Montgomery) for constants, the label (NUL-terminated, cut to label_capacity) for variables; any out
+ * pointer may be NULL */
+int lgh_circuit_node(const lgh_circuit* c, uint64_t index, uint32_t* kind, uint64_t* left, uint64_t* right, uint64_t value[4],
+                     char* label, uint64_t label_capacity);
+
+/* Expression front end (src/expression/mod.rs; ligero_amd/host/expression.hpp): handles are shared sub-expressions --
+ * using one handle twice is using the same node twice.  Constructors return NULL on error (lgh_last_error). */
+typedef struct lgh_expr lgh_expr;
+lgh_expr* lgh_expr_variable(const char* label);
+lgh_expr* lgh_expr_constant(const uint64_t value[4]);
+lgh_expr* lgh_expr_add(const lgh_expr* a, const lgh_expr* b);
+lgh_expr* lgh_expr_mul(const lgh_expr* a, const lgh_expr* b);
+lgh_expr* lgh_expr_sub(const lgh_expr* a, const lgh_expr* b);   /* a + (-1) * b, mod.rs:209-215 */
+lgh_expr* lgh_expr_neg(const lgh_expr* a);
+lgh_expr* lgh_expr_pow(const lgh_expr* a, uint64_t exponent);
+void lgh_expr_destroy(lgh_expr* e);
+/* to_arithmetic_circuit (mod.rs:59-107): the root is the circuit's last node */
+int lgh_expr_to_circuit(const lgh_expr* e, lgh_circuit** out);
 
 /* read a circom .r1cs (v1, BN254) and compile it; the output nodes are kept with the circuit */
 int lgh_circuit_from_r1cs(lgh_circuit** out, const char* r1cs_path);
@@ -57,6 +92,11 @@ int lgh_instance_info(const lgh_instance* inst, uint64_t info_out[8]);
  * elements row-major; *all_outputs_one (may be NULL) tells whether every output evaluated to 1 */
 int lgh_build_preenc(const lgh_instance* inst, const uint64_t* node_idx, const uint64_t* values, uint64_t count,
                      uint64_t* preenc_out, int* all_outputs_one);
+
+/* the same for prove_with_labels (src/ligero/mod.rs:580-611): `labels` = count NUL-terminated strings; an unknown
+ * label is "Variable not found: <label>" (LGH_ERR_PANIC) */
+int lgh_build_preenc_with_labels(const lgh_instance* inst, const char* const* labels, const uint64_t* values, uint64_t count,
+                                 uint64_t* preenc_out, int* all_outputs_one);
 
 /* r_a = A.row_mul(r): r and out have 4 * m * k elements */
 int lgh_a_row_mul(const lgh_instance* inst, const uint64_t* r, uint64_t* out);

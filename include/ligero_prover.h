@@ -30,6 +30,9 @@ void lgp_prover_destroy(lgp_prover* p);
 
 /* prove(var_assignment, mt_params, &mut test_sponge()): assignment by ORIGINAL node index, as for lgh_build_preenc */
 int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proof_out);
+/* prove_with_labels(var_assignment, mt_params, &mut test_sponge()) (src/ligero/mod.rs:580-611): variables named by
+ * label (`labels` = count NUL-terminated strings); an unknown label is "Variable not found: <label>" (LGP_ERR_PANIC) */
+int lgp_prove_with_labels(lgp_prover* p, const char* const* labels, const uint64_t* values, uint64_t count, lgp_proof** proof_out);
 /* verify(proof, mt_params, &mut test_sponge()) */
 int lgp_verify(lgp_prover* p, const lgp_proof* proof, int* accepted_out);
 void lgp_proof_destroy(lgp_proof* proof);

@@ -164,17 +164,55 @@ public:
         for (size_t i = 1; i < idx.size(); i++) acc = add(acc, idx[i]);
         return acc;
     }
-    size_t pow(size_t node, uint64_t exponent) {           // mod.rs:164-200: square-and-multiply, MSB first
-        if (node >= nodes.size()) throw std::runtime_error("Base node not in the circuit");
-        if (exponent == 0) throw std::runtime_error("pow: exponent 0");
-        int top = 63;
-        while (!((exponent >> top) & 1)) top--;
+    size_t mul_nodes(const std::vector<size_t>& idx) {     // mod.rs:156-161
+        if (idx.empty()) throw std::runtime_error("mul_nodes: empty list");
+        size_t acc = idx[0];
+        for (size_t i = 1; i < idx.size(); i++) acc = mul(acc, idx[i]);
+        return acc;
+    }
+    size_t mul_unchecked(size_t l, size_t r) {             // mod.rs:134-136
+        nodes.push_back(Node{{}, Node::Mul, l, r, {}, {}});
+        return nodes.size() - 1;
+    }
+    size_t num_gates() const {                             // mod.rs:55-63
+        size_t g = 0;
+        for (const auto& nd : nodes) g += (nd.kind == Node::Add || nd.kind == Node::Mul);
+        return g;
+    }
+    std::vector<size_t> new_variables(size_t num) {        // mod.rs:111-113
+        std::vector<size_t> v;
+        for (size_t i = 0; i < num; i++) v.push_back(new_variable());
+        return v;
+    }
+    size_t get_variable(const std::string& label) const { // mod.rs:115-117
+        const auto it = variables.find(label);
+        if (it == variables.end()) throw std::runtime_error("Variable not in circuit");
+        return it->second;
+    }
+    // pow_bigint (mod.rs:164-179): exponent as little-endian u64 limbs; pow_binary (mod.rs:188-200): square-and-multiply,
+    // most significant bit first, accumulator starts at the node itself
+    size_t pow_bigint(size_t node, const uint64_t* limbs, size_t nlimbs) {
+        if (node >= nodes.size())
+            throw std::runtime_error("Base node (" + std::to_string(node) + ") not in the circuit (which contains " + std::to_string(nodes.size()) + " nodes)");
+        long top = (long)nlimbs * 64 - 1;
+        while (top >= 0 && !((limbs[top / 64] >> (top % 64)) & 1)) top--;
+        // exponent 0: the reference's bit list is empty and pow_binary returns the node itself (x^0 is NOT 1 there)
         size_t cur = node;
-        for (int b = top - 1; b >= 0; b--) {
-            cur = mul(cur, cur);
-            if ((exponent >> b) & 1) cur = mul(cur, node);
+        for (long b = top - 1; b >= 0; b--) {
+            cur = mul_unchecked(cur, cur);
+            if ((limbs[b / 64] >> (b % 64)) & 1) cur = mul_unchecked(cur, node);
         }
         return cur;
+    }
+    size_t pow(size_t node, uint64_t exponent) { return pow_bigint(node, &exponent, 1); }   // mod.rs:182-184
+    size_t indicator(size_t node) {                        // mod.rs:203-217: x^(p-1) -- 0 at 0, 1 elsewhere
+        const E m1 = F::from_mont(F::neg(F::one()));
+        return pow_bigint(node, m1.l, F::kLimbs);
+    }
+    size_t scalar_product(const std::vector<size_t>& l, const std::vector<size_t>& r) {      // mod.rs:228-239 (zip: shorter side)
+        std::vector<size_t> products;
+        for (size_t i = 0; i < l.size() && i < r.size(); i++) products.push_back(mul_unchecked(l[i], r[i]));
+        return add_nodes(products);
     }
     size_t minus(size_t node) {                            // mod.rs:220-223
         const size_t m1 = constant(F::neg(F::one()));
@@ -213,29 +251,131 @@ public:
         for (size_t i = 0; i < ab.size(); i++) outputs.push_back(c.add_nodes({ab[i], minus_c[i], one}));
         return {std::move(c), std::move(outputs)};
     }
-    // mod.rs:325-358 (values of every node the outputs depend on; nodes only reference earlier
-    // nodes, so one forward sweep gives what the reference's recursion gives).  An unassigned
-    // variable is the reference's "Uninitialised variable" panic.
-    std::vector<E> evaluation_trace(const std::vector<std::pair<size_t, E>>& vars) const {
-        std::vector<E> val(nodes.size(), F::zero());
-        std::vector<uint8_t> set(nodes.size(), 0);
-        for (const auto& v : vars) {
-            if (v.first >= nodes.size() || nodes[v.first].kind != Node::Variable) throw std::runtime_error("Value supplied for non-variable node");
-            val[v.first] = v.second;
-            set[v.first] = 1;
+    // filter_constants (mod.rs:545-603): drops every constant whose value appeared earlier in the list and renumbers the
+    // gates' operands; returns the kept nodes and value -> index of the kept constant
+    static std::pair<std::vector<Node>, std::map<E, size_t, ElemLess<E>>> filter_constants(const std::vector<Node>& in) {
+        constexpr size_t kDropped = ~size_t{0};
+        std::map<E, size_t, ElemLess<E>> consts;
+        std::vector<size_t> filtered(in.size(), kDropped);
+        size_t removed = 0;
+        for (size_t i = 0; i < in.size(); i++) {
+            if (in[i].kind == Node::Constant) {
+                if (consts.count(in[i].value)) { removed++; continue; }
+                consts[in[i].value] = i - removed;
+            }
+            filtered[i] = i - removed;
         }
+        auto operand = [&](size_t o) {
+            if (o >= in.size()) throw std::runtime_error("index out of bounds: gate operand not in the node list");
+            return in[o].kind == Node::Constant ? consts.at(in[o].value) : filtered[o];
+        };
+        std::vector<Node> out;
+        out.reserve(in.size() - removed);
+        for (size_t i = 0; i < in.size(); i++) {
+            if (filtered[i] == kDropped) continue;
+            Node nd = in[i];
+            if (nd.kind == Node::Add || nd.kind == Node::Mul) { nd.l = operand(nd.l); nd.r = operand(nd.r); }
+            out.push_back(std::move(nd));
+        }
+        return {std::move(out), std::move(consts)};
+    }
+
+    // evaluation_trace_multioutput (mod.rs:325-358) with the reference's Option: only what the outputs depend on is
+    // evaluated (inner_evaluate, mod.rs:247-271), everything else that was not assigned stays unset; a needed variable
+    // without a value is the reference's "Uninitialised variable" panic.  Circuits made by the builders only refer to
+    // earlier nodes (one backward sweep marks what is needed, one forward sweep computes it: what the 5 M-node circuits
+    // use); circuits made from an Expression (expression.hpp) number the root last and refer forwards too, and get
+    // the reference's depth-first walk with an explicit stack instead of recursion.
+    struct Trace {
+        std::vector<E> value;
+        std::vector<uint8_t> set;      // the reference's Some / None
+    };
+    Trace evaluation_trace_multioutput(const std::vector<std::pair<size_t, E>>& vars, const std::vector<size_t>& outputs) const {
+        Trace t{std::vector<E>(nodes.size(), F::zero()), std::vector<uint8_t>(nodes.size(), 0)};
+        bool backward_only = true;
         for (size_t i = 0; i < nodes.size(); i++) {
             const Node& nd = nodes[i];
-            switch (nd.kind) {
-                case Node::Constant: val[i] = nd.value; break;
-                case Node::Variable:
-                    if (!set[i]) throw std::runtime_error("Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
-                    break;
-                case Node::Add: val[i] = F::add(val[nd.l], val[nd.r]); break;
-                case Node::Mul: val[i] = F::mul(val[nd.l], val[nd.r]); break;
+            if (nd.kind == Node::Constant) { t.value[i] = nd.value; t.set[i] = 1; }
+            else if ((nd.kind == Node::Add || nd.kind == Node::Mul) && (nd.l >= i || nd.r >= i)) backward_only = false;
+        }
+        for (const auto& v : vars) {
+            if (v.first >= nodes.size()) throw std::runtime_error("index out of bounds: assigned node not in the circuit");
+            if (nodes[v.first].kind != Node::Variable) throw std::runtime_error("Value supplied for non-variable node");
+            t.value[v.first] = v.second;
+            t.set[v.first] = 1;
+        }
+        for (size_t o : outputs)
+            if (o >= nodes.size()) throw std::runtime_error("index out of bounds: output node not in the circuit");
+        if (backward_only) {
+            std::vector<uint8_t> need(nodes.size(), 0);
+            for (size_t o : outputs) need[o] = 1;
+            for (size_t i = nodes.size(); i-- > 0;) {
+                const Node& nd = nodes[i];
+                if (need[i] && (nd.kind == Node::Add || nd.kind == Node::Mul)) need[nd.l] = need[nd.r] = 1;
+            }
+            for (size_t i = 0; i < nodes.size(); i++) {
+                const Node& nd = nodes[i];
+                if (!need[i] || t.set[i]) continue;
+                if (nd.kind == Node::Variable) throw std::runtime_error("Uninitialised variable");
+                t.value[i] = nd.kind == Node::Add ? F::add(t.value[nd.l], t.value[nd.r]) : F::mul(t.value[nd.l], t.value[nd.r]);
+                t.set[i] = 1;
+            }
+            return t;
+        }
+        std::vector<uint8_t> open(nodes.size(), 0);          // gates whose operands are being evaluated
+        std::vector<size_t> stack;
+        for (size_t o : outputs) {
+            stack.push_back(o);
+            while (!stack.empty()) {
+                const size_t i = stack.back();
+                if (t.set[i]) { stack.pop_back(); continue; }
+                const Node& nd = nodes[i];
+                if (nd.kind == Node::Variable) throw std::runtime_error("Uninitialised variable");
+                if (nd.l >= nodes.size() || nd.r >= nodes.size()) throw std::runtime_error("index out of bounds: gate operand not in the circuit");
+                if (t.set[nd.l] && t.set[nd.r]) {
+                    t.value[i] = nd.kind == Node::Add ? F::add(t.value[nd.l], t.value[nd.r]) : F::mul(t.value[nd.l], t.value[nd.r]);
+                    t.set[i] = 1;
+                    open[i] = 0;
+                    stack.pop_back();
+                    continue;
+                }
+                // an unset operand that is already open is an ancestor of this gate: the reference's recursion would not end
+                open[i] = 1;
+                for (size_t c : {nd.r, nd.l}) {
+                    if (t.set[c]) continue;
+                    if (open[c]) throw std::runtime_error("circuit has a cycle");
+                    stack.push_back(c);
+                }
             }
         }
-        return val;
+        return t;
+    }
+    Trace evaluation_trace(const std::vector<std::pair<size_t, E>>& vars, size_t node) const {   // mod.rs:279-306
+        return evaluation_trace_multioutput(vars, {node});
+    }
+    std::vector<std::pair<size_t, E>> with_labels(const std::vector<std::pair<std::string, E>>& vars) const {   // mod.rs:313-316 etc.
+        std::vector<std::pair<size_t, E>> out;
+        for (const auto& v : vars) out.emplace_back(get_variable(v.first), v.second);
+        return out;
+    }
+    E evaluate_node(const std::vector<std::pair<size_t, E>>& vars, size_t node) const {         // mod.rs:373-375
+        return evaluation_trace(vars, node).value[node];
+    }
+    E evaluate(const std::vector<std::pair<size_t, E>>& vars) const { return evaluate_node(vars, last()); }   // mod.rs:401-403
+    E evaluate_node_with_labels(const std::vector<std::pair<std::string, E>>& vars, size_t node) const { return evaluate_node(with_labels(vars), node); }
+    E evaluate_with_labels(const std::vector<std::pair<std::string, E>>& vars) const { return evaluate_node(with_labels(vars), last()); }
+    // mod.rs:381-387: the values of the output nodes in NODE order (each once), not in the order `outputs` lists them
+    std::vector<E> evaluate_multioutput(const std::vector<std::pair<size_t, E>>& vars, const std::vector<size_t>& outputs) const {
+        const Trace t = evaluation_trace_multioutput(vars, outputs);
+        std::vector<uint8_t> is_out(nodes.size(), 0);
+        for (size_t o : outputs) is_out[o] = 1;
+        std::vector<E> out;
+        for (size_t i = 0; i < nodes.size(); i++)
+            if (is_out[i] && t.set[i]) out.push_back(t.value[i]);
+        return out;
+    }
+    std::vector<E> evaluate_multioutput_with_labels(const std::vector<std::pair<std::string, E>>& vars, const std::vector<size_t>& outputs) const {
+        return evaluate_multioutput(with_labels(vars), outputs);
     }
 };
 using ArithmeticCircuit = ArithmeticCircuitT<Fr>;
@@ -481,7 +621,31 @@ public:
         std::vector<std::pair<size_t, E>> bumped;
         bumped.reserve(var_assignment.size());
         for (const auto& v : var_assignment) bumped.emplace_back(bump_index(v.first), v.second);
-        const std::vector<E> sol = circuit.evaluation_trace(bumped);
+        build_preenc_from_formatted(bumped, out, all_outputs_one);
+    }
+    // prove_with_labels (mod.rs:580-611): labels resolve through the FORMATTED circuit's variable map (insert_one has
+    // already bumped it, mod.rs:268-270), so the indices go to prove_inner as they are
+    std::vector<std::pair<size_t, E>> resolve_labels(const std::vector<std::pair<std::string, E>>& var_assignment) const {
+        std::vector<std::pair<size_t, E>> out;
+        out.reserve(var_assignment.size());
+        for (const auto& v : var_assignment) {
+            const auto it = circuit.variables.find(v.first);
+            if (it == circuit.variables.end()) throw std::runtime_error("Variable not found: " + v.first);
+            out.emplace_back(it->second, v.second);
+        }
+        return out;
+    }
+    void build_preenc_with_labels_into(const std::vector<std::pair<std::string, E>>& var_assignment, E* out, bool* all_outputs_one = nullptr) const {
+        build_preenc_from_formatted(resolve_labels(var_assignment), out, all_outputs_one);
+    }
+    // prove_inner (mod.rs:476-516): assignment by index into the formatted circuit
+    void build_preenc_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr) const {
+        // evaluation_trace_multioutput + expect on every node (mod.rs:476-478): a node the outputs do not depend on and
+        // that is not an assigned variable is a panic there, not a silently evaluated gate
+        auto trace = circuit.evaluation_trace_multioutput(bumped, outputs);
+        for (size_t i = 0; i < trace.set.size(); i++)
+            if (!trace.set[i]) throw std::runtime_error("Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
+        const std::vector<E>& sol = trace.value;
         if (all_outputs_one) {
             *all_outputs_one = true;
             for (size_t o : outputs)

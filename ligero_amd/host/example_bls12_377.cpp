@@ -7,6 +7,7 @@
 //   usage: example_bls12_377      (prints one line per case, exit code 0 = every expectation held)
 #include <cstdio>
 
+#include "expression.hpp"
 #include "prover.hpp"
 
 using namespace ligero;
@@ -109,6 +110,23 @@ static int run() {
         const bool bad = proof_and_verify(circuit, invalid);                 // assert!(!proof_and_verify(circuit, invalid_assignment))
         printf("bls12_377 %s: valid assignment %s, x + 1 %s\n", pt.first, ok ? "accepted" : "REJECTED", bad ? "ACCEPTED" : "rejected");
         failures += (ok ? 0 : 1) + (bad ? 1 : 0);
+    }
+    {   // test_proof_and_verify_expression(generate_bls12_377_expression(), [("x", x), ("y", y)]) (tests.rs:172-184, 192;
+        // expression/tests.rs:13-18): the circuit numbered from the expression DAG, variables found by label; and the
+        // same statement through prove_with_labels
+        const auto xe = ExpressionT<E>::variable("x"), ye = ExpressionT<E>::variable("y");
+        const ArithmeticCircuitT<E> ec = (1 + (1 + xe.pow(3) - ye.pow(2))).to_arithmetic_circuit();
+        std::vector<std::pair<size_t, E>> vars = {{ec.get_variable("x"), X}, {ec.get_variable("y"), Y}};
+        const bool ok = ec.get_variable("x") == 4 && ec.get_variable("y") == 0 && proof_and_verify(ec, vars);
+        vars[0].second = F::add(vars[0].second, F::one());
+        const bool bad = proof_and_verify(ec, vars);
+        LigeroInstanceT<E> lc(ec, {ec.last()}, 128);
+        HipLigeroT<E> prover(lc);
+        PoseidonSpongeT<E> ps = PoseidonSpongeT<E>::test_sponge(), vs = ps;
+        const bool labelled = prover.verify(prover.prove_with_labels({{"x", X2}, {"y", Y2}}, ps), vs);
+        printf("bls12_377 expression: valid assignment %s, x + 1 %s, prove_with_labels(2G) %s\n", ok ? "accepted" : "REJECTED",
+               bad ? "ACCEPTED" : "rejected", labelled ? "accepted" : "REJECTED");
+        failures += (ok ? 0 : 1) + (bad ? 1 : 0) + (labelled ? 0 : 1);
     }
     printf(failures ? "FAILED\n" : "test_prove_and_verify_bls12_377: ok\n");
     return failures ? 1 : 0;

@@ -1,5 +1,6 @@
 // C ABI over the host-side input pipeline (circuit.hpp): lets the pytest suite, and any other
 // FFI caller, drive the C++ mirror of the reference's front end of the path.  No GPU code.
+#include <algorithm>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -7,6 +8,7 @@
 
 #include "../../include/ligero_host.h"
 #include "host_handles.hpp"
+#include "expression.hpp"
 #include "transcript.hpp"
 
 using namespace ligero;
@@ -27,6 +29,20 @@ static int guarded(F&& f) {
 static Fr load_fr(const uint64_t* p) { Fr v; std::memcpy(v.l, p, 32); return v; }
 static void store_fr(uint64_t* p, const Fr& v) { std::memcpy(p, v.l, 32); }
 
+struct lgh_expr {
+    Expression e;
+};
+template <class F>
+static lgh_expr* make_expr(F&& f) {
+    lgh_expr* out = nullptr;
+    guarded([&] { out = new lgh_expr{f()}; return LGH_OK; });
+    return out;
+}
+static bool have(const lgh_expr* a) {
+    if (!a) g_err = "null expression";
+    return a != nullptr;
+}
+
 extern "C" {
 
 const char* lgh_last_error(void) { return g_err.c_str(); }
@@ -45,6 +61,58 @@ int64_t lgh_new_variable(lgh_circuit* c) {
     int64_t r = -1;
     int rc = guarded([&] { r = (int64_t)c->c.new_variable(); return 0; });
     return rc ? rc : r;
+}
+int64_t lgh_new_variable_with_label(lgh_circuit* c, const char* label) {
+    if (!c || !label) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.new_variable_with_label(label); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_get_variable(const lgh_circuit* c, const char* label) {
+    if (!c || !label) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.get_variable(label); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_circuit_num_gates(const lgh_circuit* c) { return c ? (int64_t)c->c.num_gates() : (int64_t)LGH_ERR_BAD_ARG; }
+int64_t lgh_pow_bigint(lgh_circuit* c, uint64_t node, const uint64_t* limbs, uint64_t nlimbs) {
+    if (!c || (!limbs && nlimbs)) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.pow_bigint(node, limbs, nlimbs); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_indicator(lgh_circuit* c, uint64_t node) {
+    if (!c) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.indicator(node); return 0; });
+    return rc ? rc : r;
+}
+int64_t lgh_scalar_product(lgh_circuit* c, const uint64_t* left, const uint64_t* right, uint64_t count) {
+    if (!c || (count && (!left || !right))) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] {
+        r = (int64_t)c->c.scalar_product(std::vector<size_t>(left, left + count), std::vector<size_t>(right, right + count));
+        return 0;
+    });
+    return rc ? rc : r;
+}
+int64_t lgh_mul_nodes(lgh_circuit* c, const uint64_t* nodes, uint64_t count) {
+    if (!c || (count && !nodes)) return LGH_ERR_BAD_ARG;
+    int64_t r = -1;
+    int rc = guarded([&] { r = (int64_t)c->c.mul_nodes(std::vector<size_t>(nodes, nodes + count)); return 0; });
+    return rc ? rc : r;
+}
+int lgh_evaluate_multioutput(const lgh_circuit* c, const uint64_t* node_idx, const uint64_t* values, uint64_t count,
+                             const uint64_t* outputs, uint64_t n_outputs, uint64_t* values_out, uint64_t* count_out) {
+    if (!c || (count && (!node_idx || !values)) || (n_outputs && (!outputs || !values_out)) || !count_out) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::vector<std::pair<size_t, Fr>> vars;
+        for (uint64_t j = 0; j < count; j++) vars.emplace_back((size_t)node_idx[j], load_fr(values + 4 * j));
+        const auto v = c->c.evaluate_multioutput(vars, std::vector<size_t>(outputs, outputs + n_outputs));
+        for (size_t j = 0; j < v.size(); j++) store_fr(values_out + 4 * j, v[j]);
+        *count_out = v.size();
+        return LGH_OK;
+    });
 }
 int64_t lgh_add(lgh_circuit* c, uint64_t l, uint64_t r_) {
     if (!c) return LGH_ERR_BAD_ARG;
@@ -69,6 +137,51 @@ int64_t lgh_minus(lgh_circuit* c, uint64_t node) {
     int64_t r = -1;
     int rc = guarded([&] { r = (int64_t)c->c.minus(node); return 0; });
     return rc ? rc : r;
+}
+
+int lgh_circuit_node(const lgh_circuit* c, uint64_t index, uint32_t* kind, uint64_t* left, uint64_t* right, uint64_t value[4], char* label, uint64_t label_capacity) {
+    if (!c || index >= c->c.nodes.size()) return LGH_ERR_BAD_ARG;
+    const Node& nd = c->c.nodes[index];
+    if (kind) *kind = (uint32_t)nd.kind;
+    if (left) *left = nd.l;
+    if (right) *right = nd.r;
+    if (value) store_fr(value, nd.value);
+    if (label && label_capacity) {
+        const size_t n = std::min<size_t>(nd.label.size(), label_capacity - 1);
+        std::memcpy(label, nd.label.data(), n);
+        label[n] = 0;
+    }
+    return LGH_OK;
+}
+
+lgh_expr* lgh_expr_variable(const char* label) {
+    if (!label) { g_err = "null label"; return nullptr; }
+    return make_expr([&] { return Expression::variable(label); });
+}
+lgh_expr* lgh_expr_constant(const uint64_t v[4]) {
+    if (!v) { g_err = "null value"; return nullptr; }
+    return make_expr([&] { return Expression::constant(load_fr(v)); });
+}
+lgh_expr* lgh_expr_add(const lgh_expr* a, const lgh_expr* b) { return have(a) && have(b) ? make_expr([&] { return a->e + b->e; }) : nullptr; }
+lgh_expr* lgh_expr_mul(const lgh_expr* a, const lgh_expr* b) { return have(a) && have(b) ? make_expr([&] { return a->e * b->e; }) : nullptr; }
+lgh_expr* lgh_expr_sub(const lgh_expr* a, const lgh_expr* b) { return have(a) && have(b) ? make_expr([&] { return a->e - b->e; }) : nullptr; }
+lgh_expr* lgh_expr_neg(const lgh_expr* a) { return have(a) ? make_expr([&] { return -a->e; }) : nullptr; }
+lgh_expr* lgh_expr_pow(const lgh_expr* a, uint64_t exponent) { return have(a) ? make_expr([&] { return a->e.pow(exponent); }) : nullptr; }
+void lgh_expr_destroy(lgh_expr* e) { delete e; }
+int lgh_expr_to_circuit(const lgh_expr* e, lgh_circuit** out) {
+    if (!e || !out) return LGH_ERR_BAD_ARG;
+    *out = nullptr;
+    return guarded([&] {
+        lgh_circuit* c = new lgh_circuit();
+        try {
+            c->c = e->e.to_arithmetic_circuit();
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+        return LGH_OK;
+    });
 }
 
 int lgh_circuit_from_r1cs(lgh_circuit** out, const char* r1cs_path) {
@@ -120,6 +233,22 @@ int lgh_build_preenc(const lgh_instance* i, const uint64_t* node_idx, const uint
         bool ok = false;
         static_assert(sizeof(Fr) == 32, "Fr is four u64 limbs");
         i->inst.build_preenc_into(vars, reinterpret_cast<Fr*>(preenc_out), &ok);
+        if (all_outputs_one) *all_outputs_one = ok ? 1 : 0;
+        return LGH_OK;
+    });
+}
+
+int lgh_build_preenc_with_labels(const lgh_instance* i, const char* const* labels, const uint64_t* values, uint64_t count, uint64_t* preenc_out, int* all_outputs_one) {
+    if (!i || (count && (!labels || !values)) || !preenc_out) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::vector<std::pair<std::string, Fr>> vars;
+        vars.reserve(count);
+        for (uint64_t j = 0; j < count; j++) {
+            if (!labels[j]) throw std::runtime_error("null label");
+            vars.emplace_back(labels[j], load_fr(values + 4 * j));
+        }
+        bool ok = false;
+        i->inst.build_preenc_with_labels_into(vars, reinterpret_cast<Fr*>(preenc_out), &ok);
         if (all_outputs_one) *all_outputs_one = ok ? 1 : 0;
         return LGH_OK;
     });

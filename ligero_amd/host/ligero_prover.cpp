@@ -62,6 +62,30 @@ int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, u
     });
 }
 
+int lgp_prove_with_labels(lgp_prover* p, const char* const* labels, const uint64_t* values, uint64_t count, lgp_proof** proof_out) {
+    if (!p || !proof_out || (count && (!labels || !values))) return LGP_ERR_BAD_ARG;
+    *proof_out = nullptr;
+    return guarded([&] {
+        std::vector<std::pair<std::string, Fr>> va;
+        for (uint64_t i = 0; i < count; i++) {
+            if (!labels[i]) throw std::runtime_error("null label");
+            Fr v;
+            std::memcpy(v.l, values + 4 * i, 32);
+            va.emplace_back(labels[i], v);
+        }
+        PoseidonSponge sponge = PoseidonSponge::test_sponge();
+        auto* pr = new lgp_proof();
+        try {
+            pr->own = p->hip.prove_with_labels(va, sponge);
+        } catch (...) {
+            delete pr;
+            throw;
+        }
+        *proof_out = pr;
+        return LGP_OK;
+    });
+}
+
 int lgp_verify(lgp_prover* p, const lgp_proof* proof, int* accepted_out) {
     if (!p || !proof || !accepted_out) return LGP_ERR_BAD_ARG;
     return guarded([&] {

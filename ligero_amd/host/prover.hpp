@@ -176,14 +176,26 @@ public:
     HipLigeroT& operator=(const HipLigeroT&) = delete;
 
     // ---------------------------------------------------------------- prove (mod.rs:435-578)
-    LigeroProof prove(const std::vector<std::pair<size_t, Fr>>& var_assignment, PoseidonSponge& sponge) {
+    LigeroProof prove(const std::vector<std::pair<size_t, E>>& var_assignment, PoseidonSponge& sponge) {   // mod.rs:435-455
+        std::vector<std::pair<size_t, E>> bumped;
+        bumped.reserve(var_assignment.size());
+        for (const auto& v : var_assignment) bumped.emplace_back(inst_.bump_index(v.first), v.second);
+        return prove_inner(bumped, sponge);
+    }
+    // mod.rs:580-611: labels resolve in the formatted circuit's variable map; "Variable not found: <label>" otherwise
+    LigeroProof prove_with_labels(const std::vector<std::pair<std::string, E>>& var_assignment, PoseidonSponge& sponge) {
+        return prove_inner(inst_.resolve_labels(var_assignment), sponge);
+    }
+
+private:
+    LigeroProof prove_inner(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {   // mod.rs:457-578
         // preenc_u straight into a buffer this prover keeps (and page-locks, so that lg_encode_commit's PCIe chunks overlap
         // the encoding): at 2^20 constraints the matrix is 1.3 GB and fresh memory for it costs more than the commitment
         if (flat_.empty()) {
             flat_.resize(4 * m_ * k_);
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
-        inst_.build_preenc_into(var_assignment, flat_.data());
+        inst_.build_preenc_from_formatted(formatted_assignment, flat_.data());
         LigeroProof proof;
         check(lg_encode_commit(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
@@ -222,6 +234,7 @@ public:
         return proof;
     }
 
+public:
     // ---------------------------------------------------------------- verify (mod.rs:613-644)
     bool verify(const LigeroProof& proof, PoseidonSponge& sponge) {
         sponge.absorb_bytes(proof.u_root.data(), 32);

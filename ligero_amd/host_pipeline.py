@@ -23,6 +23,10 @@ SYMBOLS = [
     "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_a_row_mul", "lgh_a_entries",
     "lgh_read_witness", "lgh_chacha_block", "lgh_field_elements_from_seed", "lgh_distinct_indices_from_seed", "lgh_sponge_new", "lgh_sponge_destroy",
     "lgh_sponge_absorb_bytes", "lgh_sponge_absorb_elements", "lgh_sponge_squeeze_bytes", "lgh_sponge_squeeze_elements",
+    "lgh_new_variable_with_label", "lgh_get_variable", "lgh_circuit_num_gates", "lgh_pow_bigint", "lgh_indicator", "lgh_scalar_product",
+    "lgh_mul_nodes", "lgh_evaluate_multioutput", "lgh_build_preenc_with_labels", "lgh_circuit_node",
+    "lgh_expr_variable", "lgh_expr_constant", "lgh_expr_add", "lgh_expr_mul", "lgh_expr_sub", "lgh_expr_neg", "lgh_expr_pow",
+    "lgh_expr_destroy", "lgh_expr_to_circuit",
 ]
 
 _vp, _u64, _i64, _u32, _int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
@@ -45,16 +49,29 @@ def lib():
         L.lgh_circuit_destroy.restype = None
         for name, args in (("lgh_circuit_num_nodes", [_vp]), ("lgh_constant", [_vp, _vp]), ("lgh_new_variable", [_vp]),
                            ("lgh_add", [_vp, _u64, _u64]), ("lgh_mul", [_vp, _u64, _u64]), ("lgh_pow", [_vp, _u64, _u64]),
-                           ("lgh_minus", [_vp, _u64]), ("lgh_circuit_num_outputs", [_vp])):
+                           ("lgh_minus", [_vp, _u64]), ("lgh_circuit_num_outputs", [_vp]),
+                           ("lgh_new_variable_with_label", [_vp, ctypes.c_char_p]), ("lgh_get_variable", [_vp, ctypes.c_char_p]),
+                           ("lgh_circuit_num_gates", [_vp]), ("lgh_pow_bigint", [_vp, _u64, _vp, _u64]), ("lgh_indicator", [_vp, _u64]),
+                           ("lgh_scalar_product", [_vp, _vp, _vp, _u64]), ("lgh_mul_nodes", [_vp, _vp, _u64])):
             getattr(L, name).argtypes = args
             getattr(L, name).restype = _i64
         L.lgh_circuit_from_r1cs.argtypes = [ctypes.POINTER(_vp), ctypes.c_char_p]
+        L.lgh_circuit_node.argtypes = [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _u64]
+        for name, args in (("lgh_expr_variable", [ctypes.c_char_p]), ("lgh_expr_constant", [_vp]), ("lgh_expr_add", [_vp, _vp]),
+                           ("lgh_expr_mul", [_vp, _vp]), ("lgh_expr_sub", [_vp, _vp]), ("lgh_expr_neg", [_vp]), ("lgh_expr_pow", [_vp, _u64])):
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = _vp
+        L.lgh_expr_destroy.argtypes = [_vp]
+        L.lgh_expr_destroy.restype = None
+        L.lgh_expr_to_circuit.argtypes = [_vp, ctypes.POINTER(_vp)]
         L.lgh_circuit_outputs.argtypes = [_vp, _vp]
         L.lgh_instance_new.argtypes = [ctypes.POINTER(_vp), _vp, _vp, _u64, _u32]
         L.lgh_instance_destroy.argtypes = [_vp]
         L.lgh_instance_destroy.restype = None
         L.lgh_instance_info.argtypes = [_vp, _vp]
         L.lgh_build_preenc.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
+        L.lgh_build_preenc_with_labels.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
+        L.lgh_evaluate_multioutput.argtypes = [_vp, _vp, _vp, _u64, _vp, _u64, _vp, _vp]
         L.lgh_a_row_mul.argtypes = [_vp, _vp, _vp]
         L.lgh_a_entries.argtypes = [_vp, _vp, _vp, _vp]
         L.lgh_read_witness.argtypes = [ctypes.c_char_p, _vp, _u64, _vp]
@@ -86,6 +103,12 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(_vp)
 
 
+def c_labels(labels: Sequence[str]):
+    """list of str -> a `const char* const*` argument (keep the returned array alive for the call)"""
+    arr = (ctypes.c_char_p * len(labels))(*[s.encode() for s in labels])
+    return arr
+
+
 class ArithmeticCircuit:
     """src/arithmetic_circuit/mod.rs: builders + from_constraint_system"""
 
@@ -114,6 +137,22 @@ class ArithmeticCircuit:
     def num_nodes(self) -> int:
         return _check(self._L.lgh_circuit_num_nodes(self._h), "num_nodes")
 
+    def last(self) -> int:
+        return self.num_nodes() - 1
+
+    def node(self, i: int):
+        """("Variable", label) / ("Constant", limbs) / ("Add", l, r) / ("Mul", l, r)"""
+        kind, l, r = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        val = np.zeros(4, dtype=np.uint64)
+        label = ctypes.create_string_buffer(256)
+        _check(self._L.lgh_circuit_node(self._h, i, ctypes.cast(ctypes.byref(kind), _vp), ctypes.cast(ctypes.byref(l), _vp),
+                                        ctypes.cast(ctypes.byref(r), _vp), _p(val), ctypes.cast(label, _vp), 256), "node")
+        if kind.value == 0:
+            return ("Variable", label.value.decode())
+        if kind.value == 1:
+            return ("Constant", val)
+        return ("Add" if kind.value == 2 else "Mul", l.value, r.value)
+
     def constant(self, value_mont: np.ndarray) -> int:
         v = np.ascontiguousarray(value_mont, dtype=np.uint64).reshape(4)
         return _check(self._L.lgh_constant(self._h, _p(v)), "constant")
@@ -121,8 +160,58 @@ class ArithmeticCircuit:
     def new_variable(self) -> int:
         return _check(self._L.lgh_new_variable(self._h), "new_variable")
 
+    def new_variable_with_label(self, label: str) -> int:
+        return _check(self._L.lgh_new_variable_with_label(self._h, label.encode()), "new_variable_with_label")
+
+    def new_variables(self, num: int):
+        return [self.new_variable() for _ in range(num)]
+
+    def get_variable(self, label: str) -> int:
+        return _check(self._L.lgh_get_variable(self._h, label.encode()), "get_variable")
+
+    def num_gates(self) -> int:
+        return _check(self._L.lgh_circuit_num_gates(self._h), "num_gates")
+
     def add(self, l: int, r: int) -> int:
         return _check(self._L.lgh_add(self._h, l, r), "add")
+
+    def add_nodes(self, nodes: Sequence[int]) -> int:
+        acc = nodes[0]
+        for i in nodes[1:]:
+            acc = self.add(acc, i)
+        return acc
+
+    def mul_nodes(self, nodes: Sequence[int]) -> int:
+        a = np.ascontiguousarray(nodes, dtype=np.uint64)
+        return _check(self._L.lgh_mul_nodes(self._h, _p(a), a.shape[0]), "mul_nodes")
+
+    def pow_bigint(self, node: int, exponent: int) -> int:
+        nl = max(1, (exponent.bit_length() + 63) // 64)
+        limbs = np.array([(exponent >> (64 * i)) & (2**64 - 1) for i in range(nl)], dtype=np.uint64)
+        return _check(self._L.lgh_pow_bigint(self._h, node, _p(limbs), nl), "pow_bigint")
+
+    def indicator(self, node: int) -> int:
+        return _check(self._L.lgh_indicator(self._h, node), "indicator")
+
+    def scalar_product(self, left: Sequence[int], right: Sequence[int]) -> int:
+        n = min(len(left), len(right))
+        a = np.ascontiguousarray(left[:n], dtype=np.uint64)
+        b = np.ascontiguousarray(right[:n], dtype=np.uint64)
+        return _check(self._L.lgh_scalar_product(self._h, _p(a), _p(b), n), "scalar_product")
+
+    def evaluate_multioutput(self, node_idx: Sequence[int], values_mont: np.ndarray, outputs: Sequence[int]) -> np.ndarray:
+        """evaluate_multioutput (mod.rs:381-387): output values in node order, (count, 4) Montgomery limbs"""
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(idx.shape[0], 4)
+        outs = np.ascontiguousarray(outputs, dtype=np.uint64)
+        res = np.zeros((outs.shape[0], 4), dtype=np.uint64)
+        cnt = ctypes.c_uint64(0)
+        _check(self._L.lgh_evaluate_multioutput(self._h, _p(idx), _p(vals), idx.shape[0], _p(outs), outs.shape[0], _p(res),
+                                                ctypes.cast(ctypes.byref(cnt), _vp)), "evaluate_multioutput")
+        return res[:cnt.value]
+
+    def evaluate_node(self, node_idx: Sequence[int], values_mont: np.ndarray, node: int) -> np.ndarray:
+        return self.evaluate_multioutput(node_idx, values_mont, [node])[0]
 
     def mul(self, l: int, r: int) -> int:
         return _check(self._L.lgh_mul(self._h, l, r), "mul")
@@ -132,6 +221,84 @@ class ArithmeticCircuit:
 
     def minus(self, node: int) -> int:
         return _check(self._L.lgh_minus(self._h, node), "minus")
+
+
+P_BN254_FR = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_R_BN254_FR = (1 << 256) % P_BN254_FR
+
+
+def fr_mont(value: int) -> np.ndarray:
+    """F::from(value) for BN254 Fr as the four Montgomery limbs the libraries exchange"""
+    v = (value % P_BN254_FR) * _R_BN254_FR % P_BN254_FR
+    return np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+
+
+class Expression:
+    """src/expression/mod.rs over BN254 Fr: variables and constants combined with + - * and pow into a shared DAG.  As in
+    the reference, identity is by node: `x = Expression.variable("x"); x * x` uses ONE variable node twice, while two
+    Expression.variable("x") calls are two nodes.  Python ints on either side of an operator are F::from(int) constants."""
+
+    def __init__(self, handle):
+        self._L = lib()
+        if not handle:
+            raise HostPanic("expression: " + self._L.lgh_last_error().decode())
+        self._h = _vp(handle)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.lgh_expr_destroy(self._h)
+            self._h = None
+
+    @classmethod
+    def variable(cls, label: str) -> "Expression":
+        return cls(lib().lgh_expr_variable(label.encode()))
+
+    @classmethod
+    def constant(cls, value) -> "Expression":
+        """value: a Python int (F::from) or four Montgomery limbs"""
+        v = fr_mont(value) if isinstance(value, int) else np.ascontiguousarray(value, dtype=np.uint64).reshape(4)
+        return cls(lib().lgh_expr_constant(_p(v)))
+
+    @staticmethod
+    def _lift(x) -> "Expression":
+        return x if isinstance(x, Expression) else Expression.constant(x)
+
+    def __add__(self, o):
+        rhs = Expression._lift(o)              # kept alive across the call: a temporary's handle dies with it
+        return Expression(self._L.lgh_expr_add(self._h, rhs._h))
+
+    def __radd__(self, o):
+        lhs = Expression._lift(o)
+        return Expression(self._L.lgh_expr_add(lhs._h, self._h))
+
+    def __mul__(self, o):
+        rhs = Expression._lift(o)              # kept alive across the call: a temporary's handle dies with it
+        return Expression(self._L.lgh_expr_mul(self._h, rhs._h))
+
+    def __rmul__(self, o):
+        lhs = Expression._lift(o)
+        return Expression(self._L.lgh_expr_mul(lhs._h, self._h))
+
+    def __sub__(self, o):
+        rhs = Expression._lift(o)              # kept alive across the call: a temporary's handle dies with it
+        return Expression(self._L.lgh_expr_sub(self._h, rhs._h))
+
+    def __rsub__(self, o):
+        lhs = Expression._lift(o)
+        return Expression(self._L.lgh_expr_sub(lhs._h, self._h))
+
+    def __neg__(self):
+        return Expression(self._L.lgh_expr_neg(self._h))
+
+    def pow(self, e: int) -> "Expression":
+        return Expression(self._L.lgh_expr_pow(self._h, e))
+
+    __pow__ = pow
+
+    def to_arithmetic_circuit(self) -> "ArithmeticCircuit":
+        h = _vp()
+        _check(self._L.lgh_expr_to_circuit(self._h, ctypes.byref(h)), "to_arithmetic_circuit")
+        return ArithmeticCircuit(h.value)
 
 
 class LigeroInstance:
@@ -159,6 +326,16 @@ class LigeroInstance:
         out = np.empty((self.rows, self.k, 4), dtype=np.uint64)
         ok = _int(0)
         _check(self._L.lgh_build_preenc(self._h, _p(idx), _p(vals), idx.shape[0], _p(out), ctypes.cast(ctypes.byref(ok), _vp)), "prove_inner")
+        return out, bool(ok.value)
+
+    def build_preenc_u_with_labels(self, labels: Sequence[str], values_mont: np.ndarray) -> Tuple[np.ndarray, bool]:
+        """prove_with_labels + prove_inner up to preenc_u (mod.rs:580-611, 476-516)"""
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(len(labels), 4)
+        out = np.empty((self.rows, self.k, 4), dtype=np.uint64)
+        ok = _int(0)
+        arr = c_labels(labels)
+        _check(self._L.lgh_build_preenc_with_labels(self._h, ctypes.cast(arr, _vp), _p(vals), len(labels), _p(out),
+                                                    ctypes.cast(ctypes.byref(ok), _vp)), "prove_inner")
         return out, bool(ok.value)
 
     def a_row_mul(self, r_mont: np.ndarray) -> np.ndarray:

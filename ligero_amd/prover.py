@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
-           "lgp_prove_batch", "lgp_batch_proof"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_prove_with_labels"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -34,6 +34,7 @@ def lib():
         L.lgp_prover_destroy.argtypes = [_vp]
         L.lgp_prover_destroy.restype = None
         L.lgp_prove.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(_vp)]
+        L.lgp_prove_with_labels.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(_vp)]
         L.lgp_verify.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         L.lgp_proof_destroy.argtypes = [_vp]
         L.lgp_proof_destroy.restype = None
@@ -101,6 +102,15 @@ class LigeroProver:
         vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(idx.shape[0], 4)
         h = _vp()
         _check(self._L.lgp_prove(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0], ctypes.byref(h)), "prove")
+        return Proof(h)
+
+    def prove_with_labels(self, labels: Sequence[str], values_mont: np.ndarray) -> Proof:
+        """prove_with_labels (src/ligero/mod.rs:580-611)"""
+        from .host_pipeline import c_labels
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(len(labels), 4)
+        arr = c_labels(labels)
+        h = _vp()
+        _check(self._L.lgp_prove_with_labels(self._h, ctypes.cast(arr, _vp), vals.ctypes.data_as(_vp), len(labels), ctypes.byref(h)), "prove_with_labels")
         return Proof(h)
 
     def verify(self, proof: Proof) -> bool:

@@ -141,4 +141,5 @@ def test_prove_and_verify_bls12_377():
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "test_prove_and_verify_bls12_377: ok" in r.stdout
     assert "test_construction_bls12_377 (A matrix tables): ok" in r.stdout       # tests.rs:35-142, the induced P_x / P_y / P_z / P_add
-    assert r.stdout.count("valid assignment accepted, x + 1 rejected") == 2
+    assert r.stdout.count("valid assignment accepted, x + 1 rejected") == 3       # G, 2 G, and G on the expression-made circuit
+    assert "prove_with_labels(2G) accepted" in r.stdout

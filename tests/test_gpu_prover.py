@@ -185,21 +185,70 @@ def test_reference_prove_and_verify_cases(oracle, which):
         assert not prover.verify(prover.prove(idx, bad))                 # assert!(!proof_and_verify(circuit, invalid_assignment))
 
 
+def _lemniscate_expression(hp):
+    """src/expression/tests.rs:21-26"""
+    x, y = hp.Expression.variable("x"), hp.Expression.variable("y")
+    return 1 + (x.pow(2) + y.pow(2)).pow(2) - 120 * x.pow(2) + 80 * y.pow(2), [("x", 8), ("y", 4)]
+
+
+def _determinant_expression(hp):
+    """src/expression/tests.rs:28-60 with the assignment of src/ligero/tests.rs:210-242"""
+    m = [[hp.Expression.variable(f"x_{i}_{j}") for j in range(3)] for i in range(3)]
+
+    def diagonals(js):
+        terms = [_fold(lambda a, b: a * b, [m[i][(js[i] + k) % 3] for i in range(3)]) for k in range(3)]
+        return _fold(lambda a, b: a + b, terms)
+    e = 1 + (diagonals([0, 4, 8]) - diagonals([2, 4, 6]) - hp.Expression.variable("det"))
+    vals = [2, 0, -1, 3, 5, 2, -4, 1, 4]
+    return e, [(f"x_{i}_{j}", vals[3 * i + j]) for i in range(3) for j in range(3)] + [("det", 13)]
+
+
+@pytest.mark.parametrize("which", ["lemniscate", "determinant"])
+def test_reference_prove_and_verify_expression_cases(oracle, which):
+    """test_proof_and_verify_expression (src/ligero/tests.rs:172-184, 201-205, 227-242): the circuit comes from
+    Expression::to_arithmetic_circuit (root last, gates referring forwards), variables by get_variable"""
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    e, assignment = (_lemniscate_expression if which == "lemniscate" else _determinant_expression)(hp)
+    c = e.to_arithmetic_circuit()
+    inst = hp.LigeroInstance(c, outputs=[c.last()])
+    idx = [c.get_variable(s) for s, _ in assignment]
+    good = np.stack([_mont(oracle, v) for _, v in assignment])
+    bad = good.copy()
+    bad[0] = _mont(oracle, assignment[0][1] + 1)
+    with LigeroProver(inst) as prover:
+        proof = prover.prove(idx, good)
+        assert prover.verify(proof)
+        assert not prover.verify(prover.prove(idx, bad))
+        # the same statement by label gives the same commitment
+        by_label = prover.prove_with_labels([s for s, _ in assignment], good)
+        assert prover.verify(by_label) and by_label.info()["u_root"] == proof.info()["u_root"]
+
+
 def test_reference_multioutput_1(oracle):
     """x^2 = 9, y^3 = 64, x + y = 7 as three outputs (src/ligero/tests.rs:245-362); x = 3, y = 4"""
     from ligero_amd import host_pipeline as hp
     from ligero_amd.prover import LigeroProver
     c = hp.ArithmeticCircuit()
-    x, y = c.new_variable(), c.new_variable()
+    x, y = c.new_variable_with_label("x"), c.new_variable_with_label("y")
     c1, c2, c3 = (c.constant(_mont(oracle, v)) for v in (-9 + 1, -64 + 1, -7 + 1))
     x2 = c.mul(x, x)
     y3 = c.pow(y, 3)
     s = c.add(x, y)
     outs = [c.add(x2, c1), c.add(y3, c2), c.add(s, c3)]
     inst = hp.LigeroInstance(c, outputs=outs)
+    good, bad = np.stack([_mont(oracle, 3), _mont(oracle, 4)]), np.stack([_mont(oracle, 3), _mont(oracle, 5)])
     with LigeroProver(inst) as prover:
-        assert prover.verify(prover.prove([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 4)])))
-        assert not prover.verify(prover.prove([x, y], np.stack([_mont(oracle, 3), _mont(oracle, 5)])))
+        # ligero.prove_with_labels(vec![("x", 3), ("y", 4)], ..) then verify (tests.rs:350-361): labels resolve in the
+        # circuit AFTER insert_one moved every index
+        proof = prover.prove_with_labels(["x", "y"], good)
+        assert prover.verify(proof)
+        assert not prover.verify(prover.prove_with_labels(["y", "x"], good))
+        assert not prover.verify(prover.prove_with_labels(["x", "y"], bad))
+        by_index = prover.prove([x, y], good)
+        assert prover.verify(by_index) and by_index.info()["u_root"] == proof.info()["u_root"]
+        with pytest.raises(RuntimeError, match="Variable not found: z"):
+            prover.prove_with_labels(["x", "z"], good)
 
 
 @pytest.mark.parametrize("batch", [1, 3])
