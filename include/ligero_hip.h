@@ -208,7 +208,8 @@ int lg_quadratic_constraint_poly(lg_ctx* ctx, const uint64_t* r, uint64_t* coeff
  *   lg_open_columns[_batch]                     every index j must lie in a held plane (j mod np)
  *   lg_read_codeword_rows                       needs all planes
  *   lg_linear_constraint_poly[_from_seeds],
- *   lg_quadratic_constraint_poly                need the planes s = 0 (mod 4) (the size-2k domain)
+ *   lg_quadratic_constraint_poly                need the planes s = 0 (mod 4) (the size-2k domain); on a sharded
+ *                                               commitment use lg_subproof_points / lg_subproof_finish below
  *   lg_interleaved_row_mul, lg_commit_resident  need every message row
  * A single rank that stages all planes and all rows ends up with a full commitment and no restriction.
  */
@@ -218,6 +219,35 @@ int lg_stage_merkle(lg_ctx* ctx);
 typedef enum lg_buffer { LG_BUF_PREENC = 0, LG_BUF_COEFFS = 1, LG_BUF_LEAVES = 2, LG_BUF_NODES = 3 } lg_buffer;
 /* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers). */
 int lg_device_buffer(lg_ctx* ctx, int which, void** dptr_out, size_t* bytes_out);
+/*
+ * Step 4 without a layout pass on the host side, for ranks that own equal contiguous runs of planes (rank r: planes
+ * [r np/world, (r+1) np/world)): lg_stage_digests_pack copies this rank's leaf digests into block `rank` of a library-owned
+ * staging buffer of `world` equal blocks and returns it (call lg_sync before handing it to a collective on another
+ * stream); the caller all-gathers that buffer IN PLACE; lg_stage_digests_unpack scatters all blocks into LG_BUF_LEAVES.
+ */
+int lg_stage_digests_pack(lg_ctx* ctx, uint32_t world, uint32_t rank, void** dptr_out, size_t* bytes_per_rank_out);
+int lg_stage_digests_unpack(lg_ctx* ctx, uint32_t world);
+
+/*
+ * Sub-proof polynomials of a coset-sharded commitment (also valid on an ordinary batch-1 context, where one call serves
+ * every plane).  The three polynomials are interpolated from their values on the size-2k domain = codeword indices 4 j;
+ * slot j of the 2k-element point array belongs to plane 4 (j mod np/4), and a value is a sum over ALL rows of data of that
+ * one plane -- so the rank that holds the plane computes it alone, with no cross-rank reduction:
+ *   lg_subproof_points   the values at the slots of the planes this context holds (other slots: zero), Montgomery form;
+ *                        *plane_mask_out (may be NULL) = the planes served.  challenge:
+ *                          LG_SUB_INTERLEAVED        r, 4m elements      -> preenc_u.row_mul(r) at the even slots 2 p
+ *                                                                           (message position p = codeword index 8 p)
+ *                          LG_SUB_LINEAR             r_a, 4m * k elements (as lg_linear_constraint_poly)
+ *                          LG_SUB_LINEAR_FROM_SEED   32-byte seed (as lg_linear_constraint_poly_from_seeds; a context
+ *                                                    that holds no plane of the domain needs no constraint matrix)
+ *                          LG_SUB_QUADRATIC          r, m elements       (as lg_quadratic_constraint_poly)
+ *   (caller)             all-gather the arrays, take slot j from the owner of plane 4 (j mod np/4)
+ *   lg_subproof_finish   the merged 2k points -> what the unsharded call returns: k elements (interleaved) or the 2k
+ *                        coefficients (linear, quadratic).  Needs no commitment: any context of these dimensions will do.
+ */
+enum { LG_SUB_INTERLEAVED = 0, LG_SUB_LINEAR = 1, LG_SUB_LINEAR_FROM_SEED = 2, LG_SUB_QUADRATIC = 3 };
+int lg_subproof_points(lg_ctx* ctx, int which, const void* challenge, uint64_t* points_out, uint32_t* plane_mask_out);
+int lg_subproof_finish(lg_ctx* ctx, int which, const uint64_t* points, uint64_t* out);
 
 /* Shape queries. */
 int lg_ctx_dims(const lg_ctx* ctx, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch);

@@ -23,6 +23,7 @@ SYMBOLS = [
     "lg_interleaved_row_mul", "lg_linear_constraint_poly", "lg_quadratic_constraint_poly",
     "lg_upload_constraint_matrix", "lg_linear_constraint_poly_from_seeds",
     "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_merkle", "lg_device_buffer",
+    "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
 
@@ -36,6 +37,7 @@ LG_ERR_STATE = -6
 LG_ERR_UNSUPPORTED = -7
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
 LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES = 0, 1, 2, 3
+LG_SUB_INTERLEAVED, LG_SUB_LINEAR, LG_SUB_LINEAR_FROM_SEED, LG_SUB_QUADRATIC = 0, 1, 2, 3
 LG_FIELD_BN254_FR, LG_FIELD_BLS12_377_FQ, LG_FIELD_BN254_FR_GENERIC = 0, 1, 2
 
 _vp = ctypes.c_void_p
@@ -101,6 +103,10 @@ def lib():
     L.lg_reed_solomon_interpolate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon_evaluate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon.argtypes = [_vp, _vp, _u32, _vp]
+    L.lg_stage_digests_pack.argtypes = [_vp, _u32, _u32, _vp, _vp]
+    L.lg_stage_digests_unpack.argtypes = [_vp, _u32]
+    L.lg_subproof_points.argtypes = [_vp, _int, _vp, _vp, _vp]
+    L.lg_subproof_finish.argtypes = [_vp, _int, _vp, _vp]
     L.lg_interleaved_row_mul.argtypes = [_vp, _vp, _vp]
     L.lg_linear_constraint_poly.argtypes = [_vp, _vp, _vp]
     L.lg_quadratic_constraint_poly.argtypes = [_vp, _vp, _vp]

@@ -86,6 +86,7 @@ struct lg_ctx {
     uint32_t have_planes = 0;                  // mask of the planes of d_u that belong to the current commitment
     uint32_t have_row0 = 0, have_row1 = 0;     // message rows [have_row0, have_row1) of d_preenc that belong to it
     uint8_t* d_leaves = nullptr;  // [batch][n][32]
+    uint8_t* d_digest_xchg = nullptr;   // [world][ki][planes per rank][32] staging of the sharded commit's digest all-gather
     uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
     // domain tables: 29-bit limbs, value * 2^261 mod p, three planes each (limbs 0-3 | 4-7 | 8)
     uint8_t* d_tw_fwd = nullptr;    // butterfly twiddles of the size-ki transform, pass order (lg::pass_tw_offset)
@@ -476,7 +477,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
-    void* bufs2[] = {c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
+    void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
     void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
@@ -1247,9 +1248,19 @@ static int linear_buffers(lg_ctx* c, uint32_t* per_out, uint32_t* nch_out) {
     if (rc != LG_OK) return rc;
     rc = grow(c, &c->d_scratch_a, &c->scratch_a_elems, 2 * mat);
     if (rc != LG_OK) return rc;
-    return grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)c->nplanes * R * c->ki);
+    // the planes s = 4 (mod 8) of the r_a rows' encodings, slot s >> 3 (an eighth of a codeword matrix, not a whole one)
+    return grow(c, &c->d_scratch_b, &c->scratch_b_elems, (size_t)((c->nplanes + 7) / 8) * R * c->ki);
 }
-static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_out);
+// plane_mask: the planes s = 0 (mod 4) to serve (all of them, or the owned ones of a sharded context); points_out set =
+// stop before the interpolation and hand back the 2k point values (slots of planes outside the mask are zero)
+static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out);
+// the planes of the size-2k evaluation domain (s = 0 mod 4) a sub-proof call on this context serves
+static uint32_t sub_plane_mask(const lg_ctx* c) { return (c->sharded ? own_planes_mask(c) : all_planes_mask(c)) & 0x11111111u; }
+static int sub_points_begin(lg_ctx* c) {   // unserved slots of the point array read as zero
+    if (!c->d_sub_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_sub_q), (size_t)c->batch * 2 * c->k * sizeof(fr)));
+    LG_HIP(c, hipMemsetAsync(c->d_sub_q, 0, (size_t)c->batch * 2 * c->k * sizeof(fr), c->stream));
+    return LG_OK;
+}
 
 int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_out) {
     if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
@@ -1262,7 +1273,7 @@ int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_o
     int rc = linear_buffers(c, &per, &nch);
     if (rc != LG_OK) return rc;
     LG_HIP(c, hipMemcpyAsync(c->d_scratch_a, r_a, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
-    return linear_core(c, per, nch, coeffs_out);
+    return linear_core(c, per, nch, all_planes_mask(c) & 0x11111111u, coeffs_out, nullptr);
 }
 
 int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, const uint64_t* row_idx, const uint64_t* col_idx, const uint64_t* values) {
@@ -1305,13 +1316,8 @@ int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, cons
     return LG_OK;
 }
 
-int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* coeffs_out) {
-    if (!c || !seeds || !coeffs_out) return LG_ERR_BAD_ARG;
-    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
-    if (!c->committed || !c->a_loaded) return LG_ERR_STATE;
-    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
-    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly_from_seeds"); if (rc_ != LG_OK) return rc_; }
-    LG_HIP(c, hipSetDevice(c->device));
+// r_linear (ChaCha20 + F::rand from the seeds) and r_a = A.row_mul(r_linear) into d_scratch_a, then linear_core
+static int linear_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
     uint32_t per, nch;
     int rc = linear_buffers(c, &per, &nch);
     if (rc != LG_OK) return rc;
@@ -1341,7 +1347,7 @@ int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64
     m.r = c->d_rlin; m.out = c->d_scratch_a; m.heavy = c->d_a_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)n;
     LG_LAUNCH(c, lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->stream, m);
     if (c->a_nheavy) LG_LAUNCH(c, lg::sparse_row_mul_heavy_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, m);
-    rc = linear_core(c, per, nch, coeffs_out);   // synchronises on the stream when it reads the coefficients back
+    rc = linear_core(c, per, nch, plane_mask, coeffs_out, points_out);   // synchronises on the stream when it reads the result back
     if (rc != LG_OK) return rc;
     uint32_t flag = 0;
     LG_HIP(c, hipMemcpy(&flag, c->d_short_flag, 4, hipMemcpyDeviceToHost));
@@ -1352,7 +1358,17 @@ int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64
     return LG_OK;
 }
 
-static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_out) {
+int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* coeffs_out) {
+    if (!c || !seeds || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (!c->committed || !c->a_loaded) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly_from_seeds"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    return linear_from_seeds(c, seeds, all_planes_mask(c) & 0x11111111u, coeffs_out, nullptr);
+}
+
+static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
     const uint32_t rows = c->rows, O = 1u << c->logo;
     const uint64_t R = c->total_rows;
     const size_t mat = (size_t)R * c->k;
@@ -1365,19 +1381,25 @@ static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_o
     {
         lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, (uint32_t)R);
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
-        lg::NttArgs e = eval_args(c, d_rc, c->d_scratch_b, plane, 0, (uint32_t)R, true);
-        e.ncos = 0;
-        for (uint32_t s = 4; s < c->nplanes; s += 8) e.cosets[e.ncos++] = (uint8_t)s;
-        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, e));
+        // one launch per computed plane, each into its own slot: the kernel addresses plane s at out + s * plane_stride
+        for (uint32_t s = 4; s < c->nplanes; s += 8) {
+            if (!(plane_mask & (1u << s))) continue;
+            lg::NttArgs e = eval_args(c, d_rc, c->d_scratch_b + (uint64_t)(s >> 3) * plane - (uint64_t)s * plane, plane, 0, (uint32_t)R, true);
+            e.ncos = 1;
+            e.cosets[0] = (uint8_t)s;
+            LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, e));
+        }
     }
+    if (points_out) { rc = sub_points_begin(c); if (rc != LG_OK) return rc; }
     for (uint32_t s = 0; s < c->nplanes; s += 4) {
+        if (!(plane_mask & (1u << s))) continue;
         lg::RowSumArgs a;
         memset(&a, 0, sizeof(a));
         a.a = c->d_u + (uint64_t)s * plane; a.a_proof = (uint64_t)rows * c->ki; a.a_row = c->ki; a.a_col = 1;   // u_i on this plane (canonical)
         if ((s & 7) == 0) {  // message plane 8c': r_i there = r_a[i][O j + c'] (Montgomery)
             a.b = d_ra + (s >> 3); a.b_proof = (uint64_t)rows * c->k; a.b_row = c->k; a.b_col = O;
         } else {             // computed plane (canonical)
-            a.b = c->d_scratch_b + (uint64_t)s * plane; a.b_proof = (uint64_t)rows * c->ki; a.b_row = c->ki; a.b_col = 1;
+            a.b = c->d_scratch_b + (uint64_t)(s >> 3) * plane; a.b_proof = (uint64_t)rows * c->ki; a.b_row = c->ki; a.b_col = 1;
         }
         a.partial = c->d_sub_partial;
         a.rows = rows; a.cols = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
@@ -1387,9 +1409,11 @@ static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint64_t* coeffs_o
         rc = sub_finish(c, nch, c->ki, (s & 7) == 0 ? c->r2 : c->r3, c->d_sub_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);
         if (rc != LG_OK) return rc;
     }
+    if (points_out) return read_back(c, points_out, c->d_sub_q, (size_t)c->batch * 2 * c->k * sizeof(fr));
     return sub_interpolate_2k(c, coeffs_out);
 }
 
+static int quadratic_core(lg_ctx* c, const uint64_t* r, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out);
 int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_out) {
     if (!c || !r || !coeffs_out) return LG_ERR_BAD_ARG;
     if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_quadratic_constraint_poly(c->gf, r, coeffs_out); }
@@ -1398,6 +1422,9 @@ int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_quadratic_constraint_poly"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
+    return quadratic_core(c, r, all_planes_mask(c) & 0x11111111u, coeffs_out, nullptr);
+}
+static int quadratic_core(lg_ctx* c, const uint64_t* r, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
     const uint32_t m = c->rows / 4;
     uint32_t per;
     const uint32_t nch = sub_chunks(m, &per);
@@ -1405,7 +1432,9 @@ int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_
     if (rc != LG_OK) return rc;
     LG_HIP(c, hipMemcpyAsync(c->d_sub_r, r, (size_t)c->batch * m * sizeof(fr), hipMemcpyHostToDevice, c->stream));
     const uint64_t plane = c->total_rows * c->ki;
+    if (points_out) { rc = sub_points_begin(c); if (rc != LG_OK) return rc; }
     for (uint32_t s = 0; s < c->nplanes; s += 4) {
+        if (!(plane_mask & (1u << s))) continue;
         lg::QuadSumArgs a;
         memset(&a, 0, sizeof(a));
         a.u = c->d_u + (uint64_t)s * plane;
@@ -1418,7 +1447,85 @@ int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_
         rc = sub_finish(c, nch, c->ki, c->r2, c->d_sub_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);   // plain -> Montgomery
         if (rc != LG_OK) return rc;
     }
+    if (points_out) return read_back(c, points_out, c->d_sub_q, (size_t)c->batch * 2 * c->k * sizeof(fr));
     return sub_interpolate_2k(c, coeffs_out);
+}
+
+// ---- the same three sums as POINT VALUES on the planes this context holds (coset-sharded commitments) --------
+// The polynomials above are interpolated from their values at the size-2k domain, codeword indices 4 j, j = (np/4) q + s/4 for
+// plane s = 0 (mod 4).  Every such value is a sum over ALL rows of data of ONE plane, so the rank owning the plane computes
+// it alone; the host layer all-gathers the 2k-slot arrays (slot j belongs to plane 4 (j mod np/4)) and any rank interpolates.
+// preenc_u.row_mul(r) is the same thing on the planes s = 0 (mod 8): message position p is codeword index 8 p, slot 2 p.
+int lg_subproof_points(lg_ctx* c, int which, const void* challenge, uint64_t* points_out, uint32_t* plane_mask_out) {
+    if (!c || !challenge || !points_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (c->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (!c->committed) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    uint32_t mask = sub_plane_mask(c);
+    if (which == LG_SUB_INTERLEAVED) mask &= 0x01010101u;
+    if (plane_mask_out) *plane_mask_out = mask;
+    { const int rc_ = need_planes(c, mask, "lg_subproof_points"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    int rc = LG_OK;
+    switch (which) {
+        case LG_SUB_INTERLEAVED: {
+            uint32_t per;
+            const uint32_t nch = sub_chunks(c->rows, &per);
+            rc = sub_buffers(c, (size_t)nch * 2 * c->k, c->total_rows);
+            if (rc != LG_OK) return rc;
+            LG_HIP(c, hipMemcpyAsync(c->d_sub_r, challenge, (size_t)c->total_rows * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+            rc = sub_points_begin(c);
+            if (rc != LG_OK) return rc;
+            const uint64_t plane = c->total_rows * c->ki;
+            for (uint32_t s = 0; s < c->nplanes; s += 8) {
+                if (!(mask & (1u << s))) continue;
+                lg::RowSumArgs a;
+                memset(&a, 0, sizeof(a));
+                a.a = c->d_u + (uint64_t)s * plane; a.a_proof = (uint64_t)c->rows * c->ki; a.a_row = c->ki; a.a_col = 1;   // canonical
+                a.b = nullptr; a.r = c->d_sub_r;                                                                        // Montgomery
+                a.partial = c->d_sub_partial;
+                a.rows = c->rows; a.cols = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
+                LG_LAUNCH(c, lg::rowsum_mul_kernel, dim3((c->ki + 255) / 256, nch, 1), dim3(256), 0, c->stream, a);
+                rc = sub_finish(c, nch, c->ki, c->r2, c->d_sub_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);   // plain -> Montgomery
+                if (rc != LG_OK) return rc;
+            }
+            return read_back(c, points_out, c->d_sub_q, (size_t)2 * c->k * sizeof(fr));
+        }
+        case LG_SUB_LINEAR: {
+            if (mask == 0) { memset(points_out, 0, (size_t)2 * c->k * sizeof(fr)); return LG_OK; }
+            uint32_t per, nch;
+            rc = linear_buffers(c, &per, &nch);
+            if (rc != LG_OK) return rc;
+            LG_HIP(c, hipMemcpyAsync(c->d_scratch_a, challenge, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+            return linear_core(c, per, nch, mask, nullptr, points_out);
+        }
+        case LG_SUB_LINEAR_FROM_SEED:
+            if (mask == 0) { memset(points_out, 0, (size_t)2 * c->k * sizeof(fr)); return LG_OK; }   // no plane, no work (and no matrix needed)
+            if (!c->a_loaded) return LG_ERR_STATE;
+            return linear_from_seeds(c, static_cast<const uint8_t*>(challenge), mask, nullptr, points_out);
+        case LG_SUB_QUADRATIC:
+            if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
+            if (mask == 0) { memset(points_out, 0, (size_t)2 * c->k * sizeof(fr)); return LG_OK; }
+            return quadratic_core(c, static_cast<const uint64_t*>(challenge), mask, nullptr, points_out);
+        default: return LG_ERR_BAD_ARG;
+    }
+}
+
+int lg_subproof_finish(lg_ctx* c, int which, const uint64_t* points, uint64_t* out) {
+    if (!c || !points || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (which == LG_SUB_INTERLEAVED) {   // the values at the message positions are the result
+        for (uint32_t p = 0; p < c->k; p++) memcpy(out + 4 * (size_t)p, points + 4 * (size_t)(2 * p), sizeof(fr));
+        return LG_OK;
+    }
+    if (which != LG_SUB_LINEAR && which != LG_SUB_LINEAR_FROM_SEED && which != LG_SUB_QUADRATIC) return LG_ERR_BAD_ARG;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    LG_HIP(c, hipSetDevice(c->device));
+    if (!c->d_sub_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_sub_q), (size_t)2 * c->k * sizeof(fr)));
+    LG_HIP(c, hipMemcpyAsync(c->d_sub_q, points, (size_t)2 * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    return sub_interpolate_2k(c, out);
 }
 
 // ---- staged commit for one proof sharded over several GPUs ----------------
@@ -1553,6 +1660,50 @@ int lg_stage_merkle(lg_ctx* c) {
     LG_HIP(c, hipGetLastError());
     c->committed = true;
     c->staging = false;
+    return LG_OK;
+}
+
+// Digest exchange of the sharded commit without a host-side layout pass: pack copies the leaf digests of this rank's planes into
+// block `rank` of a staging buffer of `world` equal blocks ([q][plane of the run][32] each), the host layer all-gathers the
+// buffer in place, unpack scatters every block back into leaf order j = np q + s.
+static int digest_run(lg_ctx* c, uint32_t world, uint32_t* per_out) {
+    if (world == 0 || c->nplanes % world != 0) {
+        snprintf(c->err, sizeof(c->err), "%u coset planes cannot be dealt to %u ranks in equal runs", c->nplanes, world);
+        return LG_ERR_BAD_ARG;
+    }
+    *per_out = c->nplanes / world;
+    return LG_OK;
+}
+int lg_stage_digests_pack(lg_ctx* c, uint32_t world, uint32_t rank, void** dptr_out, size_t* bytes_per_rank_out) {
+    if (!c || !dptr_out || !bytes_per_rank_out || rank >= world) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1) return LG_ERR_STATE;
+    uint32_t per;
+    { const int rc_ = digest_run(c, world, &per); if (rc_ != LG_OK) return rc_; }
+    uint32_t run = 0;
+    for (uint32_t s = rank * per; s < (rank + 1) * per; s++) run |= 1u << s;
+    { const int rc_ = need_planes(c, run, "lg_stage_digests_pack"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    const size_t block = (size_t)c->ki * per * 32;
+    if (!c->d_digest_xchg) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_digest_xchg), (size_t)c->n * 32));
+    LG_HIP(c, hipMemcpy2DAsync(c->d_digest_xchg + (size_t)rank * block, (size_t)per * 32, c->d_leaves + (size_t)rank * per * 32, (size_t)c->nplanes * 32,
+                               (size_t)per * 32, c->ki, hipMemcpyDeviceToDevice, c->stream));
+    *dptr_out = c->d_digest_xchg;
+    *bytes_per_rank_out = block;
+    return LG_OK;
+}
+int lg_stage_digests_unpack(lg_ctx* c, uint32_t world) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1 || !c->d_digest_xchg) return LG_ERR_STATE;
+    uint32_t per;
+    { const int rc_ = digest_run(c, world, &per); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    const size_t block = (size_t)c->ki * per * 32;
+    for (uint32_t o = 0; o < world; o++)
+        LG_HIP(c, hipMemcpy2DAsync(c->d_leaves + (size_t)o * per * 32, (size_t)c->nplanes * 32, c->d_digest_xchg + (size_t)o * block, (size_t)per * 32,
+                                   (size_t)per * 32, c->ki, hipMemcpyDeviceToDevice, c->stream));
     return LG_OK;
 }
 

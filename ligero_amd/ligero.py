@@ -289,6 +289,28 @@ class LigeroCommitter:
         self._chk(self._L.lg_quadratic_constraint_poly(self._ctx, _ptr(r), _ptr(out)), "lg_quadratic_constraint_poly")
         return out
 
+    def subproof_points(self, which: int, challenge):
+        """lg_subproof_points (batch 1): the values of a sub-proof polynomial at the slots of the coset planes this context
+        holds -> ((2k, 4) Montgomery, plane mask).  challenge: r (4m), r_a (4m * k), a 32-byte seed, or r (m) by `which`."""
+        if which == _ffi.LG_SUB_LINEAR_FROM_SEED:
+            ch = np.frombuffer(bytes(challenge), dtype=np.uint8).copy()
+            if ch.size != 32:
+                raise ValueError("a 32-byte seed")
+        else:
+            want = {_ffi.LG_SUB_INTERLEAVED: self.rows, _ffi.LG_SUB_LINEAR: self.rows * self.k, _ffi.LG_SUB_QUADRATIC: self.rows // 4}[which]
+            ch = np.ascontiguousarray(challenge, dtype=np.uint64).reshape(want, self.ew)
+        out = np.empty((2 * self.k, self.ew), dtype=np.uint64)
+        mask = ctypes.c_uint32(0)
+        self._chk(self._L.lg_subproof_points(self._ctx, which, _ptr(ch), _ptr(out), ctypes.cast(ctypes.byref(mask), _vp)), "lg_subproof_points")
+        return out, int(mask.value)
+
+    def subproof_finish(self, which: int, points) -> np.ndarray:
+        """lg_subproof_finish: merged (2k, 4) points -> (k, 4) preenc_u_lc (interleaved) or (2k, 4) coefficients"""
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(2 * self.k, self.ew)
+        out = np.empty((self.k if which == _ffi.LG_SUB_INTERLEAVED else 2 * self.k, self.ew), dtype=np.uint64)
+        self._chk(self._L.lg_subproof_finish(self._ctx, which, _ptr(pts), _ptr(out)), "lg_subproof_finish")
+        return out
+
     def pipeline_chunks(self) -> int:
         """launches of the evaluate / column-hash kernels per commit (1 for small commits)"""
         n = ctypes.c_uint32(0)

@@ -116,6 +116,18 @@ class HipStageBackend:
         """[n, 32] uint8 view of the resident leaf digests"""
         return self._buffer(_ffi.LG_BUF_LEAVES).view(self.n, 32)
 
+    def digests_pack(self, world: int, rank: int):
+        """lg_stage_digests_pack: this rank's leaf digests into block `rank` of the staging buffer -> [world, block] uint8 view of
+        it (all-gather it in place after sync())"""
+        import torch
+        ptr, size = _vp(), ctypes.c_size_t()
+        _ffi.check(self._L.lg_stage_digests_pack(self.c._ctx, world, rank, ctypes.cast(ctypes.byref(ptr), _vp), ctypes.cast(ctypes.byref(size), _vp)),
+                   "lg_stage_digests_pack", self.c._ctx)
+        return torch.as_tensor(_CudaArray(ptr.value, world * size.value), device=f"cuda:{self.device}").view(world, size.value)
+
+    def digests_unpack(self, world: int):
+        _ffi.check(self._L.lg_stage_digests_unpack(self.c._ctx, world), "lg_stage_digests_unpack", self.c._ctx)
+
     def root(self) -> bytes:
         return self.c.root()
 
