@@ -28,6 +28,26 @@ const char* lgp_last_error(void);
 int lgp_prover_create(lgp_prover** out, const lgh_instance* inst, int device);
 void lgp_prover_destroy(lgp_prover* p);
 
+/*
+ * ONE proof over several GPUs (BASELINE configs[3]): one prover per rank (= per GPU), created with the
+ * same instance and a description of the group.  lgp_prove / lgp_prove_with_labels must then be called on every rank with
+ * the same assignment (the transcript is replicated); each rank commits its row shard and its coset planes, serves the
+ * sub-proof points and the opened columns it holds, and every rank returns the complete proof -- identical to the one an
+ * ordinary prover makes.  The exchanges are the caller's: two callbacks, both returning 0 on success
+ *   all_gather_device  in place on DEVICE memory: device_buf holds `world` blocks of bytes_per_rank, block `rank` is this
+ *                      rank's contribution (the coefficient rows: 4m k 32 B in total; the leaf digests: n 32 B)
+ *   all_gather_host    equal HOST blocks: recv holds `world` blocks of `bytes` (sub-proof points: 2k 32 B per rank; the
+ *                      opened columns: about t / world columns per rank)
+ * With world = 1 the callbacks may be NULL.  lgp_verify works on such a prover as on any other.
+ */
+typedef struct lgp_comm {
+    uint32_t world, rank;
+    void* user;
+    int (*all_gather_device)(void* user, void* device_buf, uint64_t bytes_per_rank);
+    int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes);
+} lgp_comm;
+int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int device, const lgp_comm* comm);
+
 /* prove(var_assignment, mt_params, &mut test_sponge()): assignment by ORIGINAL node index, as for lgh_build_preenc */
 int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proof_out);
 /* prove_with_labels(var_assignment, mt_params, &mut test_sponge()) (src/ligero/mod.rs:580-611): variables named by
@@ -55,6 +75,8 @@ const lgp_proof* lgp_batch_proof(const lgp_batch_prover* p, uint32_t index);
 /* inspection: info_out = { len(preenc_u_lc), len(linear poly), len(quadratic poly), opened columns per sub-proof,
  * column length, auth path length }; root_out = u_root */
 int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_out[32]);
+/* field-by-field equality of two proofs (u_root, preenc_u_lc, both polynomials, every opened column and path) */
+int lgp_proof_equal(const lgp_proof* a, const lgp_proof* b, int* equal_out);
 /* (the proof-corruption hook the tamper tests use lives in a separate test-only library: ligero_amd/host/ligero_prover_testhooks.cpp) */
 
 #ifdef __cplusplus

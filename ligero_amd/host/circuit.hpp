@@ -640,6 +640,12 @@ public:
     }
     // prove_inner (mod.rs:476-516): assignment by index into the formatted circuit
     void build_preenc_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr) const {
+        build_preenc_range_from_formatted(bumped, 0, 4 * m * k, out, all_outputs_one);
+    }
+    // the same, but only elements [elem_begin, elem_end) of the flat row-major 4m x k matrix, written to out[0 ..): the row
+    // shard one rank of a coset-sharded proof uploads (elem = row * k; the trace is still evaluated in full)
+    void build_preenc_range_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, size_t elem_begin, size_t elem_end, E* out,
+                                           bool* all_outputs_one = nullptr) const {
         // evaluation_trace_multioutput + expect on every node (mod.rs:476-478): a node the outputs do not depend on and
         // that is not an assigned variable is a panic there, not a silently evaluated gate
         auto trace = circuit.evaluation_trace_multioutput(bumped, outputs);
@@ -652,15 +658,18 @@ public:
                 if (!F::eq(sol[o], F::one())) *all_outputs_one = false;
         }
         const size_t mk = m * k;
-        std::memset(static_cast<void*>(out), 0, 4 * mk * sizeof(E));      // the all-zero limbs are the field's zero
-        E *x = out, *y = out + mk, *z = out + 2 * mk, *w = out + 3 * mk;
+        if (elem_end > 4 * mk || elem_begin > elem_end) throw std::runtime_error("build_preenc: element range outside the 4m x k matrix");
+        std::memset(static_cast<void*>(out), 0, (elem_end - elem_begin) * sizeof(E));      // the all-zero limbs are the field's zero
+        auto put = [&](size_t flat, const E& v) {
+            if (flat >= elem_begin && flat < elem_end) out[flat - elem_begin] = v;
+        };
         size_t pos = 0;
         for (size_t i = 0; i < circuit.nodes.size(); i++) {
             const Node& nd = circuit.nodes[i];
             if (nd.kind == Node::Constant && i != 0) continue;
             if (pos >= mk) throw std::runtime_error("solution vector longer than m * k");
-            w[pos] = sol[i];
-            if (nd.kind == Node::Mul) { x[pos] = sol[nd.l]; y[pos] = sol[nd.r]; z[pos] = sol[i]; }
+            put(3 * mk + pos, sol[i]);                                                       // w
+            if (nd.kind == Node::Mul) { put(pos, sol[nd.l]); put(mk + pos, sol[nd.r]); put(2 * mk + pos, sol[i]); }   // x, y, z
             pos++;
         }
     }

@@ -39,6 +39,19 @@ int lgp_prover_create(lgp_prover** out, const lgh_instance* inst, int device) {
 }
 void lgp_prover_destroy(lgp_prover* p) { delete p; }
 
+int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int device, const lgp_comm* comm) {
+    if (!out || !inst || !comm) return LGP_ERR_BAD_ARG;
+    *out = nullptr;
+    return guarded([&] {
+        ligero::ShardComm sc;
+        sc.world = comm->world; sc.rank = comm->rank; sc.user = comm->user;
+        sc.all_gather_device = comm->all_gather_device;
+        sc.all_gather_host = comm->all_gather_host;
+        *out = new lgp_prover(inst->inst, device, sc);
+        return LGP_OK;
+    });
+}
+
 int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proof_out) {
     if (!p || !proof_out || (count && (!node_idx || !values))) return LGP_ERR_BAD_ARG;
     *proof_out = nullptr;
@@ -142,6 +155,31 @@ int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_ou
     info_out[4] = p.interleaved_proof.open.columns.empty() ? 0 : p.interleaved_proof.open.columns[0].size();
     info_out[5] = p.interleaved_proof.open.paths.empty() ? 0 : p.interleaved_proof.open.paths[0].auth_path.size();
     std::memcpy(root_out, p.u_root.data(), 32);
+    return LGP_OK;
+}
+
+static bool same_elems(const std::vector<Fr>& a, const std::vector<Fr>& b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(Fr)) == 0);
+}
+static bool same_open(const ligero::OpenedColumns& a, const ligero::OpenedColumns& b) {
+    if (a.columns.size() != b.columns.size() || a.paths.size() != b.paths.size()) return false;
+    for (size_t i = 0; i < a.columns.size(); i++)
+        if (!same_elems(a.columns[i], b.columns[i])) return false;
+    for (size_t i = 0; i < a.paths.size(); i++)
+        if (a.paths[i].leaf_index != b.paths[i].leaf_index || a.paths[i].leaf_sibling_hash != b.paths[i].leaf_sibling_hash ||
+            a.paths[i].auth_path != b.paths[i].auth_path)
+            return false;
+    return true;
+}
+int lgp_proof_equal(const lgp_proof* a, const lgp_proof* b, int* equal_out) {
+    if (!a || !b || !equal_out) return LGP_ERR_BAD_ARG;
+    const LigeroProof &x = *a->view, &y = *b->view;
+    *equal_out = x.u_root == y.u_root && same_elems(x.interleaved_proof.preenc_u_lc, y.interleaved_proof.preenc_u_lc) &&
+                 same_open(x.interleaved_proof.open, y.interleaved_proof.open) &&
+                 same_elems(x.linear_constraints_proof.polynomial, y.linear_constraints_proof.polynomial) &&
+                 same_open(x.linear_constraints_proof.open, y.linear_constraints_proof.open) &&
+                 same_elems(x.quadratic_constraints_proof.polynomial, y.quadratic_constraints_proof.polynomial) &&
+                 same_open(x.quadratic_constraints_proof.open, y.quadratic_constraints_proof.open);
     return LGP_OK;
 }
 

@@ -16,6 +16,8 @@
 // the Rust crate's is not established.  The algebra (what is computed from given challenges,
 // and every check the verifier makes) follows the reference line by line.
 #pragma once
+#include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -144,6 +146,18 @@ inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
     if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
 }
 
+// One proof over several GPUs: one prover object per rank, every rank runs the same (deterministic)
+// transcript; the exchanges are the host layer's -- RCCL through torch.distributed in ligero_amd/prover.py, anything else
+// that implements these two calls elsewhere.  Both return 0 on success.
+struct ShardComm {
+    uint32_t world = 1, rank = 0;
+    void* user = nullptr;
+    // in-place all-gather on DEVICE memory: device_buf holds `world` blocks of bytes_per_rank, block `rank` is this rank's
+    int (*all_gather_device)(void* user, void* device_buf, uint64_t bytes_per_rank) = nullptr;
+    // all-gather of equal HOST blocks: recv holds `world` blocks of `bytes`
+    int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes) = nullptr;
+};
+
 // E = Fr: the tuned BN254 device path, linear-test challenges generated on the device.  Any other element type (the
 // reference's second test field, ark_bls12_377::Fq): a generic-field context (lg_ctx_create_field), challenges and A.row_mul on
 // the host, the same device calls otherwise.
@@ -168,6 +182,37 @@ public:
         while ((size_t{1} << logn_) < n_) logn_++;
         if constexpr (kDeviceChallenges) upload_constraint_matrix(ctx_, inst.a);
     }
+    // One rank of a proof sharded over comm.world GPUs: this rank's context holds its row shard of preenc_u, ALL coefficient
+    // rows (after the all-gather) and only its own coset planes of U.  Every rank must call prove() with the same
+    // assignment; every rank gets the complete proof (identical to the unsharded prover's).
+    HipLigeroT(const LigeroInstance& inst, int device, const ShardComm& comm) : inst_(inst), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t), comm_(comm) {
+        static_assert(kDeviceChallenges, "sharded proofs run on the tuned BN254 device path");
+        if (comm.world == 0 || comm.rank >= comm.world) throw std::runtime_error("ShardComm: rank outside the world");
+        if (comm.world > 1 && (!comm.all_gather_device || !comm.all_gather_host)) throw std::runtime_error("ShardComm: a world of several ranks needs both all-gathers");
+        sharded_ = true;
+        const uint32_t rows = (uint32_t)(4 * m_);
+        nplanes_ = k_ <= 4096 ? 8 : (uint32_t)(8 * (k_ / 4096));       // the library's plane rule (include/ligero_hip.h); checked below
+        if (nplanes_ % comm.world != 0)
+            throw std::runtime_error(std::to_string(nplanes_) + " coset planes cannot be dealt to " + std::to_string(comm.world) + " ranks in equal runs");
+        planes_per_rank_ = nplanes_ / comm.world;
+        shard_rows_ = (rows + comm.world - 1) / comm.world;             // equal (padded) row shards: one all-gather whatever rows % world is
+        row0_ = std::min(rows, comm.rank * shard_rows_);
+        row1_ = std::min(rows, (comm.rank + 1) * shard_rows_);
+        const int st = lg_ctx_create_sharded(&ctx_, device, rows, (uint32_t)k_, (uint32_t)n_, comm.rank * planes_per_rank_, planes_per_rank_,
+                                             comm.world * shard_rows_);
+        if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_sharded");
+        uint32_t np = 0, p0 = 0, pc = 0;
+        if (lg_ctx_planes(ctx_, &np, &p0, &pc) != LG_OK || np != nplanes_ || p0 != comm.rank * planes_per_rank_ || pc != planes_per_rank_) {
+            lg_ctx_destroy(ctx_);
+            throw std::runtime_error("sharded context does not hold the planes asked for");
+        }
+        logn_ = 0;
+        while ((size_t{1} << logn_) < n_) logn_++;
+        own_mask_ = 0;
+        for (uint32_t s = p0; s < p0 + pc; s++) own_mask_ |= 1u << s;
+        // the linear test's challenges and A.row_mul run where a plane of the size-2k domain (s = 0 mod 4) lives: only those ranks hold A
+        if (own_mask_ & 0x11111111u) upload_constraint_matrix(ctx_, inst.a);
+    }
     ~HipLigeroT() {
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
         lg_ctx_destroy(ctx_);
@@ -191,6 +236,9 @@ private:
     LigeroProof prove_inner(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {   // mod.rs:457-578
         // preenc_u straight into a buffer this prover keeps (and page-locks, so that lg_encode_commit's PCIe chunks overlap
         // the encoding): at 2^20 constraints the matrix is 1.3 GB and fresh memory for it costs more than the commitment
+        if constexpr (kDeviceChallenges) {
+            if (sharded_) return prove_inner_sharded(formatted_assignment, sponge);
+        }
         if (flat_.empty()) {
             flat_.resize(4 * m_ * k_);
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
@@ -230,6 +278,136 @@ private:
             proof.quadratic_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
             proof.quadratic_constraints_proof.open = open_columns(sponge);
+        }
+        return proof;
+    }
+
+    // ---------------------------------------------------------------- the same proof over comm_.world GPUs
+    void comm_check(int rc, const char* what) const {
+        if (rc != 0) throw std::runtime_error(std::string(what) + ": the host layer's collective failed (" + std::to_string(rc) + ")");
+    }
+    // mod.rs:521-551 as the five stages of DESIGN.md section 7
+    void sharded_commit(const std::vector<std::pair<size_t, E>>& formatted_assignment, Digest& root) {
+        const size_t own = (size_t)(row1_ - row0_) * k_;
+        if (flat_.size() != std::max<size_t>(own, 1)) {
+            if (pinned_) lg_host_unregister(ctx_, flat_.data());
+            flat_.assign(std::max<size_t>(own, 1), F::zero());
+            pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
+        }
+        inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data());
+        check(lg_stage_interpolate(ctx_, own ? flat_[0].l : nullptr, row0_, row1_ - row0_), "lg_stage_interpolate");
+        if (comm_.world > 1) {
+            void* d = nullptr;
+            size_t bytes = 0;
+            check(lg_device_buffer(ctx_, LG_BUF_COEFFS, &d, &bytes), "lg_device_buffer");
+            check(lg_sync(ctx_), "lg_sync");
+            comm_check(comm_.all_gather_device(comm_.user, d, (uint64_t)shard_rows_ * k_ * sizeof(Fr)), "all-gather of the coefficient rows");
+        }
+        check(lg_stage_evaluate_hash(ctx_, own_mask_), "lg_stage_evaluate_hash");
+        if (comm_.world > 1) {
+            void* d = nullptr;
+            size_t bytes = 0;
+            check(lg_stage_digests_pack(ctx_, comm_.world, comm_.rank, &d, &bytes), "lg_stage_digests_pack");
+            check(lg_sync(ctx_), "lg_sync");
+            comm_check(comm_.all_gather_device(comm_.user, d, bytes), "all-gather of the leaf digests");
+            check(lg_stage_digests_unpack(ctx_, comm_.world), "lg_stage_digests_unpack");
+        }
+        check(lg_stage_merkle(ctx_), "lg_stage_merkle");
+        check(lg_read_root(ctx_, root.data()), "lg_read_root");
+    }
+    // the 2k point values of one sub-proof polynomial: this rank's slots from the device, the others' from their owners
+    std::vector<Fr> sharded_points(int which, const void* challenge) {
+        std::vector<Fr> mine(2 * k_);
+        check(lg_subproof_points(ctx_, which, challenge, mine[0].l, nullptr), "lg_subproof_points");
+        if (comm_.world == 1) return mine;
+        std::vector<Fr> all((size_t)comm_.world * 2 * k_);
+        comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), 2 * k_ * sizeof(Fr)), "all-gather of the sub-proof points");
+        for (size_t j = 0; j < 2 * k_; j++) {
+            const uint32_t plane = 4 * (uint32_t)(j % (nplanes_ / 4));     // slot j of the size-2k domain = codeword index 4 j
+            mine[j] = all[(size_t)(plane / planes_per_rank_) * 2 * k_ + j];
+        }
+        return mine;
+    }
+    std::vector<Fr> sharded_poly(int which, const void* challenge) {
+        const std::vector<Fr> points = sharded_points(which, challenge);
+        std::vector<Fr> out(which == LG_SUB_INTERLEAVED ? k_ : 2 * k_);
+        check(lg_subproof_finish(ctx_, which, points[0].l, out[0].l), "lg_subproof_finish");
+        return out;
+    }
+    // mod.rs:935-955: column j is opened by the rank that holds plane j mod np; fixed-size blocks (the most any rank opens) go
+    // through one host all-gather, and every rank assembles the openings in index order
+    OpenedColumns sharded_open_columns(PoseidonSponge& sponge) {
+        const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
+        const size_t t = indices.size(), rows = 4 * m_, plen = (size_t)logn_ - 1;
+        auto owner_of = [&](uint64_t j) { return (uint32_t)((j % nplanes_) / planes_per_rank_); };
+        std::vector<uint32_t> count(comm_.world, 0);
+        for (uint64_t j : indices) count[owner_of(j)]++;
+        const size_t most = *std::max_element(count.begin(), count.end());
+        const size_t col_bytes = rows * sizeof(Fr), rec = col_bytes + 32 + plen * 32;   // one opening: column | leaf sibling | path
+        std::vector<uint8_t> mine(std::max<size_t>(most * rec, 1), 0);
+        std::vector<uint32_t> idx;
+        for (uint64_t j : indices)
+            if (owner_of(j) == comm_.rank) idx.push_back((uint32_t)j);
+        if (!idx.empty()) {
+            std::vector<Fr> cols(idx.size() * rows);
+            std::vector<uint8_t> sib(idx.size() * 32), paths(idx.size() * plen * 32 + 1);
+            check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)idx.size(), cols[0].l, sib.data(), paths.data()), "lg_open_columns");
+            for (size_t c = 0; c < idx.size(); c++) {
+                uint8_t* p = &mine[c * rec];
+                memcpy(p, &cols[c * rows], col_bytes);
+                memcpy(p + col_bytes, &sib[32 * c], 32);
+                memcpy(p + col_bytes + 32, &paths[32 * c * plen], plen * 32);
+            }
+        }
+        std::vector<uint8_t> all;
+        const uint8_t* blocks = mine.data();
+        if (comm_.world > 1) {
+            all.resize((size_t)comm_.world * mine.size());
+            comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), mine.size()), "all-gather of the opened columns");
+            blocks = all.data();
+        }
+        OpenedColumns out;
+        std::vector<uint32_t> next(comm_.world, 0);
+        for (size_t c = 0; c < t; c++) {
+            const uint32_t o = owner_of(indices[c]);
+            const uint8_t* p = blocks + (size_t)o * mine.size() + (size_t)next[o]++ * rec;
+            std::vector<Fr> col(rows);
+            memcpy(static_cast<void*>(col.data()), p, col_bytes);
+            out.columns.push_back(std::move(col));
+            MerklePath mp;
+            mp.leaf_index = indices[c];
+            memcpy(mp.leaf_sibling_hash.data(), p + col_bytes, 32);
+            mp.auth_path.resize(plen);
+            for (size_t l = 0; l < plen; l++) memcpy(mp.auth_path[l].data(), p + col_bytes + 32 + 32 * l, 32);
+            out.paths.push_back(std::move(mp));
+        }
+        return out;
+    }
+    LigeroProof prove_inner_sharded(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {
+        LigeroProof proof;
+        sharded_commit(formatted_assignment, proof.u_root);                                           // mod.rs:521-551
+        sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
+        {   // prove_interleaved, mod.rs:646-669
+            const std::vector<Fr> r = get_field_elements_from_prng<E>(4 * m_, sponge.squeeze_seed());
+            proof.interleaved_proof.preenc_u_lc = sharded_poly(LG_SUB_INTERLEAVED, r[0].l);
+            sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
+            proof.interleaved_proof.open = sharded_open_columns(sponge);
+        }
+        {   // prove_linear_constraints, mod.rs:712-747
+            const std::array<uint8_t, 32> seed = sponge.squeeze_seed();
+            std::vector<Fr> poly = sharded_poly(LG_SUB_LINEAR_FROM_SEED, seed.data());
+            trim_zeros(poly);
+            proof.linear_constraints_proof.polynomial = poly;
+            sponge.absorb_elements(poly);
+            proof.linear_constraints_proof.open = sharded_open_columns(sponge);
+        }
+        {   // prove_quadratic_constraints, mod.rs:832-859
+            const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
+            std::vector<Fr> poly = sharded_poly(LG_SUB_QUADRATIC, r[0].l);
+            trim_zeros(poly);
+            proof.quadratic_constraints_proof.polynomial = poly;
+            sponge.absorb_elements(poly);
+            proof.quadratic_constraints_proof.open = sharded_open_columns(sponge);
         }
         return proof;
     }
@@ -376,8 +554,12 @@ private:
     size_t m_, k_, n_, t_;
     int logn_ = 0;
     lg_ctx* ctx_ = nullptr;
-    std::vector<Fr> flat_;      // preenc_u of the proof being made (reused between proofs)
+    std::vector<Fr> flat_;      // preenc_u of the proof being made (reused between proofs); a sharded prover: its row shard
     bool pinned_ = false;
+    // sharded provers only
+    ShardComm comm_;
+    bool sharded_ = false;
+    uint32_t nplanes_ = 0, planes_per_rank_ = 0, shard_rows_ = 0, row0_ = 0, row1_ = 0, own_mask_ = 0;
 };
 using HipLigero = HipLigeroT<Fr>;
 

@@ -12,6 +12,7 @@ using ligero::LigeroProof;
 struct lgp_prover {
     HipLigero hip;
     lgp_prover(const LigeroInstance& inst, int device) : hip(inst, device) {}
+    lgp_prover(const LigeroInstance& inst, int device, const ligero::ShardComm& comm) : hip(inst, device, comm) {}
 };
 struct lgp_proof {
     LigeroProof own;                 // storage of a proof this handle owns (lgp_prove, lgp_prove_batch)

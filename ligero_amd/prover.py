@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_prove_with_labels"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -36,6 +36,8 @@ def lib():
         L.lgp_prove.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(_vp)]
         L.lgp_prove_with_labels.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.POINTER(_vp)]
         L.lgp_verify.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
+        L.lgp_sharded_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_int, _vp]
+        L.lgp_proof_equal.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         L.lgp_proof_destroy.argtypes = [_vp]
         L.lgp_proof_destroy.restype = None
         L.lgp_proof_info.argtypes = [_vp, _vp, _vp]
@@ -82,6 +84,9 @@ class LigeroProver:
         self._L = lib()
         self._inst = instance          # keeps the host instance alive
         self._h = _vp()
+        self._create(instance, device)
+
+    def _create(self, instance, device):
         _check(self._L.lgp_prover_create(ctypes.byref(self._h), instance._h, device), "lgp_prover_create")
 
     def close(self):
@@ -117,6 +122,91 @@ class LigeroProver:
         ok = ctypes.c_int(0)
         _check(self._L.lgp_verify(self._h, proof._h, ctypes.byref(ok)), "verify")
         return bool(ok.value)
+
+
+_AG_DEVICE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64)
+_AG_HOST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64)
+
+
+class _LgpComm(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("user", _vp), ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST)]
+
+
+class ShardedLigeroProver(LigeroProver):
+    """ONE proof over the ranks of a torch.distributed group, one process and one GPU per rank (include/ligero_prover.h:
+    lgp_sharded_prover_create).  Every rank constructs it with the same instance and calls prove() /
+    prove_with_labels() with the same assignment; every rank gets the complete proof, identical to LigeroProver's.  The
+    two exchanges the C++ prover asks for are served here: the in-place device all-gather (coefficient rows, leaf digests)
+    with `dist.all_gather_into_tensor` on a tensor aliasing the library's buffer -- backend "nccl" = RCCL over xGMI -- and
+    the host all-gather (sub-proof points, opened columns) through pinned staging on the same backend (plain CPU tensors
+    under gloo)."""
+
+    def __init__(self, instance: LigeroInstance, dist=None, group=None, device: int = 0):
+        self._dist, self._group, self._device = dist, group, device
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.comm_error: Optional[str] = None
+        self._cb_device = _AG_DEVICE(self._all_gather_device)      # kept alive with the prover
+        self._cb_host = _AG_HOST(self._all_gather_host)
+        super().__init__(instance, device)
+
+    def _create(self, instance, device):
+        if self.world > 1:
+            self._comm = _LgpComm(self.world, self.rank, None, self._cb_device, self._cb_host)
+        else:
+            self._comm = _LgpComm(1, 0, None, _AG_DEVICE(), _AG_HOST())
+        _check(self._L.lgp_sharded_prover_create(ctypes.byref(self._h), instance._h, device, ctypes.cast(ctypes.byref(self._comm), _vp)),
+               "lgp_sharded_prover_create")
+
+    def _all_gather_device(self, _user, ptr, bytes_per_rank):
+        try:
+            import torch
+            from .sharded import _CudaArray
+            buf = torch.as_tensor(_CudaArray(int(ptr), self.world * int(bytes_per_rank)), device=f"cuda:{self._device}")
+            mine = buf[self.rank * bytes_per_rank:(self.rank + 1) * bytes_per_rank]
+            self._dist.all_gather_into_tensor(buf, mine, group=self._group)
+            torch.cuda.synchronize(buf.device)
+            return 0
+        except Exception as e:          # an exception must not unwind through the C++ caller
+            self.comm_error = f"all_gather_device: {e!r}"
+            return -1
+
+    def _all_gather_host(self, _user, send, recv, nbytes):
+        try:
+            import torch
+            nbytes = int(nbytes)
+            src = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(int(send))))
+            dst = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * (nbytes * self.world)).from_address(int(recv))))
+            if self._dist.get_backend(self._group) == "nccl":          # RCCL moves device memory: stage through the GPU
+                dev = torch.device(f"cuda:{self._device}")
+                gathered = torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev)
+                self._dist.all_gather_into_tensor(gathered, src.to(dev), group=self._group)
+                dst.copy_(gathered.cpu())
+            else:
+                self._dist.all_gather_into_tensor(dst, src.clone(), group=self._group)
+            return 0
+        except Exception as e:
+            self.comm_error = f"all_gather_host: {e!r}"
+            return -1
+
+    def prove(self, node_idx, values_mont) -> Proof:
+        try:
+            return super().prove(node_idx, values_mont)
+        except RuntimeError as e:
+            raise RuntimeError(f"{e} [{self.comm_error}]") if self.comm_error else e
+
+    def prove_with_labels(self, labels, values_mont) -> Proof:
+        try:
+            return super().prove_with_labels(labels, values_mont)
+        except RuntimeError as e:
+            raise RuntimeError(f"{e} [{self.comm_error}]") if self.comm_error else e
+
+
+def proofs_equal(a: Proof, b: Proof) -> bool:
+    """field-by-field equality (lgp_proof_equal)"""
+    eq = ctypes.c_int(0)
+    _check(lib().lgp_proof_equal(a._h, b._h, ctypes.byref(eq)), "lgp_proof_equal")
+    return bool(eq.value)
 
 
 class LigeroBatchProver:
