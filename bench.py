@@ -160,27 +160,24 @@ def full_prover_rate(device: int, steps: int = 5):
             "note": "full prove() incl. transcript on host threads; host bound; transcript unpinned vs the Rust crates"}
 
 
-def s20_prover_rate(device: int, proofs: int = 2):
-    """BASELINE configs[2] as a PROOF rate: the synthetic 2^20-constraint repeated-squaring R1CS (tools/gen_repeated_squaring_r1cs.py,
-    SURVEY 8d) -> C++ host pipeline (from_constraint_system, LigeroCircuit::new, evaluation trace, preenc_u) -> device prover
-    (commit + three sub-proofs + openings).  Setup (R1CS compile, constraint matrix A with 46.6 M entries, upload) is reported apart."""
+def repeated_squaring_instance(log_n: int):
+    """the synthetic 2^log_n-constraint repeated-squaring R1CS (tools/gen_repeated_squaring_r1cs.py) through the C++ host
+    pipeline (from_constraint_system, LigeroCircuit::new) -> (instance, variable indices, Montgomery values, setup seconds)"""
     import importlib.util
     import tempfile
     from ligero_amd import host_pipeline as hp
-    from ligero_amd.prover import LigeroProver
     spec = importlib.util.spec_from_file_location("gen_rs", os.path.join(ROOT, "tools", "gen_repeated_squaring_r1cs.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     with tempfile.TemporaryDirectory() as d:
         t0 = time.perf_counter()
-        r1cs = os.path.join(d, "rs20.r1cs")
-        gen.write_r1cs(r1cs, 20)
-        wit = gen.witness(20, 1)
+        r1cs = os.path.join(d, f"rs{log_n}.r1cs")
+        gen.write_r1cs(r1cs, log_n)
+        wit = gen.witness(log_n, 1)
         t_gen = time.perf_counter() - t0
         t0 = time.perf_counter()
         inst = hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(r1cs))
         t_inst = time.perf_counter() - t0
-    dims = (inst.m, inst.k, inst.n, inst.t)
     mask = (1 << 64) - 1
     p = gen.P
     vals = np.empty((len(wit) - 1, 4), dtype=np.uint64)
@@ -188,6 +185,61 @@ def s20_prover_rate(device: int, proofs: int = 2):
         vm = (v << 256) % p                                   # Montgomery form
         vals[j] = (vm & mask, (vm >> 64) & mask, (vm >> 128) & mask, vm >> 192)
     idx = np.arange(1, len(wit), dtype=np.uint64)
+    return inst, idx, vals, {"generate_r1cs_and_witness": t_gen, "compile_and_ligero_new": t_inst}
+
+
+def sharded_prove_leg(torch, dist, world: int, rank: int, device: int, log_n: int = 20, proofs: int = 2, force: bool = False):
+    """ONE complete proof (commit + three sub-proofs + openings, replicated transcript) of the 2^log_n-constraint R1CS over the
+    `world` ranks (ligero_amd.prover.ShardedLigeroProver): each rank commits its row shard and coset planes,
+    the sub-proof points come from the ranks that hold the planes of the size-2k domain, every rank ends with the whole proof.
+    Timed like the headline: barrier + sync, max over ranks."""
+    from ligero_amd.prover import ShardedLigeroProver
+    flag_dev = f"cuda:{device}" if dist.get_backend() == "nccl" else "cpu"
+
+    def all_ranks_ok(ok: bool) -> bool:                      # a rank that failed must not leave the others inside a collective
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    err, inst, sp = None, None, None
+    try:
+        inst, idx, vals, setup = repeated_squaring_instance(log_n)
+        sp = ShardedLigeroProver(inst, dist, device=device, collectives_at_world_1=force)
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if not all_ranks_ok(err is None):
+        if sp is not None:
+            sp.close()
+        return {"error": err or "setup failed on another rank"}
+    with sp:
+        proof = sp.prove(idx, vals)                           # first proof: buffers, tables
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(proofs):
+            proof = sp.prove(idx, vals)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=flag_dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item()) / proofs
+        accepted = sp.verify(proof) if rank == 0 else None
+        root = proof.info()["u_root"].hex()
+    return {"value": 1.0 / dt, "unit": "proofs/s", "s_per_proof": dt, "proofs_timed": proofs, "n_gpus": world,
+            "workload": f"one proof of the 2^{log_n}-constraint repeated-squaring R1CS over {world} GPU(s)",
+            "dims_m_k_n_t": (inst.m, inst.k, inst.n, inst.t), "u_root": root, "verifies": accepted, "setup_s": setup,
+            "note": "the host side (evaluation trace, transcript) is replicated on every rank and is most of a proof's time; the device "
+                    "side is sharded: row shard + coset planes per rank, two device all-gathers, sub-proof points from the plane owners"}
+
+
+def s20_prover_rate(device: int, proofs: int = 2):
+    """BASELINE configs[2] as a PROOF rate: the synthetic 2^20-constraint repeated-squaring R1CS -> C++ host pipeline
+    (from_constraint_system, LigeroCircuit::new, evaluation trace, preenc_u) -> device prover (commit + three sub-proofs + openings).
+    Setup (R1CS compile, constraint matrix A with 46.6 M entries, upload) is reported apart."""
+    from ligero_amd.prover import LigeroProver
+    inst, idx, vals, setup = repeated_squaring_instance(20)
+    t_gen, t_inst = setup["generate_r1cs_and_witness"], setup["compile_and_ligero_new"]
+    dims = (inst.m, inst.k, inst.n, inst.t)
     t0 = time.perf_counter()
     with LigeroProver(inst, device=device) as prover:
         t_upload = time.perf_counter() - t0
@@ -486,6 +538,14 @@ def main():
                            "parallelism": f"row-sharded interpolation + all-gather + coset-sharded evaluate/hash x{world}"},
                 "sharded_commit": res,
             }
+        if not args.no_cpu_baseline:
+            try:
+                sp_res = sharded_prove_leg(torch, dist, world, rank, local_rank, {"s22": 22, "s20": 20, "s18": 18}[args.workload], 2, force_dist)
+            except Exception as e:
+                sp_res = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                line["sharded_prove"] = sp_res
+        if rank == 0:
             print(json.dumps(line), flush=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -503,6 +563,13 @@ def main():
             sharded = sharded_commit_leg(torch, dist, backend, args.sharded_leg, world, rank, local_rank, 5, 2)
         except Exception as e:  # the headline line must survive a failure of the extra leg
             sharded = {"error": f"{type(e).__name__}: {e}"}
+    sharded_prove = None
+    if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
+        # ... and one complete PROOF over all of them (2^20 constraints; 2^18 with the quick shapes)
+        try:
+            sharded_prove = sharded_prove_leg(torch, dist, world, rank, local_rank, 20 if args.sharded_leg in ("s22", "s20") else 18, 2, force_dist)
+        except Exception as e:
+            sharded_prove = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         commits = args.steps * batch * world
@@ -541,6 +608,8 @@ def main():
             line["valu_roofline"] = vr
         if sharded is not None:
             line["sharded_commit"] = sharded
+        if sharded_prove is not None:
+            line["sharded_prove"] = sharded_prove
         if extras and args.workload == "poseidon":
             # BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
             one = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=1, device=local_rank)

@@ -38,10 +38,14 @@ void lgp_prover_destroy(lgp_prover* p);
  *                      rank's contribution (the coefficient rows: 4m k 32 B in total; the leaf digests: n 32 B)
  *   all_gather_host    equal HOST blocks: recv holds `world` blocks of `bytes` (sub-proof points: 2k 32 B per rank; the
  *                      opened columns: about t / world columns per rank)
- * With world = 1 the callbacks may be NULL.  lgp_verify works on such a prover as on any other.
+ * With world = 1 the callbacks may be NULL, unless flags has LGP_COMM_EXCHANGE_AT_WORLD_1: then the (identity) collectives
+ * are issued all the same -- the way to run the exact RCCL calls on a one-GPU box.  lgp_verify works on such a prover as on
+ * any other.
  */
+enum { LGP_COMM_EXCHANGE_AT_WORLD_1 = 1 };
 typedef struct lgp_comm {
     uint32_t world, rank;
+    uint32_t flags;
     void* user;
     int (*all_gather_device)(void* user, void* device_buf, uint64_t bytes_per_rank);
     int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes);

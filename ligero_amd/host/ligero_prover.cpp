@@ -45,6 +45,7 @@ int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int de
     return guarded([&] {
         ligero::ShardComm sc;
         sc.world = comm->world; sc.rank = comm->rank; sc.user = comm->user;
+        sc.exchange_at_world_1 = (comm->flags & LGP_COMM_EXCHANGE_AT_WORLD_1) != 0;
         sc.all_gather_device = comm->all_gather_device;
         sc.all_gather_host = comm->all_gather_host;
         *out = new lgp_prover(inst->inst, device, sc);

@@ -151,6 +151,7 @@ inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
 // that implements these two calls elsewhere.  Both return 0 on success.
 struct ShardComm {
     uint32_t world = 1, rank = 0;
+    bool exchange_at_world_1 = false;   // issue the collectives in a one-rank group too (identities): runs the exact RCCL calls on a one-GPU box
     void* user = nullptr;
     // in-place all-gather on DEVICE memory: device_buf holds `world` blocks of bytes_per_rank, block `rank` is this rank's
     int (*all_gather_device)(void* user, void* device_buf, uint64_t bytes_per_rank) = nullptr;
@@ -188,7 +189,8 @@ public:
     HipLigeroT(const LigeroInstance& inst, int device, const ShardComm& comm) : inst_(inst), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t), comm_(comm) {
         static_assert(kDeviceChallenges, "sharded proofs run on the tuned BN254 device path");
         if (comm.world == 0 || comm.rank >= comm.world) throw std::runtime_error("ShardComm: rank outside the world");
-        if (comm.world > 1 && (!comm.all_gather_device || !comm.all_gather_host)) throw std::runtime_error("ShardComm: a world of several ranks needs both all-gathers");
+        exchange_ = comm.world > 1 || comm.exchange_at_world_1;
+        if (exchange_ && (!comm.all_gather_device || !comm.all_gather_host)) throw std::runtime_error("ShardComm: both all-gathers are needed");
         sharded_ = true;
         const uint32_t rows = (uint32_t)(4 * m_);
         nplanes_ = k_ <= 4096 ? 8 : (uint32_t)(8 * (k_ / 4096));       // the library's plane rule (include/ligero_hip.h); checked below
@@ -296,7 +298,7 @@ private:
         }
         inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data());
         check(lg_stage_interpolate(ctx_, own ? flat_[0].l : nullptr, row0_, row1_ - row0_), "lg_stage_interpolate");
-        if (comm_.world > 1) {
+        if (exchange_) {
             void* d = nullptr;
             size_t bytes = 0;
             check(lg_device_buffer(ctx_, LG_BUF_COEFFS, &d, &bytes), "lg_device_buffer");
@@ -304,7 +306,7 @@ private:
             comm_check(comm_.all_gather_device(comm_.user, d, (uint64_t)shard_rows_ * k_ * sizeof(Fr)), "all-gather of the coefficient rows");
         }
         check(lg_stage_evaluate_hash(ctx_, own_mask_), "lg_stage_evaluate_hash");
-        if (comm_.world > 1) {
+        if (exchange_) {
             void* d = nullptr;
             size_t bytes = 0;
             check(lg_stage_digests_pack(ctx_, comm_.world, comm_.rank, &d, &bytes), "lg_stage_digests_pack");
@@ -319,7 +321,7 @@ private:
     std::vector<Fr> sharded_points(int which, const void* challenge) {
         std::vector<Fr> mine(2 * k_);
         check(lg_subproof_points(ctx_, which, challenge, mine[0].l, nullptr), "lg_subproof_points");
-        if (comm_.world == 1) return mine;
+        if (!exchange_) return mine;
         std::vector<Fr> all((size_t)comm_.world * 2 * k_);
         comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), 2 * k_ * sizeof(Fr)), "all-gather of the sub-proof points");
         for (size_t j = 0; j < 2 * k_; j++) {
@@ -361,7 +363,7 @@ private:
         }
         std::vector<uint8_t> all;
         const uint8_t* blocks = mine.data();
-        if (comm_.world > 1) {
+        if (exchange_) {
             all.resize((size_t)comm_.world * mine.size());
             comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), mine.size()), "all-gather of the opened columns");
             blocks = all.data();
@@ -558,7 +560,7 @@ private:
     bool pinned_ = false;
     // sharded provers only
     ShardComm comm_;
-    bool sharded_ = false;
+    bool sharded_ = false, exchange_ = false;
     uint32_t nplanes_ = 0, planes_per_rank_ = 0, shard_rows_ = 0, row0_ = 0, row1_ = 0, own_mask_ = 0;
 };
 using HipLigero = HipLigeroT<Fr>;

@@ -129,7 +129,8 @@ _AG_HOST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64)
 
 
 class _LgpComm(ctypes.Structure):
-    _fields_ = [("world", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("user", _vp), ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST)]
+    _fields_ = [("world", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("user", _vp),
+                ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST)]
 
 
 class ShardedLigeroProver(LigeroProver):
@@ -141,8 +142,11 @@ class ShardedLigeroProver(LigeroProver):
     the host all-gather (sub-proof points, opened columns) through pinned staging on the same backend (plain CPU tensors
     under gloo)."""
 
-    def __init__(self, instance: LigeroInstance, dist=None, group=None, device: int = 0):
+    def __init__(self, instance: LigeroInstance, dist=None, group=None, device: int = 0, collectives_at_world_1: bool = False):
+        """collectives_at_world_1: issue the (identity) all-gathers in a one-rank group too -- the exact RCCL calls of the
+        multi-GPU path on a one-GPU box (tests, bench.py)"""
         self._dist, self._group, self._device = dist, group, device
+        self._force = bool(collectives_at_world_1) and dist is not None
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
         self.comm_error: Optional[str] = None
@@ -151,10 +155,10 @@ class ShardedLigeroProver(LigeroProver):
         super().__init__(instance, device)
 
     def _create(self, instance, device):
-        if self.world > 1:
-            self._comm = _LgpComm(self.world, self.rank, None, self._cb_device, self._cb_host)
+        if self.world > 1 or self._force:
+            self._comm = _LgpComm(self.world, self.rank, 1 if self._force else 0, None, self._cb_device, self._cb_host)
         else:
-            self._comm = _LgpComm(1, 0, None, _AG_DEVICE(), _AG_HOST())
+            self._comm = _LgpComm(1, 0, 0, None, _AG_DEVICE(), _AG_HOST())
         _check(self._L.lgp_sharded_prover_create(ctypes.byref(self._h), instance._h, device, ctypes.cast(ctypes.byref(self._comm), _vp)),
                "lgp_sharded_prover_create")
 

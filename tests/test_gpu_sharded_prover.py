@@ -94,3 +94,35 @@ def test_sharded_proof_equals_the_single_gpu_proof(which, world):
         assert r["root"] == last["ref_root"], rank                        # every rank holds the complete, same proof
         assert r["info"] == last["info"], rank
         assert r["again"] and r["accepted_by_sharded"] and r["wrong_rejected"], (rank, r)
+
+
+def _rccl_worker(out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from ligero_amd.prover import LigeroProver, ShardedLigeroProver, proofs_equal
+        inst, idx, vals = _poseidon_case()
+        with ShardedLigeroProver(inst, dist, device=0, collectives_at_world_1=True) as sp, LigeroProver(inst) as single:
+            proof = sp.prove(idx, vals)
+            out["equal"] = proofs_equal(proof, single.prove(idx, vals))
+            out["accepted"] = single.verify(proof)
+            out["error"] = sp.comm_error
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_prover_over_rccl_at_world_1():
+    """backend "nccl" = RCCL: the device all-gathers on the library's buffers and the host all-gathers staged through the GPU, as
+    the multi-GPU run issues them (identities in a one-rank group)"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    p = mp.get_context("spawn").Process(target=_rccl_worker, args=(out,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert out["error"] is None and out["equal"] and out["accepted"]
