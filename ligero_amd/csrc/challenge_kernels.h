@@ -166,15 +166,20 @@ __global__ void __launch_bounds__(256) sparse_row_mul_kernel(SparseRowMulArgs a)
     fr_reduce(red, acc);
     fr_store(a.out + (uint64_t)proof * a.cols + col, red);
 }
-// grid (heavy columns, batch): the workgroup strides over the column's entries and tree-reduces in LDS
-__global__ void __launch_bounds__(256) sparse_row_mul_heavy_kernel(SparseRowMulArgs a) {
-    __shared__ fr part[256];
-    const uint32_t col = a.heavy[blockIdx.x], proof = blockIdx.y;
-    const fr* r = a.r + (uint64_t)proof * a.rows_in;
-    fr acc;
-#pragma unroll
-    for (int l = 0; l < 8; l++) acc.v[l] = 0;
-    for (uint32_t e = a.col_ptr[col] + threadIdx.x; e < a.col_ptr[col + 1]; e += 256) sparse_accumulate(a, r, e, acc);
+// Heavy columns are cut into segments of kHeavySegment entries so that one column with a million entries (the constant-one
+// column of a circuit with a million outputs: every "+ 1" refers to it) spreads over the chip instead of one workgroup.
+//   1. grid (segments, batch): the workgroup strides over its segment and tree-reduces in LDS -> seg_partial[proof][segment]
+//   2. grid (heavy columns, batch): the same over the column's partial sums -> out
+constexpr uint32_t kHeavySegment = 2048;
+struct HeavySegArgs {
+    SparseRowMulArgs m;
+    const uint32_t* seg_begin;     // [nseg + 1] entry range of segment i = [seg_begin[i], seg_end[i])
+    const uint32_t* seg_end;
+    const uint32_t* heavy_seg_ptr; // [nheavy + 1] segments of heavy column h = [heavy_seg_ptr[h], heavy_seg_ptr[h + 1])
+    fr* seg_partial;               // [batch][nseg] lazy sums
+    uint32_t nseg;
+};
+__device__ __forceinline__ fr block_sum(fr acc, fr* part) {
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
@@ -185,10 +190,35 @@ __global__ void __launch_bounds__(256) sparse_row_mul_heavy_kernel(SparseRowMulA
         }
         __syncthreads();
     }
+    return part[0];
+}
+__global__ void __launch_bounds__(256) sparse_row_mul_heavy_segments_kernel(HeavySegArgs a) {
+    __shared__ fr part[256];
+    const uint32_t seg = blockIdx.x, proof = blockIdx.y;
+    const fr* r = a.m.r + (uint64_t)proof * a.m.rows_in;
+    fr acc;
+#pragma unroll
+    for (int l = 0; l < 8; l++) acc.v[l] = 0;
+    for (uint32_t e = a.seg_begin[seg] + threadIdx.x; e < a.seg_end[seg]; e += 256) sparse_accumulate(a.m, r, e, acc);
+    const fr total = block_sum(acc, part);
+    if (threadIdx.x == 0) fr_store(a.seg_partial + (uint64_t)proof * a.nseg + seg, total);
+}
+__global__ void __launch_bounds__(256) sparse_row_mul_heavy_finish_kernel(HeavySegArgs a) {
+    __shared__ fr part[256];
+    const uint32_t h = blockIdx.x, proof = blockIdx.y;
+    const fr* partial = a.seg_partial + (uint64_t)proof * a.nseg;
+    fr acc;
+#pragma unroll
+    for (int l = 0; l < 8; l++) acc.v[l] = 0;
+    for (uint32_t i = a.heavy_seg_ptr[h] + threadIdx.x; i < a.heavy_seg_ptr[h + 1]; i += 256) {
+        const fr t = fr_load(partial + i);
+        fr_add_lazy(acc, acc, t);
+    }
+    const fr total = block_sum(acc, part);
     if (threadIdx.x == 0) {
         fr red;
-        fr_reduce(red, part[0]);
-        fr_store(a.out + (uint64_t)proof * a.cols + col, red);
+        fr_reduce(red, total);
+        fr_store(a.m.out + (uint64_t)proof * a.m.cols + a.m.heavy[h], red);
     }
 }
 

@@ -61,6 +61,8 @@ struct lg_ctx {
     // constraint matrix A in CSC form (lg_upload_constraint_matrix) and the device-side challenge generator
     uint32_t* d_a_colptr = nullptr; uint32_t* d_a_row = nullptr; fr* d_a_val = nullptr;
     uint32_t* d_a_heavy = nullptr; uint32_t a_nheavy = 0;   // columns with more than lg::kHeavyColumn entries
+    uint32_t* d_a_seg = nullptr; uint32_t a_nseg = 0;       // their segments: [seg_begin | seg_end | heavy_seg_ptr] (challenge_kernels.h)
+    fr* d_a_seg_partial = nullptr;                          // [batch][a_nseg]
     uint64_t a_rows = 0, a_nnz = 0; bool a_loaded = false;
     uint32_t* d_seeds = nullptr;           // [batch][8]
     uint32_t* d_cc_counts = nullptr; size_t cc_counts_cap = 0;
@@ -477,7 +479,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
-    void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
+    void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_a_seg, c->d_a_seg_partial, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
     void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
@@ -1298,12 +1300,31 @@ int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, cons
     std::vector<uint32_t> heavy;
     for (uint64_t cc = 0; cc < cols; cc++)
         if (colptr[cc + 1] - colptr[cc] > lg::kHeavyColumn) heavy.push_back((uint32_t)cc);
-    for (void* b : {(void*)c->d_a_colptr, (void*)c->d_a_row, (void*)c->d_a_val, (void*)c->d_a_heavy})
+    // segments of the heavy columns: [seg_begin (nseg) | seg_end (nseg) | heavy_seg_ptr (nheavy + 1)]
+    std::vector<uint32_t> seg_begin, seg_end, heavy_seg_ptr{0};
+    for (uint32_t cc : heavy) {
+        for (uint32_t e = colptr[cc]; e < colptr[cc + 1]; e += lg::kHeavySegment) {
+            seg_begin.push_back(e);
+            seg_end.push_back(std::min(colptr[cc + 1], e + lg::kHeavySegment));
+        }
+        heavy_seg_ptr.push_back((uint32_t)seg_begin.size());
+    }
+    for (void* b : {(void*)c->d_a_colptr, (void*)c->d_a_row, (void*)c->d_a_val, (void*)c->d_a_heavy, (void*)c->d_a_seg, (void*)c->d_a_seg_partial})
         if (b) LG_HIP(c, hipFree(b));
-    c->d_a_colptr = nullptr; c->d_a_row = nullptr; c->d_a_val = nullptr; c->d_a_heavy = nullptr; c->a_loaded = false;
+    c->d_a_colptr = nullptr; c->d_a_row = nullptr; c->d_a_val = nullptr; c->d_a_heavy = nullptr; c->d_a_seg = nullptr; c->d_a_seg_partial = nullptr;
+    c->a_loaded = false;
     LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_heavy), (heavy.size() ? heavy.size() : 1) * 4));
     if (!heavy.empty()) LG_HIP(c, hipMemcpy(c->d_a_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice));
     c->a_nheavy = (uint32_t)heavy.size();
+    c->a_nseg = (uint32_t)seg_begin.size();
+    if (c->a_nseg) {
+        std::vector<uint32_t> seg(seg_begin);
+        seg.insert(seg.end(), seg_end.begin(), seg_end.end());
+        seg.insert(seg.end(), heavy_seg_ptr.begin(), heavy_seg_ptr.end());
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_seg), seg.size() * 4));
+        LG_HIP(c, hipMemcpy(c->d_a_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_seg_partial), (size_t)c->batch * c->a_nseg * sizeof(fr)));
+    }
     LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_colptr), colptr.size() * 4));
     LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_row), (nnz ? nnz : 1) * 4));
     LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_a_val), (nnz ? nnz : 1) * sizeof(fr)));
@@ -1346,7 +1367,14 @@ static int linear_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t plane_mas
     m.col_ptr = c->d_a_colptr; m.ent_row = c->d_a_row; m.ent_val = c->d_a_val;
     m.r = c->d_rlin; m.out = c->d_scratch_a; m.heavy = c->d_a_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)n;
     LG_LAUNCH(c, lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->stream, m);
-    if (c->a_nheavy) LG_LAUNCH(c, lg::sparse_row_mul_heavy_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, m);
+    if (c->a_nheavy) {
+        lg::HeavySegArgs h;
+        h.m = m;
+        h.seg_begin = c->d_a_seg; h.seg_end = c->d_a_seg + c->a_nseg; h.heavy_seg_ptr = c->d_a_seg + 2 * (size_t)c->a_nseg;
+        h.seg_partial = c->d_a_seg_partial; h.nseg = c->a_nseg;
+        LG_LAUNCH(c, lg::sparse_row_mul_heavy_segments_kernel, dim3(c->a_nseg, c->batch), dim3(256), 0, c->stream, h);
+        LG_LAUNCH(c, lg::sparse_row_mul_heavy_finish_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, h);
+    }
     rc = linear_core(c, per, nch, plane_mask, coeffs_out, points_out);   // synchronises on the stream when it reads the result back
     if (rc != LG_OK) return rc;
     uint32_t flag = 0;

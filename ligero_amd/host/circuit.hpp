@@ -290,13 +290,43 @@ public:
         std::vector<E> value;
         std::vector<uint8_t> set;      // the reference's Some / None
     };
-    Trace evaluation_trace_multioutput(const std::vector<std::pair<size_t, E>>& vars, const std::vector<size_t>& outputs) const {
-        Trace t{std::vector<E>(nodes.size(), F::zero()), std::vector<uint8_t>(nodes.size(), 0)};
+    // What does not depend on the assignment, computed once per (circuit, outputs) by callers that evaluate repeatedly
+    // (LigeroInstance): whether gates only refer backwards, and which nodes the outputs need.
+    struct EvalPlan {
         bool backward_only = true;
+        std::vector<uint8_t> need;     // backward_only circuits: 1 = some output depends on the node
+    };
+    EvalPlan eval_plan(const std::vector<size_t>& outputs) const {
+        EvalPlan p;
+        for (size_t i = 0; i < nodes.size() && p.backward_only; i++) {
+            const Node& nd = nodes[i];
+            if ((nd.kind == Node::Add || nd.kind == Node::Mul) && (nd.l >= i || nd.r >= i)) p.backward_only = false;
+        }
+        for (size_t o : outputs)
+            if (o >= nodes.size()) throw std::runtime_error("index out of bounds: output node not in the circuit");
+        if (p.backward_only) {
+            p.need.assign(nodes.size(), 0);
+            for (size_t o : outputs) p.need[o] = 1;
+            for (size_t i = nodes.size(); i-- > 0;) {
+                const Node& nd = nodes[i];
+                if (p.need[i] && (nd.kind == Node::Add || nd.kind == Node::Mul)) p.need[nd.l] = p.need[nd.r] = 1;
+            }
+        }
+        return p;
+    }
+    Trace evaluation_trace_multioutput(const std::vector<std::pair<size_t, E>>& vars, const std::vector<size_t>& outputs) const {
+        Trace t;
+        evaluation_trace_into(t, eval_plan(outputs), vars, outputs);
+        return t;
+    }
+    // the same into storage the caller keeps between evaluations (a 5 M-node trace is 170 MB: fresh memory for it costs more
+    // than the field arithmetic)
+    void evaluation_trace_into(Trace& t, const EvalPlan& plan, const std::vector<std::pair<size_t, E>>& vars, const std::vector<size_t>& outputs) const {
+        t.value.resize(nodes.size());
+        t.set.assign(nodes.size(), 0);
         for (size_t i = 0; i < nodes.size(); i++) {
             const Node& nd = nodes[i];
             if (nd.kind == Node::Constant) { t.value[i] = nd.value; t.set[i] = 1; }
-            else if ((nd.kind == Node::Add || nd.kind == Node::Mul) && (nd.l >= i || nd.r >= i)) backward_only = false;
         }
         for (const auto& v : vars) {
             if (v.first >= nodes.size()) throw std::runtime_error("index out of bounds: assigned node not in the circuit");
@@ -304,15 +334,8 @@ public:
             t.value[v.first] = v.second;
             t.set[v.first] = 1;
         }
-        for (size_t o : outputs)
-            if (o >= nodes.size()) throw std::runtime_error("index out of bounds: output node not in the circuit");
-        if (backward_only) {
-            std::vector<uint8_t> need(nodes.size(), 0);
-            for (size_t o : outputs) need[o] = 1;
-            for (size_t i = nodes.size(); i-- > 0;) {
-                const Node& nd = nodes[i];
-                if (need[i] && (nd.kind == Node::Add || nd.kind == Node::Mul)) need[nd.l] = need[nd.r] = 1;
-            }
+        if (plan.backward_only) {
+            const std::vector<uint8_t>& need = plan.need;
             for (size_t i = 0; i < nodes.size(); i++) {
                 const Node& nd = nodes[i];
                 if (!need[i] || t.set[i]) continue;
@@ -320,7 +343,7 @@ public:
                 t.value[i] = nd.kind == Node::Add ? F::add(t.value[nd.l], t.value[nd.r]) : F::mul(t.value[nd.l], t.value[nd.r]);
                 t.set[i] = 1;
             }
-            return t;
+            return;
         }
         std::vector<uint8_t> open(nodes.size(), 0);          // gates whose operands are being evaluated
         std::vector<size_t> stack;
@@ -348,7 +371,6 @@ public:
                 }
             }
         }
-        return t;
     }
     Trace evaluation_trace(const std::vector<std::pair<size_t, E>>& vars, size_t node) const {   // mod.rs:279-306
         return evaluation_trace_multioutput(vars, {node});
@@ -605,6 +627,8 @@ public:
             else index_map[i] = i - seen;
         }
         for (size_t o : outs) outputs.push_back(bump_index(o));
+        plan_ = circuit.eval_plan(outputs);
+        build_program(sol_vec_length);
         a = generate_matrices(index_map, m * k);
     }
 
@@ -639,16 +663,84 @@ public:
         build_preenc_from_formatted(resolve_labels(var_assignment), out, all_outputs_one);
     }
     // prove_inner (mod.rs:476-516): assignment by index into the formatted circuit
-    void build_preenc_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr) const {
-        build_preenc_range_from_formatted(bumped, 0, 4 * m * k, out, all_outputs_one);
+    // what a prover keeps between proofs of one instance: the trace storage, and which buffer already holds a preenc_u
+    struct Scratch {
+        typename ArithmeticCircuitT<E>::Trace trace;
+        const E* filled = nullptr;
+        size_t filled_begin = 0, filled_end = 0;
+        void buffer_replaced() { filled = nullptr; }     // call when the buffer is reallocated or written by anything else
+    };
+    void build_preenc_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
+        build_preenc_range_from_formatted(bumped, 0, 4 * m * k, out, all_outputs_one, scratch);
     }
     // the same, but only elements [elem_begin, elem_end) of the flat row-major 4m x k matrix, written to out[0 ..): the row
     // shard one rank of a coset-sharded proof uploads (elem = row * k; the trace is still evaluated in full)
     void build_preenc_range_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, size_t elem_begin, size_t elem_end, E* out,
-                                           bool* all_outputs_one = nullptr) const {
+                                           bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
+        const size_t mk = m * k;
+        if (elem_end > 4 * mk || elem_begin > elem_end) throw std::runtime_error("build_preenc: element range outside the 4m x k matrix");
+        typename ArithmeticCircuitT<E>::Trace local;
+        typename ArithmeticCircuitT<E>::Trace& trace = scratch ? scratch->trace : local;
+        // the all-zero limbs are the field's zero.  WHICH elements get a value depends on the circuit alone, so a buffer that
+        // already holds an earlier preenc_u of this instance (same range) needs no second pass over its 1.3 GB
+        const bool zeroed = scratch && scratch->filled == out && scratch->filled_begin == elem_begin && scratch->filled_end == elem_end;
+        if (!zeroed) std::memset(static_cast<void*>(out), 0, (elem_end - elem_begin) * sizeof(E));
+        if (scratch) { scratch->filled = out; scratch->filled_begin = elem_begin; scratch->filled_end = elem_end; }
+        if (!prog_.kind.empty()) {
+            // One pass over the compact program: evaluate node i and drop its value(s) into x / y / z / w at once.  (The
+            // node structs are 88 bytes each; walking 5 M of them twice -- trace, then assembly -- was memory-bound.)
+            std::vector<E>& val = trace.value;
+            std::vector<uint8_t>& set = trace.set;
+            const size_t nn = prog_.kind.size();
+            val.resize(nn);
+            set.assign(nn, 0);
+            for (const auto& v : bumped) {
+                if (v.first >= nn) throw std::runtime_error("index out of bounds: assigned node not in the circuit");
+                if (prog_.kind[v.first] != Node::Variable) throw std::runtime_error("Value supplied for non-variable node");
+                val[v.first] = v.second;
+                set[v.first] = 1;
+            }
+            const bool whole = elem_begin == 0 && elem_end == 4 * mk;
+            auto put = [&](size_t flat, const E& v) {
+                if (whole) out[flat] = v;
+                else if (flat >= elem_begin && flat < elem_end) out[flat - elem_begin] = v;
+            };
+            size_t pos = 0, ci = 0;
+            for (size_t i = 0; i < nn; i++) {
+                const uint8_t kd = prog_.kind[i];
+                if (kd == Node::Constant) {
+                    val[i] = prog_.constants[ci++];
+                    if (i != 0) continue;                                   // only the leading one takes a position (mod.rs:491)
+                    put(3 * mk + pos, val[i]);
+                } else if (kd == Node::Variable) {
+                    if (!set[i])
+                        throw std::runtime_error(plan_.need[i] ? "Uninitialised variable"
+                                                               : "Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
+                    put(3 * mk + pos, val[i]);
+                } else {
+                    const E& a = val[prog_.l[i]];
+                    const E& b = val[prog_.r[i]];
+                    if (kd == Node::Mul) {
+                        const E z = F::mul(a, b);
+                        put(pos, a); put(mk + pos, b); put(2 * mk + pos, z);
+                        val[i] = z;
+                    } else {
+                        val[i] = F::add(a, b);
+                    }
+                    put(3 * mk + pos, val[i]);
+                }
+                pos++;
+            }
+            if (all_outputs_one) {
+                *all_outputs_one = true;
+                for (size_t o : outputs)
+                    if (!F::eq(val[o], F::one())) *all_outputs_one = false;
+            }
+            return;
+        }
         // evaluation_trace_multioutput + expect on every node (mod.rs:476-478): a node the outputs do not depend on and
         // that is not an assigned variable is a panic there, not a silently evaluated gate
-        auto trace = circuit.evaluation_trace_multioutput(bumped, outputs);
+        circuit.evaluation_trace_into(trace, plan_, bumped, outputs);
         for (size_t i = 0; i < trace.set.size(); i++)
             if (!trace.set[i]) throw std::runtime_error("Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
         const std::vector<E>& sol = trace.value;
@@ -657,9 +749,6 @@ public:
             for (size_t o : outputs)
                 if (!F::eq(sol[o], F::one())) *all_outputs_one = false;
         }
-        const size_t mk = m * k;
-        if (elem_end > 4 * mk || elem_begin > elem_end) throw std::runtime_error("build_preenc: element range outside the 4m x k matrix");
-        std::memset(static_cast<void*>(out), 0, (elem_end - elem_begin) * sizeof(E));      // the all-zero limbs are the field's zero
         auto put = [&](size_t flat, const E& v) {
             if (flat >= elem_begin && flat < elem_end) out[flat - elem_begin] = v;
         };
@@ -693,6 +782,33 @@ private:
         for (auto& kv : circuit.variables) kv.second = bump_index(kv.second);
     }
 
+    typename ArithmeticCircuitT<E>::EvalPlan plan_;
+    // the circuit as three flat arrays + the constants in node order, for circuits the one-pass builder can take: gates refer
+    // backwards only, every gate is needed by some output (otherwise prove_inner panics, and the general path words the panic),
+    // indices fit 32 bits, the solution vector fits m k
+    struct Program {
+        std::vector<uint8_t> kind;
+        std::vector<uint32_t> l, r;
+        std::vector<E> constants;
+    } prog_;
+    void build_program(size_t sol_vec_length) {
+        const size_t nn = circuit.nodes.size();
+        if (!plan_.backward_only || nn >= 0xffffffffull || sol_vec_length > m * k) return;
+        for (size_t i = 0; i < nn; i++) {
+            const Node& nd = circuit.nodes[i];
+            if ((nd.kind == Node::Add || nd.kind == Node::Mul) && !plan_.need[i]) return;
+        }
+        prog_.kind.resize(nn);
+        prog_.l.resize(nn);
+        prog_.r.resize(nn);
+        for (size_t i = 0; i < nn; i++) {
+            const Node& nd = circuit.nodes[i];
+            prog_.kind[i] = (uint8_t)nd.kind;
+            prog_.l[i] = (uint32_t)nd.l;
+            prog_.r[i] = (uint32_t)nd.r;
+            if (nd.kind == Node::Constant) prog_.constants.push_back(nd.value);
+        }
+    }
     static constexpr size_t kNoIndex = ~size_t{0};
     static size_t at(const std::vector<size_t>& m, size_t key) {
         // the reference unwraps here (mod.rs:345 etc.): a gate whose operands are both constants panics

@@ -146,6 +146,18 @@ inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
     if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
 }
 
+// LG_PROVER_TIMING=1: per-phase wall time of the provers on stderr
+struct PhaseTimer {
+    bool on = getenv("LG_PROVER_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  %-36s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 // One proof over several GPUs: one prover object per rank, every rank runs the same (deterministic)
 // transcript; the exchanges are the host layer's -- RCCL through torch.distributed in ligero_amd/prover.py, anything else
 // that implements these two calls elsewhere.  Both return 0 on success.
@@ -217,6 +229,7 @@ public:
     }
     ~HipLigeroT() {
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
+        if (cols_pinned_) lg_host_unregister(ctx_, cols_stage_.data());
         lg_ctx_destroy(ctx_);
     }
     HipLigeroT(const HipLigeroT&) = delete;
@@ -245,17 +258,23 @@ private:
             flat_.resize(4 * m_ * k_);
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
-        inst_.build_preenc_from_formatted(formatted_assignment, flat_.data());
+        PhaseTimer tm;
+        inst_.build_preenc_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_);
+        tm.mark("evaluation trace + preenc_u (host)");
         LigeroProof proof;
         check(lg_encode_commit(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
+        tm.mark("lg_encode_commit (H2D + commit)");
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
 
         {   // prove_interleaved, mod.rs:646-669
             const std::vector<Fr> r = get_field_elements_from_prng<E>(4 * m_, sponge.squeeze_seed());
             proof.interleaved_proof.preenc_u_lc.resize(k_);
             check(lg_interleaved_row_mul(ctx_, r[0].l, proof.interleaved_proof.preenc_u_lc[0].l), "lg_interleaved_row_mul");
+            tm.mark("interleaved: challenges + row_mul");
             sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
+            tm.mark("interleaved: sponge absorbs k elements");
             proof.interleaved_proof.open = open_columns(sponge);
+            tm.mark("interleaved: open_columns");
         }
         {   // prove_linear_constraints, mod.rs:712-747
             // r_linear (ChaCha20 + F::rand) and r_a = A.row_mul(r_linear) are produced on the device from the seed
@@ -267,19 +286,25 @@ private:
                 const std::vector<Fr> r_a = inst_.a.row_mul(get_field_elements_from_prng<E>(4 * m_ * k_, seed));
                 check(lg_linear_constraint_poly(ctx_, r_a[0].l, poly[0].l), "lg_linear_constraint_poly");
             }
+            tm.mark("linear: challenges + polynomial");
             trim_zeros(poly);
             proof.linear_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
+            tm.mark("linear: sponge absorbs 2k elements");
             proof.linear_constraints_proof.open = open_columns(sponge);
+            tm.mark("linear: open_columns");
         }
         {   // prove_quadratic_constraints, mod.rs:832-859
             const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
             std::vector<Fr> poly(2 * k_);
             check(lg_quadratic_constraint_poly(ctx_, r[0].l, poly[0].l), "lg_quadratic_constraint_poly");
+            tm.mark("quadratic: challenges + polynomial");
             trim_zeros(poly);
             proof.quadratic_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
+            tm.mark("quadratic: sponge absorbs 2k elements");
             proof.quadratic_constraints_proof.open = open_columns(sponge);
+            tm.mark("quadratic: open_columns");
         }
         return proof;
     }
@@ -294,9 +319,10 @@ private:
         if (flat_.size() != std::max<size_t>(own, 1)) {
             if (pinned_) lg_host_unregister(ctx_, flat_.data());
             flat_.assign(std::max<size_t>(own, 1), F::zero());
+            scratch_.buffer_replaced();
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
-        inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data());
+        inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data(), nullptr, &scratch_);
         check(lg_stage_interpolate(ctx_, own ? flat_[0].l : nullptr, row0_, row1_ - row0_), "lg_stage_interpolate");
         if (exchange_) {
             void* d = nullptr;
@@ -438,7 +464,14 @@ private:
         const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
         const size_t t = indices.size(), rows = 4 * m_, plen = (size_t)logn_ - 1;
         std::vector<uint32_t> idx(indices.begin(), indices.end());
-        std::vector<Fr> cols(t * rows);
+        // the columns land in a buffer this prover keeps and page-locks (156 columns of the 2^20-constraint proof are 50 MB:
+        // pageable, freshly faulted memory made each of the three openings cost more than the commitment)
+        if (cols_stage_.size() != t * rows) {
+            if (cols_pinned_) lg_host_unregister(ctx_, cols_stage_.data());
+            cols_stage_.resize(t * rows);
+            cols_pinned_ = lg_host_register(ctx_, cols_stage_.data(), cols_stage_.size() * sizeof(Fr)) == LG_OK;
+        }
+        std::vector<Fr>& cols = cols_stage_;
         std::vector<uint8_t> sib(t * 32), paths(t * plen * 32 + 1);
         check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)t, cols[0].l, sib.data(), paths.data()), "lg_open_columns");
         OpenedColumns out;
@@ -558,6 +591,9 @@ private:
     lg_ctx* ctx_ = nullptr;
     std::vector<Fr> flat_;      // preenc_u of the proof being made (reused between proofs); a sharded prover: its row shard
     bool pinned_ = false;
+    std::vector<Fr> cols_stage_;   // opened columns as they come off the device (reused, page-locked)
+    bool cols_pinned_ = false;
+    typename LigeroInstance::Scratch scratch_;   // trace storage and the "flat_ already holds a preenc_u" note, kept between proofs
     // sharded provers only
     ShardComm comm_;
     bool sharded_ = false, exchange_ = false;
@@ -657,18 +693,6 @@ private:
     uint64_t gen_ = 0;
     bool stop_ = false;
     std::exception_ptr err_;
-};
-
-// LG_PROVER_TIMING=1: per-phase wall time of HipLigeroBatch::prove on stderr
-struct PhaseTimer {
-    bool on = getenv("LG_PROVER_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
-    void mark(const char* what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "  %-36s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
-        last = now;
-    }
 };
 
 class HipLigeroBatch {
