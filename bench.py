@@ -232,12 +232,12 @@ def sharded_prove_leg(torch, dist, world: int, rank: int, device: int, log_n: in
                     "side is sharded: row shard + coset planes per rank, two device all-gathers, sub-proof points from the plane owners"}
 
 
-def s20_prover_rate(device: int, proofs: int = 2):
-    """BASELINE configs[2] as a PROOF rate: the synthetic 2^20-constraint repeated-squaring R1CS -> C++ host pipeline
-    (from_constraint_system, LigeroCircuit::new, evaluation trace, preenc_u) -> device prover (commit + three sub-proofs + openings).
-    Setup (R1CS compile, constraint matrix A with 46.6 M entries, upload) is reported apart."""
+def s20_prover_rate(device: int, proofs: int = 2, log_n: int = 20):
+    """BASELINE configs[2] (log_n = 20) / configs[3] on one GPU (log_n = 22) as a PROOF rate: the synthetic 2^log_n-constraint
+    repeated-squaring R1CS -> C++ host pipeline (from_constraint_system, LigeroCircuit::new, evaluation trace, preenc_u) -> device prover
+    (commit + three sub-proofs + openings).  Setup (R1CS compile, constraint matrix A with 46.6 M entries at 2^20, upload) is reported apart."""
     from ligero_amd.prover import LigeroProver
-    inst, idx, vals, setup = repeated_squaring_instance(20)
+    inst, idx, vals, setup = repeated_squaring_instance(log_n)
     t_gen, t_inst = setup["generate_r1cs_and_witness"], setup["compile_and_ligero_new"]
     dims = (inst.m, inst.k, inst.n, inst.t)
     t0 = time.perf_counter()
@@ -250,7 +250,7 @@ def s20_prover_rate(device: int, proofs: int = 2):
         dt = (time.perf_counter() - t0) / proofs
         root = proof.info()["u_root"].hex()
     return {"value": 1.0 / dt, "unit": "proofs/s", "s_per_proof": dt, "proofs_timed": proofs, "dims_m_k_n_t": dims,
-            "dims_match_survey": dims == (2509, 4096, 32768, 156), "nodes": inst.num_nodes, "a_nnz": inst.a_nnz, "u_root": root,
+            "dims_match_survey": dims == {20: (2509, 4096, 32768, 156), 22: (5017, 8192, 65536, 156)}.get(log_n, dims), "nodes": inst.num_nodes, "a_nnz": inst.a_nnz, "u_root": root,
             "setup_s": {"generate_r1cs_and_witness": t_gen, "compile_and_ligero_new": t_inst, "prover_create_upload_A": t_upload},
             "note": "one proof at a time (single HipLigero prover): host evaluation trace + preenc_u assembly, then device; transcript unpinned"}
 
@@ -599,6 +599,12 @@ def main():
         if large:
             gold = golden_large(args.workload)
             line["root_matches_golden"] = (root[:32].hex() == gold["root"]) if gold else None
+            if extras:      # the same shape as a PROOF rate, from the actual R1CS (2^22: about a minute of setup, 30 GB of host memory)
+                del pre
+                try:
+                    line["full_prover_from_r1cs"] = s20_prover_rate(local_rank, 2, {"s22": 22, "s20": 20, "s18": 18}[args.workload])
+                except Exception as e:
+                    line["full_prover_from_r1cs"] = {"error": f"{type(e).__name__}: {e}"}
         if copy_gbs:
             line["roofline"]["measured_copy_GBs"] = copy_gbs
             line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / copy_gbs

@@ -77,3 +77,42 @@ def test_s20_from_r1cs_commit_prove_verify(oracle, tmp_path):
         bad = w[1:].copy()
         bad[777] = bad[778]                                        # break one squaring
         assert not prover.verify(prover.prove(idx, bad))
+
+
+def test_s22_from_r1cs_prove_verify(tmp_path):
+    """BASELINE configs[3] on ONE GPU, as a proof from the actual 2^22-constraint R1CS: (m, k, n, t) = (5017, 8192, 65 536, 156) as
+    SURVEY 8d derives; U is 42 GB, the constraint matrix 186 M entries, the folded k = 8192 transforms and the 16-plane layout serve
+    the commitment and all three sub-proofs; the verifier accepts, and rejects a proof whose opened column was altered.  (The
+    commitment of this shape is pinned against the streamed oracle by test_gpu_parity.py on seeded data.)"""
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    gen = _gen()
+    r1cs = str(tmp_path / "rs22.r1cs")
+    gen.write_r1cs(r1cs, 22)
+    wit = gen.witness(22, 1)
+    t0 = time.time()
+    circ = hp.ArithmeticCircuit.from_r1cs(r1cs)
+    assert circ.num_nodes() == 5 * (1 << 22) + 3
+    inst = hp.LigeroInstance(circ)
+    assert (inst.m, inst.k, inst.n, inst.t) == (5017, 8192, 65536, 156)
+    t_setup = time.time() - t0
+    mask = (1 << 64) - 1
+    vals = np.empty((len(wit) - 1, 4), dtype=np.uint64)
+    for j, v in enumerate(wit[1:]):
+        vm = (v << 256) % gen.P
+        vals[j] = (vm & mask, (vm >> 64) & mask, (vm >> 128) & mask, vm >> 192)
+    idx = np.arange(1, len(wit), dtype=np.uint64)
+    with LigeroProver(inst) as prover:
+        proof = prover.prove(idx, vals)
+        t1 = time.time()
+        proof = prover.prove(idx, vals)
+        t_prove = time.time() - t1
+        info = proof.info()
+        assert info["opened_columns"] == 156 and info["column_len"] == 4 * 5017 and info["auth_path_len"] == 15
+        assert info["linear_poly"] <= 2 * 8192 and info["quadratic_poly"] <= 2 * 8192 and info["preenc_u_lc"] == 8192
+        t1 = time.time()
+        assert prover.verify(proof)
+        t_verify = time.time() - t1
+        print(f"s22 from r1cs: setup {t_setup:.1f} s, prove {t_prove:.2f} s, verify {t_verify:.1f} s")
+        tamper(proof, 5, 4321)
+        assert not prover.verify(proof)
