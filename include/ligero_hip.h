@@ -187,6 +187,16 @@ int lg_upload_constraint_matrix(lg_ctx* ctx, uint64_t num_rows, uint64_t nnz, co
                                 const uint64_t* values);
 int lg_linear_constraint_poly_from_seeds(lg_ctx* ctx, const uint8_t* seeds, uint64_t* coeffs_out);
 int lg_quadratic_constraint_poly(lg_ctx* ctx, const uint64_t* r, uint64_t* coeffs_out);
+/*
+ * The VERIFIER's side of the linear test (src/ligero/mod.rs:748-830) for one proof, on the device: r_linear from the 32-byte
+ * seed and r_a = A.row_mul(r_linear) as above, every r_a row interpolated and encoded on the large domain (mod.rs:773-781,
+ * 815-818), and for each of the t opened indices idx[c] the sum over i of r_i(eta_idx[c]) * cols[c][i], where cols (t * rows
+ * elements, Montgomery) are the columns the proof carries -> sums_out (t elements, Montgomery), to be compared with the
+ * proof's polynomial at eta_idx[c] (mod.rs:820-829).  Needs lg_upload_constraint_matrix, batch 1, an unsharded context; the
+ * encodings are written where a commitment's codeword matrix lives, so a commitment held by this context is void afterwards.
+ */
+int lg_verifier_linear_sums_from_seed(lg_ctx* ctx, const uint8_t* seed, const uint32_t* idx, uint32_t t, const uint64_t* cols,
+                                      uint64_t* sums_out);
 
 /*
  * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU

@@ -1337,11 +1337,13 @@ int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, cons
     return LG_OK;
 }
 
-// r_linear (ChaCha20 + F::rand from the seeds) and r_a = A.row_mul(r_linear) into d_scratch_a, then linear_core
-static int linear_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
+// r_linear (ChaCha20 + F::rand from the seeds) and r_a = A.row_mul(r_linear) into d_scratch_a (launches only; the caller
+// checks the candidate-stream flag with linear_seed_flag once the stream has been synchronised)
+static int linear_ra_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t* per_out, uint32_t* nch_out) {
     uint32_t per, nch;
     int rc = linear_buffers(c, &per, &nch);
     if (rc != LG_OK) return rc;
+    *per_out = per; *nch_out = nch;
     const uint64_t n = (uint64_t)c->rows * c->k;      // 4 m k challenges per proof
     if (n > 0x7fffffffull) return LG_ERR_UNSUPPORTED;
     // 75.6 % of the 32-byte chunks are accepted; 1.5 chunks per element leaves > 50 standard deviations of margin
@@ -1375,15 +1377,113 @@ static int linear_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t plane_mas
         LG_LAUNCH(c, lg::sparse_row_mul_heavy_segments_kernel, dim3(c->a_nseg, c->batch), dim3(256), 0, c->stream, h);
         LG_LAUNCH(c, lg::sparse_row_mul_heavy_finish_kernel, dim3(c->a_nheavy, c->batch), dim3(256), 0, c->stream, h);
     }
-    rc = linear_core(c, per, nch, plane_mask, coeffs_out, points_out);   // synchronises on the stream when it reads the result back
-    if (rc != LG_OK) return rc;
+    return LG_OK;
+}
+static int linear_seed_flag(lg_ctx* c) {
     uint32_t flag = 0;
     LG_HIP(c, hipMemcpy(&flag, c->d_short_flag, 4, hipMemcpyDeviceToHost));
     if (flag) {
-        snprintf(c->err, sizeof(c->err), "ChaCha candidate stream too short for %llu elements", (unsigned long long)n);
+        snprintf(c->err, sizeof(c->err), "ChaCha candidate stream too short for %llu elements", (unsigned long long)c->rows * c->k);
         return LG_ERR_STATE;
     }
     return LG_OK;
+}
+static int linear_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
+    uint32_t per, nch;
+    int rc = linear_ra_from_seeds(c, seeds, &per, &nch);
+    if (rc != LG_OK) return rc;
+    rc = linear_core(c, per, nch, plane_mask, coeffs_out, points_out);   // synchronises on the stream when it reads the result back
+    if (rc != LG_OK) return rc;
+    return linear_seed_flag(c);
+}
+
+// The VERIFIER's side of the linear test (mod.rs:748-830) on the device: r_linear from the seed, r_a = A.row_mul(r_linear), every
+// r_a row interpolated and encoded on the large domain (mod.rs:773-781, 815-818), and for each opened column j the sum
+// sum_i r_i(eta_j) * U[i][j] with the column the proof carries.  The encodings go where a commitment's codeword matrix lives,
+// so a commitment this context held is void afterwards.
+int lg_verifier_linear_sums_from_seed(lg_ctx* c, const uint8_t* seed, const uint32_t* idx, uint32_t t, const uint64_t* cols, uint64_t* sums_out) {
+    if (!c || !seed || (t && (!idx || !cols || !sums_out))) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (c->sharded) {
+        snprintf(c->err, sizeof(c->err), "lg_verifier_linear_sums_from_seed needs room for every coset plane; a sharded context holds [%u, %u)", c->own_plane0,
+                 c->own_plane0 + c->own_planes);
+        return LG_ERR_STATE;
+    }
+    if (!c->a_loaded) return LG_ERR_STATE;
+    for (uint32_t i = 0; i < t; i++)
+        if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
+    if (t == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    // nothing of an earlier commit may still be reading or writing U, the leaves or the tree
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    if (c->stream_h) LG_HIP(c, hipStreamSynchronize(c->stream_h));
+    LG_HIP(c, hipStreamSynchronize(c->stream));
+    c->committed = false; c->staging = false; c->have_planes = 0;
+    uint32_t per, nch;
+    int rc = linear_ra_from_seeds(c, seed, &per, &nch);
+    if (rc != LG_OK) return rc;
+    const uint64_t R = c->total_rows;
+    const size_t mat = (size_t)R * c->k;
+    const uint64_t plane = R * c->ki;
+    fr* d_ra = c->d_scratch_a;
+    fr* d_rc = c->d_scratch_a + mat;
+    {
+        lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, (uint32_t)R);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+        lg::NttArgs e = eval_args(c, d_rc, c->d_u, plane, 0, (uint32_t)R, true);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, e));
+    }
+    // gathered[c][i] = r_i(eta_j) for the opened j (Montgomery), next to the proof's columns
+    rc = grow(c, &c->d_scratch_c, &c->scratch_c_elems, 2 * (size_t)t * c->rows);
+    if (rc != LG_OK) return rc;
+    if (c->idx_cap < t) {
+        if (c->d_idx) LG_HIP(c, hipFree(c->d_idx));
+        c->d_idx = nullptr; c->idx_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_idx), (size_t)t * sizeof(uint32_t)));
+        c->idx_cap = t;
+    }
+    fr* d_gath = c->d_scratch_c;
+    fr* d_cols = c->d_scratch_c + (size_t)t * c->rows;
+    LG_HIP(c, hipMemcpyAsync(c->d_idx, idx, (size_t)t * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    LG_HIP(c, hipMemcpyAsync(d_cols, cols, (size_t)t * c->rows * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    lg::GatherArgs g;
+    memset(&g, 0, sizeof(g));
+    g.u = c->d_u; g.leaves = c->d_leaves; g.nodes = c->d_nodes; g.idx = c->d_idx; g.cols = d_gath;
+    // only the column threads are wanted, but the tail of the last workgroup falls into the kernel's path section: give it
+    // real memory to write (what it writes -- pieces of a stale tree -- is never read)
+    const uint32_t plen = (uint32_t)c->logn - 1;
+    const size_t path_bytes = (size_t)t * (plen + 1) * 32;
+    if (c->path_cap < path_bytes) {
+        if (c->d_path_out) LG_HIP(c, hipFree(c->d_path_out));
+        c->d_path_out = nullptr; c->path_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_path_out), path_bytes));
+        c->path_cap = path_bytes;
+    }
+    g.sib = c->d_path_out; g.paths = c->d_path_out + (size_t)t * 32;
+    g.r2 = c->r2; g.plane_stride = plane; g.lognp = (uint32_t)c->lognp; g.proof0 = 0;
+    g.rows = c->rows; g.k = c->ki; g.n = c->n; g.logn = (uint32_t)c->logn; g.t = t;
+    const uint64_t threads = (uint64_t)t * c->rows;
+    LG_LAUNCH(c, lg::gather_columns_kernel, dim3((uint32_t)((threads + 255) / 256), 1), dim3(256), 0, c->stream, g);
+    // sums[c] = sum_i gathered[c][i] (*) cols[c][i]: "columns" of the row-sum kernel = the t openings, its rows = the 4m entries
+    const uint32_t nchs = sub_chunks(c->rows, &per);
+    rc = sub_buffers(c, std::max<size_t>((size_t)nchs * t, (size_t)nch * 2 * c->k), 1);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->d_sub_r, &c->sub_r_elems, t);       // the t sums
+    if (rc != LG_OK) return rc;
+    lg::RowSumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = d_gath; a.a_row = 1; a.a_col = c->rows;
+    a.b = d_cols; a.b_row = 1; a.b_col = c->rows;
+    a.partial = c->d_sub_partial;
+    a.rows = c->rows; a.cols = t; a.rows_per_chunk = per; a.nchunks = nchs;
+    LG_LAUNCH(c, lg::rowsum_mul_kernel, dim3((t + 255) / 256, nchs, 1), dim3(256), 0, c->stream, a);
+    // Montgomery x Montgomery -> Montgomery already: multiply by one (R) only to normalise
+    LG_LAUNCH(c, lg::rowsum_finish_kernel, dim3((t + 255) / 256, 1, 1), dim3(256), 0, c->stream, c->d_sub_partial, nchs, t, to_dev(lg_host::kOneMont), c->d_sub_r,
+              1u, 0u, (uint64_t)t);
+    rc = read_back(c, sums_out, c->d_sub_r, (size_t)t * sizeof(fr));
+    if (rc != LG_OK) return rc;
+    return linear_seed_flag(c);
 }
 
 int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* coeffs_out) {

@@ -522,6 +522,9 @@ private:
 
     // mod.rs:748-830
     bool verify_linear(const ConstraintsProof& p, const Digest& root, PoseidonSponge& sponge) {
+        if constexpr (kDeviceChallenges) {   // LG_VERIFY_ON_HOST=1 keeps the line-by-line host version below (tests run both)
+            if (!sharded_ && !getenv("LG_VERIFY_ON_HOST")) return verify_linear_on_device(p, root, sponge);
+        }
         const std::vector<Fr> r_linear = get_field_elements_from_prng<E>(4 * m_ * k_, sponge.squeeze_seed());
         const std::vector<Fr> r_a = inst_.a.row_mul(r_linear);
         // r_polys = small_domain.ifft of every k-chunk of r_a (mod.rs:773-781)
@@ -550,6 +553,38 @@ private:
                 for (size_t i = 0; i < rows; i++) acc[c] = fr_add(acc[c], fr_mul(r_evals[i * n_ + j], p.open.columns[c][i0 + i]));
             }
         }
+        const size_t cofactor = n_ / (2 * k_);
+        const Fr wn = F::domain_generator(logn_);
+        for (size_t c = 0; c < nopen; c++) {   // sum_i r_i(eta_j) * U_{i, j} = q(eta_j), mod.rs:820-829
+            const size_t j = p.open.paths[c].leaf_index;
+            const Fr eval = (j % cofactor == 0) ? inter[j / cofactor] : poly_evaluate(p.polynomial, F::pow_u64(wn, j));
+            if (!fr_eq(acc[c], eval)) return false;
+        }
+        return true;
+    }
+
+    // the same checks with the 4 m k challenges, A.row_mul and the 4m encodings of the r_a rows on the device
+    // (lg_verifier_linear_sums_from_seed): at 2^20 constraints the host version spends seconds drawing 41 M field elements
+    // from ChaCha20 and reading 10 GB of encodings back
+    bool verify_linear_on_device(const ConstraintsProof& p, const Digest& root, PoseidonSponge& sponge) {
+        const std::array<uint8_t, 32> seed = sponge.squeeze_seed();
+        if (!p.polynomial.empty() && p.polynomial.size() - 1 >= 2 * k_ - 1) return false;      // degree check, mod.rs:783
+        std::vector<Fr> q = p.polynomial;
+        q.resize(2 * k_, fr_zero());
+        const std::vector<Fr> inter = host_fft(q);                                             // intermediate_domain.fft
+        Fr sum = fr_zero();
+        for (size_t c = 0; c < 2 * k_; c += 2) sum = fr_add(sum, inter[c]);
+        if (!fr_is_zero(sum)) return false;                                                    // mod.rs:794
+        sponge.absorb_elements(p.polynomial);
+        if (!verify_column_openings(p.open, root, sponge)) return false;
+        const size_t nopen = p.open.columns.size(), rows = 4 * m_;
+        std::vector<uint32_t> idx(nopen);
+        std::vector<Fr> flat(nopen * rows), acc(nopen);
+        for (size_t c = 0; c < nopen; c++) {
+            idx[c] = (uint32_t)p.open.paths[c].leaf_index;
+            memcpy(static_cast<void*>(&flat[c * rows]), p.open.columns[c].data(), rows * sizeof(Fr));   // (sizes checked by verify_column_openings)
+        }
+        if (nopen) check(lg_verifier_linear_sums_from_seed(ctx_, seed.data(), idx.data(), (uint32_t)nopen, flat[0].l, acc[0].l), "lg_verifier_linear_sums_from_seed");
         const size_t cofactor = n_ / (2 * k_);
         const Fr wn = F::domain_generator(logn_);
         for (size_t c = 0; c < nopen; c++) {   // sum_i r_i(eta_j) * U_{i, j} = q(eta_j), mod.rs:820-829

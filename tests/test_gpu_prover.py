@@ -291,3 +291,30 @@ def test_cpp_example_program_from_files():
         assert "u_root = " + json.load(open(os.path.join(GOLDEN, "vectors.json")))["poseidon"]["root"] in out.stdout
     bad = subprocess.run([exe, os.path.join(GOLDEN, "cube.r1cs"), os.path.join(GOLDEN, "poseidon_witness.json")], capture_output=True, text=True)
     assert bad.returncode == 3 and "error:" in bad.stderr
+
+
+def test_device_and_host_verifiers_of_the_linear_test_agree(poseidon, monkeypatch):
+    """verify_linear (mod.rs:748-830) runs its 4 m k challenges, A.row_mul and the encodings of the r_a rows on the device
+    (lg_verifier_linear_sums_from_seed); LG_VERIFY_ON_HOST=1 keeps the host restatement: both must accept a good proof and
+    reject the same corruptions -- of the polynomial, of an opened column, of the witness"""
+    inst, prover, idx, vals = poseidon
+    good = prover.prove(idx, vals)
+    bad_poly = prover.prove(idx, vals)
+    tamper(bad_poly, 2, 3)                       # coefficient 3 of the linear test's polynomial: the sum over the small domain (mod.rs:794)
+                                                 # only sees coefficients 0 and k, so only the column sums (mod.rs:820-829) can catch this
+    bad_col = prover.prove(idx, vals)
+    tamper(bad_col, 5, 1000)                     # an element of one of its opened columns
+    wrong = vals.copy()
+    wrong[5] = wrong[6]
+    bad_wit = prover.prove(idx, wrong)
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("LG_VERIFY_ON_HOST", "1")
+        else:
+            monkeypatch.delenv("LG_VERIFY_ON_HOST", raising=False)
+        assert prover.verify(good), host
+        assert not prover.verify(bad_poly), host
+        assert not prover.verify(bad_col), host
+        assert not prover.verify(bad_wit), host
+    # the verifier wrote over the prover's commitment; the next proof is unaffected
+    assert prover.verify(prover.prove(idx, vals))
