@@ -313,6 +313,27 @@ private:
     void comm_check(int rc, const char* what) const {
         if (rc != 0) throw std::runtime_error(std::string(what) + ": the host layer's collective failed (" + std::to_string(rc) + ")");
     }
+    // A rank that fails between two exchanges must not leave the others waiting inside the next one: before every exchange the
+    // ranks all-gather one status word each, and all of them throw if any reports a failure.  `step` runs this rank's part.
+    template <class Fn>
+    void together(const char* what, Fn&& step) {
+        std::string err;
+        try {
+            step();
+        } catch (const std::exception& e) {
+            err = e.what();
+        }
+        if (!exchange_) {
+            if (!err.empty()) throw std::runtime_error(err);
+            return;
+        }
+        const uint32_t mine = err.empty() ? 0u : 1u;
+        std::vector<uint32_t> all(comm_.world, 0);
+        comm_check(comm_.all_gather_host(comm_.user, &mine, all.data(), sizeof(uint32_t)), "status exchange");
+        if (!err.empty()) throw std::runtime_error(err);
+        for (uint32_t r = 0; r < comm_.world; r++)
+            if (all[r]) throw std::runtime_error(std::string(what) + " failed on rank " + std::to_string(r));
+    }
     // mod.rs:521-551 as the five stages of DESIGN.md section 7
     void sharded_commit(const std::vector<std::pair<size_t, E>>& formatted_assignment, Digest& root) {
         const size_t own = (size_t)(row1_ - row0_) * k_;
@@ -322,21 +343,25 @@ private:
             scratch_.buffer_replaced();
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
-        inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data(), nullptr, &scratch_);
-        check(lg_stage_interpolate(ctx_, own ? flat_[0].l : nullptr, row0_, row1_ - row0_), "lg_stage_interpolate");
+        void* d = nullptr;
+        size_t bytes = 0;
+        together("the interpolation of a row shard", [&] {
+            inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data(), nullptr, &scratch_);
+            check(lg_stage_interpolate(ctx_, own ? flat_[0].l : nullptr, row0_, row1_ - row0_), "lg_stage_interpolate");
+            if (exchange_) {
+                check(lg_device_buffer(ctx_, LG_BUF_COEFFS, &d, &bytes), "lg_device_buffer");
+                check(lg_sync(ctx_), "lg_sync");
+            }
+        });
+        if (exchange_) comm_check(comm_.all_gather_device(comm_.user, d, (uint64_t)shard_rows_ * k_ * sizeof(Fr)), "all-gather of the coefficient rows");
+        together("the evaluation of a rank's coset planes", [&] {
+            check(lg_stage_evaluate_hash(ctx_, own_mask_), "lg_stage_evaluate_hash");
+            if (exchange_) {
+                check(lg_stage_digests_pack(ctx_, comm_.world, comm_.rank, &d, &bytes), "lg_stage_digests_pack");
+                check(lg_sync(ctx_), "lg_sync");
+            }
+        });
         if (exchange_) {
-            void* d = nullptr;
-            size_t bytes = 0;
-            check(lg_device_buffer(ctx_, LG_BUF_COEFFS, &d, &bytes), "lg_device_buffer");
-            check(lg_sync(ctx_), "lg_sync");
-            comm_check(comm_.all_gather_device(comm_.user, d, (uint64_t)shard_rows_ * k_ * sizeof(Fr)), "all-gather of the coefficient rows");
-        }
-        check(lg_stage_evaluate_hash(ctx_, own_mask_), "lg_stage_evaluate_hash");
-        if (exchange_) {
-            void* d = nullptr;
-            size_t bytes = 0;
-            check(lg_stage_digests_pack(ctx_, comm_.world, comm_.rank, &d, &bytes), "lg_stage_digests_pack");
-            check(lg_sync(ctx_), "lg_sync");
             comm_check(comm_.all_gather_device(comm_.user, d, bytes), "all-gather of the leaf digests");
             check(lg_stage_digests_unpack(ctx_, comm_.world), "lg_stage_digests_unpack");
         }
@@ -346,7 +371,7 @@ private:
     // the 2k point values of one sub-proof polynomial: this rank's slots from the device, the others' from their owners
     std::vector<Fr> sharded_points(int which, const void* challenge) {
         std::vector<Fr> mine(2 * k_);
-        check(lg_subproof_points(ctx_, which, challenge, mine[0].l, nullptr), "lg_subproof_points");
+        together("a sub-proof's point values", [&] { check(lg_subproof_points(ctx_, which, challenge, mine[0].l, nullptr), "lg_subproof_points"); });
         if (!exchange_) return mine;
         std::vector<Fr> all((size_t)comm_.world * 2 * k_);
         comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), 2 * k_ * sizeof(Fr)), "all-gather of the sub-proof points");
@@ -376,7 +401,8 @@ private:
         std::vector<uint32_t> idx;
         for (uint64_t j : indices)
             if (owner_of(j) == comm_.rank) idx.push_back((uint32_t)j);
-        if (!idx.empty()) {
+        together("the opening of a rank's columns", [&] {
+            if (idx.empty()) return;
             std::vector<Fr> cols(idx.size() * rows);
             std::vector<uint8_t> sib(idx.size() * 32), paths(idx.size() * plen * 32 + 1);
             check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)idx.size(), cols[0].l, sib.data(), paths.data()), "lg_open_columns");
@@ -386,7 +412,7 @@ private:
                 memcpy(p + col_bytes, &sib[32 * c], 32);
                 memcpy(p + col_bytes + 32, &paths[32 * c * plen], plen * 32);
             }
-        }
+        });
         std::vector<uint8_t> all;
         const uint8_t* blocks = mine.data();
         if (exchange_) {

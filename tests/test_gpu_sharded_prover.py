@@ -126,3 +126,40 @@ def test_sharded_prover_over_rccl_at_world_1():
     p.join(300)
     assert p.exitcode == 0
     assert out["error"] is None and out["equal"] and out["accepted"]
+
+
+def _failing_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ligero_amd.prover import ShardedLigeroProver
+        inst, names, vals = _small_case()
+        with ShardedLigeroProver(inst, dist, device=0) as sp:
+            try:
+                if rank == 1:
+                    sp.prove_with_labels(names[:1], vals[:1])               # this rank "forgets" y: its trace fails
+                else:
+                    sp.prove_with_labels(names, vals)
+                out[rank] = "no error"
+            except RuntimeError as e:
+                out[rank] = str(e)
+            # the group is still usable: the next proof goes through on every rank
+            out[f"next{rank}"] = sp.verify(sp.prove_with_labels(names, vals))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_leave_the_others_inside_a_collective():
+    """before every exchange the ranks trade one status word: when one rank's step throws, every rank throws instead of
+    waiting for it forever"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_failing_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert "Uninitialised variable" in out[1]
+    assert "failed on rank 1" in out[0]
+    assert out["next0"] and out["next1"]
