@@ -193,7 +193,14 @@ public:
         if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_field");
         logn_ = 0;
         while ((size_t{1} << logn_) < n_) logn_++;
-        if constexpr (kDeviceChallenges) upload_constraint_matrix(ctx_, inst.a);
+        if constexpr (kDeviceChallenges) {
+            try {
+                upload_constraint_matrix(ctx_, inst.a);
+            } catch (...) {     // a constructor that throws runs no destructor
+                lg_ctx_destroy(ctx_);
+                throw;
+            }
+        }
     }
     // One rank of a proof sharded over comm.world GPUs: this rank's context holds its row shard of preenc_u, ALL coefficient
     // rows (after the all-gather) and only its own coset planes of U.  Every rank must call prove() with the same
@@ -225,7 +232,14 @@ public:
         own_mask_ = 0;
         for (uint32_t s = p0; s < p0 + pc; s++) own_mask_ |= 1u << s;
         // the linear test's challenges and A.row_mul run where a plane of the size-2k domain (s = 0 mod 4) lives: only those ranks hold A
-        if (own_mask_ & 0x11111111u) upload_constraint_matrix(ctx_, inst.a);
+        if (own_mask_ & 0x11111111u) {
+            try {
+                upload_constraint_matrix(ctx_, inst.a);
+            } catch (...) {
+                lg_ctx_destroy(ctx_);
+                throw;
+            }
+        }
     }
     ~HipLigeroT() {
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
