@@ -680,7 +680,6 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
             p = mul(p, w8);
             pi = mul(pi, w8i);
         }
-        Fr kk = {{k, 0, 0, 0}};
         c->one29 = to_f29_plain(kOneMont);
         c->oneq29 = to_f29_quot(kOneMont);
         c->scale29 = to_f29(inv_k);

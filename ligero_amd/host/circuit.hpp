@@ -718,14 +718,14 @@ public:
                                                                : "Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends");
                     put(3 * mk + pos, val[i]);
                 } else {
-                    const E& a = val[prog_.l[i]];
-                    const E& b = val[prog_.r[i]];
+                    const E& lhs = val[prog_.l[i]];
+                    const E& rhs = val[prog_.r[i]];
                     if (kd == Node::Mul) {
-                        const E z = F::mul(a, b);
-                        put(pos, a); put(mk + pos, b); put(2 * mk + pos, z);
+                        const E z = F::mul(lhs, rhs);
+                        put(pos, lhs); put(mk + pos, rhs); put(2 * mk + pos, z);
                         val[i] = z;
                     } else {
-                        val[i] = F::add(a, b);
+                        val[i] = F::add(lhs, rhs);
                     }
                     put(3 * mk + pos, val[i]);
                 }
