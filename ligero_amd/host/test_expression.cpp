@@ -8,6 +8,7 @@
 //   src/expression/tests.rs:303-345   test_to_arithmetic_circuit_2   exact nodes and trace (a gate referring forwards)
 //   src/expression/tests.rs:347-387   test_to_arithmetic_circuit_3 / _4 / _5
 //   src/arithmetic_circuit/tests.rs:350-393   test_constant_filtering
+//   src/matrices/mod.rs:195-209               test_mat_mul_sparse
 // usage: test_expression      (one line per test; exit code = number of failures)
 #include <algorithm>
 #include <array>
@@ -160,6 +161,13 @@ int main() {
             const std::vector<N> want = {var<FqE>("x"), cst(fq(3)), var<FqE>("y"), mul<FqE>(14, 1), cst(fq(-1)), mul<FqE>(3, 1), mul<FqE>(1, 1), cst(fq(4)),
                                          mul<FqE>(6, 6), add<FqE>(7, 4), add<FqE>(7, 1), mul<FqE>(4, 4), cst(fq(-2)), var<FqE>("z"), add<FqE>(10, 4)};
             report("test_constant_filtering", same_nodes(ArithmeticCircuitT<FqE>::filter_constants(nodes).first, want));
+        }
+        {   // src/matrices/mod.rs:195-209 test_mat_mul_sparse: the reference's known answer for SparseMatrix::row_mul
+            SparseMatrixT<Fr> m(3);
+            m.push_row({{fr(1), 0}, {fr(8), 2}});
+            m.push_row({{fr(4), 1}, {fr(5), 2}});
+            const std::vector<Fr> got = m.row_mul({fr(-5), fr(17)});
+            report("test_mat_mul_sparse", got.size() == 3 && FF::eq(got[0], fr(-5)) && FF::eq(got[1], fr(68)) && FF::eq(got[2], fr(45)));
         }
         {
             // a long chain is built, compiled, evaluated and released without recursion

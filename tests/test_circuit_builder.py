@@ -250,7 +250,8 @@ def test_cpp_expression_suite():
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     for name in ("test_get_variables", "test_same_reference", "test_to_arithmetic_circuit_1", "test_to_arithmetic_circuit_2",
-                 "test_to_arithmetic_circuit_3", "test_to_arithmetic_circuit_4", "test_to_arithmetic_circuit_5", "test_constant_filtering"):
+                 "test_to_arithmetic_circuit_3", "test_to_arithmetic_circuit_4", "test_to_arithmetic_circuit_5", "test_constant_filtering",
+                 "test_mat_mul_sparse"):
         assert name + ": ok" in out.stdout
 
 

@@ -329,6 +329,19 @@ def test_staged_commit_matches_oracle(lg, oracle, rows, k):
         be.close()
 
 
+def test_mat_mul_dense_known_answer(lg, oracle):
+    """the reference's own known answer for DenseMatrix::row_mul (src/matrices/mod.rs:180-193), the operation prove_interleaved
+    runs on preenc_u (mod.rs:658): [[1, 2, 8], [3, 4, 5]] with v = [-5, 17] -> [46, 58, 45]; a fourth zero column makes k a power of two"""
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    mont = lambda vs: oracle.to_mont(oracle.ints_to_limbs([v % P for v in vs]))
+    m = mont([1, 2, 8, 0, 3, 4, 5, 0]).reshape(2, 4, 4)
+    with lg.LigeroCommitter(rows=2, k=4) as c:
+        c.upload(m)
+        c.commit_resident()
+        got = c.interleaved_row_mul(mont([-5, 17]))[0]
+    assert oracle.limbs_to_ints(oracle.from_mont(got)) == [46, 58, 45, 0]
+
+
 @pytest.mark.parametrize("rows,k,batch", [(12, 8, 1), (344, 128, 1), (20, 64, 3), (344, 128, 5), (8, 4096, 1), (4, 8192, 2)])
 def test_subproof_polynomials_match_oracle(lg, oracle, rows, k, batch):
     """next rows of the path: the arithmetic of prove_interleaved (mod.rs:658),
