@@ -79,6 +79,33 @@ def sweep(budget: float, seed: int) -> int:
                 for b in range(batch):
                     want = oracle.quadratic_constraint_poly(coeffs[b * rows:(b + 1) * rows], r[b])
                     assert np.array_equal(got[b], want), ("quad", rows, k, batch, b, seed)
+            if batch == 1 and k <= 8192 and rng.integers(4) == 0:
+                # the same proof coset-sharded over 2 / 4 / 8 contexts (one process, exchanges as device copies): root, owner-served
+                # openings, and the three sub-proof polynomials from the plane owners' point values
+                from ligero_amd import _ffi
+                from ligero_amd.sharded import HipStageBackend
+                from sharded_inprocess import merge_points, sharded_commit
+                world = int(rng.choice([2, 4, 8]))
+                r_il = random_mont(seed + 2, rows).reshape(rows, 4)
+                r_a = random_mont(seed + 3, rows * k).reshape(rows, k, 4)
+                r_q = random_mont(seed + 4, rows // 4).reshape(rows // 4, 4)
+                wants = ((_ffi.LG_SUB_INTERLEAVED, r_il, c.interleaved_row_mul(r_il)[0]), (_ffi.LG_SUB_LINEAR, r_a, c.linear_constraint_poly(r_a)[0]),
+                         (_ffi.LG_SUB_QUADRATIC, r_q, c.quadratic_constraint_poly(r_q)[0]))
+                bes = [HipStageBackend(rows, k, device=0, world=world, rank=r) for r in range(world)]
+                try:
+                    assert all(rt == roots[:32] for rt in sharded_commit(bes, pre)), ("sharded root", rows, k, world, seed)
+                    per = bes[0].nplanes // world
+                    for j in idx:
+                        owner = (int(j) % bes[0].nplanes) // per
+                        gc, gs, gp = bes[owner].open_columns([int(j)])
+                        tc, ts, tp = c.open_columns([int(j)])
+                        assert np.array_equal(gc, tc) and np.array_equal(gs, ts) and np.array_equal(gp, tp), ("sharded open", rows, k, world, seed)
+                    for which, ch, want in wants:
+                        merged, _ = merge_points([be.c.subproof_points(which, ch) for be in bes], bes[0].nplanes)
+                        assert np.array_equal(bes[int(rng.integers(world))].c.subproof_finish(which, merged), want), ("sharded sub-proof", which, rows, k, world, seed)
+                finally:
+                    for be in bes:
+                        be.close()
         n_cases += 1
     for var in ("LG_FORCE_CHUNKS", "LG_HASH_QUAD_MAX_COLUMNS", "LG_ASYNC_HASH"):
         os.environ.pop(var, None)
