@@ -115,7 +115,7 @@ def usable_cpus() -> int:
     return n
 
 
-def full_prover_rate(device: int, steps: int = 5):
+def full_prover_rate(device: int, steps: int = 8):
     """proofs/s of the complete prove() (ligero_amd/host/prover.hpp: commit + three sub-proofs + openings + transcript)
     on the 64 committed Poseidon witnesses, batch-wide device calls + host threads.  The transcript is the restated
     test_sponge() -- unpinned against the Rust crates -- so this is the cost of the same work, not a
@@ -136,6 +136,8 @@ def full_prover_rate(device: int, steps: int = 5):
     # others; measured on the GPU box (16 usable CPUs): 1 prover 2 600 proofs/s, 4 provers 4 500 proofs/s
     import threading
     nprov, threads = 4, max(1, usable_cpus() // 2)
+    if os.environ.get("LIGERO_BENCH_PROVERS"):      # "provers x threads", e.g. 8x4 (tools: finding the best split of the host cores)
+        nprov, threads = (int(x) for x in os.environ["LIGERO_BENCH_PROVERS"].split("x"))
     provers = [LigeroBatchProver(inst, 64, device=device, threads=threads) for _ in range(nprov)]
     try:
         for bp in provers:

@@ -127,6 +127,11 @@ int lgh_sponge_absorb_bytes(lgh_sponge* s, const uint8_t* data, uint64_t len);
 int lgh_sponge_absorb_elements(lgh_sponge* s, const uint64_t* elems, uint64_t count);
 int lgh_sponge_squeeze_bytes(lgh_sponge* s, uint64_t n, uint8_t* out);
 int lgh_sponge_squeeze_elements(lgh_sponge* s, uint64_t n, uint64_t* out);
+/* absorb_elements on EIGHT sponges at once: elems = 8 * count elements, sponge-major.  Where the host has AVX-512 IFMA and the
+ * sponges are in step the eight states advance on the lanes of one vector (ligero_amd/host/poseidon_ifma.hpp); the states are
+ * the same as after eight lgh_sponge_absorb_elements calls either way.  lgh_ifma_available: 1 if the vector path can run here. */
+int lgh_sponge_absorb_elements_x8(lgh_sponge* const sponges[8], const uint64_t* elems, uint64_t count);
+int lgh_ifma_available(void);
 
 #ifdef __cplusplus
 }

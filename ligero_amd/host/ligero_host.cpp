@@ -338,6 +338,24 @@ int lgh_sponge_absorb_elements(lgh_sponge* s, const uint64_t* elems, uint64_t co
         return LGH_OK;
     });
 }
+int lgh_sponge_absorb_elements_x8(lgh_sponge* const sponges[8], const uint64_t* elems, uint64_t count) {
+    if (!sponges || (!elems && count)) return LGH_ERR_BAD_ARG;
+    for (int j = 0; j < 8; j++)
+        if (!sponges[j]) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::vector<std::vector<Fr>> v(8, std::vector<Fr>(count));
+        PoseidonSponge* sp[8];
+        const std::vector<Fr>* el[8];
+        for (int j = 0; j < 8; j++) {
+            for (size_t i = 0; i < count; i++) v[j][i] = load_fr(elems + 4 * ((size_t)j * count + i));
+            sp[j] = &sponges[j]->s;
+            el[j] = &v[j];
+        }
+        PoseidonSponge::absorb_elements_x8(sp, el);
+        return LGH_OK;
+    });
+}
+int lgh_ifma_available(void) { return ifma::available() ? 1 : 0; }
 int lgh_sponge_squeeze_bytes(lgh_sponge* s, uint64_t n, uint8_t* out) {
     if (!s || (!out && n)) return LGH_ERR_BAD_ARG;
     return guarded([&] {

@@ -827,10 +827,8 @@ public:
         tm.mark("absorb root, r_interleaved (host)");
         check(lg_interleaved_row_mul(ctx_, r_int[0].l, lc[0].l), "lg_interleaved_row_mul");
         tm.mark("interleaved row_mul (device)");
-        parallel_for(B, [&](size_t b) {
-            proofs[b].interleaved_proof.preenc_u_lc.assign(lc.begin() + b * k_, lc.begin() + (b + 1) * k_);
-            sponge[b].absorb_elements(proofs[b].interleaved_proof.preenc_u_lc);
-        });
+        parallel_for(B, [&](size_t b) { proofs[b].interleaved_proof.preenc_u_lc.assign(lc.begin() + b * k_, lc.begin() + (b + 1) * k_); });
+        absorb_all(sponge, [&](size_t b) -> const std::vector<Fr>& { return proofs[b].interleaved_proof.preenc_u_lc; });
         open_all(sponge, [&](size_t b) -> OpenedColumns& { return proofs[b].interleaved_proof.open; });
         tm.mark("absorb + open interleaved");
         // linear test: only the 32-byte seeds go to the device; r_linear and r_a = A.row_mul(r_linear) are made there
@@ -873,9 +871,26 @@ private:
             std::vector<Fr>& p = get(b).polynomial;
             p.assign(poly.begin() + b * 2 * k_, poly.begin() + (b + 1) * 2 * k_);
             trim_zeros(p);
-            sponge[b].absorb_elements(p);
         });
+        absorb_all(sponge, [&](size_t b) -> const std::vector<Fr>& { return get(b).polynomial; });
         open_all(sponge, [&](size_t b) -> OpenedColumns& { return get(b).open; });
+    }
+    // sponge[b].absorb_elements(get(b)) for every proof of the batch, eight proofs per task: the eight sponges advance in lock-step
+    // on the lanes of one vector where the host has AVX-512 IFMA (transcript.hpp absorb_elements_x8); same states either way
+    template <class Get>
+    void absorb_all(std::vector<PoseidonSponge>& sponge, Get&& get) {
+        const size_t B = batch_, groups = (B + 7) / 8;
+        parallel_for(groups, [&](size_t g) {
+            const size_t b0 = 8 * g, cnt = std::min<size_t>(8, B - b0);
+            if (cnt == 8) {
+                PoseidonSponge* sp[8];
+                const std::vector<Fr>* el[8];
+                for (size_t j = 0; j < 8; j++) { sp[j] = &sponge[b0 + j]; el[j] = &get(b0 + j); }
+                PoseidonSponge::absorb_elements_x8(sp, el);
+            } else {
+                for (size_t j = 0; j < cnt; j++) sponge[b0 + j].absorb_elements(get(b0 + j));
+            }
+        });
     }
     // open_columns (mod.rs:935-955) of every proof with one gather launch and one copy
     template <class Get>

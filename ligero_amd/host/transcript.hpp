@@ -25,9 +25,11 @@
 #include <cstdint>
 #include <cstring>
 #include <set>
+#include <type_traits>
 #include <vector>
 
 #include "circuit.hpp"
+#include "poseidon_ifma.hpp"
 
 namespace ligero {
 
@@ -237,6 +239,40 @@ public:
             }
             absorb_internal(idx, elems);
         }
+    }
+    // absorb_elements on EIGHT sponges at once (the proofs of a batch run the same schedule on independent states): with AVX-512
+    // IFMA the eight states ride the eight lanes of a vector (poseidon_ifma.hpp, about five times the scalar rate); without it,
+    // or when the sponges are not in step (mode, position, lengths -- e.g. polynomials trimmed to different degrees), or for
+    // another field or sponge shape, eight ordinary calls.  Same states either way, bit for bit.
+    static bool same_ark(const std::vector<std::array<Fr, 3>>& a, const std::vector<std::array<Fr, 3>>& b) {
+        return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
+    }
+    static void absorb_elements_x8(PoseidonSpongeT* const sp[8], const std::vector<Fr>* const elems[8]) {
+        if constexpr (std::is_same<E, lg_host::Fr>::value) {
+            bool vec = ifma::available() && !elems[0]->empty() && sp[0]->alpha_ == 17 && sp[0]->mds_is_test_;
+            for (size_t j = 1; j < 8 && vec; j++)
+                vec = sp[j]->squeezing_ == sp[0]->squeezing_ && sp[j]->next_index_ == sp[0]->next_index_ && elems[j]->size() == elems[0]->size() &&
+                      sp[j]->alpha_ == 17 && sp[j]->mds_is_test_ && sp[j]->full_rounds_ == sp[0]->full_rounds_ &&
+                      sp[j]->partial_rounds_ == sp[0]->partial_rounds_ && same_ark(sp[j]->ark_, sp[0]->ark_);
+#if LG_HAVE_IFMA_BUILD
+            if (vec) {
+                // one engine per process: every sponge here is a test_sponge() (the comparison above checked the round constants)
+                static const std::vector<std::array<Fr, 3>> engine_ark = sp[0]->ark_;
+                static const ifma::Engine engine(engine_ark, sp[0]->full_rounds_, sp[0]->partial_rounds_);
+                if (same_ark(sp[0]->ark_, engine_ark) && sp[0]->full_rounds_ == 8 && sp[0]->partial_rounds_ == 31) {
+                    Fr* states[8];
+                    const Fr* data[8];
+                    for (size_t j = 0; j < 8; j++) { states[j] = sp[j]->state_.data(); data[j] = elems[j]->data(); }
+                    const bool first = sp[0]->squeezing_ || sp[0]->next_index_ == kRate;
+                    const size_t start = first ? 0 : sp[0]->next_index_;
+                    const size_t next = engine.absorb8(states, data, elems[0]->size(), start, first);
+                    for (size_t j = 0; j < 8; j++) { sp[j]->squeezing_ = false; sp[j]->next_index_ = next; }
+                    return;
+                }
+            }
+#endif
+        }
+        for (size_t j = 0; j < 8; j++) sp[j]->absorb_elements(*elems[j]);
     }
     std::vector<Fr> squeeze_native_field_elements(size_t n) {
         std::vector<Fr> out(n);

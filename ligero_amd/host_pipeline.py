@@ -26,7 +26,7 @@ SYMBOLS = [
     "lgh_new_variable_with_label", "lgh_get_variable", "lgh_circuit_num_gates", "lgh_pow_bigint", "lgh_indicator", "lgh_scalar_product",
     "lgh_mul_nodes", "lgh_evaluate_multioutput", "lgh_build_preenc_with_labels", "lgh_circuit_node",
     "lgh_expr_variable", "lgh_expr_constant", "lgh_expr_add", "lgh_expr_mul", "lgh_expr_sub", "lgh_expr_neg", "lgh_expr_pow",
-    "lgh_expr_destroy", "lgh_expr_to_circuit",
+    "lgh_expr_destroy", "lgh_expr_to_circuit", "lgh_sponge_absorb_elements_x8", "lgh_ifma_available",
 ]
 
 _vp, _u64, _i64, _u32, _int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
@@ -85,6 +85,7 @@ def lib():
         L.lgh_sponge_absorb_bytes.argtypes = [_vp, _vp, _u64]
         L.lgh_sponge_absorb_elements.argtypes = [_vp, _vp, _u64]
         L.lgh_sponge_squeeze_bytes.argtypes = [_vp, _u64, _vp]
+        L.lgh_sponge_absorb_elements_x8.argtypes = [_vp, _vp, _u64]
         L.lgh_sponge_squeeze_elements.argtypes = [_vp, _u64, _vp]
         _lib = L
     return _lib
@@ -420,3 +421,16 @@ class PoseidonSponge:
         out = np.empty((max(n, 1), 4), dtype=np.uint64)
         _check(self._L.lgh_sponge_squeeze_elements(self._h, n, _p(out)), "squeeze_native_field_elements")
         return out[:n]
+
+
+def ifma_available() -> bool:
+    """True where the eight-sponges-per-vector path of the transcript (AVX-512 IFMA) can run"""
+    return bool(lib().lgh_ifma_available())
+
+
+def sponges_absorb_elements_x8(sponges: Sequence["PoseidonSponge"], elems_mont: np.ndarray):
+    """absorb_elements on eight sponges at once: elems_mont (8, count, 4)"""
+    assert len(sponges) == 8
+    e = np.ascontiguousarray(elems_mont, dtype=np.uint64).reshape(8, -1, 4)
+    handles = (_vp * 8)(*[s._h for s in sponges])
+    _check(lib().lgh_sponge_absorb_elements_x8(ctypes.cast(handles, _vp), _p(e) if e.size else None, e.shape[1]), "absorb x8")

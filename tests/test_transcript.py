@@ -80,3 +80,34 @@ def test_transcript_order_of_prove_is_reproducible():
         s.absorb_elements(hp.field_elements_from_seed(seed1, 5))
         outs.append((seed1, s.squeeze_bytes(32)))
     assert outs[0] == outs[1] and outs[0][0] != outs[0][1]
+
+
+def test_eight_sponges_in_lock_step_equal_eight_separate_sponges():
+    """absorb_elements_x8 (AVX-512 IFMA where the host has it: eight sponges on the lanes of one vector, radix-2^52 Montgomery
+    products; eight ordinary calls elsewhere, or when the sponges fall out of step) leaves the same states as the scalar sponge:
+    random lengths, field corners, mode switches in between, sponges deliberately out of step"""
+    rng = random.Random(23)
+    a = [hp.PoseidonSponge() for _ in range(8)]
+    b = [hp.PoseidonSponge() for _ in range(8)]
+    print("IFMA path available:", hp.ifma_available())
+    for step in range(14):
+        count = (1, 2, 3, 0)[step] if step < 4 else rng.randrange(1, 260)
+        vals = [[rng.randrange(tm.P) for _ in range(count)] for _ in range(8)]
+        if step == 5:
+            vals[2][0], vals[3][0], vals[4][0] = 0, tm.P - 1, 1
+        limbs = np.stack([to_mont_limbs(v) if count else np.zeros((0, 4), dtype=np.uint64) for v in vals]) if count else np.zeros((8, 0, 4), dtype=np.uint64)
+        for j in range(8):
+            a[j].absorb_elements(limbs[j])
+        hp.sponges_absorb_elements_x8(b, limbs)
+        if step % 3 == 2:                                       # squeeze: the next absorb starts with a permutation
+            n = rng.choice((1, 32, 63))
+            for j in range(8):
+                assert a[j].squeeze_bytes(n) == b[j].squeeze_bytes(n), (step, j)
+        if step == 7:                                           # sponge 6 falls out of step: the group falls back, still equal
+            a[6].absorb_bytes(b"x")
+            b[6].absorb_bytes(b"x")
+        if step == 9:                                           # back in step after everybody squeezed
+            for j in range(8):
+                assert a[j].squeeze_bytes(32) == b[j].squeeze_bytes(32)
+    for j in range(8):
+        assert a[j].squeeze_bytes(64) == b[j].squeeze_bytes(64), j
