@@ -452,30 +452,41 @@ private:
         return out;
     }
     LigeroProof prove_inner_sharded(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {
+        PhaseTimer tm;
         LigeroProof proof;
         sharded_commit(formatted_assignment, proof.u_root);                                           // mod.rs:521-551
+        tm.mark("sharded: trace + row shard + commit");
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
         {   // prove_interleaved, mod.rs:646-669
             const std::vector<Fr> r = get_field_elements_from_prng<E>(4 * m_, sponge.squeeze_seed());
             proof.interleaved_proof.preenc_u_lc = sharded_poly(LG_SUB_INTERLEAVED, r[0].l);
+            tm.mark("sharded: interleaved points + finish");
             sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
+            tm.mark("sharded: sponge absorbs k elements");
             proof.interleaved_proof.open = sharded_open_columns(sponge);
+            tm.mark("sharded: open_columns");
         }
         {   // prove_linear_constraints, mod.rs:712-747
             const std::array<uint8_t, 32> seed = sponge.squeeze_seed();
             std::vector<Fr> poly = sharded_poly(LG_SUB_LINEAR_FROM_SEED, seed.data());
+            tm.mark("sharded: linear points + finish");
             trim_zeros(poly);
             proof.linear_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
+            tm.mark("sharded: sponge absorbs 2k elements");
             proof.linear_constraints_proof.open = sharded_open_columns(sponge);
+            tm.mark("sharded: open_columns");
         }
         {   // prove_quadratic_constraints, mod.rs:832-859
             const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
             std::vector<Fr> poly = sharded_poly(LG_SUB_QUADRATIC, r[0].l);
+            tm.mark("sharded: quadratic points + finish");
             trim_zeros(poly);
             proof.quadratic_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
+            tm.mark("sharded: sponge absorbs 2k elements");
             proof.quadratic_constraints_proof.open = sharded_open_columns(sponge);
+            tm.mark("sharded: open_columns");
         }
         return proof;
     }
