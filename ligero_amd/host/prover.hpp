@@ -146,6 +146,20 @@ inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
     if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
 }
 
+// CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period")
+inline unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            const unsigned q = (unsigned)((quota + period - 1) / period);
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    }
+    return n;
+}
+
 // LG_PROVER_TIMING=1: per-phase wall time of the provers on stderr
 struct PhaseTimer {
     bool on = getenv("LG_PROVER_TIMING") != nullptr;
@@ -548,8 +562,25 @@ private:
             if (open.columns[c].size() != 4 * m_) return false;
             if (open.paths[c].leaf_index != indices[c]) return false;
             if (open.paths[c].auth_path.size() != (size_t)logn_ - 1) return false;
-            if (!merkle_path_verify(open.paths[c], root, column_hash(open.columns[c]))) return false;
         }
+        // column hashes: independent, and at 2^20 constraints 156 columns of 10 036 elements each (three times per proof) are
+        // most of what is left of verify() on one thread
+        const size_t nc = indices.size();
+        std::vector<Digest> hashes(nc);
+        const size_t workers = (4 * m_ >= 2048 && nc > 1) ? std::min<size_t>({(size_t)usable_cpus(), 16, nc}) : 1;
+        auto hash_some = [&](size_t w) {
+            for (size_t c = w; c < nc; c += workers) hashes[c] = column_hash(open.columns[c]);
+        };
+        if (workers > 1) {
+            std::vector<std::thread> th;
+            for (size_t w = 1; w < workers; w++) th.emplace_back(hash_some, w);
+            hash_some(0);
+            for (auto& t : th) t.join();
+        } else {
+            hash_some(0);
+        }
+        for (size_t c = 0; c < nc; c++)
+            if (!merkle_path_verify(open.paths[c], root, hashes[c])) return false;
         return true;
     }
 
@@ -692,20 +723,6 @@ using HipLigero = HipLigeroT<Fr>;
 // the C ABI (commit, the three row reductions, the three openings), the per-proof transcript work between
 // them (sponge, ChaCha challenges, A.row_mul) runs on host threads.  Same transcript and same proofs as
 // `batch` calls of HipLigero::prove.
-// CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period")
-inline unsigned usable_cpus() {
-    unsigned n = std::max(1u, std::thread::hardware_concurrency());
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        long long quota = 0, period = 0;
-        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
-            const unsigned q = (unsigned)((quota + period - 1) / period);
-            if (q >= 1 && q < n) n = q;
-        }
-        fclose(f);
-    }
-    return n;
-}
-
 // Persistent worker threads for the per-proof host phases (a dozen short phases per batch: spawning 32 threads
 // for each costs more than some of the phases)
 class WorkerPool {
