@@ -258,6 +258,7 @@ public:
     ~HipLigeroT() {
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
         if (cols_pinned_) lg_host_unregister(ctx_, cols_stage_.data());
+        release_exchange();
         lg_ctx_destroy(ctx_);
     }
     HipLigeroT(const HipLigeroT&) = delete;
@@ -424,46 +425,58 @@ private:
         std::vector<uint32_t> count(comm_.world, 0);
         for (uint64_t j : indices) count[owner_of(j)]++;
         const size_t most = *std::max_element(count.begin(), count.end());
-        const size_t col_bytes = rows * sizeof(Fr), rec = col_bytes + 32 + plen * 32;   // one opening: column | leaf sibling | path
-        std::vector<uint8_t> mine(std::max<size_t>(most * rec, 1), 0);
+        // a rank's block: [most columns][most leaf siblings][most paths] -- lg_open_columns writes straight into it, the blocks are
+        // all-gathered as they are.  Both buffers are kept and page-locked (the host all-gather stages through the GPU under RCCL).
+        const size_t col_bytes = rows * sizeof(Fr);
+        const size_t block = std::max<size_t>(most * (col_bytes + 32 + plen * 32), 1) + 1;
+        reserve_exchange(block);
+        uint8_t* mine = xchg_send_.data();
         std::vector<uint32_t> idx;
         for (uint64_t j : indices)
             if (owner_of(j) == comm_.rank) idx.push_back((uint32_t)j);
         together("the opening of a rank's columns", [&] {
             if (idx.empty()) return;
-            std::vector<Fr> cols(idx.size() * rows);
-            std::vector<uint8_t> sib(idx.size() * 32), paths(idx.size() * plen * 32 + 1);
-            check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)idx.size(), cols[0].l, sib.data(), paths.data()), "lg_open_columns");
-            for (size_t c = 0; c < idx.size(); c++) {
-                uint8_t* p = &mine[c * rec];
-                memcpy(p, &cols[c * rows], col_bytes);
-                memcpy(p + col_bytes, &sib[32 * c], 32);
-                memcpy(p + col_bytes + 32, &paths[32 * c * plen], plen * 32);
-            }
+            check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)idx.size(), reinterpret_cast<uint64_t*>(mine), mine + most * col_bytes,
+                                  mine + most * (col_bytes + 32)),
+                  "lg_open_columns");
         });
-        std::vector<uint8_t> all;
-        const uint8_t* blocks = mine.data();
+        const uint8_t* blocks = mine;
         if (exchange_) {
-            all.resize((size_t)comm_.world * mine.size());
-            comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), mine.size()), "all-gather of the opened columns");
-            blocks = all.data();
+            comm_check(comm_.all_gather_host(comm_.user, mine, xchg_recv_.data(), block), "all-gather of the opened columns");
+            blocks = xchg_recv_.data();
         }
         OpenedColumns out;
         std::vector<uint32_t> next(comm_.world, 0);
         for (size_t c = 0; c < t; c++) {
             const uint32_t o = owner_of(indices[c]);
-            const uint8_t* p = blocks + (size_t)o * mine.size() + (size_t)next[o]++ * rec;
+            const uint8_t* base = blocks + (size_t)o * block;
+            const size_t i = next[o]++;
             std::vector<Fr> col(rows);
-            memcpy(static_cast<void*>(col.data()), p, col_bytes);
+            memcpy(static_cast<void*>(col.data()), base + i * col_bytes, col_bytes);
             out.columns.push_back(std::move(col));
             MerklePath mp;
             mp.leaf_index = indices[c];
-            memcpy(mp.leaf_sibling_hash.data(), p + col_bytes, 32);
+            memcpy(mp.leaf_sibling_hash.data(), base + most * col_bytes + 32 * i, 32);
             mp.auth_path.resize(plen);
-            for (size_t l = 0; l < plen; l++) memcpy(mp.auth_path[l].data(), p + col_bytes + 32 + 32 * l, 32);
+            for (size_t l = 0; l < plen; l++) memcpy(mp.auth_path[l].data(), base + most * (col_bytes + 32) + 32 * (i * plen + l), 32);
             out.paths.push_back(std::move(mp));
         }
         return out;
+    }
+    // send / receive buffers of the opened-columns exchange: grown with a quarter of slack (how many columns a rank owns varies from
+    // opening to opening), page-locked while they live
+    void reserve_exchange(size_t block) {
+        if (xchg_send_.size() >= block) return;
+        release_exchange();
+        xchg_send_.assign(block + block / 4, 0);
+        xchg_recv_.assign(exchange_ ? (size_t)comm_.world * xchg_send_.size() : 1, 0);
+        xchg_send_pinned_ = lg_host_register(ctx_, xchg_send_.data(), xchg_send_.size()) == LG_OK;
+        xchg_recv_pinned_ = lg_host_register(ctx_, xchg_recv_.data(), xchg_recv_.size()) == LG_OK;
+    }
+    void release_exchange() {
+        if (xchg_send_pinned_) lg_host_unregister(ctx_, xchg_send_.data());
+        if (xchg_recv_pinned_) lg_host_unregister(ctx_, xchg_recv_.data());
+        xchg_send_pinned_ = xchg_recv_pinned_ = false;
     }
     LigeroProof prove_inner_sharded(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {
         PhaseTimer tm;
@@ -714,6 +727,8 @@ private:
     // sharded provers only
     ShardComm comm_;
     bool sharded_ = false, exchange_ = false;
+    std::vector<uint8_t> xchg_send_, xchg_recv_;   // opened-columns exchange (reserve_exchange)
+    bool xchg_send_pinned_ = false, xchg_recv_pinned_ = false;
     uint32_t nplanes_ = 0, planes_per_rank_ = 0, shard_rows_ = 0, row0_ = 0, row1_ = 0, own_mask_ = 0;
 };
 using HipLigero = HipLigeroT<Fr>;

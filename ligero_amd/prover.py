@@ -184,8 +184,10 @@ class ShardedLigeroProver(LigeroProver):
             if self._dist.get_backend(self._group) == "nccl":          # RCCL moves device memory: stage through the GPU
                 dev = torch.device(f"cuda:{self._device}")
                 gathered = torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev)
-                self._dist.all_gather_into_tensor(gathered, src.to(dev), group=self._group)
-                dst.copy_(gathered.cpu())
+                mine = gathered[self.rank * nbytes:(self.rank + 1) * nbytes]
+                mine.copy_(src)                                       # (the C++ side page-locks its large blocks: plain DMA both ways)
+                self._dist.all_gather_into_tensor(gathered, mine, group=self._group)
+                dst.copy_(gathered)
             else:
                 self._dist.all_gather_into_tensor(dst, src.clone(), group=self._group)
             return 0
