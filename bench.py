@@ -490,6 +490,15 @@ def main():
                     help="multi-GPU poseidon run: shape of the extra coset-sharded single-proof leg (RCCL all-gathers)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (librccl prints a five-line version banner on file
+    # descriptor 1 when a communicator is created; gloo logs its connections): everything but the result line goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: dict):
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -548,7 +557,7 @@ def main():
             if rank == 0:
                 line["sharded_prove"] = sp_res
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit(line)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -663,7 +672,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
             line["vs_cpu_baseline"] = {"ratio": line["value"] / line["cpu_baseline"]["value"],
                                        "of": "cpu_baseline.value (1-core port of the reference-shaped path); a reported ratio, not the target"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
