@@ -567,6 +567,29 @@ def main():
     pre = synthetic_preenc(seed, batch * rows * k).reshape(batch * rows, k, 4)
     elapsed, stage, launches, root = resident_run(ligero_amd, torch, dist, backend, args.workload, pre, local_rank, args.steps, args.warmup, world)
 
+    # The extra multi-GPU legs below run collectives of their own.  Should one of them hang (a rank that died inside a leg leaves the
+    # others waiting in an all-gather), the headline measured above must still come out: after LIGERO_BENCH_LEG_TIMEOUT seconds
+    # (default 300) rank 0 prints the line without the extra legs and every rank leaves.
+    watchdog = None
+    if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
+        import threading
+
+        def bail():
+            if rank == 0:
+                commits_ = args.steps * batch * world
+                emit({"metric": "RS-encoded field-elems/sec (Ligero encode+commit, Poseidon R1CS shape)" if args.workload == "poseidon"
+                                else "RS-encoded field-elems/sec (Ligero encode+commit)",
+                      "value": commits_ * rows * n / elapsed, "unit": "field-elems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "u32 limbs (BN254 Fr, 254-bit Montgomery) + u32 ARX hashes", "data": "synthetic",
+                      "config": {"workload": f"{args.workload}: {batch} x ({rows} x {k} -> {n}) per GPU per step", "rows": rows, "k": k, "n": n,
+                                 "batch_per_gpu": batch, "parallelism": f"independent proofs x{world}"},
+                      "stage_ms": {s_: stage[s_] for s_ in ("interpolate", "evaluate", "colhash", "merkle")}, "root0": root[:32].hex(),
+                      "sharded_commit": {"error": "the extra sharded legs did not finish in time; headline only"}})
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("LIGERO_BENCH_LEG_TIMEOUT", "300")), bail)
+        watchdog.daemon = True
+        watchdog.start()
     sharded = None
     if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
         # the same ranks, one large proof over all of them: the driver's scaling run thereby measures the RCCL path too
@@ -581,6 +604,8 @@ def main():
             sharded_prove = sharded_prove_leg(torch, dist, world, rank, local_rank, 20 if args.sharded_leg in ("s22", "s20") else 18, 2, force_dist)
         except Exception as e:
             sharded_prove = {"error": f"{type(e).__name__}: {e}"}
+    if watchdog is not None:
+        watchdog.cancel()
 
     if rank == 0:
         commits = args.steps * batch * world
