@@ -550,10 +550,21 @@ def main():
                 "sharded_commit": res,
             }
         if not args.no_cpu_baseline:
+            import threading
+
+            def bail():       # the proof leg hangs: the commit line measured above still comes out
+                if rank == 0:
+                    line["sharded_prove"] = {"error": "did not finish in time"}
+                    emit(line)
+                os._exit(0)
+            watchdog = threading.Timer(float(os.environ.get("LIGERO_BENCH_LEG_TIMEOUT", "600")), bail)
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 sp_res = sharded_prove_leg(torch, dist, world, rank, local_rank, {"s22": 22, "s20": 20, "s18": 18}[args.workload], 2, force_dist)
             except Exception as e:
                 sp_res = {"error": f"{type(e).__name__}: {e}"}
+            watchdog.cancel()
             if rank == 0:
                 line["sharded_prove"] = sp_res
         if rank == 0:
