@@ -308,3 +308,43 @@ def test_expression_circuit_through_ligero_front_half(hp, fr):
     assert ok and ok2 and np.array_equal(by_index, by_label)
     _, bad = inst.build_preenc_u_with_labels(["x", "y"], fr.monts([9, 4]))
     assert not bad
+
+
+def test_multiplication_r1cs(hp, fr):
+    """src/arithmetic_circuit/tests.rs:174-187: multiplication.r1cs compiled by from_constraint_system; (a, b, c) = (6, 3, 2) on
+    wires 1..3 makes the last node (the single output) evaluate to 1"""
+    import os
+    from conftest import GOLDEN
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "multiplication.r1cs"))
+    assert _evaluate(c, fr, [(1, 6), (2, 3), (3, 2)]) == 1
+    assert _evaluate(c, fr, [(1, 6), (2, 3), (3, 3)]) != 1
+
+
+def test_cube_multioutput(hp, fr):
+    """src/arithmetic_circuit/tests.rs:189-241: cube.r1cs -> 15 nodes, both outputs 1 at (x, x^3) = (3, 9) ... wires (1, 2) = (3, 9);
+    three ways of building x^3 - 26 give the SAME circuit (3 gates) and evaluate to 1 at x = 3"""
+    import os
+    from conftest import GOLDEN
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "cube.r1cs"))
+    assert c.num_nodes() == 15
+    got = c.evaluate_multioutput([1, 2], fr.monts([3, 9]), c.outputs)
+    assert [fr.int(g) for g in got] == [1, 1]
+
+    def clever(build):
+        k = hp.ArithmeticCircuit()
+        x = k.new_variable()
+        cubed = build(k, x)
+        k.add(cubed, k.constant(fr.mont(-26)))
+        return k
+    circuits = [clever(lambda k, x: k.pow(x, 3)), clever(lambda k, x: k.mul(k.mul(x, x), x)), clever(lambda k, x: k.mul_nodes([x, x, x]))]
+    for k in circuits:
+        assert _evaluate(k, fr, [(0, 3)]) == 1
+        assert k.num_gates() == 3
+
+    def nodes(k):
+        out = []
+        for i in range(k.num_nodes()):
+            nd = k.node(i)
+            out.append((nd[0], fr.int(nd[1])) if nd[0] == "Constant" else nd)
+        return out
+    assert nodes(circuits[0]) == nodes(circuits[1]) == nodes(circuits[2])            # assert_eq!(clever_circuit, another_clever_circuit) ...
