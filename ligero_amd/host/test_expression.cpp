@@ -149,6 +149,15 @@ int main() {
             const bool off = FQ::eq(c.evaluate_with_labels({{"x", fq(2)}, {"y", fq(4)}}), FQ::one());
             report("test_to_arithmetic_circuit_4", on && !off);
         }
+        {   // src/arithmetic_circuit/tests.rs:17-33, 296-306 test_bls12_377_circuit: the builder-made y^2 = x^3 + 1 circuit over Fq
+            ArithmeticCircuitT<FqE> c;
+            const size_t one = c.constant(FQ::one());
+            const size_t x = c.new_variable(), y = c.new_variable();
+            const size_t y2 = c.pow(y, 2), my2 = c.minus(y2), x3 = c.pow(x, 3);
+            c.add_nodes({x3, one, my2, one});
+            report("test_bls12_377_circuit", x == 1 && y == 2 && FQ::eq(c.evaluate({{1, fq(2)}, {2, fq(3)}}), FQ::one()) &&
+                                                 !FQ::eq(c.evaluate({{1, fq(2)}, {2, fq(5)}}), FQ::one()));
+        }
         {
             const auto c = generate_lemniscate_expression().to_arithmetic_circuit();
             report("test_to_arithmetic_circuit_5", FF::eq(c.evaluate_with_labels({{"x", fr(8)}, {"y", fr(4)}}), FF::one()));
