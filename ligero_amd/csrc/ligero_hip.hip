@@ -43,7 +43,7 @@ struct lg_ctx {
     hipEvent_t ev_done = nullptr;          // "tree of this commit is complete"
     hipEvent_t ev_hashed = nullptr, ev_tree = nullptr;   // single-chunk commits: leaves complete / tree complete (on stream_h)
     bool async_tree = true;                // LG_ASYNC_TREE=0 turns the overlap below off (A/B knob)
-    bool tree_pending = false;             // the tree of the last commit is still being built on stream_h
+    bool tree_pending = false;             // the tree of the last commit is still being built on stream_h / stream_t
     // single-chunk commits: the column hash of commit i runs on stream_h BESIDE the interpolation / evaluation of commit
     // i + 1 (one wave per SIMD of a latency chain fills issue slots instead of holding the machine): U is double buffered
     bool async_hash = true;                // LG_ASYNC_HASH=0: hash on the encode stream, one U buffer (A/B knob)
@@ -87,7 +87,14 @@ struct lg_ctx {
     // what the resident commitment covers (a staged commit may hold only some planes / message rows)
     uint32_t have_planes = 0;                  // mask of the planes of d_u that belong to the current commitment
     uint32_t have_row0 = 0, have_row1 = 0;     // message rows [have_row0, have_row1) of d_preenc that belong to it
-    uint8_t* d_leaves = nullptr;  // [batch][n][32]
+    uint8_t* d_leaves = nullptr;  // [batch][n][32]    (of the current commitment: one of d_leaves_pp)
+    // Single-chunk commits with the hash overlap on: leaves and nodes are double-buffered like U, and the tree has a stream of its
+    // own, so that the tree of commit i runs beside the column hash of commit i + 1 (a stream of small commitments is bound by
+    // the longest of its three chains -- encode, hash, tree -- instead of hash + tree)
+    uint8_t* d_leaves_pp[2] = {nullptr, nullptr};
+    uint8_t* d_nodes_pp[2] = {nullptr, nullptr};
+    hipStream_t stream_t = nullptr;
+    hipEvent_t ev_leaves_free[2] = {nullptr, nullptr};   // "the tree that read leaves[p] / wrote nodes[p] is done" (on stream_t)
     uint8_t* d_digest_xchg = nullptr;   // [world][ki][planes per rank][32] staging of the sharded commit's digest all-gather
     uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
     // domain tables: 29-bit limbs, value * 2^261 mod p, three planes each (limbs 0-3 | 4-7 | 8)
@@ -476,13 +483,14 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->stream_h) hipStreamSynchronize(c->stream_h);
     if (c->stream_up) hipStreamSynchronize(c->stream_up);
     if (c->stream_dn) hipStreamSynchronize(c->stream_dn);
+    if (c->stream_t) hipStreamSynchronize(c->stream_t);
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
     void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_a_seg, c->d_a_seg_partial, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
-    void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves, c->d_nodes, c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
+    void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves_pp[0], c->d_nodes_pp[0], c->d_leaves_pp[1], c->d_nodes_pp[1], c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
                     c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -501,6 +509,9 @@ void lg_ctx_destroy(lg_ctx* c) {
         if (e) hipEventDestroy(e);
     if (c->ev_hashed) hipEventDestroy(c->ev_hashed);
     if (c->ev_tree) hipEventDestroy(c->ev_tree);
+    for (auto& e : c->ev_leaves_free)
+        if (e) hipEventDestroy(e);
+    if (c->stream_t) hipStreamDestroy(c->stream_t);
     if (c->stream_up) hipStreamDestroy(c->stream_up);
     if (c->stream_dn) hipStreamDestroy(c->stream_dn);
     if (c->stream_h) hipStreamDestroy(c->stream_h);
@@ -553,6 +564,8 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_dn, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking));
+        for (auto& e : c->ev_leaves_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->ev_chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->ev_up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->ev_coef) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
@@ -576,6 +589,8 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
         }
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
+        c->d_leaves_pp[0] = c->d_leaves;
+        c->d_nodes_pp[0] = c->d_nodes;
         // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
         using namespace lg_host;
         const Fr wn = domain_generator(logn);
@@ -832,6 +847,15 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         if (!c->d_u_pp[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_pp[par]), (size_t)c->nplanes * plane * sizeof(fr)));
         c->d_u = c->d_u_pp[par];
         LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_hash_free[par], 0));   // (never recorded = no-op)
+        // ... and hashes into the other leaf buffer / builds the other tree (readers use c->d_leaves / c->d_nodes: this commitment's)
+        if (!c->d_leaves_pp[par]) {
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves_pp[par]), (size_t)c->batch * c->n * 32));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes_pp[par]), (size_t)c->batch * (c->n - 1) * 32));
+        }
+        // what an earlier commitment left queued against the buffers about to become "current" is covered below: the hash waits
+        // for the tree that last read leaves[par]; read-backs of the previous commitment were issued on the encode stream
+        c->d_leaves = c->d_leaves_pp[par];
+        c->d_nodes = c->d_nodes_pp[par];
     }
     if (prof) LG_HIP(c, hipEventRecord(ev[0], c->stream));
     if (streamed) {
@@ -887,9 +911,13 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
             LG_HIP(c, hipStreamWaitEvent(hs, c->ev_chunk[i], 0));
         }
         if (async_hash) {
-            // the hash follows the previous commit's tree on stream_h by stream order; it only waits for this encoding
+            // the hash waits for this encoding, and for the tree (two commits ago, on the tree stream) that read the leaf buffer it is
+            // about to rewrite; the previous commit's tree reads the OTHER buffer and runs beside this hash
             LG_HIP(c, hipEventRecord(c->ev_hashed, c->stream));
             LG_HIP(c, hipStreamWaitEvent(hs, c->ev_hashed, 0));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_leaves_free[c->u_parity], 0));   // (never recorded = no-op)
+            // (a tree that an earlier, differently scheduled commit left reading either buffer ran on stream_h -- stream order -- or on
+            // the encode stream, before the event just waited for)
         } else if (i == 0) {   // the previous commit's tree may still be reading the leaves this hash is about to rewrite
             const int rc = settle_tree(c);
             if (rc != LG_OK) return rc;
@@ -939,8 +967,12 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
     if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
     if (async_hash) LG_HIP(c, hipEventRecord(c->ev_hash_free[c->u_parity], hs));
     const bool async_tree = c->async_tree && nchunks == 1;
-    hipStream_t ms = async_tree ? c->stream_h : hs;
-    if (async_tree && !async_hash) {
+    // with the hash overlap on, the tree goes to its own stream (it follows this hash by event; the next commit's hash, on
+    // stream_h, does not queue behind it)
+    hipStream_t ms = async_hash ? c->stream_t : (async_tree ? c->stream_h : hs);
+    if (async_hash) {
+        LG_HIP(c, hipStreamWaitEvent(ms, c->ev_hash_free[c->u_parity], 0));   // recorded just above: this commit's hash is done
+    } else if (async_tree) {
         LG_HIP(c, hipEventRecord(c->ev_hashed, c->stream));
         LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_hashed, 0));
     }
@@ -967,8 +999,9 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         LG_HIP(c, hipEventRecord(ev[5], ms));
         c->prof_commits++;
     }
+    if (async_hash) LG_HIP(c, hipEventRecord(c->ev_leaves_free[c->u_parity], ms));
     if (async_tree) {
-        LG_HIP(c, hipEventRecord(c->ev_tree, c->stream_h));
+        LG_HIP(c, hipEventRecord(c->ev_tree, ms));
         c->tree_pending = true;
     }
     // everything issued later on the encode stream (read-backs, the next commit) sees the tree
