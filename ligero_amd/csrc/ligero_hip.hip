@@ -47,9 +47,15 @@ struct lg_ctx {
     // single-chunk commits: the column hash of commit i runs on stream_h BESIDE the interpolation / evaluation of commit
     // i + 1 (one wave per SIMD of a latency chain fills issue slots instead of holding the machine): U is double buffered
     bool async_hash = true;                // LG_ASYNC_HASH=0: hash on the encode stream, one U buffer (A/B knob)
-    fr* d_u_pp[2] = {nullptr, nullptr};    // [0] = d_u_alloc, [1] allocated by the first overlapped commit
-    int u_parity = 0;
-    hipEvent_t ev_hash_free[2] = {nullptr, nullptr};   // "the hash that read U[p] is done" (on stream_h)
+    // Overlapped single-chunk commits rotate through a ring of U / leaf / node buffers: two deep, or three deep with a second hash
+    // stream when U is small (a lone small proof is a chain of dependent Blake2s compressions: two of those chains in flight)
+    static constexpr int kRing = 3;
+    fr* d_u_pp[kRing] = {nullptr, nullptr, nullptr};    // [0] = d_u_alloc, the others allocated by the first overlapped commits
+    int u_parity = 0;                                   // ring slot of the current commitment
+    int ring_depth = 2;
+    uint64_t async_seq = 0;                             // overlapped commits issued: picks the hash stream
+    hipStream_t stream_h2 = nullptr;                    // second hash stream (ring_depth == 3)
+    hipEvent_t ev_hash_free[kRing] = {nullptr, nullptr, nullptr};   // "the hash that read U[p] is done" (on its hash stream)
     uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
     gf_state* gf = nullptr;                // set for contexts over a generic field (lg_ctx_create_field): every supported
                                            // entry point forwards to generic_path.hip, the others return LG_ERR_UNSUPPORTED
@@ -91,10 +97,10 @@ struct lg_ctx {
     // Single-chunk commits with the hash overlap on: leaves and nodes are double-buffered like U, and the tree has a stream of its
     // own, so that the tree of commit i runs beside the column hash of commit i + 1 (a stream of small commitments is bound by
     // the longest of its three chains -- encode, hash, tree -- instead of hash + tree)
-    uint8_t* d_leaves_pp[2] = {nullptr, nullptr};
-    uint8_t* d_nodes_pp[2] = {nullptr, nullptr};
+    uint8_t* d_leaves_pp[3] = {nullptr, nullptr, nullptr};
+    uint8_t* d_nodes_pp[3] = {nullptr, nullptr, nullptr};
     hipStream_t stream_t = nullptr;
-    hipEvent_t ev_leaves_free[2] = {nullptr, nullptr};   // "the tree that read leaves[p] / wrote nodes[p] is done" (on stream_t)
+    hipEvent_t ev_leaves_free[3] = {nullptr, nullptr, nullptr};   // "the tree that read leaves[p] / wrote nodes[p] is done" (on stream_t)
     uint8_t* d_digest_xchg = nullptr;   // [world][ki][planes per rank][32] staging of the sharded commit's digest all-gather
     uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
     // domain tables: 29-bit limbs, value * 2^261 mod p, three planes each (limbs 0-3 | 4-7 | 8)
@@ -484,13 +490,14 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->stream_up) hipStreamSynchronize(c->stream_up);
     if (c->stream_dn) hipStreamSynchronize(c->stream_dn);
     if (c->stream_t) hipStreamSynchronize(c->stream_t);
+    if (c->stream_h2) hipStreamSynchronize(c->stream_h2);
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
     void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_a_seg, c->d_a_seg_partial, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
-    void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves_pp[0], c->d_nodes_pp[0], c->d_leaves_pp[1], c->d_nodes_pp[1], c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
+    void* bufs[] = {c->sharded ? c->d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->d_leaves_pp[0], c->d_nodes_pp[0], c->d_leaves_pp[1], c->d_nodes_pp[1], c->d_leaves_pp[2], c->d_nodes_pp[2], c->d_tw_fwd, c->d_tw_inv, c->d_coset_tw, c->d_fold_inv, c->d_first2,
                     c->d_scratch_a, c->d_scratch_b, c->d_scratch_c, c->d_idx, c->d_path_out, c->d_hstate};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -505,6 +512,7 @@ void lg_ctx_destroy(lg_ctx* c) {
         if (e) hipEventDestroy(e);
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->d_u_pp[1]) hipFree(c->d_u_pp[1]);
+    if (c->d_u_pp[2]) hipFree(c->d_u_pp[2]);
     for (auto& e : c->ev_hash_free)
         if (e) hipEventDestroy(e);
     if (c->ev_hashed) hipEventDestroy(c->ev_hashed);
@@ -512,6 +520,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     for (auto& e : c->ev_leaves_free)
         if (e) hipEventDestroy(e);
     if (c->stream_t) hipStreamDestroy(c->stream_t);
+    if (c->stream_h2) hipStreamDestroy(c->stream_h2);
     if (c->stream_up) hipStreamDestroy(c->stream_up);
     if (c->stream_dn) hipStreamDestroy(c->stream_dn);
     if (c->stream_h) hipStreamDestroy(c->stream_h);
@@ -565,6 +574,7 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_dn, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->stream_t, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->stream_h2, hipStreamNonBlocking));
         for (auto& e : c->ev_leaves_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->ev_chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->ev_up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
@@ -586,6 +596,9 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_alloc), (size_t)c->own_planes * plane * sizeof(fr)));
             c->d_u = c->d_u_alloc - (size_t)c->own_plane0 * plane;   // never dereferenced outside the owned planes
             c->d_u_pp[0] = c->d_u_alloc;
+            // a third ring slot costs one more U: only where U is small, i.e. where a commit is latency-bound (LG_RING_DEPTH overrides)
+            c->ring_depth = ((size_t)c->nplanes * plane * sizeof(fr) <= (size_t{64} << 20)) ? 3 : 2;
+            if (const char* rd = getenv("LG_RING_DEPTH")) { const int v = atoi(rd); if (v == 2 || v == 3) c->ring_depth = v; }
         }
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
@@ -840,10 +853,12 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
     // one chunk: the hash of THIS commit has nothing of its own to hide behind; it is put beside the NEXT commit's encoding
     // (async_hash) -- or, with that off, everything stays on the encode stream (no cross-stream waits)
     const bool async_hash = c->async_hash && c->async_tree && nchunks == 1;
-    hipStream_t hs = (nchunks > 1 || async_hash) ? c->stream_h : c->stream;
+    // (three deep: consecutive overlapped commits alternate between the two hash streams, so two column-hash chains run at once)
+    hipStream_t hs = (nchunks > 1 || async_hash) ? ((async_hash && c->ring_depth == 3 && ((c->async_seq + 1) & 1)) ? c->stream_h2 : c->stream_h) : c->stream;
     if (async_hash) {
         // this commit encodes into the other U buffer; the hash that last read it (two commits ago) must be done
-        const int par = (c->u_parity ^= 1);
+        const int par = c->u_parity = (c->u_parity + 1) % c->ring_depth;
+        c->async_seq++;
         if (!c->d_u_pp[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_pp[par]), (size_t)c->nplanes * plane * sizeof(fr)));
         c->d_u = c->d_u_pp[par];
         LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_hash_free[par], 0));   // (never recorded = no-op)
@@ -1449,7 +1464,8 @@ int lg_verifier_linear_sums_from_seed(lg_ctx* c, const uint8_t* seed, const uint
     LG_HIP(c, hipSetDevice(c->device));
     // nothing of an earlier commit may still be reading or writing U, the leaves or the tree
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
-    if (c->stream_h) LG_HIP(c, hipStreamSynchronize(c->stream_h));
+    for (hipStream_t st : {c->stream_h, c->stream_h2, c->stream_t})
+        if (st) LG_HIP(c, hipStreamSynchronize(st));
     LG_HIP(c, hipStreamSynchronize(c->stream));
     c->committed = false; c->staging = false; c->have_planes = 0;
     uint32_t per, nch;

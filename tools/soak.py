@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Determinism soak of the commit pipeline: thousands of back-to-back resident commits alternating between two inputs, the roots
 read back only now and then (so the asynchronous hash / tree overlap runs unthrottled in between) and compared with the roots of
-the same inputs committed alone.   python tools/soak.py [seconds] [workload: poseidon|s20]"""
+the same inputs committed alone.   python tools/soak.py [seconds] [workload: poseidon|single|s20]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ import ligero_amd
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 wl = sys.argv[2] if len(sys.argv) > 2 else "poseidon"
-rows, k, batch = (344, 128, 64) if wl == "poseidon" else (10036, 4096, 1)
+rows, k, batch = {"poseidon": (344, 128, 64), "single": (344, 128, 1), "s20": (10036, 4096, 1)}[wl]   # "single": the three-deep ring
 rng = np.random.default_rng(99)
 
 
