@@ -23,17 +23,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, rows, k, out):
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _rank_body(rank, world, dist, rows, k):
+    from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
+    pre = random_mont(515, rows * k).reshape(rows, k, 4)               # same seed on every rank
+    be = HipStageBackend(rows, k, device=0, world=world, rank=rank)     # only this rank's planes of U are allocated
     try:
-        from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
-        pre = random_mont(515, rows * k).reshape(rows, k, 4)               # same seed on every rank
-        be = HipStageBackend(rows, k, device=0, world=world, rank=rank)     # only this rank's planes of U are allocated
         sc = CosetShardedCommitter(be, dist)
         r0, r1 = sc.row_range()
         root = sc.commit(pre[r0:r1])
@@ -45,8 +39,20 @@ def _worker(rank, world, port, rows, k, out):
             refused = False
         except Exception as e:                                              # LigeroHipError(status = LG_ERR_STATE)
             refused = getattr(e, "status", None) == -6
-        out[rank] = (root, {j: (c.tobytes(), s.tobytes(), p.tobytes()) for j, (c, s, p) in opened.items()}, refused, dict(sc.stage_ms))
+        return (root, {j: (c.tobytes(), s.tobytes(), p.tobytes()) for j, (c, s, p) in opened.items()}, refused, dict(sc.stage_ms))
+    finally:
         be.close()
+
+
+def _worker(rank, world, port, rows, k, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out[rank] = _rank_body(rank, world, dist, rows, k)
     finally:
         dist.destroy_process_group()
 
@@ -92,12 +98,18 @@ def test_world2_with_the_chunked_stage_pipeline(oracle, monkeypatch, rows, k, ch
 
 @pytest.mark.parametrize("world,rows,k", [(4, 21, 128), (8, 12, 128), (8, 7, 8192)])
 def test_world4_and_world8_on_one_gpu(oracle, world, rows, k):
-    """the world sizes of the driver's scaling run with the real device backend (all ranks share this box's GPU, gloo collectives):
-    one or two planes per rank at k = 128, two of sixteen at the folded k = 8192; ragged and empty row shards"""
-    import torch.multiprocessing as mp
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), rows, k, out), nprocs=world, join=True)
+    """the world sizes of the driver's scaling run with the real device backend (all ranks share this box's GPU): one or two
+    planes per rank at k = 128, two of sixteen at the folded k = 8192; ragged and empty row shards.  World 4 is four gloo
+    processes; world 8 is eight contexts on eight threads of this process (tests/thread_dist.py) -- the GPU box admits at most
+    six processes on its card"""
+    if world <= 4:
+        import torch.multiprocessing as mp
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), rows, k, out), nprocs=world, join=True)
+    else:
+        from thread_dist import run_ranks
+        out = dict(enumerate(run_ranks(world, lambda rank, dist: _rank_body(rank, world, dist, rows, k))))
     pre = random_mont(515, rows * k).reshape(rows, k, 4)
     ref = oracle.encode_commit(pre, k, 8 * k)
     ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], [0, 5, 8 * k - 1])

@@ -164,6 +164,27 @@ def test_world4_and_world8_gloo(oracle, world, rows, k):
     assert sorted(seen) == list(range(8 * k)) and covered == rows
 
 
+def test_thread_ranks_equal_the_gloo_group(oracle):
+    """tests/thread_dist.py (eight ranks as threads of one process -- what the GPU tests use at world 8, where the GPU box's
+    limit of six processes per card rules out a process per rank) gives the commitment the gloo process group gives"""
+    from thread_dist import run_ranks
+    from ligero_amd.sharded import CosetShardedCommitter
+    world, rows, k = 8, 12, 4
+    pre = random_mont(99, rows * k).reshape(rows, k, 4)
+
+    def body(rank, tdist):
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), tdist)
+        r0, r1 = sc.row_range()
+        return sc.commit(pre[r0:r1]), sorted(sc.open_columns(list(range(8 * k))))
+
+    res = run_ranks(world, body)
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    assert all(root == ref["root"] for root, _ in res)
+    assert sorted(j for _, opened in res for j in opened) == list(range(8 * k))
+    with pytest.raises(ZeroDivisionError):                                  # a failing rank surfaces; nobody hangs in a collective
+        run_ranks(2, lambda rank, d: 1 // rank if rank == 0 else d.all_gather_into_tensor(torch.zeros(2), torch.zeros(1)), timeout=20)
+
+
 def test_single_process_degenerate(oracle):
     from ligero_amd.sharded import CosetShardedCommitter, owned_planes, padded_shard_range, padded_shard_rows, shard_range
     rows, k = 5, 8
