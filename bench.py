@@ -699,6 +699,20 @@ def main():
                 del pre20
             except Exception as e:
                 line["s20"] = {"error": f"{type(e).__name__}: {e}"}
+            # BASELINE configs[3]'s shape on ONE GPU (k = 8192 folded transforms, 16 planes, U = 42 GB resident): 3 commits, golden root
+            try:
+                r22, k22, _ = WORKLOADS["s22"]
+                pre22 = synthetic_preenc(LARGE_SEED, r22 * k22).reshape(-1, k22, 4)
+                e22, st22, l22, root22 = resident_run(ligero_amd, torch, None, backend, "s22", pre22, local_rank, 3, 1, 1)
+                del pre22
+                d22, srl22 = roofline_of("s22", st22, l22, tfile)
+                gold = golden_large("s22")
+                line["s22"] = {"workload": f"s22: 1 x ({r22} x {k22} -> {8 * k22})", "steps": 3, "ms_per_step": e22 / 3 * 1e3,
+                               "value": 3 * r22 * 8 * k22 / e22, "unit": "field-elems/s", "roofline": d22, "stage_rooflines": srl22,
+                               "valu_roofline": valu_roofline_of("s22", st22), "root": root22[:32].hex(),
+                               "root_matches_golden": (root22[:32].hex() == gold["root"]) if gold else None}
+            except Exception as e:
+                line["s22"] = {"error": f"{type(e).__name__}: {e}"}
             line["full_prover"] = full_prover_rate(local_rank)
             try:
                 line["s20"]["full_prover_from_r1cs"] = s20_prover_rate(local_rank)
