@@ -117,11 +117,14 @@ int run(const char* name, int cus, uint32_t* buf, long long* dcyc, int ops_per_i
         CK(hipEventElapsedTime(&ms, e0, e1));
         std::vector<long long> c(grid);
         CK(hipMemcpy(c.data(), dcyc, grid * 8, hipMemcpyDeviceToHost));
-        double avg = 0;
-        for (auto v : c) avg += v;
+        double avg = 0, mx = 0;
+        for (auto v : c) { avg += v; if (v > mx) mx = (double)v; }
         avg /= grid;
         const double waveops = (double)iters * ops_per_iter * W;  // per SIMD
-        printf(" | W=%d %6.2f cyc/op (%5.2f ns/op, %.2f GHz)", W, avg / waveops, ms * 1e6 / waveops, avg / (ms * 1e6));
+        // "GHz" = MEAN wave lifetime / kernel time: the SIMD issues oldest-wave-first, so with W waves per SIMD the waves finish one
+        // after the other and the mean lifetime is ~(W + 1) / 2W of the kernel -- NOT a clock.  "clk" = LONGEST lifetime / kernel
+        // time is the clock the chip held (correction)
+        printf(" | W=%d %6.2f cyc/op (%5.2f ns/op, %.2f GHz, clk %.2f)", W, avg / waveops, ms * 1e6 / waveops, avg / (ms * 1e6), mx / (ms * 1e6));
     }
     printf("\n");
     return 0;
