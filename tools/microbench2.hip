@@ -10,7 +10,7 @@
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
 
-enum Op { MAD_IND, MAD_DEP, MAD_CARRYOUT, MULLO, MULHI, ADD, ADDCO_CHAIN, ADD64, CNDMASK, MOV, MAD_SGPR, ADD3, MAD_ADDC_PAIR };
+enum Op { MAD_IND, MAD_DEP, MAD_CARRYOUT, MULLO, MULHI, ADD, ADDCO_CHAIN, ADD64, CNDMASK, MOV, MAD_SGPR, ADD3, MAD_ADDC_PAIR, MAD_ADD_GROUPED };
 
 template <int OP>
 __global__ void kern(uint32_t* out, uint32_t a0, int iters, long long* cyc) {
@@ -63,6 +63,10 @@ __global__ void kern(uint32_t* out, uint32_t a0, int iters, long long* cyc) {
             REP8(asm volatile("v_mad_u64_u32 %0, %8, %9, %10, %0\n v_add_u32 %4, %4, %9\n v_mad_u64_u32 %1, %8, %9, %10, %1\n v_add_u32 %5, %5, %9\n"
                               "v_mad_u64_u32 %2, %8, %9, %10, %2\n v_add_u32 %6, %6, %9\n v_mad_u64_u32 %3, %8, %9, %10, %3\n v_add_u32 %7, %7, %9\n"
                               : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=s"(cy) : "v"(a), "v"(b));)
+        } else if constexpr (OP == MAD_ADD_GROUPED) {  // the same 1 : 1 mix, four of a class in a row instead of alternating
+            REP8(asm volatile("v_mad_u64_u32 %0, %8, %9, %10, %0\n v_mad_u64_u32 %1, %8, %9, %10, %1\n v_mad_u64_u32 %2, %8, %9, %10, %2\n v_mad_u64_u32 %3, %8, %9, %10, %3\n"
+                              "v_add_u32 %4, %4, %9\n v_add_u32 %5, %5, %9\n v_add_u32 %6, %6, %9\n v_add_u32 %7, %7, %9\n"
+                              : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=s"(cy) : "v"(a), "v"(b));)
         }
     }
     long long t1 = clock64();
@@ -114,6 +118,7 @@ int main() {
     run<MAD_SGPR>("mad_u64 sgpr", cus, buf, dcyc, 64);
     run<MAD_CARRYOUT>("mad+addc(vcc)", cus, buf, dcyc, 64);
     run<MAD_ADDC_PAIR>("mad+add indep", cus, buf, dcyc, 64);
+    run<MAD_ADD_GROUPED>("mad x4, add x4", cus, buf, dcyc, 64);
     run<MULLO>("mul_lo_u32", cus, buf, dcyc, 64);
     run<MULHI>("mul_hi_u32", cus, buf, dcyc, 64);
     run<ADD>("add_u32", cus, buf, dcyc, 64);
