@@ -18,6 +18,7 @@ def sweep(budget: float, seed: int) -> int:
     """random cases until `budget` seconds have passed; returns how many ran (every one asserted bit-exact)"""
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
+    t_mark = time.time()
     n_cases = 0
     P_LIMBS = np.array([0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)
     while time.time() < t_end:
@@ -107,6 +108,9 @@ def sweep(budget: float, seed: int) -> int:
                     for be in bes:
                         be.close()
         n_cases += 1
+        if time.time() - t_mark > 30.0:       # a long run must keep writing: the GPU box takes 7 silent minutes for a hang
+            t_mark = time.time()
+            print(f"  ... {n_cases} cases, {t_end - t_mark:.0f} s left", flush=True)
     for var in ("LG_FORCE_CHUNKS", "LG_HASH_QUAD_MAX_COLUMNS", "LG_ASYNC_HASH"):
         os.environ.pop(var, None)
     return n_cases

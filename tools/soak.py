@@ -28,6 +28,7 @@ for x in inputs:
 assert want[0] != want[1]
 n = checks = 0
 t_end = time.time() + budget
+t_mark = time.time()
 with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c, ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as d:
     ctxs = [c, d]
     ctxs[0].upload(inputs[0])
@@ -42,6 +43,9 @@ with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c, ligero_amd.Li
         for w in (0, 1):
             assert ctxs[w].root() == want[w], ("root changed", n, w)
         checks += 2
+        if time.time() - t_mark > 30.0:            # keep writing: the GPU box takes 7 silent minutes for a hang
+            t_mark = time.time()
+            print(f"  ... {n} commits, {checks} checks", flush=True)
         if rng.integers(8) == 0:                   # swap the resident inputs: uploads race with nothing they should not
             inputs.reverse(); want.reverse()
             ctxs[0].upload(inputs[0]); ctxs[1].upload(inputs[1])
