@@ -225,6 +225,15 @@ int lg_verifier_linear_sums_from_seed(lg_ctx* ctx, const uint8_t* seed, const ui
  */
 int lg_stage_interpolate(lg_ctx* ctx, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows);
 int lg_stage_evaluate_hash(lg_ctx* ctx, uint32_t plane_mask);
+/*
+ * Step 3 in two halves, for a caller whose all-gather of the coefficient rows is cut into pieces that arrive while earlier
+ * pieces are being evaluated (the exchange then hides behind the evaluation): lg_stage_evaluate_rows evaluates the planes of
+ * plane_mask for rows [row0, row0 + nrows) of LG_BUF_COEFFS -- any rows, in any order, every row exactly once -- and
+ * lg_stage_hash then hashes the columns of those planes over ALL rows (mod.rs:536-542; a column's Blake2s absorbs the rows in
+ * order, so it cannot start before the last piece).  Together they equal lg_stage_evaluate_hash(plane_mask).
+ */
+int lg_stage_evaluate_rows(lg_ctx* ctx, uint32_t plane_mask, uint32_t row0, uint32_t nrows);
+int lg_stage_hash(lg_ctx* ctx, uint32_t plane_mask);
 int lg_stage_merkle(lg_ctx* ctx);
 typedef enum lg_buffer { LG_BUF_PREENC = 0, LG_BUF_COEFFS = 1, LG_BUF_LEAVES = 2, LG_BUF_NODES = 3 } lg_buffer;
 /* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers). */

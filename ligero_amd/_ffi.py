@@ -22,7 +22,7 @@ SYMBOLS = [
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
     "lg_interleaved_row_mul", "lg_linear_constraint_poly", "lg_quadratic_constraint_poly",
     "lg_upload_constraint_matrix", "lg_linear_constraint_poly_from_seeds", "lg_verifier_linear_sums_from_seed",
-    "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_merkle", "lg_device_buffer",
+    "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_evaluate_rows", "lg_stage_hash", "lg_stage_merkle", "lg_device_buffer",
     "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
@@ -113,6 +113,8 @@ def lib():
     L.lg_quadratic_constraint_poly.argtypes = [_vp, _vp, _vp]
     L.lg_stage_interpolate.argtypes = [_vp, _vp, _u32, _u32]
     L.lg_stage_evaluate_hash.argtypes = [_vp, _u32]
+    L.lg_stage_evaluate_rows.argtypes = [_vp, _u32, _u32, _u32]
+    L.lg_stage_hash.argtypes = [_vp, _u32]
     L.lg_stage_merkle.argtypes = [_vp]
     L.lg_device_buffer.argtypes = [_vp, _int, _vp, _vp]
     L.lg_ctx_dims.argtypes = [_vp, _vp, _vp, _vp, _vp]

@@ -1813,6 +1813,68 @@ int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
     return LG_OK;
 }
 
+// Split form of lg_stage_evaluate_hash for a caller that receives the coefficient rows piece by piece (an all-gather cut into pieces
+// that arrive while earlier pieces are being evaluated): evaluate ANY rows that are there, in any order, then hash once all are done.
+static int stage_plane_args(lg_ctx* c, uint32_t plane_mask) {
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (c->batch != 1) return LG_ERR_STATE;
+    if (c->nplanes < 32 && (plane_mask >> c->nplanes) != 0) return LG_ERR_BAD_ARG;
+    if (plane_mask & ~own_planes_mask(c)) {
+        snprintf(c->err, sizeof(c->err), "plane mask 0x%x reaches outside the planes [%u, %u) this sharded context holds", plane_mask, c->own_plane0,
+                 c->own_plane0 + c->own_planes);
+        return LG_ERR_BAD_ARG;
+    }
+    return LG_OK;
+}
+
+int lg_stage_evaluate_rows(lg_ctx* c, uint32_t plane_mask, uint32_t row0, uint32_t nrows) {
+    if (!c) return LG_ERR_BAD_ARG;
+    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
+    if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
+    if (c->committed) { c->committed = false; c->have_planes = 0; }   // re-evaluating over a finished commitment voids it
+    if (nrows == 0 || plane_mask == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint64_t plane = c->total_rows * c->ki;
+    lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, true);
+    a.ncos = 0;
+    for (uint32_t s = 0; s < c->nplanes; s++)
+        if (plane_mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
+    a.chunk_rows = nrows;
+    LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+    return LG_OK;
+}
+
+int lg_stage_hash(lg_ctx* c, uint32_t plane_mask) {
+    if (!c) return LG_ERR_BAD_ARG;
+    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
+    if (c->committed) { c->committed = false; c->have_planes = 0; }
+    if (plane_mask == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }   // the previous tree may still read the leaves
+    const uint64_t plane = c->total_rows * c->ki;
+    for (uint32_t s = 0; s < c->nplanes;) {   // one launch per run of consecutive planes, all rows in one go (no state to carry)
+        if (!(plane_mask & (1u << s))) { s++; continue; }
+        uint32_t e2 = s;
+        while (e2 + 1 < c->nplanes && (plane_mask & (1u << (e2 + 1)))) e2++;
+        lg::ColHashArgs h;
+        memset(&h, 0, sizeof(h));
+        h.u = reinterpret_cast<const uint4*>(c->d_u);
+        h.leaves = c->d_leaves;
+        h.state = c->d_hstate;
+        h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
+        h.proof_begin = 0; h.proof_count = 1;
+        h.row_begin = 0; h.row_end = c->rows;
+        h.first = true; h.last = true;
+        h.plane_begin = s; h.plane_count = e2 - s + 1;
+        h.plane_stride = plane;
+        const uint64_t threads = (uint64_t)h.plane_count * c->ki;
+        LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, h);
+        s = e2 + 1;
+    }
+    c->have_planes |= plane_mask;
+    return LG_OK;
+}
+
 int lg_stage_merkle(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only

@@ -101,6 +101,21 @@ class HipStageBackend:
             mask |= 1 << s
         _ffi.check(self._L.lg_stage_evaluate_hash(self.c._ctx, mask), "lg_stage_evaluate_hash", self.c._ctx)
 
+    @staticmethod
+    def _mask(planes: Sequence[int]) -> int:
+        mask = 0
+        for s in planes:
+            mask |= 1 << s
+        return mask
+
+    def stage_evaluate_rows(self, planes: Sequence[int], row0: int, nrows: int):
+        """the planes' evaluation of rows [row0, row0 + nrows) only (any rows, any order; lg_stage_evaluate_rows)"""
+        _ffi.check(self._L.lg_stage_evaluate_rows(self.c._ctx, self._mask(planes), row0, nrows), "lg_stage_evaluate_rows", self.c._ctx)
+
+    def stage_hash(self, planes: Sequence[int]):
+        """the planes' column hashes over all rows, once every row is evaluated (lg_stage_hash)"""
+        _ffi.check(self._L.lg_stage_hash(self.c._ctx, self._mask(planes)), "lg_stage_hash", self.c._ctx)
+
     def stage_merkle(self):
         _ffi.check(self._L.lg_stage_merkle(self.c._ctx), "lg_stage_merkle", self.c._ctx)
 
@@ -142,12 +157,17 @@ class CosetShardedCommitter:
     """One proof over `world` ranks.  `backend` does the device work; `dist` is torch.distributed
     (already initialised) or None for a single process."""
 
-    def __init__(self, backend, dist=None, group=None, collectives_at_world_1: bool = False):
+    def __init__(self, backend, dist=None, group=None, collectives_at_world_1: bool = False, exchange_pieces: int = 1):
         """collectives_at_world_1: issue the two all-gathers even in a one-rank group (they are identities then) -- lets a
-        one-GPU box run the exact RCCL calls of the multi-GPU path (bench.py LIGERO_BENCH_FORCE_DIST, tests)."""
+        one-GPU box run the exact RCCL calls of the multi-GPU path (bench.py LIGERO_BENCH_FORCE_DIST, tests).
+        exchange_pieces > 1: the coefficient all-gather is cut into that many pieces (piece c = the c-th slice of EVERY rank's
+        shard, so every piece uses all links), issued asynchronously, and the evaluation of piece c runs while piece c + 1
+        is on the wire; the column hash, which needs the rows in order, follows the last piece (commit_pipelined)."""
         self.be = backend
         self.dist = dist
         self.group = group
+        self.pieces = max(1, int(exchange_pieces))
+        self._piece_buf = [None, None]
         self.force = bool(collectives_at_world_1) and dist is not None
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
@@ -162,6 +182,8 @@ class CosetShardedCommitter:
     def commit(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
         """preenc_rows_local: this rank's rows [row_range()) of preenc_u (None: they are resident from an earlier
         commit).  Returns u_root."""
+        if self.pieces > 1 and (self.world > 1 or self.force):
+            return self.commit_pipelined(preenc_rows_local)
         be, dist = self.be, self.dist
         ms = self.stage_ms = {}
         r0, r1 = self.row_range()
@@ -201,6 +223,88 @@ class CosetShardedCommitter:
         be.sync()
         lap("merkle")
         return be.root()
+
+    def piece_plan(self) -> List[Tuple[int, int]]:
+        """[(first row inside a shard, rows)] of the exchange pieces: equal slices of the padded shard, the last one short"""
+        per = -(-self.shard_rows // min(self.pieces, max(1, self.shard_rows)))
+        return [(o, min(per, self.shard_rows - o)) for o in range(0, self.shard_rows, per)]
+
+    def commit_pipelined(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
+        """commit() with the coefficient all-gather hidden behind the evaluation.  Piece c of the exchange is rows
+        [o_c, o_c + n_c) of every rank's shard: one all_gather_into_tensor into a staging buffer (two, alternating) and one
+        strided copy into LG_BUF_COEFFS; its rows are then evaluated (lg_stage_evaluate_rows, one call per source shard, padding
+        rows of the last shard skipped) while the next piece is in flight.  stage_ms: `allgather_coeffs` is the time this
+        rank spent WAITING for pieces, `evaluate_hash` the rest of the loop plus the hash."""
+        import torch
+        be, dist = self.be, self.dist
+        ms = self.stage_ms = {}
+        r0, r1 = self.row_range()
+        t = time.perf_counter()
+        be.stage_interpolate(preenc_rows_local, r0, r1 - r0)
+        be.sync()
+        ms["interpolate"] = (time.perf_counter() - t) * 1e3
+        coeffs = be.coeffs_bytes()                                   # [world * shard_rows, k * 32]
+        width = coeffs.shape[1]
+        shards = coeffs.view(self.world, self.shard_rows, width)
+        plan = self.piece_plan()
+        cap = plan[0][1]
+        for i in (0, 1):
+            if self._piece_buf[i] is None or self._piece_buf[i].device != coeffs.device or self._piece_buf[i].shape != (self.world, cap, width):
+                self._piece_buf[i] = torch.empty((self.world, cap, width), dtype=coeffs.dtype, device=coeffs.device)
+
+        def start(c):
+            o, n = plan[c]
+            out = self._piece_buf[c & 1][:, :n, :] if n == cap else self._piece_buf[c & 1].view(-1)[:self.world * n * width].view(self.world, n, width)
+            mine = shards[self.rank, o:o + n, :]
+            return out, dist.all_gather_into_tensor(out.reshape(-1), mine.reshape(-1), group=self.group, async_op=True)
+
+        wait_s = 0.0
+        t_loop = time.perf_counter()
+        pending = start(0)
+        for c, (o, n) in enumerate(plan):
+            out, work = pending
+            tw = time.perf_counter()
+            work.wait()                                              # torch's current stream now follows the collective ...
+            self._stream_sync(coeffs)                                # ... and the host follows that stream (NOT the library's streams,
+            wait_s += time.perf_counter() - tw                       #     where the previous piece may still be being evaluated)
+            # every other rank's slice goes to its place (this rank's own rows are already there)
+            for g in range(self.world):
+                if g != self.rank:
+                    shards[g, o:o + n, :].copy_(out[g])
+            self._stream_sync(coeffs)                                # the library's stream may read them from here on
+            if c + 1 < len(plan):
+                pending = start(c + 1)                               # on the wire while the rows below are evaluated
+            for g in range(self.world):
+                a = g * self.shard_rows + o
+                b = min(a + n, be.rows)                              # the last shard is short: its padding rows are never evaluated
+                if b > a:
+                    be.stage_evaluate_rows(self.planes, a, b - a)
+        be.stage_hash(self.planes)
+        be.sync()
+        ms["allgather_coeffs"] = wait_s * 1e3
+        ms["evaluate_hash"] = (time.perf_counter() - t_loop - wait_s) * 1e3
+        t = time.perf_counter()
+        if self.world > 1 or self.force:
+            np_, per = be.nplanes, len(self.planes)
+            leaves = be.leaves_bytes().view(be.n // np_, self.world, per, 32)
+            mine = leaves[:, self.rank].contiguous()
+            if self._digest_buf is None or self._digest_buf.device != mine.device:
+                self._digest_buf = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(self._digest_buf.view(-1), mine.view(-1), group=self.group)
+            leaves.copy_(self._digest_buf.permute(1, 0, 2, 3))
+            self._device_sync(leaves)
+        ms["allgather_digests"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        be.stage_merkle()
+        be.sync()
+        ms["merkle"] = (time.perf_counter() - t) * 1e3
+        return be.root()
+
+    @staticmethod
+    def _stream_sync(t):
+        if t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
 
     @staticmethod
     def _device_sync(t):

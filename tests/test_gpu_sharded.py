@@ -23,14 +23,16 @@ def _free_port():
     return p
 
 
-def _rank_body(rank, world, dist, rows, k):
+def _rank_body(rank, world, dist, rows, k, pieces=1):
     from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
     pre = random_mont(515, rows * k).reshape(rows, k, 4)               # same seed on every rank
     be = HipStageBackend(rows, k, device=0, world=world, rank=rank)     # only this rank's planes of U are allocated
     try:
-        sc = CosetShardedCommitter(be, dist)
+        sc = CosetShardedCommitter(be, dist, exchange_pieces=pieces)
         r0, r1 = sc.row_range()
         root = sc.commit(pre[r0:r1])
+        if pieces > 1:
+            assert sc.commit(None) == root                                     # resident rows, staging buffers reused
         opened = sc.open_columns([0, 5, 8 * k - 1])
         # a column of a plane the OTHER rank owns must be refused by the C ABI itself, not served from foreign memory
         foreign = ((rank + 1) % world) * (be.nplanes // world)                # first plane of the next rank
@@ -44,7 +46,7 @@ def _rank_body(rank, world, dist, rows, k):
         be.close()
 
 
-def _worker(rank, world, port, rows, k, out):
+def _worker(rank, world, port, rows, k, out, pieces=1):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -52,7 +54,7 @@ def _worker(rank, world, port, rows, k, out):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out[rank] = _rank_body(rank, world, dist, rows, k)
+        out[rank] = _rank_body(rank, world, dist, rows, k, pieces)
     finally:
         dist.destroy_process_group()
 
@@ -121,6 +123,70 @@ def test_world4_and_world8_on_one_gpu(oracle, world, rows, k):
         assert refused
         got.update(opened)
     assert got == want
+
+
+@pytest.mark.parametrize("world,rows,k,pieces", [(2, 21, 128, 3), (2, 6, 4096, 2), (2, 5, 8192, 2), (4, 10, 128, 4), (8, 23, 128, 2), (8, 9, 8192, 3)])
+def test_pipelined_exchange_on_the_real_backend(oracle, world, rows, k, pieces):
+    """CosetShardedCommitter(exchange_pieces > 1): the coefficient all-gather in pieces (asynchronous, slice c of every rank's
+    shard), lg_stage_evaluate_rows on the rows of a piece while the next one is on the wire, lg_stage_hash after the last --
+    root and owner-served openings equal the oracle's; ragged / short / empty shards, folded k = 8192, a second commit from
+    resident rows.  Worlds 2 and 4: gloo processes; world 8: threads of this process (tests/thread_dist.py)"""
+    if world <= 4:
+        import torch.multiprocessing as mp
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), rows, k, out, pieces), nprocs=world, join=True)
+    else:
+        from thread_dist import run_ranks
+        out = dict(enumerate(run_ranks(world, lambda rank, dist: _rank_body(rank, world, dist, rows, k, pieces))))
+    pre = random_mont(515, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k)
+    ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], [0, 5, 8 * k - 1])
+    want = {j: (ecols[i].tobytes(), esib[i].tobytes(), epaths[i].tobytes()) for i, j in enumerate([0, 5, 8 * k - 1])}
+    got = {}
+    for rank in range(world):
+        root, opened, refused, stage_ms = out[rank]
+        assert root == ref["root"], rank
+        assert refused
+        assert set(stage_ms) == {"interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle"}
+        got.update(opened)
+    assert got == want
+
+
+def _rccl_pipelined_worker(rows, k, pieces, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
+        pre = random_mont(617, rows * k).reshape(rows, k, 4)
+        be = HipStageBackend(rows, k, device=0, world=1, rank=0)
+        sc = CosetShardedCommitter(be, dist, collectives_at_world_1=True, exchange_pieces=pieces)
+        out["root"] = sc.commit(pre)
+        out["again"] = sc.commit(None)
+        out["plan"] = sc.piece_plan()
+        be.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_exchange_over_rccl_at_world_1(oracle):
+    """the asynchronous RCCL all-gathers of the pipelined commit (async_op=True on staging buffers, strided copy into the
+    library's coefficient buffer, evaluation from the library's own stream meanwhile) at world size 1 on this box's GPU"""
+    import torch.multiprocessing as mp
+    rows, k, pieces = 37, 1024, 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    p = mp.get_context("spawn").Process(target=_rccl_pipelined_worker, args=(rows, k, pieces, out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    pre = random_mont(617, rows * k).reshape(rows, k, 4)
+    want = oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
+    assert out["root"] == want and out["again"] == want and len(out["plan"]) == 4
 
 
 def test_partial_commitments_refuse_foreign_data(oracle):

@@ -32,6 +32,7 @@ class OracleStageBackend:
         self.leaves = np.zeros((self.n, 32), dtype=np.uint8)
         self.nodes = None
         self.u = {}
+        self._fresh = True
 
     def stage_interpolate(self, preenc_rows, row0, nrows):
         self.preenc[row0:row0 + nrows] = np.asarray(preenc_rows).reshape(nrows, self.k, 4)
@@ -45,6 +46,25 @@ class OracleStageBackend:
                 j = 8 * q + s
                 self.leaves[j] = np.frombuffer(self.orc.col_hash(u[:, j]), dtype=np.uint8)
         self.u = u
+
+    def stage_evaluate_rows(self, planes, row0, nrows):
+        """split form (lg_stage_evaluate_rows): any rows, any order, each exactly once"""
+        if not isinstance(self.u, np.ndarray) or self._fresh:
+            self.u = np.zeros((self.rows, self.n, 4), dtype=np.uint64)
+            self._seen = np.zeros(self.rows, dtype=bool)
+            self._fresh = False
+        assert not self._seen[row0:row0 + nrows].any(), "a row evaluated twice"
+        for r in range(row0, row0 + nrows):
+            self.u[r] = self.orc.reed_solomon_evaluate(self.coeffs[r], self.n)
+        self._seen[row0:row0 + nrows] = True
+
+    def stage_hash(self, planes):
+        assert self._seen.all(), "lg_stage_hash before every row was evaluated"
+        for s in planes:
+            for q in range(self.k):
+                j = 8 * q + s
+                self.leaves[j] = np.frombuffer(self.orc.col_hash(self.u[:, j]), dtype=np.uint8)
+        self._fresh = True
 
     def stage_merkle(self):
         self.nodes = self.orc.merkle_tree(self.leaves)
@@ -183,6 +203,54 @@ def test_thread_ranks_equal_the_gloo_group(oracle):
     assert sorted(j for _, opened in res for j in opened) == list(range(8 * k))
     with pytest.raises(ZeroDivisionError):                                  # a failing rank surfaces; nobody hangs in a collective
         run_ranks(2, lambda rank, d: 1 // rank if rank == 0 else d.all_gather_into_tensor(torch.zeros(2), torch.zeros(1)), timeout=20)
+
+
+def _worker_pieces(rank, world, port, rows, k, pieces, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ligero_amd.sharded import CosetShardedCommitter
+        pre = random_mont(31, rows * k).reshape(rows, k, 4)
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), dist, exchange_pieces=pieces)
+        r0, r1 = sc.row_range()
+        root = sc.commit(pre[r0:r1])
+        again = sc.commit(pre[r0:r1])                                       # the staging buffers are reused
+        out[rank] = (root, again, sc.piece_plan(), sorted(sc.stage_ms))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rows,k,pieces", [(2, 12, 4, 2), (2, 13, 4, 3), (4, 9, 2, 2), (2, 3, 4, 8)])
+def test_pipelined_exchange_matches_single_process(oracle, world, rows, k, pieces):
+    """exchange_pieces > 1: the coefficient all-gather in pieces (slice c of every shard), issued asynchronously, rows evaluated
+    as they arrive, hash after the last piece -- even, ragged and short last shards, more pieces than shard rows"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_pieces, args=(world, _free_port(), rows, k, pieces, out), nprocs=world, join=True)
+    pre = random_mont(31, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    shard = -(-rows // world)
+    for rank in range(world):
+        root, again, plan, stages = out[rank]
+        assert root == ref["root"] and again == ref["root"], rank
+        assert sum(n for _, n in plan) == shard and [o for o, _ in plan] == sorted(o for o, _ in plan) and len(plan) <= pieces
+        assert stages == ["allgather_coeffs", "allgather_digests", "evaluate_hash", "interpolate", "merkle"]
+
+
+def test_pipelined_exchange_on_eight_thread_ranks(oracle):
+    from thread_dist import run_ranks
+    from ligero_amd.sharded import CosetShardedCommitter
+    world, rows, k = 8, 21, 4
+    pre = random_mont(32, rows * k).reshape(rows, k, 4)
+
+    def body(rank, tdist):
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), tdist, exchange_pieces=2)
+        r0, r1 = sc.row_range()
+        return sc.commit(pre[r0:r1])
+
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    assert all(root == ref["root"] for root in run_ranks(world, body))
 
 
 def test_single_process_degenerate(oracle):

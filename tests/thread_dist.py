@@ -30,7 +30,17 @@ class ThreadRankDist:
     def get_backend(self, group=None):
         return "gloo"                      # host tensors stay on the host, device tensors on the device
 
-    def all_gather_into_tensor(self, out, inp, group=None):
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        self._all_gather(out, inp)
+        if async_op:
+            class _Done:                   # the exchange above is synchronous: nothing left to wait for
+                @staticmethod
+                def wait():
+                    return True
+            return _Done()
+        return None
+
+    def _all_gather(self, out, inp):
         s = self._s
         n = inp.numel()
         assert out.numel() == s.world * n
