@@ -208,6 +208,12 @@ class CosetShardedCommitter:
         be.stage_evaluate_hash(self.planes)
         be.sync()
         lap("evaluate_hash")
+        return self._digests_and_tree(ms)
+
+    def _digests_and_tree(self, ms: Dict[str, float]) -> bytes:
+        """steps 4 and 5: all-gather of the leaf digests, replicated tree"""
+        be = self.be
+        t = time.perf_counter()
         if self.world > 1 or self.force:
             import torch
             np_, per = be.nplanes, len(self.planes)
@@ -215,13 +221,14 @@ class CosetShardedCommitter:
             mine = leaves[:, self.rank].contiguous()
             if self._digest_buf is None or self._digest_buf.device != mine.device:
                 self._digest_buf = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(self._digest_buf.view(-1), mine.view(-1), group=self.group)   # flat: gloo insists on 1-D shapes
+            self.dist.all_gather_into_tensor(self._digest_buf.view(-1), mine.view(-1), group=self.group)   # flat: gloo insists on 1-D shapes
             leaves.copy_(self._digest_buf.permute(1, 0, 2, 3))                  # one strided copy back into leaf order
             self._device_sync(leaves)
-        lap("allgather_digests")
+        ms["allgather_digests"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
         be.stage_merkle()
         be.sync()
-        lap("merkle")
+        ms["merkle"] = (time.perf_counter() - t) * 1e3
         return be.root()
 
     def piece_plan(self) -> List[Tuple[int, int]]:
@@ -283,22 +290,7 @@ class CosetShardedCommitter:
         be.sync()
         ms["allgather_coeffs"] = wait_s * 1e3
         ms["evaluate_hash"] = (time.perf_counter() - t_loop - wait_s) * 1e3
-        t = time.perf_counter()
-        if self.world > 1 or self.force:
-            np_, per = be.nplanes, len(self.planes)
-            leaves = be.leaves_bytes().view(be.n // np_, self.world, per, 32)
-            mine = leaves[:, self.rank].contiguous()
-            if self._digest_buf is None or self._digest_buf.device != mine.device:
-                self._digest_buf = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(self._digest_buf.view(-1), mine.view(-1), group=self.group)
-            leaves.copy_(self._digest_buf.permute(1, 0, 2, 3))
-            self._device_sync(leaves)
-        ms["allgather_digests"] = (time.perf_counter() - t) * 1e3
-        t = time.perf_counter()
-        be.stage_merkle()
-        be.sync()
-        ms["merkle"] = (time.perf_counter() - t) * 1e3
-        return be.root()
+        return self._digests_and_tree(ms)
 
     @staticmethod
     def _stream_sync(t):
