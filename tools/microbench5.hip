@@ -45,11 +45,12 @@
 #define I_SWZ(n) "ds_swizzle_b32 %" #n ", %" #n " offset:0x101f\n"          /* bitmask mode: xor 4 */
 #define I_BPERM(n) "ds_bpermute_b32 %" #n ", %8, %" #n "\n"
 #define I_PLANE16(n) "v_permlane16_swap_b32 %" #n ", %" #n "\n"
+#define I_XORSDWA(n) "v_xor_b32_sdwa %" #n ", %" #n ", %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
 #define I_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
 #define I_MAD_SCONST(n) "v_mad_u64_u32 %" #n ", vcc, %8, 0x0f05360, %" #n "\n"
 
 enum Op { LSHR64, LSHL64, CND_VCC, CND_SGPR, BFI, ALIGNBIT, ANDOR, LSHLOR, LSHLADD, AND, XOR, LSHR32, SUB, ADDLIT, MOVDPP_QP, MOVDPP_ROR, ADDDPP, XORDPP, PERM, BITOP3,
-          MADU24, MULU24, MULHIU24, FMA64, MUL64F, ADD64F, FMA32, PKFMA32, MADI64, SWZ, BPERM, ADD3, MAD_LIT };
+          MADU24, MULU24, MULHIU24, FMA64, MUL64F, ADD64F, FMA32, PKFMA32, MADI64, SWZ, BPERM, ADD3, MAD_LIT, XORSDWA };
 
 template <int OP>
 __global__ void kern(uint32_t* out, uint32_t a0, int iters, long long* cyc) {
@@ -92,6 +93,7 @@ __global__ void kern(uint32_t* out, uint32_t a0, int iters, long long* cyc) {
         else if constexpr (OP == SWZ) { OP8_32(I_SWZ) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         else if constexpr (OP == BPERM) { OP8_32(I_BPERM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         else if constexpr (OP == ADD3) { OP8_32(I_ADD3) }
+        else if constexpr (OP == XORSDWA) { OP8_32(I_XORSDWA) }
 
     }
     long long t1 = clock64();
@@ -142,7 +144,7 @@ int main() {
 #define RUN(OP, NAME) run<OP>(NAME, cus, buf, dcyc, 64);
     RUN(LSHR64, "v_lshrrev_b64") RUN(LSHL64, "v_lshlrev_b64") RUN(CND_VCC, "v_cndmask vcc") RUN(CND_SGPR, "v_cndmask_e64 sgpr")
     RUN(BFI, "v_bfi_b32") RUN(ALIGNBIT, "v_alignbit_b32") RUN(ANDOR, "v_and_or_b32") RUN(LSHLOR, "v_lshl_or_b32") RUN(LSHLADD, "v_lshl_add_u32")
-    RUN(ADD3, "v_add3_u32") RUN(AND, "v_and_b32") RUN(XOR, "v_xor_b32") RUN(LSHR32, "v_lshrrev_b32") RUN(SUB, "v_sub_u32") RUN(ADDLIT, "v_add_u32 literal")
+    RUN(XORSDWA, "v_xor_b32_sdwa word") RUN(ADD3, "v_add3_u32") RUN(AND, "v_and_b32") RUN(XOR, "v_xor_b32") RUN(LSHR32, "v_lshrrev_b32") RUN(SUB, "v_sub_u32") RUN(ADDLIT, "v_add_u32 literal")
     RUN(MOVDPP_QP, "v_mov_dpp quad_perm") RUN(MOVDPP_ROR, "v_mov_dpp row_ror:8") RUN(ADDDPP, "v_add_u32_dpp qp") RUN(XORDPP, "v_xor_b32_dpp qp")
     RUN(PERM, "v_perm_b32") RUN(BITOP3, "v_bitop3_b32") RUN(MADU24, "v_mad_u32_u24") RUN(MULU24, "v_mul_u32_u24") RUN(MULHIU24, "v_mul_hi_u32_u24")
     RUN(MADI64, "v_mad_i64_i32")
