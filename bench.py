@@ -583,7 +583,7 @@ def main():
                 if rank == 0:
                     line["sharded_prove"] = {"error": "did not finish in time"}
                     emit(line)
-                os._exit(0)
+                os._exit(3)      # every rank leaves with a failure status: the launcher must not take a hung collective for success
             watchdog = threading.Timer(float(os.environ.get("LIGERO_BENCH_LEG_TIMEOUT", "600")), bail)
             watchdog.daemon = True
             watchdog.start()
@@ -626,7 +626,7 @@ def main():
                       "stage_ms": {s_: stage[s_] for s_ in ("interpolate", "evaluate", "colhash", "merkle")}, "root0": root[:32].hex(),
                       "sharded_commit": partial.get("sharded_commit", {"error": "the extra sharded legs did not finish in time; headline only"}),
                       "sharded_legs_note": "a sharded leg did not finish in time: what had completed is reported"})
-            os._exit(0)
+            os._exit(3)          # non-zero on every rank (the partial line above is still usable)
         watchdog = threading.Timer(float(os.environ.get("LIGERO_BENCH_LEG_TIMEOUT", "300")), bail)
         watchdog.daemon = True
         watchdog.start()

@@ -52,7 +52,7 @@ const char* lg_status_string(int status);
 const char* lg_last_error(const lg_ctx* ctx);
 /* ABI version of this header: bumped on any incompatible change. */
 uint32_t lg_abi_version(void);
-#define LG_ABI_VERSION 2u
+#define LG_ABI_VERSION 3u
 
 /*
  * Context for `batch` independent commitments of identical shape (batch = 1 for
@@ -234,10 +234,39 @@ int lg_stage_evaluate_hash(lg_ctx* ctx, uint32_t plane_mask);
  */
 int lg_stage_evaluate_rows(lg_ctx* ctx, uint32_t plane_mask, uint32_t row0, uint32_t nrows);
 int lg_stage_hash(lg_ctx* ctx, uint32_t plane_mask);
+/*
+ * ROW-RELAY commit of one proof over several GPUs (the literal reading of "rows shard naturally"):
+ * rank g keeps its rows END TO END -- an ordinary batch-1 context of its own row count, every coset plane of those rows --
+ * and what travels is not data but the 72-byte Blake2s state of every column (mod.rs:536-542 hashes a column's rows in
+ * order, so the ranks take turns on it):
+ *   1. lg_stage_interpolate(rows, 0, local rows); lg_stage_evaluate_rows(all planes, 0, local rows)
+ *   2. (caller) receive LG_BUF_HSTATE from the rank that holds the rows before these     [not for global row 0]
+ *   3. lg_stage_hash_rows     the rows [row0, row0 + nrows) of this context are rows [col_pos, col_pos + nrows) of columns
+ *                             that are col_rows rows long (the length prefix of serialize_compressed): col_pos = 0 starts
+ *                             the columns, otherwise their states are resumed from LG_BUF_HSTATE; col_pos + nrows =
+ *                             col_rows finalises them into LG_BUF_LEAVES, otherwise the states return to LG_BUF_HSTATE.
+ *                             Any row position, odd ones included.  Queued on the library's hash stream behind everything
+ *                             issued so far: the hash of one row range runs beside the evaluation of the next.
+ *   4. (caller) send LG_BUF_HSTATE on / the rank with the last rows broadcasts LG_BUF_LEAVES (n * 32 bytes)
+ *   5. lg_stage_merkle        on every rank; lg_open_columns then returns this rank's ROWS of the opened columns (the
+ *                             caller concatenates the ranks' pieces in row order) and complete authentication paths
+ * A rank may hold several row ranges (e.g. its share of each of the X, Y, Z, W blocks): one call per range, in column order.
+ * lg_stage_hash(mask) = lg_stage_hash_rows(mask, 0, rows, 0, rows).
+ */
+int lg_stage_hash_rows(lg_ctx* ctx, uint32_t plane_mask, uint32_t row0, uint32_t nrows, uint64_t col_pos, uint64_t col_rows);
 int lg_stage_merkle(lg_ctx* ctx);
-typedef enum lg_buffer { LG_BUF_PREENC = 0, LG_BUF_COEFFS = 1, LG_BUF_LEAVES = 2, LG_BUF_NODES = 3 } lg_buffer;
-/* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers). */
+/* LG_BUF_HSTATE: [coset plane][slot q][LG_HSTATE_BYTES] -- chaining value (32 B), then the bytes of the block in progress
+ * (8 after an even number of rows, 40 after an odd one), padded; plane-major, so the states of a run of planes are contiguous */
+typedef enum lg_buffer { LG_BUF_PREENC = 0, LG_BUF_COEFFS = 1, LG_BUF_LEAVES = 2, LG_BUF_NODES = 3, LG_BUF_HSTATE = 4 } lg_buffer;
+#define LG_HSTATE_BYTES 80u
+/* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers).  Asking for LG_BUF_PREENC of an
+ * unsharded context hands the whole matrix to the caller: every row counts as present afterwards (fill it, then
+ * lg_commit_resident).  LG_BUF_LEAVES / LG_BUF_NODES name the buffers of the CURRENT commitment: overlapped single-chunk
+ * commits rotate through a ring of them, so the pointers are valid until the next commit on this context. */
 int lg_device_buffer(lg_ctx* ctx, int which, void** dptr_out, size_t* bytes_out);
+/* The HIP stream (hipStream_t) every call of this context is ordered on.  Work the caller enqueues on it -- a collective on
+ * the buffers above -- is ordered with the library's own: no host synchronisation is needed around an exchange. */
+int lg_ctx_stream(lg_ctx* ctx, void** stream_out);
 /*
  * Step 4 without a layout pass on the host side, for ranks that own equal contiguous runs of planes (rank r: planes
  * [r np/world, (r+1) np/world)): lg_stage_digests_pack copies this rank's leaf digests into block `rank` of a library-owned

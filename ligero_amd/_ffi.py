@@ -22,7 +22,7 @@ SYMBOLS = [
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
     "lg_interleaved_row_mul", "lg_linear_constraint_poly", "lg_quadratic_constraint_poly",
     "lg_upload_constraint_matrix", "lg_linear_constraint_poly_from_seeds", "lg_verifier_linear_sums_from_seed",
-    "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_evaluate_rows", "lg_stage_hash", "lg_stage_merkle", "lg_device_buffer",
+    "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_evaluate_rows", "lg_stage_hash", "lg_stage_hash_rows", "lg_stage_merkle", "lg_device_buffer", "lg_ctx_stream",
     "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
@@ -36,7 +36,8 @@ LG_ERR_OOM = -5
 LG_ERR_STATE = -6
 LG_ERR_UNSUPPORTED = -7
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
-LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES = 0, 1, 2, 3
+LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES, LG_BUF_HSTATE = 0, 1, 2, 3, 4
+LG_HSTATE_BYTES = 80
 LG_SUB_INTERLEAVED, LG_SUB_LINEAR, LG_SUB_LINEAR_FROM_SEED, LG_SUB_QUADRATIC = 0, 1, 2, 3
 LG_FIELD_BN254_FR, LG_FIELD_BLS12_377_FQ, LG_FIELD_BN254_FR_GENERIC = 0, 1, 2
 
@@ -115,6 +116,8 @@ def lib():
     L.lg_stage_evaluate_hash.argtypes = [_vp, _u32]
     L.lg_stage_evaluate_rows.argtypes = [_vp, _u32, _u32, _u32]
     L.lg_stage_hash.argtypes = [_vp, _u32]
+    L.lg_stage_hash_rows.argtypes = [_vp, _u32, _u32, _u32, ctypes.c_uint64, ctypes.c_uint64]
+    L.lg_ctx_stream.argtypes = [_vp, _vp]
     L.lg_stage_merkle.argtypes = [_vp]
     L.lg_device_buffer.argtypes = [_vp, _int, _vp, _vp]
     L.lg_ctx_dims.argtypes = [_vp, _vp, _vp, _vp, _vp]

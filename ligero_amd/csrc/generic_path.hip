@@ -211,7 +211,13 @@ void gf_destroy(gf_state* g) {
 uint32_t gf_element_words64(const gf_state* g) { return (uint32_t)g->hf.n; }
 bool gf_committed(const gf_state* g) { return g->committed; }
 
-int gf_create(gf_state** out, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch, hipStream_t stream, char* err, size_t errlen) {
+// one row per workgroup in LDS: k * 4 NW bytes of the 160 KiB
+static bool row_fits_lds(uint32_t k, int nw) { return (size_t)k * 4 * nw <= 128 * 1024; }
+
+// tables_only: just what an inverse transform of single rows needs (the size-2k domain of the sub-proof polynomials) -- no
+// message / codeword / tree buffers, no omega_n table
+static int gf_create_impl(gf_state** out, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch, hipStream_t stream, char* err, size_t errlen,
+                          bool tables_only) {
     *out = nullptr;
     gf_state* g = new (std::nothrow) gf_state();
     if (!g) return LG_ERR_OOM;
@@ -222,24 +228,29 @@ int gf_create(gf_state** out, int field, uint32_t rows, uint32_t k, uint32_t n, 
     g->total_rows = (uint64_t)rows * batch;
     while ((1u << g->logk) < k) g->logk++;
     while ((1u << g->logn) < n) g->logn++;
-    // one row per workgroup in LDS: k * 4 NW bytes of the 160 KiB
-    if ((size_t)k * 4 * g->nw > 128 * 1024 || g->logn > g->hf.two_adicity) { delete g; return LG_ERR_UNSUPPORTED; }
+    if (!row_fits_lds(k, g->nw) || (tables_only ? g->logk : g->logn) > g->hf.two_adicity) {
+        if (err) snprintf(err, errlen, "generic-field kernels keep one row of k = %u elements (%d bytes each) in LDS: at most 128 KiB", k, 4 * g->nw);
+        delete g;
+        return LG_ERR_UNSUPPORTED;
+    }
     const size_t eb = 4 * (size_t)g->nw, mat = (size_t)g->total_rows * k;
     auto body = [&]() -> int {
-        GF_HIP(g, hipMalloc(&g->d_pre, mat * eb));
         GF_HIP(g, hipMalloc(&g->d_coeffs, mat * eb));
-        GF_HIP(g, hipMalloc(&g->d_u, 8 * mat * eb));
-        GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_leaves), (size_t)batch * n * 32));
-        GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_nodes), (size_t)batch * (n - 1) * 32));
+        if (!tables_only) {
+            GF_HIP(g, hipMalloc(&g->d_pre, mat * eb));
+            GF_HIP(g, hipMalloc(&g->d_u, 8 * mat * eb));
+            GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_leaves), (size_t)batch * n * 32));
+            GF_HIP(g, hipMalloc(reinterpret_cast<void**>(&g->d_nodes), (size_t)batch * (n - 1) * 32));
+        }
         // tables: powers of omega_k, omega_k^-1 (k/2 each) and omega_n (n), Montgomery form
         const HostField& f = g->hf;
         const int L = f.n;
-        uint64_t wn[6], wk[6], wki[6];
-        f.domain_generator(wn, g->logn);
+        uint64_t wn[6] = {0, 0, 0, 0, 0, 0}, wk[6], wki[6];
+        if (!tables_only) f.domain_generator(wn, g->logn);
         f.domain_generator(wk, g->logk);
         f.inverse(wki, wk);
         const size_t half = k / 2 ? k / 2 : 1;
-        std::vector<uint64_t> tf(half * L), ti(half * L), tn((size_t)n * L);
+        std::vector<uint64_t> tf(half * L), ti(half * L), tn(tables_only ? 0 : (size_t)n * L);
         uint64_t a[6], b[6];
         memcpy(a, f.r1, 8 * L); memcpy(b, f.r1, 8 * L);
         for (size_t e = 0; e < half; e++) {
@@ -247,19 +258,32 @@ int gf_create(gf_state** out, int field, uint32_t rows, uint32_t k, uint32_t n, 
             f.mul(a, a, wk); f.mul(b, b, wki);
         }
         memcpy(a, f.r1, 8 * L);
-        for (size_t e = 0; e < n; e++) { memcpy(&tn[e * L], a, 8 * L); f.mul(a, a, wn); }
+        for (size_t e = 0; e * L < tn.size(); e++) { memcpy(&tn[e * L], a, 8 * L); f.mul(a, a, wn); }
         GF_HIP(g, hipMalloc(&g->d_tw_fwd, tf.size() * 8));
         GF_HIP(g, hipMalloc(&g->d_tw_inv, ti.size() * 8));
-        GF_HIP(g, hipMalloc(&g->d_wn, tn.size() * 8));
         GF_HIP(g, hipMemcpy(g->d_tw_fwd, tf.data(), tf.size() * 8, hipMemcpyHostToDevice));
         GF_HIP(g, hipMemcpy(g->d_tw_inv, ti.data(), ti.size() * 8, hipMemcpyHostToDevice));
-        GF_HIP(g, hipMemcpy(g->d_wn, tn.data(), tn.size() * 8, hipMemcpyHostToDevice));
+        if (!tn.empty()) {
+            GF_HIP(g, hipMalloc(&g->d_wn, tn.size() * 8));
+            GF_HIP(g, hipMemcpy(g->d_wn, tn.data(), tn.size() * 8, hipMemcpyHostToDevice));
+        }
         return LG_OK;
     };
     const int rc = body();
     if (rc != LG_OK) { gf_destroy(g); return rc; }
     *out = g;
     return LG_OK;
+}
+int gf_create(gf_state** out, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch, hipStream_t stream, char* err, size_t errlen) {
+    return gf_create_impl(out, field, rows, k, n, batch, stream, err, errlen, false);
+}
+// the linear and quadratic sub-proof polynomials go through a size-2k inverse transform, whose row must fit LDS as well:
+// refused up front with a message, not in the middle of a proof
+static int need_2k_row(gf_state* g, const char* what) {
+    if (row_fits_lds(2 * g->k, g->nw) && g->logk + 1 <= g->hf.two_adicity) return LG_OK;
+    if (g->err) snprintf(g->err, g->errlen, "%s interpolates on the size-2k domain: a row of 2k = %u elements of %d bytes does not fit the 128 KiB of LDS the "
+                         "generic-field kernels use (k <= %u for this field)", what, 2 * g->k, 4 * g->nw, (unsigned)(128 * 1024 / (4 * g->nw) / 2));
+    return LG_ERR_UNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------------------------- launches
@@ -479,7 +503,7 @@ int gf_interleaved_row_mul(gf_state* g, const uint64_t* r, uint64_t* out) {
 template <int NW>
 static int interpolate_2k(gf_state* g, const void* d_points, uint64_t* coeffs_out) {
     if (!g->aux2k) {
-        const int rc = gf_create(&g->aux2k, g->field, 1, 2 * g->k, 16 * g->k, 1, g->stream, g->err, g->errlen);
+        const int rc = gf_create_impl(&g->aux2k, g->field, 1, 2 * g->k, 16 * g->k, 1, g->stream, g->err, g->errlen, true);
         if (rc != LG_OK) return rc;
     }
     gf_state* x = g->aux2k;
@@ -514,6 +538,7 @@ static int linear_t(gf_state* g, const uint64_t* r_a, uint64_t* coeffs_out) {
 int gf_linear_constraint_poly(gf_state* g, const uint64_t* r_a, uint64_t* coeffs_out) {
     if (g->batch != 1) return LG_ERR_UNSUPPORTED;
     if (!g->committed) return LG_ERR_STATE;
+    { const int rc_ = need_2k_row(g, "lg_linear_constraint_poly"); if (rc_ != LG_OK) return rc_; }
     return g->nw == 12 ? linear_t<12>(g, r_a, coeffs_out) : linear_t<8>(g, r_a, coeffs_out);
 }
 
@@ -536,5 +561,6 @@ static int quadratic_t(gf_state* g, const uint64_t* r, uint64_t* coeffs_out) {
 int gf_quadratic_constraint_poly(gf_state* g, const uint64_t* r, uint64_t* coeffs_out) {
     if (g->batch != 1 || (g->rows & 3)) return LG_ERR_UNSUPPORTED;
     if (!g->committed) return LG_ERR_STATE;
+    { const int rc_ = need_2k_row(g, "lg_quadratic_constraint_poly"); if (rc_ != LG_OK) return rc_; }
     return g->nw == 12 ? quadratic_t<12>(g, r, coeffs_out) : quadratic_t<8>(g, r, coeffs_out);
 }

@@ -63,29 +63,41 @@ __device__ __forceinline__ void b2s_compress(uint32_t (&h)[8], const uint32_t (&
     h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
 
+// Parked state of one column between two launches: chaining value + the bytes of the current, still incomplete 64-byte block.
+// After an EVEN number of rows those are 8 bytes (the tail of the last row, or the length prefix), after an odd number 40
+// (8 + one whole row): kColStateVec uint4 per column = h[8] | m[0..9] | unused.  The same record travels between GPUs when a
+// column is hashed by several ranks in turn (row-relay commit, lg_stage_hash_rows).
+constexpr int kColStateVec = 5;
+
 struct ColHashArgs {
     const uint4* u;         // coset planes [8][total_rows][k], canonical integers, 2 x uint4 per element
     uint8_t* leaves;        // [batch][n][32]
-    uint4* state;           // [batch][np][k][3]: chaining value + 8 carried bytes between row chunks
-    uint32_t rows;          // rows per proof (4m)
+    uint4* state;           // [batch][np][k][kColStateVec]: chaining value + carried bytes between row chunks
+    uint32_t rows;          // rows per proof (4m) of THIS matrix (addressing)
     uint32_t k;             // elements per plane row (ki)
     uint32_t lognp;         // log2 of the number of planes np (n = np * k)
     uint32_t proof_begin;   // first proof hashed by this launch
     uint32_t proof_count;   // proofs hashed by this launch
-    uint32_t row_begin;     // rows [row_begin, row_end) of each proof are absorbed; row_begin is even
+    uint32_t row_begin;     // rows [row_begin, row_end) of each proof are absorbed
     uint32_t row_end;
     uint32_t plane_begin;   // planes [plane_begin, plane_begin + plane_count) are hashed (all of them in a
     uint32_t plane_count;   // single-GPU commit; the planes a rank owns when a proof is coset-sharded)
     uint32_t first;         // 1: start from the initial state; 0: resume from `state`
     uint32_t last;          // 1: finalise and write the leaf digest; 0: save `state`
     uint64_t plane_stride;  // in elements
+    // position of row_begin inside the COLUMN and the column's length: the same as row_begin / rows unless this matrix is a
+    // row shard of a larger one (row-relay commit: a rank holds rows [col_pos, col_pos + nrows) of a column of col_rows)
+    uint64_t col_pos;
+    uint64_t col_rows;
 };
 
 // One lane per column.  Thread id -> (proof b, coset s, q) with q fastest, so a wave reads
 // 64 adjacent elements (2 KiB contiguous) of one row per step.  A column can be absorbed in
 // several launches over consecutive row ranges (the commit pipeline hashes a chunk of rows
-// while the next chunk is still being encoded): the chaining value and the 8 bytes that
-// straddle the 64-byte block boundary are parked in `state` in between.
+// while the next chunk is still being encoded; the row-relay commit hands a column from GPU to
+// GPU): the chaining value and the bytes of the incomplete block are parked in `state` in
+// between.  Row ranges may start and end anywhere -- a 64-byte block is 8 carried bytes + one row +
+// 24 bytes of the next, so an odd position carries 40 bytes instead of 8.
 static __global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const ColHashArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = (uint64_t)a.proof_count * a.plane_count * a.k;
@@ -96,26 +108,42 @@ static __global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const Co
     // element (row i) = p[i * 2k], p[i * 2k + 1]
     const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + a.row_begin) * a.k + q);
     const uint64_t step = 2 * (uint64_t)a.k;
-    uint4* st = a.state + 3 * ((((uint64_t)b << a.lognp) + s) * a.k + q);
+    uint4* st = a.state + kColStateVec * ((((uint64_t)b << a.lognp) + s) * a.k + q);
 
     uint32_t h[8];
     uint32_t m[16];
+    const bool odd_start = (a.col_pos & 1) != 0;   // wave-uniform
     if (a.first) {
 #pragma unroll
         for (int i = 0; i < 8; i++) h[i] = b2s_iv(i);
         h[0] ^= 0x01010020u;
-        m[0] = a.rows;  // LE64(rows): serialize_compressed length prefix of Vec<F>
-        m[1] = 0;
+        m[0] = (uint32_t)a.col_rows;  // LE64(rows): serialize_compressed length prefix of Vec<F>
+        m[1] = (uint32_t)(a.col_rows >> 32);
     } else {
         const uint4 s0 = st[0], s1 = st[1], s2 = st[2];
         h[0] = s0.x; h[1] = s0.y; h[2] = s0.z; h[3] = s0.w;
         h[4] = s1.x; h[5] = s1.y; h[6] = s1.z; h[7] = s1.w;
         m[0] = s2.x; m[1] = s2.y;
+        if (odd_start) {
+            const uint4 s3 = st[3], s4 = st[4];
+            m[2] = s2.z; m[3] = s2.w; m[4] = s3.x; m[5] = s3.y; m[6] = s3.z; m[7] = s3.w; m[8] = s4.x; m[9] = s4.y;
+        }
     }
-    uint64_t t = (uint64_t)a.row_begin * 32;  // bytes compressed so far (whole blocks)
-    const uint32_t nrows = a.row_end - a.row_begin;
-    const uint32_t pairs = nrows >> 1;
+    uint64_t t = (a.col_pos >> 1) * 64;  // bytes compressed so far (whole blocks)
+    uint32_t nrows = a.row_end - a.row_begin;
     uint4 a0, a1, b0, b1;
+    if (odd_start && nrows) {
+        // the block in progress already holds 8 + 32 bytes: the first 24 bytes of this row complete it
+        a0 = p[0]; a1 = p[1];
+        m[10] = a0.x; m[11] = a0.y; m[12] = a0.z; m[13] = a0.w; m[14] = a1.x; m[15] = a1.y;
+        t += 64;
+        b2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), false);
+        m[0] = a1.z;
+        m[1] = a1.w;
+        p += step;
+        nrows--;
+    }
+    const uint32_t pairs = nrows >> 1;
     if (pairs) { a0 = p[0]; a1 = p[1]; b0 = p[step]; b1 = p[step + 1]; }
     for (uint32_t i = 0; i < pairs; i++) {
         m[2] = a0.x; m[3] = a0.y; m[4] = a0.z; m[5] = a0.w; m[6] = a1.x; m[7] = a1.y; m[8] = a1.z; m[9] = a1.w;
@@ -128,19 +156,30 @@ static __global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const Co
         m[0] = c0;
         m[1] = c1;
     }
+    const bool odd_end = (nrows & 1) != 0;   // one more row, at an even position: it joins the carried bytes
+    if (odd_end) {
+        a0 = p[0]; a1 = p[1];
+        m[2] = a0.x; m[3] = a0.y; m[4] = a0.z; m[5] = a0.w; m[6] = a1.x; m[7] = a1.y; m[8] = a1.z; m[9] = a1.w;
+    }
     if (!a.last) {
         st[0] = make_uint4(h[0], h[1], h[2], h[3]);
         st[1] = make_uint4(h[4], h[5], h[6], h[7]);
-        st[2] = make_uint4(m[0], m[1], 0, 0);
+        if (odd_end) {
+            st[2] = make_uint4(m[0], m[1], m[2], m[3]);
+            st[3] = make_uint4(m[4], m[5], m[6], m[7]);
+            st[4] = make_uint4(m[8], m[9], 0, 0);
+        } else {
+            st[2] = make_uint4(m[0], m[1], 0, 0);
+        }
         return;
     }
+    if (odd_end) {
 #pragma unroll
-    for (int i = 2; i < 16; i++) m[i] = 0;
-    if (nrows & 1) {
-        a0 = p[0]; a1 = p[1];
-        m[2] = a0.x; m[3] = a0.y; m[4] = a0.z; m[5] = a0.w; m[6] = a1.x; m[7] = a1.y; m[8] = a1.z; m[9] = a1.w;
+        for (int i = 10; i < 16; i++) m[i] = 0;
         t += 40;
     } else {
+#pragma unroll
+        for (int i = 2; i < 16; i++) m[i] = 0;
         t += 8;
     }
     b2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), true);

@@ -3,6 +3,7 @@
 // gfx950 only; there is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,11 @@ struct lg_ctx {
     hipEvent_t ev_coef[kMaxChunks] = {};   // "rows of chunk c are interpolated"
     hipEvent_t ev_done = nullptr;          // "tree of this commit is complete"
     hipEvent_t ev_hashed = nullptr, ev_tree = nullptr;   // single-chunk commits: leaves complete / tree complete (on stream_h)
+    // staged hashes (lg_stage_hash_rows) run on stream_h behind everything issued so far on the encode stream and the encode
+    // stream does not wait for them until something reads their result (settle_hash): the hash of one row range runs beside
+    // the evaluation of the next
+    hipEvent_t ev_stage_in = nullptr, ev_stage_hash = nullptr;
+    bool hash_pending = false;
     bool async_tree = true;                // LG_ASYNC_TREE=0 turns the overlap below off (A/B knob)
     bool tree_pending = false;             // the tree of the last commit is still being built on stream_h / stream_t
     // single-chunk commits: the column hash of commit i runs on stream_h BESIDE the interpolation / evaluation of commit
@@ -56,7 +62,7 @@ struct lg_ctx {
     uint64_t async_seq = 0;                             // overlapped commits issued: picks the hash stream
     hipStream_t stream_h2 = nullptr;                    // second hash stream (ring_depth == 3)
     hipEvent_t ev_hash_free[kRing] = {nullptr, nullptr, nullptr};   // "the hash that read U[p] is done" (on its hash stream)
-    uint4* d_hstate = nullptr;             // [batch][8][k][3] Blake2s state between row chunks
+    uint4* d_hstate = nullptr;             // [batch][np][ki][lg::kColStateVec] Blake2s state between row chunks / ranks (LG_BUF_HSTATE)
     gf_state* gf = nullptr;                // set for contexts over a generic field (lg_ctx_create_field): every supported
                                            // entry point forwards to generic_path.hip, the others return LG_ERR_UNSUPPORTED
     lg_ctx* aux2k = nullptr;               // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
@@ -363,6 +369,7 @@ static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon
     a.scale = c->scale29;
     a.rows = rows; a.row0 = row0; a.ncos = 0;
     a.plane_stride = 0;
+    a.canon_mask = 0xffffffffu;
     return a;
 }
 // with_message: also evaluate the planes that coincide with the message (needed when only
@@ -517,6 +524,8 @@ void lg_ctx_destroy(lg_ctx* c) {
         if (e) hipEventDestroy(e);
     if (c->ev_hashed) hipEventDestroy(c->ev_hashed);
     if (c->ev_tree) hipEventDestroy(c->ev_tree);
+    if (c->ev_stage_in) hipEventDestroy(c->ev_stage_in);
+    if (c->ev_stage_hash) hipEventDestroy(c->ev_stage_hash);
     for (auto& e : c->ev_leaves_free)
         if (e) hipEventDestroy(e);
     if (c->stream_t) hipStreamDestroy(c->stream_t);
@@ -582,10 +591,12 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_done, lg_event_flags()));
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_hashed, lg_event_flags()));
         LG_HIP(c, hipEventCreateWithFlags(&c->ev_tree, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->ev_stage_in, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->ev_stage_hash, lg_event_flags()));
         if (const char* e = getenv("LG_ASYNC_TREE")) c->async_tree = atoi(e) != 0;
         if (const char* e = getenv("LG_ASYNC_HASH")) c->async_hash = atoi(e) != 0;
         for (auto& e : c->ev_hash_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * 48));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * sizeof(uint4) * lg::kColStateVec));
         const size_t mat = (size_t)c->total_rows * k;
         // sharded: the message rows arrive shard by shard (lg_stage_interpolate allocates what it is given), the
         // coefficient buffer is padded so that equal all-gather shards fit, and only the owned planes of U exist
@@ -604,6 +615,9 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
         c->d_leaves_pp[0] = c->d_leaves;
         c->d_nodes_pp[0] = c->d_nodes;
+        // an unsharded context owns the whole of d_preenc from the start (a zero-copy producer may fill LG_BUF_PREENC and call
+        // lg_commit_resident); only a staged commit in progress narrows the range
+        if (!c->sharded) { c->have_row0 = 0; c->have_row1 = rows; }
         // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
         using namespace lg_host;
         const Fr wn = domain_generator(logn);
@@ -777,6 +791,12 @@ int lg_ctx_planes(const lg_ctx* c, uint32_t* nplanes, uint32_t* plane_begin, uin
     return LG_OK;
 }
 
+int lg_ctx_stream(lg_ctx* c, void** stream_out) {
+    if (!c || !stream_out) return LG_ERR_BAD_ARG;
+    *stream_out = static_cast<void*>(c->stream);
+    return LG_OK;
+}
+
 int lg_ctx_dims(const lg_ctx* c, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch) {
     if (!c) return LG_ERR_BAD_ARG;
     if (rows) *rows = c->rows;
@@ -830,6 +850,15 @@ static int settle_tree(lg_ctx* c) {
     return LG_OK;
 }
 
+// the same for staged column hashes queued on the hash stream (lg_stage_hash_rows)
+static int settle_hash(lg_ctx* c) {
+    if (c->hash_pending) {
+        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stage_hash, 0));
+        c->hash_pending = false;
+    }
+    return LG_OK;
+}
+
 // The commit (mod.rs:521-551).  host_pre == nullptr: the matrix is resident in d_preenc.  Otherwise the
 // rows are streamed from host memory chunk by chunk (same row range of every proof: one strided copy),
 // so that the PCIe transfer of chunk c+1 overlaps the encoding of chunk c; host_coeffs (optional)
@@ -844,6 +873,7 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         if (rc_ != LG_OK) return rc_;
     }
     LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     const uint64_t plane = c->total_rows * c->ki;
     const bool streamed = host_pre != nullptr;
     const bool prof = c->profiling && c->ev_valid && !streamed;
@@ -856,17 +886,18 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
     // (three deep: consecutive overlapped commits alternate between the two hash streams, so two column-hash chains run at once)
     hipStream_t hs = (nchunks > 1 || async_hash) ? ((async_hash && c->ring_depth == 3 && ((c->async_seq + 1) & 1)) ? c->stream_h2 : c->stream_h) : c->stream;
     if (async_hash) {
-        // this commit encodes into the other U buffer; the hash that last read it (two commits ago) must be done
-        const int par = c->u_parity = (c->u_parity + 1) % c->ring_depth;
-        c->async_seq++;
+        // this commit encodes into the other U buffer; the hash that last read it (two commits ago) must be done.  The slot's three
+        // buffers are allocated on first use, each checked on its own, and the context only moves to the slot once all three exist:
+        // a failed allocation leaves the previous commitment and the ring position as they were
+        const int par = (c->u_parity + 1) % c->ring_depth;
         if (!c->d_u_pp[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_pp[par]), (size_t)c->nplanes * plane * sizeof(fr)));
+        if (!c->d_leaves_pp[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves_pp[par]), (size_t)c->batch * c->n * 32));
+        if (!c->d_nodes_pp[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes_pp[par]), (size_t)c->batch * (c->n - 1) * 32));
+        c->u_parity = par;
+        c->async_seq++;
         c->d_u = c->d_u_pp[par];
         LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_hash_free[par], 0));   // (never recorded = no-op)
         // ... and hashes into the other leaf buffer / builds the other tree (readers use c->d_leaves / c->d_nodes: this commitment's)
-        if (!c->d_leaves_pp[par]) {
-            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves_pp[par]), (size_t)c->batch * c->n * 32));
-            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes_pp[par]), (size_t)c->batch * (c->n - 1) * 32));
-        }
         // what an earlier commitment left queued against the buffers about to become "current" is covered below: the hash waits
         // for the tree that last read leaves[par]; read-backs of the previous commitment were issued on the encode stream
         c->d_leaves = c->d_leaves_pp[par];
@@ -951,6 +982,7 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         h.last = ch.row_end == c->rows;
         h.plane_begin = 0; h.plane_count = c->nplanes;
         h.plane_stride = plane;
+        h.col_pos = h.row_begin; h.col_rows = c->rows;
         const uint64_t threads = (uint64_t)ch.proof_count * c->n;
         if (h.first && h.last && threads <= c->quad_hash_max_columns) {
             // few columns (a single small proof): the one-lane-per-column kernel would be one latency chain per SIMD;
@@ -1032,10 +1064,17 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
     return LG_OK;
 }
 
+// a commit that fails half way leaves no commitment behind (the buffers may be partly rewritten)
+static int commit_checked(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeffs) {
+    const int rc = commit_core(c, host_pre, host_coeffs);
+    if (rc != LG_OK && rc != LG_ERR_STATE) c->committed = false;
+    return rc;
+}
+
 int lg_commit_resident(lg_ctx* c) {
     if (!c) return LG_ERR_BAD_ARG;
     if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_commit(c->gf, nullptr, nullptr); }
-    return commit_core(c, nullptr, nullptr);
+    return commit_checked(c, nullptr, nullptr);
 }
 
 int lg_host_register(lg_ctx* c, void* ptr, size_t bytes) {
@@ -1079,6 +1118,7 @@ int lg_sync(lg_ctx* c) {
     if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_sync(c->gf); }
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipStreamSynchronize(c->stream));
     return LG_OK;
 }
@@ -1125,7 +1165,7 @@ int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, ui
     if (!c || !preenc || !root_out) return LG_ERR_BAD_ARG;
     if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); const int rc_ = gf_commit(c->gf, preenc, coeffs_out); return rc_ != LG_OK ? rc_ : gf_read_root(c->gf, root_out); }
     // rows stream in (and coefficients out) while earlier rows are being encoded
-    const int rc = commit_core(c, preenc, coeffs_out);
+    const int rc = commit_checked(c, preenc, coeffs_out);
     if (rc != LG_OK) return rc;
     return lg_read_root(c, root_out);
 }
@@ -1705,9 +1745,14 @@ int lg_subproof_finish(lg_ctx* c, int which, const uint64_t* points, uint64_t* o
 }
 
 // ---- staged commit for one proof sharded over several GPUs ----------------
-// Rank g interpolates its row shard, the host layer all-gathers the coefficient rows (RCCL),
-// then rank g evaluates and hashes the planes it owns for ALL rows, the host layer all-gathers
-// the leaf digests, and every rank builds the (replicated) tree.
+// Coset-sharded: rank g interpolates its row shard, the host layer all-gathers the coefficient rows (RCCL), then rank g
+// evaluates and hashes the planes it owns for ALL rows, the host layer all-gathers the leaf digests, and every rank builds
+// the (replicated) tree.  Row-relay: rank g keeps its rows end to end (all planes) and the columns' Blake2s states travel
+// from rank to rank (lg_stage_hash_rows).
+static uint32_t message_planes_mask(const lg_ctx* c) {   // planes s = 0 (mod 8): they hold the canonical message itself
+    return all_planes_mask(c) & 0x01010101u;
+}
+
 int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows) {
     if (!c) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
@@ -1715,6 +1760,9 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
     if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
     if (nrows == 0) return LG_OK;
     LG_HIP(c, hipSetDevice(c->device));
+    // the interpolation rewrites message planes of U: nothing of an earlier commitment may still be reading them
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     if (c->sharded) {
         // the message rows of a sharded proof exist only shard by shard: hold exactly the range handed over
         const bool inside = c->d_preenc_alloc && row0 >= c->pre_row0 && (uint64_t)row0 + nrows <= (uint64_t)c->pre_row0 + c->pre_rows;
@@ -1730,7 +1778,17 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
     }
     if (preenc_rows)
         LG_HIP(c, hipMemcpyAsync(c->d_preenc + (size_t)row0 * c->k, preenc_rows, (size_t)nrows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
-    lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, nullptr, row0, nrows);
+    // The code is systematic: the message planes (s = 0 mod 8) of these rows ARE the message, so the interpolation writes their
+    // canonical copy into the ones this context holds and the evaluation skips them for these rows (a rank of a coset-sharded
+    // proof still has to evaluate them for the rows it only receives coefficients of)
+    const uint32_t msg_held = message_planes_mask(c) & own_planes_mask(c);
+    lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, msg_held ? c->d_u : nullptr, row0, nrows);
+    if (msg_held) {
+        a.plane_stride = c->total_rows * c->ki;
+        a.canon_mask = 0;
+        for (uint32_t cc = 0; cc < (1u << c->logo); cc++)
+            if (msg_held & (1u << (8 * cc))) a.canon_mask |= 1u << cc;
+    }
     LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
     // a staged commit starts (or grows by an adjacent row range); what an earlier commitment left in U is void
     if (c->staging && row0 == c->have_row1) c->have_row1 = row0 + nrows;
@@ -1742,79 +1800,6 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
     return LG_OK;
 }
 
-int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
-    if (!c) return LG_ERR_BAD_ARG;
-    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
-    if (c->batch != 1) return LG_ERR_STATE;
-    if (c->nplanes < 32 && (plane_mask >> c->nplanes) != 0) return LG_ERR_BAD_ARG;
-    if (plane_mask & ~own_planes_mask(c)) {
-        snprintf(c->err, sizeof(c->err), "plane mask 0x%x reaches outside the planes [%u, %u) this sharded context holds", plane_mask, c->own_plane0,
-                 c->own_plane0 + c->own_planes);
-        return LG_ERR_BAD_ARG;
-    }
-    if (c->committed) { c->committed = false; c->have_planes = 0; }   // re-evaluating over a finished commitment voids it
-    LG_HIP(c, hipSetDevice(c->device));
-    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
-    const uint64_t plane = c->total_rows * c->ki;
-    // every owned plane -- including the ones that coincide with the message -- is produced by
-    // the evaluation kernel from the gathered coefficients, so no second exchange is needed
-    lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, 0, c->rows, true);
-    a.ncos = 0;
-    for (uint32_t s = 0; s < c->nplanes; s++)
-        if (plane_mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
-    if (a.ncos == 0) return LG_OK;
-    // Row chunks, as in commit_core: while the encode stream evaluates chunk i + 1 of the owned planes, the hash stream absorbs
-    // chunk i into the column states (S22 on one rank: 104 -> 92 ms; on 8 ranks each rank's share of it)
-    Chunk chunks[lg_ctx::kMaxChunks];
-    const int nchunks = plan_chunks(c, chunks);
-    hipStream_t hs = nchunks > 1 ? c->stream_h : c->stream;
-    if (nchunks > 1) {
-        LG_HIP(c, hipEventRecord(c->ev_done, c->stream));     // earlier work on the encode stream (the previous tree) may read the leaves
-        LG_HIP(c, hipStreamWaitEvent(hs, c->ev_done, 0));
-    }
-    for (int i = 0; i < nchunks; i++) {
-        const Chunk& ch = chunks[i];
-        lg::NttArgs e = a;
-        e.row0 = ch.row_begin;
-        e.rows = ch.row_end - ch.row_begin;
-        e.chunk_rows = e.rows;
-        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, e));
-        if (nchunks > 1) {
-            LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
-            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_chunk[i], 0));
-        }
-        // hash the owned planes: one launch per run of consecutive planes (the kernel takes a plane range)
-        for (uint32_t s = 0; s < c->nplanes;) {
-            if (!(plane_mask & (1u << s))) { s++; continue; }
-            uint32_t e2 = s;
-            while (e2 + 1 < c->nplanes && (plane_mask & (1u << (e2 + 1)))) e2++;
-            lg::ColHashArgs h;
-            memset(&h, 0, sizeof(h));
-            h.u = reinterpret_cast<const uint4*>(c->d_u);
-            h.leaves = c->d_leaves;
-            h.state = c->d_hstate;
-            h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
-            h.proof_begin = 0; h.proof_count = 1;
-            h.row_begin = ch.row_begin; h.row_end = ch.row_end;
-            h.first = ch.row_begin == 0;
-            h.last = ch.row_end == c->rows;
-            h.plane_begin = s; h.plane_count = e2 - s + 1;
-            h.plane_stride = plane;
-            const uint64_t threads = (uint64_t)h.plane_count * c->ki;
-            LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
-            s = e2 + 1;
-        }
-    }
-    if (nchunks > 1) {   // later work on the encode stream (lg_stage_merkle, the caller's all-gather after lg_sync) sees the leaves
-        LG_HIP(c, hipEventRecord(c->ev_done, hs));
-        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
-    }
-    c->have_planes |= plane_mask;
-    return LG_OK;
-}
-
-// Split form of lg_stage_evaluate_hash for a caller that receives the coefficient rows piece by piece (an all-gather cut into pieces
-// that arrive while earlier pieces are being evaluated): evaluate ANY rows that are there, in any order, then hash once all are done.
 static int stage_plane_args(lg_ctx* c, uint32_t plane_mask) {
     if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     if (c->batch != 1) return LG_ERR_STATE;
@@ -1827,32 +1812,32 @@ static int stage_plane_args(lg_ctx* c, uint32_t plane_mask) {
     return LG_OK;
 }
 
-int lg_stage_evaluate_rows(lg_ctx* c, uint32_t plane_mask, uint32_t row0, uint32_t nrows) {
-    if (!c) return LG_ERR_BAD_ARG;
-    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
-    if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
-    if (c->committed) { c->committed = false; c->have_planes = 0; }   // re-evaluating over a finished commitment voids it
-    if (nrows == 0 || plane_mask == 0) return LG_OK;
-    LG_HIP(c, hipSetDevice(c->device));
+// evaluation of the planes of plane_mask for rows [r0, r1) from LG_BUF_COEFFS.  Rows this context interpolated itself during
+// the staged commit in progress ([have_row0, have_row1)) already have their message planes (lg_stage_interpolate).
+static int stage_evaluate_range(lg_ctx* c, uint32_t plane_mask, uint32_t r0, uint32_t r1) {
+    if (r1 <= r0 || plane_mask == 0) return LG_OK;
     const uint64_t plane = c->total_rows * c->ki;
-    lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, true);
-    a.ncos = 0;
-    for (uint32_t s = 0; s < c->nplanes; s++)
-        if (plane_mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
-    a.chunk_rows = nrows;
-    LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+    const uint32_t h0 = c->staging ? c->have_row0 : 0, h1 = c->staging ? c->have_row1 : 0;
+    const uint32_t seg[4] = {r0, std::min(r1, std::max(r0, h0)), std::min(r1, std::max(r0, h1)), r1};
+    for (int i = 0; i < 3; i++) {
+        if (seg[i + 1] <= seg[i]) continue;
+        const uint32_t mask = (i == 1) ? (plane_mask & ~message_planes_mask(c)) : plane_mask;
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, seg[i], seg[i + 1] - seg[i], true);
+        a.ncos = 0;
+        for (uint32_t s = 0; s < c->nplanes; s++)
+            if (mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
+        if (a.ncos == 0) continue;
+        a.chunk_rows = a.rows;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+    }
     return LG_OK;
 }
 
-int lg_stage_hash(lg_ctx* c, uint32_t plane_mask) {
-    if (!c) return LG_ERR_BAD_ARG;
-    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
-    if (c->committed) { c->committed = false; c->have_planes = 0; }
-    if (plane_mask == 0) return LG_OK;
-    LG_HIP(c, hipSetDevice(c->device));
-    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }   // the previous tree may still read the leaves
+// column hashes of the planes of plane_mask over rows [row0, row0 + nrows) of this context's U, which are rows
+// [col_pos, col_pos + nrows) of columns of col_rows rows; one launch per run of consecutive planes, on stream `hs`
+static int stage_hash_launch(lg_ctx* c, hipStream_t hs, uint32_t plane_mask, uint32_t row0, uint32_t nrows, uint64_t col_pos, uint64_t col_rows) {
     const uint64_t plane = c->total_rows * c->ki;
-    for (uint32_t s = 0; s < c->nplanes;) {   // one launch per run of consecutive planes, all rows in one go (no state to carry)
+    for (uint32_t s = 0; s < c->nplanes;) {
         if (!(plane_mask & (1u << s))) { s++; continue; }
         uint32_t e2 = s;
         while (e2 + 1 < c->nplanes && (plane_mask & (1u << (e2 + 1)))) e2++;
@@ -1863,16 +1848,89 @@ int lg_stage_hash(lg_ctx* c, uint32_t plane_mask) {
         h.state = c->d_hstate;
         h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
         h.proof_begin = 0; h.proof_count = 1;
-        h.row_begin = 0; h.row_end = c->rows;
-        h.first = true; h.last = true;
+        h.row_begin = row0; h.row_end = row0 + nrows;
+        h.first = col_pos == 0;
+        h.last = col_pos + nrows == col_rows;
         h.plane_begin = s; h.plane_count = e2 - s + 1;
         h.plane_stride = plane;
+        h.col_pos = col_pos; h.col_rows = col_rows;
         const uint64_t threads = (uint64_t)h.plane_count * c->ki;
-        LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, h);
+        LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
         s = e2 + 1;
+    }
+    return LG_OK;
+}
+
+int lg_stage_evaluate_hash(lg_ctx* c, uint32_t plane_mask) {
+    if (!c) return LG_ERR_BAD_ARG;
+    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
+    if (c->committed) { c->committed = false; c->have_planes = 0; }   // re-evaluating over a finished commitment voids it
+    if (plane_mask == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    // Row chunks, as in commit_core: while the encode stream evaluates chunk i + 1 of the owned planes, the hash stream absorbs
+    // chunk i into the column states (S22 on one rank: 104 -> 92 ms; on 8 ranks each rank's share of it)
+    Chunk chunks[lg_ctx::kMaxChunks];
+    const int nchunks = plan_chunks(c, chunks);
+    hipStream_t hs = nchunks > 1 ? c->stream_h : c->stream;
+    if (nchunks > 1) {
+        LG_HIP(c, hipEventRecord(c->ev_done, c->stream));     // earlier work on the encode stream (the previous tree) may read the leaves
+        LG_HIP(c, hipStreamWaitEvent(hs, c->ev_done, 0));
+    }
+    for (int i = 0; i < nchunks; i++) {
+        const Chunk& ch = chunks[i];
+        { const int rc_ = stage_evaluate_range(c, plane_mask, ch.row_begin, ch.row_end); if (rc_ != LG_OK) return rc_; }
+        if (nchunks > 1) {
+            LG_HIP(c, hipEventRecord(c->ev_chunk[i], c->stream));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_chunk[i], 0));
+        }
+        { const int rc_ = stage_hash_launch(c, hs, plane_mask, ch.row_begin, ch.row_end - ch.row_begin, ch.row_begin, c->rows); if (rc_ != LG_OK) return rc_; }
+    }
+    if (nchunks > 1) {   // later work on the encode stream (lg_stage_merkle, the caller's all-gather after lg_sync) sees the leaves
+        LG_HIP(c, hipEventRecord(c->ev_done, hs));
+        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
     }
     c->have_planes |= plane_mask;
     return LG_OK;
+}
+
+// Split form of lg_stage_evaluate_hash for a caller that receives the coefficient rows piece by piece (an all-gather cut into pieces
+// that arrive while earlier pieces are being evaluated): evaluate ANY rows that are there, in any order, then hash once all are done.
+int lg_stage_evaluate_rows(lg_ctx* c, uint32_t plane_mask, uint32_t row0, uint32_t nrows) {
+    if (!c) return LG_ERR_BAD_ARG;
+    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
+    if ((uint64_t)row0 + nrows > c->rows) return LG_ERR_BAD_ARG;
+    if (c->committed) { c->committed = false; c->have_planes = 0; }   // re-evaluating over a finished commitment voids it
+    if (nrows == 0 || plane_mask == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    return stage_evaluate_range(c, plane_mask, row0, row0 + nrows);
+}
+
+// Column hashes of a ROW RANGE: rows [row0, row0 + nrows) of this context are rows [col_pos, col_pos + nrows) of columns
+// that are col_rows rows long (mod.rs:536-542: the length prefix is col_rows).  col_pos = 0 starts the columns, otherwise
+// their Blake2s states are resumed from LG_BUF_HSTATE; col_pos + nrows = col_rows finalises them into LG_BUF_LEAVES,
+// otherwise the states go back to LG_BUF_HSTATE.  The launch is queued on the hash stream behind everything issued so far.
+int lg_stage_hash_rows(lg_ctx* c, uint32_t plane_mask, uint32_t row0, uint32_t nrows, uint64_t col_pos, uint64_t col_rows) {
+    if (!c) return LG_ERR_BAD_ARG;
+    { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
+    if ((uint64_t)row0 + nrows > c->rows || nrows == 0 || col_pos + nrows > col_rows) return LG_ERR_BAD_ARG;
+    if (c->committed) { c->committed = false; c->have_planes = 0; }
+    if (plane_mask == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }   // the previous tree may still read the leaves
+    LG_HIP(c, hipEventRecord(c->ev_stage_in, c->stream));               // the rows just evaluated, a state just received
+    LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_stage_in, 0));
+    { const int rc_ = stage_hash_launch(c, c->stream_h, plane_mask, row0, nrows, col_pos, col_rows); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipEventRecord(c->ev_stage_hash, c->stream_h));
+    c->hash_pending = true;
+    c->have_planes |= plane_mask;
+    return LG_OK;
+}
+
+int lg_stage_hash(lg_ctx* c, uint32_t plane_mask) {
+    if (!c) return LG_ERR_BAD_ARG;
+    return lg_stage_hash_rows(c, plane_mask, 0, c->rows, 0, c->rows);
 }
 
 int lg_stage_merkle(lg_ctx* c) {
@@ -1880,6 +1938,7 @@ int lg_stage_merkle(lg_ctx* c) {
     if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     lg::MerkleArgs m;
     m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
     uint32_t depth = (uint32_t)c->logn;
@@ -1923,6 +1982,7 @@ int lg_stage_digests_pack(lg_ctx* c, uint32_t world, uint32_t rank, void** dptr_
     { const int rc_ = need_planes(c, run, "lg_stage_digests_pack"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     const size_t block = (size_t)c->ki * per * 32;
     if (!c->d_digest_xchg) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_digest_xchg), (size_t)c->n * 32));
     LG_HIP(c, hipMemcpy2DAsync(c->d_digest_xchg + (size_t)rank * block, (size_t)per * 32, c->d_leaves + (size_t)rank * per * 32, (size_t)c->nplanes * 32,
@@ -1948,19 +2008,22 @@ int lg_stage_digests_unpack(lg_ctx* c, uint32_t world) {
 int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
     if (!c || !dptr_out || !bytes_out) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
-    if (which == LG_BUF_LEAVES || which == LG_BUF_NODES) {   // the caller will touch them outside our streams' order
+    if (which == LG_BUF_LEAVES || which == LG_BUF_NODES || which == LG_BUF_HSTATE) {   // the caller will touch them outside our streams' order
         LG_HIP(c, hipSetDevice(c->device));
-        const int rc_ = settle_tree(c);
-        if (rc_ != LG_OK) return rc_;
+        { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+        { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     }
     switch (which) {
         case LG_BUF_PREENC:   // sharded: the allocated row range [pre_row0, pre_row0 + pre_rows) only
+            // unsharded: the caller takes the whole matrix over (a zero-copy producer), so every row counts as present again
+            if (!c->sharded && !c->staging) { c->have_row0 = 0; c->have_row1 = c->rows; }
             *dptr_out = c->sharded ? c->d_preenc_alloc : c->d_preenc;
             *bytes_out = (size_t)(c->sharded ? c->pre_rows : c->total_rows) * c->k * sizeof(fr);
             break;
         case LG_BUF_COEFFS: *dptr_out = c->d_coeffs; *bytes_out = (size_t)c->coeff_rows_alloc * c->k * sizeof(fr); break;
         case LG_BUF_LEAVES: *dptr_out = c->d_leaves; *bytes_out = (size_t)c->batch * c->n * 32; break;
         case LG_BUF_NODES: *dptr_out = c->d_nodes; *bytes_out = (size_t)c->batch * (c->n - 1) * 32; break;
+        case LG_BUF_HSTATE: *dptr_out = c->d_hstate; *bytes_out = (size_t)c->batch * c->n * LG_HSTATE_BYTES; break;
         default: return LG_ERR_BAD_ARG;
     }
     return LG_OK;

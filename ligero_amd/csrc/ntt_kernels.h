@@ -60,6 +60,8 @@ struct NttArgs {
     uint32_t ncos;       // evaluate only: number of planes in `cosets`
     uint8_t cosets[32];  // evaluate only: plane ids (0 .. 8 O - 1)
     uint64_t plane_stride;  // elements between planes (= total_rows * ki)
+    uint32_t canon_mask;    // interpolate, O > 1: bit c set = message plane 8 c exists behind canon_out (a coset-sharded context
+                            // holds only some of them); ignored for O = 1 (canon_out null or not)
 };
 
 // compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- expanded in the front end, so
@@ -469,6 +471,7 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
             constexpr int O = 1 << LOGO;
             for (int j = t; j < K; j += Plan::kThreadsPerNtt) {
                 const uint32_t dd = (uint32_t)j + (sel << LOGK);
+                if (!((a.canon_mask >> (dd & (O - 1))) & 1u)) continue;   // a message plane this (sharded) context does not hold
                 f29 cv;
                 mul29_small(cv, unpack29(fr_load(a.in + row_in + dd)), 32u);
                 fr_store_stream(canon + (size_t)(8u * (dd & (O - 1))) * a.plane_stride + (dd >> LOGO), pack29_reduced(cv));

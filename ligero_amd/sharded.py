@@ -315,6 +315,247 @@ class CosetShardedCommitter:
         return {j: (cols[i], sib[i], paths[i]) for i, j in enumerate(mine)}
 
 
+# ---------------------------------------------------------------------------------------------- row-relay mode
+def relay_row_ranges(rows: int, world: int, rank: int, layout: str = "contiguous") -> List[Tuple[int, int]]:
+    """[(first row in the column, rows)] this rank keeps in row-relay mode, in column order (empty ranges dropped).
+    "contiguous": one balanced range per rank.  "blocks": the rank's share of each of the four row blocks X, Y, Z, W of
+    preenc_u (mod.rs:516; rows = 4m) -- its rows then form a small [X; Y; Z; W] matrix of their own, which is what the
+    quadratic test's row triples (x_i, y_i, z_i) need to stay on one rank."""
+    if layout == "contiguous":
+        a, b = shard_range(rows, world, rank)
+        return [(a, b - a)] if b > a else []
+    if layout != "blocks":
+        raise ValueError(f"unknown relay layout {layout!r}")
+    if rows % 4:
+        raise ValueError("the block layout needs rows = 4 m")
+    m = rows // 4
+    a, b = shard_range(m, world, rank)
+    return [(blk * m + a, b - a) for blk in range(4)] if b > a else []
+
+
+def relay_chain(rows: int, world: int, layout: str = "contiguous") -> List[Tuple[int, int, int, int]]:
+    """every range of every rank in column order: [(first row, rows, owner rank, first row inside the owner's matrix)]"""
+    chain = []
+    for r in range(world):
+        local = 0
+        for pos, n in relay_row_ranges(rows, world, r, layout):
+            chain.append((pos, n, r, local))
+            local += n
+    chain.sort()
+    assert sum(n for _, n, _, _ in chain) == rows and all(chain[i][0] + chain[i][1] == chain[i + 1][0] for i in range(len(chain) - 1))
+    return chain
+
+
+class HipRelayBackend:
+    """One rank of a row-relay commit on this rank's GPU: an ordinary batch-1 context of the rank's OWN row count
+    (include/ligero_hip.h: lg_stage_interpolate / lg_stage_evaluate_rows / lg_stage_hash_rows / lg_stage_merkle)."""
+
+    def __init__(self, local_rows: int, k: int, device: int = 0):
+        from .ligero import LigeroCommitter
+        self.local_rows, self.k, self.n, self.device = local_rows, k, 8 * k, device
+        self.nplanes = 8 if k <= 4096 else 8 * (k // 4096)
+        self.ki = self.n // self.nplanes
+        # a rank without rows still takes part in the broadcast of the digests and builds the tree
+        self.c = LigeroCommitter(rows=max(1, local_rows), k=k, batch=1, device=device)
+        self._L = _ffi.lib()
+        self._all = (1 << self.nplanes) - 1
+
+    def _buffer(self, which: int):
+        import torch
+        ptr, size = _vp(), ctypes.c_size_t()
+        _ffi.check(self._L.lg_device_buffer(self.c._ctx, which, ctypes.cast(ctypes.byref(ptr), _vp), ctypes.cast(ctypes.byref(size), _vp)),
+                   "lg_device_buffer", self.c._ctx)
+        return torch.as_tensor(_CudaArray(ptr.value, size.value), device=f"cuda:{self.device}")
+
+    def stream(self):
+        """the library's stream as a torch stream: collectives issued under it are ordered with the library's calls"""
+        import torch
+        ptr = _vp()
+        _ffi.check(self._L.lg_ctx_stream(self.c._ctx, ctypes.cast(ctypes.byref(ptr), _vp)), "lg_ctx_stream", self.c._ctx)
+        return torch.cuda.ExternalStream(ptr.value, device=f"cuda:{self.device}")
+
+    def pipeline_chunks(self) -> int:
+        return self.c.pipeline_chunks()
+
+    def stage_interpolate(self, preenc_rows: Optional[np.ndarray], row0: int, nrows: int):
+        p = None
+        if preenc_rows is not None:
+            preenc_rows = np.ascontiguousarray(preenc_rows, dtype=np.uint64)
+            assert preenc_rows.size == nrows * self.k * 4
+            p = preenc_rows.ctypes.data_as(_vp)
+        _ffi.check(self._L.lg_stage_interpolate(self.c._ctx, p, row0, nrows), "lg_stage_interpolate", self.c._ctx)
+
+    def stage_evaluate_rows(self, row0: int, nrows: int):
+        _ffi.check(self._L.lg_stage_evaluate_rows(self.c._ctx, self._all, row0, nrows), "lg_stage_evaluate_rows", self.c._ctx)
+
+    def stage_hash_rows(self, plane0: int, nplanes: int, row0: int, nrows: int, col_pos: int, col_rows: int):
+        mask = ((1 << nplanes) - 1) << plane0
+        _ffi.check(self._L.lg_stage_hash_rows(self.c._ctx, mask, row0, nrows, col_pos, col_rows), "lg_stage_hash_rows", self.c._ctx)
+
+    def hstate_bytes(self):
+        """[nplanes, ki * LG_HSTATE_BYTES] uint8 view of the parked Blake2s states (settles the hash stream)"""
+        return self._buffer(_ffi.LG_BUF_HSTATE).view(self.nplanes, self.ki * _ffi.LG_HSTATE_BYTES)
+
+    def leaves_bytes(self):
+        return self._buffer(_ffi.LG_BUF_LEAVES).view(self.n, 32)
+
+    def stage_merkle(self):
+        _ffi.check(self._L.lg_stage_merkle(self.c._ctx), "lg_stage_merkle", self.c._ctx)
+
+    def sync(self):
+        self.c.sync()
+
+    def root(self) -> bytes:
+        return self.c.root()
+
+    def open_columns(self, indices):
+        """this rank's ROWS of the opened columns, the siblings and the (complete) paths"""
+        cols, sib, paths = self.c.open_columns(indices)
+        return cols[:, :self.local_rows], sib, paths
+
+    def close(self):
+        self.c.close()
+
+
+class RowRelayCommitter:
+    """ONE proof over `world` ranks, rows sharded END TO END (BASELINE.json north_star: "rows shard naturally ... all-gather
+    of column digests"): rank g interpolates and evaluates every coset plane of its own rows and keeps them; a column's
+    Blake2s (mod.rs:536-542) absorbs the rows in order, so the ranks take turns and the 72-byte state of every column is
+    handed from rank to rank -- n * 80 bytes per hop instead of the 4m * k * 32-byte coefficient all-gather of the
+    coset-sharded mode.  The rank with the last rows broadcasts the n digests and every rank builds the tree.
+
+    `make_backend(local_rows)` builds this rank's backend (HipRelayBackend; the CPU tests inject an oracle-backed double).
+    plane_groups P > 1 cuts every hop into P runs of planes: rank g works on group c while rank g + 1 works on group c - 1.
+    That pays only if a hash launch over fewer columns is faster -- on MI355X it is not (one lane per column, one wave per SIMD
+    at most: a latency chain whose length does not depend on the number of columns) -- so the default is 1.
+    layout: relay_row_ranges()."""
+
+    def __init__(self, make_backend, rows: int, dist=None, group=None, plane_groups: int = 1, layout: str = "contiguous",
+                 collectives_at_world_1: bool = False):
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.rows, self.layout = rows, layout
+        self.chain = relay_chain(rows, self.world, layout)
+        self.mine = [(pos, n, local) for pos, n, r, local in self.chain if r == self.rank]
+        self.local_rows = sum(n for _, n, _ in self.mine)
+        self.be = make_backend(self.local_rows)
+        self.groups = max(1, min(int(plane_groups), self.be.nplanes))
+        while self.be.nplanes % self.groups:
+            self.groups -= 1
+        if layout != "contiguous":
+            # the block layout's chain wraps around (rank G - 1 hands back to rank 0): with several groups in flight a rank
+            # would have to send and receive in the same step, which plain blocking sends cannot express; one group = a strictly
+            # sequential chain, which is also the faster choice (see the class comment)
+            self.groups = 1
+        self.force = bool(collectives_at_world_1) and dist is not None
+        self.stage_ms: Dict[str, float] = {}
+        self._stream = self.be.stream() if hasattr(self.be, "stream") else None
+        self._nccl = dist is not None and dist.get_backend(group) == "nccl"
+
+    def row_ranges(self, rank: Optional[int] = None) -> List[Tuple[int, int]]:
+        return relay_row_ranges(self.rows, self.world, self.rank if rank is None else rank, self.layout)
+
+    # -- the three transfers; device tensors go through RCCL as they are, any other backend gets host copies
+    def _send(self, t, dst):
+        self.dist.send(t if self._nccl or not t.is_cuda else t.cpu(), dst, group=self.group)
+
+    def _recv(self, t, src):
+        if self._nccl or not t.is_cuda:
+            self.dist.recv(t, src, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.recv(h, src, group=self.group)
+            t.copy_(h)
+
+    def _broadcast(self, t, src):
+        if self._nccl or not t.is_cuda:
+            self.dist.broadcast(t, src, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.broadcast(h, src, group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+
+    def commit(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
+        """preenc_rows_local: this rank's rows (its ranges, concatenated in column order), or None when they are resident from
+        an earlier commit.  Returns u_root."""
+        import contextlib
+        import torch
+        be = self.be
+        ctx = torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
+        marks = []
+
+        def mark(name):
+            if self._stream is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(self._stream)
+                marks.append((name, e))
+            else:
+                marks.append((name, time.perf_counter()))
+
+        with ctx:
+            mark("start")
+            per, gp = be.nplanes // self.groups, self.groups
+            head_done = False
+            if self.local_rows:
+                be.stage_interpolate(preenc_rows_local, 0, self.local_rows)
+                # evaluate in row chunks; the rank that holds the first rows of the columns hashes each chunk as soon as it is
+                # evaluated (the library queues the hash on its second stream, beside the evaluation of the next chunk)
+                pos0, n0, local0 = self.mine[0]
+                nch = max(1, min(be.pipeline_chunks() if hasattr(be, "pipeline_chunks") else 1, n0))
+                head = pos0 == 0
+                for c in range(nch):
+                    a, b = (n0 * c) // nch, (n0 * (c + 1)) // nch
+                    be.stage_evaluate_rows(local0 + a, b - a)
+                    if head:
+                        be.stage_hash_rows(0, be.nplanes, local0 + a, b - a, pos0 + a, self.rows)
+                head_done = head
+                rest0 = local0 + n0
+                if self.local_rows > rest0:
+                    be.stage_evaluate_rows(rest0, self.local_rows - rest0)
+            mark("encode")
+            exchange = self.world > 1
+            # the relay: every range of the chain in column order, every plane group of it in turn
+            for i, (pos, n, owner, local) in enumerate(self.chain):
+                prev_owner = self.chain[i - 1][2] if i > 0 else None
+                next_owner = self.chain[i + 1][2] if i + 1 < len(self.chain) else None
+                if owner != self.rank:
+                    continue
+                for g in range(gp):
+                    if exchange and prev_owner is not None and prev_owner != self.rank:
+                        self._recv(be.hstate_bytes()[g * per:(g + 1) * per], prev_owner)
+                    if not (head_done and i == 0):
+                        be.stage_hash_rows(g * per, per, local, n, pos, self.rows)
+                    if exchange and next_owner is not None and next_owner != self.rank:
+                        self._send(be.hstate_bytes()[g * per:(g + 1) * per], next_owner)
+            mark("relay")
+            if exchange or self.force:
+                self._broadcast(be.leaves_bytes(), self.chain[-1][2] if exchange else 0)
+            mark("digests")
+            be.stage_merkle()
+            mark("merkle")
+        be.sync()
+        ms = self.stage_ms = {}
+        for (_, a), (name, b) in zip(marks, marks[1:]):
+            ms[name] = a.elapsed_time(b) if self._stream is not None else (b - a) * 1e3
+        return be.root()
+
+    def open_columns(self, indices: Sequence[int]):
+        """every rank holds ITS ROWS of every column: returns (rows of the columns [t, local_rows, 4] in this rank's own row
+        order, leaf siblings, authentication paths); assemble_columns() merges the ranks' pieces"""
+        return self.be.open_columns([int(j) for j in indices])
+
+    def assemble_columns(self, pieces: Sequence[np.ndarray]) -> np.ndarray:
+        """pieces[r] = rank r's rows of the opened columns ([t, local_rows_r, 4]) -> the columns [t, rows, 4] (u.column(j),
+        src/matrices/mod.rs:169-171)"""
+        t = pieces[0].shape[0]
+        out = np.empty((t, self.rows, 4), dtype=np.uint64)
+        for pos, n, owner, local in self.chain:
+            out[:, pos:pos + n] = pieces[owner][:, local:local + n]
+        return out
+
+
 class ShardedBatchCommitter:
     """Independent proofs dealt to ranks (weak scaling, no data-path collective).
     `make_committer(batch_local)` builds this rank's committer (a `LigeroCommitter` on the GPU)."""

@@ -1,8 +1,9 @@
 """Test helper: `world` ranks as THREADS of one process, each with an object that quacks like the part of torch.distributed
-the sharded paths use (get_world_size / get_rank / get_backend / all_gather_into_tensor).  The GPU box allows at most six
+the sharded paths use (get_world_size / get_rank / get_backend / all_gather_into_tensor / send / recv / broadcast).  The GPU box allows at most six
 processes on its card at once, so the world-8 layouts of the driver's scaling run are exercised here with eight sharded
 contexts of the real device backend on eight threads of the test process (the library's contexts are independent and its
 entry points release the GIL under ctypes); worlds of two and four also run as real gloo process groups elsewhere."""
+import queue
 import threading
 
 import torch
@@ -13,6 +14,8 @@ class _Shared:
         self.world = world
         self.barrier = threading.Barrier(world, timeout=timeout)
         self.slots = [None] * world
+        self.timeout = timeout
+        self.mail = {(a, b): queue.Queue() for a in range(world) for b in range(world)}   # point to point: one FIFO per (src, dst)
 
 
 class ThreadRankDist:
@@ -39,6 +42,33 @@ class ThreadRankDist:
                     return True
             return _Done()
         return None
+
+    # point to point and broadcast (the row-relay commit): a message is a clone of the tensor, taken once the sender's device
+    # work is complete -- the receiver copies it in and waits for its own device
+    def send(self, tensor, dst, group=None):
+        if tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+        self._s.mail[(self._rank, dst)].put(tensor.detach().clone())
+
+    def recv(self, tensor, src, group=None):
+        msg = self._s.mail[(src, self._rank)].get(timeout=self._s.timeout)
+        assert msg.numel() == tensor.numel()
+        tensor.view(-1).copy_(msg.view(-1))
+        if tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+
+    def broadcast(self, tensor, src, group=None):
+        s = self._s
+        if self._rank == src:
+            if tensor.is_cuda:
+                torch.cuda.synchronize(tensor.device)
+            s.slots[src] = tensor.detach().clone()
+        s.barrier.wait()
+        if self._rank != src:
+            tensor.view(-1).copy_(s.slots[src].view(-1))
+            if tensor.is_cuda:
+                torch.cuda.synchronize(tensor.device)
+        s.barrier.wait()
 
     def _all_gather(self, out, inp):
         s = self._s
