@@ -410,6 +410,18 @@ class HipRelayBackend:
 
     def open_columns(self, indices):
         """this rank's ROWS of the opened columns, the siblings and the (complete) paths"""
+        if self.local_rows == 0:
+            # a rank without rows holds the (replicated) tree only: Path::leaf_sibling_hash and auth_path (root side first) read
+            # off the heap-ordered nodes, as lg_open_columns does on the device
+            leaves, nodes = self.c.leaves()[0], self.c.nodes()[0]
+            logn = self.n.bit_length() - 1
+            idx = [int(j) for j in indices]
+            sib = np.stack([leaves[j ^ 1] for j in idx]) if idx else np.empty((0, 32), dtype=np.uint8)
+            paths = np.empty((len(idx), logn - 1, 32), dtype=np.uint8)
+            for c, j in enumerate(idx):
+                for depth in range(1, logn):
+                    paths[c, depth - 1] = nodes[((1 << depth) - 1) + ((j >> (logn - depth)) ^ 1)]
+            return np.empty((len(idx), 0, 4), dtype=np.uint64), sib, paths
         cols, sib, paths = self.c.open_columns(indices)
         return cols[:, :self.local_rows], sib, paths
 

@@ -554,3 +554,42 @@ def test_column_hash_kernels_agree_with_oracle(lg, oracle, monkeypatch, quad, ro
             ref = oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, n, want_u=False)
             assert np.array_equal(leaves[b], ref["leaves"]), (quad, b)
             assert roots[32 * b:32 * b + 32] == ref["root"]
+
+
+@pytest.mark.parametrize("rows,k,batch", [(9, 128, 1), (6, 64, 3)])
+def test_zero_copy_producer_fills_preenc_then_commits_resident(lg, oracle, rows, k, batch):
+    """the route include/ligero_hip.h documents for zero-copy producers: write LG_BUF_PREENC through lg_device_buffer on a
+    FRESH context, lg_commit_resident, root = oracle (the message-row gate must not refuse it); and again after a
+    staged commit narrowed the held row range"""
+    import ctypes
+    import torch
+    from ligero_amd import _ffi
+    from ligero_amd.sharded import _CudaArray
+    L = _ffi.lib()
+    pre = random_mont(2718, batch * rows * k).reshape(batch * rows, k, 4)
+    want = b"".join(oracle.encode_commit(pre[b * rows:(b + 1) * rows], k, 8 * k, want_u=False)["root"] for b in range(batch))
+    with lg.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
+        def fill():
+            ptr, size = ctypes.c_void_p(), ctypes.c_size_t()
+            _ffi.check(L.lg_device_buffer(c._ctx, _ffi.LG_BUF_PREENC, ctypes.cast(ctypes.byref(ptr), ctypes.c_void_p), ctypes.cast(ctypes.byref(size), ctypes.c_void_p)),
+                       "lg_device_buffer", c._ctx)
+            assert size.value == pre.nbytes
+            t = torch.as_tensor(_CudaArray(ptr.value, size.value), device="cuda:0")
+            t.copy_(torch.from_numpy(pre.view(np.uint8).reshape(-1)))
+            torch.cuda.synchronize()
+        fill()
+        c.commit_resident()
+        assert c.root() == want
+        assert np.array_equal(c.interleaved_row_mul(pre[:, 0]).shape, (batch, k, 4))
+        if batch == 1:
+            # a staged commit of a few rows narrows what the context holds: lg_commit_resident refuses ...
+            _ffi.check(L.lg_stage_interpolate(c._ctx, pre[:2].ctypes.data_as(ctypes.c_void_p), 0, 2), "lg_stage_interpolate", c._ctx)
+            with pytest.raises(_ffi.LigeroHipError) as e:
+                c.commit_resident()
+            assert e.value.status == _ffi.LG_ERR_STATE
+            _ffi.check(L.lg_stage_evaluate_hash(c._ctx, 0xff), "lg_stage_evaluate_hash", c._ctx)
+            _ffi.check(L.lg_stage_merkle(c._ctx), "lg_stage_merkle", c._ctx)
+            # ... until the producer takes the whole matrix over again
+            fill()
+            c.commit_resident()
+            assert c.root() == want

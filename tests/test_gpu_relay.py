@@ -44,6 +44,7 @@ def test_parked_states_equal_the_model(oracle, rows, k, cuts):
             be.stage_evaluate_rows(0, rows)
             be.stage_hash_rows(0, np_, 0, cut, 0, rows)
             if cut < rows:
+                be.sync()                      # (the copy below runs on torch's stream, not the library's)
                 got = be.hstate_bytes().cpu().numpy().reshape(np_, ki, mr.HSTATE_BYTES)
                 h = mr.ColumnRelayHasher(n, rows)
                 h.absorb(canon[:cut])
