@@ -312,85 +312,114 @@ def golden_large(workload: str):
 
 def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, rank: int, local_rank: int, steps: int, warmup: int,
                        partial: dict = None):
-    """ONE proof of the `workload` shape coset-sharded over `world` ranks (BASELINE configs[3]); returns the result dict on
-    every rank.  Timed region: barrier + sync, `steps` commits with the message rows resident, barrier + sync, max over ranks.
-    Two modes are timed one after the other: the coefficient all-gather as ONE collective before the evaluation, and cut into
-    LIGERO_BENCH_EXCHANGE_PIECES (default 4) asynchronous pieces that hide behind it (`pipelined`); `value` is the faster one.
-    `partial` (rank 0's watchdog reads it) receives the first mode's result before the second starts."""
-    from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
+    """ONE proof of the `workload` shape over `world` ranks (BASELINE configs[3]); returns the result dict on every rank.
+    Timed region: barrier + sync, `steps` commits QUEUED back to back with the message rows resident (each commit is one
+    library call -- lg_commit_sharded / lg_commit_row_relay -- whose exchanges come back through TorchComm on the library's own
+    streams; no host synchronisation inside), barrier + sync, max over ranks.  Three modes are timed one after the other and
+    `value` is the fastest whose root equals the first mode's:
+      coset-sharded, ONE coefficient all-gather          (row shard -> all-gather -> each rank evaluates + hashes its planes)
+      coset-sharded, LIGERO_BENCH_EXCHANGE_PIECES pieces (default 4: piece p + 1 on the wire while piece p is evaluated and hashed)
+      row relay                                          (rows end to end, the columns' Blake2s states handed from rank to rank)
+    `partial` (rank 0's watchdog reads it) receives the first mode's result before the others start."""
+    from ligero_amd.sharded import CosetShardedCommitter, HipRelayBackend, HipStageBackend, RowRelayCommitter
     rows, k, _ = WORKLOADS[workload]
     n = 8 * k
-    be = HipStageBackend(rows, k, device=local_rank, world=world, rank=rank)
+    gold = golden_large(workload)
+    dev = "cuda" if backend == "nccl" else "cpu"
+
+    def fence(be):
+        be.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(committer, first_input, names):
+        root = committer.commit(first_input)   # uploads this rank's rows; later commits find them resident
+        for _ in range(max(0, warmup - 1)):
+            committer.commit(None)
+        committer.be.profile(True)             # restart the HIP-event stage averages
+        fence(committer.be)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            committer.commit_queued(None)
+        fence(committer.be)
+        elapsed = time.perf_counter() - t0
+        root = committer.be.root()
+        sm = committer.be.shard_stage_ms()
+        stage = torch.tensor([elapsed] + [sm[s] for s in names], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(stage, op=dist.ReduceOp.MAX)
+        stage = [float(x) for x in stage.tolist()]
+        return root, stage[0], dict(zip(names, stage[1:]))
+
+    def local_rows(ranges):
+        return np.concatenate([shard_rows_of_seeded_matrix(LARGE_SEED, k, a, a + cnt) for a, cnt in ranges]) if ranges else None
+
+    coset_names = ("interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle")
+    pieces = int(os.environ.get("LIGERO_BENCH_EXCHANGE_PIECES", "4"))
+    be = HipStageBackend(rows, k, device=local_rank, world=world, rank=rank, pieces=pieces)
     try:
         sc = CosetShardedCommitter(be, dist, collectives_at_world_1=True)     # dist is None in a plain one-GPU run
-        r0, r1 = sc.row_range()
-        pre = shard_rows_of_seeded_matrix(LARGE_SEED, k, r0, r1)
-        names = ("interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle")
-
-        def fence():
-            be.sync()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-                torch.cuda.synchronize()
-
-        def timed(committer, first_input):
-            root = committer.commit(first_input)   # uploads this rank's rows; later commits find them resident
-            for _ in range(max(0, warmup - 1)):
-                committer.commit(None)
-            acc = {s: 0.0 for s in names}
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                root = committer.commit(None)
-                for s in names:
-                    acc[s] += committer.stage_ms[s]
-            fence()
-            elapsed = time.perf_counter() - t0
-            stage = torch.tensor([elapsed] + [acc[s] / steps for s in names], dtype=torch.float64,
-                                 device="cuda" if backend == "nccl" else "cpu")
-            if dist is not None:
-                dist.all_reduce(stage, op=dist.ReduceOp.MAX)
-            stage = [float(x) for x in stage.tolist()]
-            return root, stage[0], stage
-
-        root, elapsed, stage = timed(sc, pre)
-        gold = golden_large(workload)
+        mine = sc.row_ranges()
+        root, elapsed, stage = timed(sc, local_rows(mine), coset_names)
         coeff_bytes = rows * k * 32
-        ag_ms = stage[2]
+        ag_ms = stage["allgather_coeffs"]
         out = {
-            "workload": f"{workload}: 1 x ({rows} x {k} -> {n}) coset-sharded over {world} GPU(s)",
+            "workload": f"{workload}: 1 x ({rows} x {k} -> {n}) over {world} GPU(s)",
             "value": steps * rows * n / elapsed, "unit": "field-elems/s", "ms_per_commit": 1e3 * elapsed / steps,
             "steps": steps, "scaling": "strong", "n_gpus": world, "collective_backend": backend if world > 1 else None,
-            "stage_ms_max_over_ranks": dict(zip(names, stage[1:])),
-            "row_shard": [r0, r1], "rows_per_shard_padded": sc.shard_rows, "planes_per_rank": len(sc.planes),
+            "stage_ms_max_over_ranks": stage, "stage_ms_source": "HIP events on the library's stream (lg_shard_profile_read)",
+            "row_shard": list(mine[0]) if mine else None, "planes_per_rank": len(sc.planes),
             "u_bytes_per_rank": len(sc.planes) * rows * (k if k <= 4096 else 4096) * 32,
             "allgather_coeffs_GBs_per_rank_ingress": (coeff_bytes * (world - 1) / world) / (ag_ms * 1e-3) / 1e9 if world > 1 and ag_ms > 0 else None,
             "root": root.hex(), "root_matches_golden": (root.hex() == gold["root"]) if gold else None,
-            "mode": "one all-gather, then evaluate + hash",
+            "mode": "coset-sharded: one all-gather, then evaluate + hash",
         }
+        out["coset_one_allgather_ms_per_commit"] = out["ms_per_commit"]
         if partial is not None:
             partial["sharded_commit"] = dict(out)
-        pieces = int(os.environ.get("LIGERO_BENCH_EXCHANGE_PIECES", "4"))
-        if dist is not None and pieces > 1:
+        best = elapsed
+        if pieces > 1:
             try:
                 sp = CosetShardedCommitter(be, dist, collectives_at_world_1=True, exchange_pieces=pieces)
-                proot, pelapsed, pstage = timed(sp, None)       # the rows are resident from the first mode
+                proot, pelapsed, pstage = timed(sp, local_rows(sp.row_ranges()), coset_names)      # another row ownership: upload again
                 out["pipelined"] = {
-                    "exchange_pieces": len(sp.piece_plan()), "ms_per_commit": 1e3 * pelapsed / steps, "value": steps * rows * n / pelapsed,
-                    "stage_ms_max_over_ranks": dict(zip(names, pstage[1:])),
-                    "note": "allgather_coeffs = time spent waiting for pieces; the rest of the exchange ran beside the evaluation",
+                    "exchange_pieces": sp.pieces, "ms_per_commit": 1e3 * pelapsed / steps, "value": steps * rows * n / pelapsed,
+                    "stage_ms_max_over_ranks": pstage,
+                    "note": "allgather_coeffs = waiting for the last piece; the exchange ran on its own stream beside the evaluation, the hash piece by piece",
                     "root_matches_golden": (proot.hex() == gold["root"]) if gold else None, "root_equals_unpipelined": proot == root,
                 }
-                if pelapsed < elapsed and proot == root:
+                if pelapsed < best and proot == root:
+                    best = pelapsed
                     out["value"], out["ms_per_commit"] = steps * rows * n / pelapsed, 1e3 * pelapsed / steps
-                    out["mode"] = f"all-gather in {len(sp.piece_plan())} asynchronous pieces beside the evaluation, hash after the last"
-                    out["unpipelined_ms_per_commit"] = 1e3 * elapsed / steps
+                    out["mode"] = f"coset-sharded: all-gather in {sp.pieces} pieces beside the evaluation, hash piece by piece"
             except Exception as e:
                 out["pipelined"] = {"error": f"{type(e).__name__}: {e}"}
-        return out
     finally:
         be.close()
+    if os.environ.get("LIGERO_BENCH_ROW_RELAY", "1") != "0":
+        rc = None
+        try:
+            rc = RowRelayCommitter(lambda local: HipRelayBackend(local, k, device=local_rank), rows, dist, collectives_at_world_1=True)
+            rroot, relapsed, rstage = timed(rc, local_rows(rc.row_ranges()), ("encode", "relay", "digests", "merkle"))
+            out["row_relay"] = {
+                "ms_per_commit": 1e3 * relapsed / steps, "value": steps * rows * n / relapsed, "stage_ms_max_over_ranks": rstage,
+                "rows_per_rank": rc.local_rows, "hop_bytes": n * 80, "u_bytes_per_rank": rc.local_rows * n * 32,
+                "note": "rows sharded end to end; no coefficient all-gather: the Blake2s state of every column (80 B) is handed from rank to rank, "
+                        "the last rank broadcasts the n digests; `relay` on a rank includes waiting for the ranks before it",
+                "root_matches_golden": (rroot.hex() == gold["root"]) if gold else None, "root_equals_coset_sharded": rroot == root,
+            }
+            if relapsed < best and rroot == root:
+                best = relapsed
+                out["value"], out["ms_per_commit"] = steps * rows * n / relapsed, 1e3 * relapsed / steps
+                out["mode"] = "row relay: rows end to end, column hash states handed from rank to rank"
+        except Exception as e:
+            out["row_relay"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if rc is not None:
+                rc.be.close()
+    return out
 
 
 def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps):
@@ -568,12 +597,12 @@ def main():
         res = sharded_commit_leg(torch, dist, backend, args.workload, world, rank, local_rank, steps, min(args.warmup, 3))
         if rank == 0:
             line = {
-                "metric": "RS-encoded field-elems/sec (Ligero encode+commit, one proof coset-sharded over the GPUs)",
+                "metric": "RS-encoded field-elems/sec (Ligero encode+commit, one proof sharded over the GPUs)",
                 "value": res["value"], "unit": "field-elems/s", "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 3),
                 "ms_per_step": res["ms_per_commit"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "u32 limbs (BN254 Fr, 254-bit Montgomery) + u32 ARX hashes", "data": "synthetic",
                 "config": {"workload": res["workload"], "rows": rows, "k": k, "n": n,
-                           "parallelism": f"row-sharded interpolation + all-gather + coset-sharded evaluate/hash x{world}"},
+                           "parallelism": f"one proof over x{world}: {res['mode']}"},
                 "sharded_commit": res,
             }
         if not args.no_cpu_baseline:

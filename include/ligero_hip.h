@@ -43,7 +43,8 @@ typedef enum lg_status {
     LG_ERR_HIP = -4,        /* a HIP runtime call failed; see lg_last_error() */
     LG_ERR_OOM = -5,        /* device or host allocation failed */
     LG_ERR_STATE = -6,      /* call order violated (e.g. open_columns before a commitment) */
-    LG_ERR_UNSUPPORTED = -7 /* shape not supported by this build (k > 2^14) */
+    LG_ERR_UNSUPPORTED = -7, /* shape not supported by this build (k > 2^14) */
+    LG_ERR_COMM = -8         /* a caller-supplied communication callback (lg_comm) failed */
 } lg_status;
 
 /* Human-readable text for a status code (static storage). */
@@ -275,6 +276,57 @@ int lg_ctx_stream(lg_ctx* ctx, void** stream_out);
  */
 int lg_stage_digests_pack(lg_ctx* ctx, uint32_t world, uint32_t rank, void** dptr_out, size_t* bytes_per_rank_out);
 int lg_stage_digests_unpack(lg_ctx* ctx, uint32_t world);
+
+/*
+ * ONE CALL PER COMMIT for a proof sharded over several GPUs: the stages above as one stream-ordered sequence inside the
+ * library -- no host synchronisation between them -- with the exchanges done by the caller's collective library through four
+ * callbacks.  A Rust host binds these two functions and serves lg_comm with its RCCL binding;
+ * ligero_amd/sharded.py serves it with torch.distributed.
+ *
+ * Every callback acts on DEVICE memory and is ORDERED ON `stream` (a hipStream_t of the library): enqueue the collective on
+ * that stream (ncclAllGather(..., stream)) or make that stream wait for it.  A callback must not wait for the device on the
+ * host and returns 0 on success; anything else makes the commit fail with LG_ERR_COMM.
+ *   all_gather   in place: device_buf holds `world` blocks of bytes_per_rank, block `rank` is this rank's contribution
+ *   send / recv  point to point (row relay only)
+ *   broadcast    from `root` to every rank (row relay only)
+ */
+typedef struct lg_comm {
+    uint32_t world, rank;
+    uint32_t flags; /* LG_COMM_EXCHANGE_AT_WORLD_1: issue the (identity) collectives in a one-rank group too */
+    void* user;
+    int (*all_gather)(void* user, void* device_buf, uint64_t bytes_per_rank, void* stream);
+    int (*send)(void* user, const void* device_buf, uint64_t bytes, uint32_t dst, void* stream);
+    int (*recv)(void* user, void* device_buf, uint64_t bytes, uint32_t src, void* stream);
+    int (*broadcast)(void* user, void* device_buf, uint64_t bytes, uint32_t root, void* stream);
+} lg_comm;
+enum { LG_COMM_EXCHANGE_AT_WORLD_1 = 1 };
+/*
+ * Coset-sharded commit (steps 1-5 of lg_stage_*; ctx from lg_ctx_create_sharded with the plane run [rank np/world, (rank + 1)
+ * np/world)).  Row ownership: the rows are cut into `pieces` (1..8) pieces of world * sub rows and rank g owns sub-block g of
+ * every piece (lg_shard_row_ranges; pieces = 1: equal shards of ceil(rows / world) rows) -- so piece p of the coefficient
+ * all-gather is ONE in-place collective on whole rows of LG_BUF_COEFFS, it is on the wire (on a second stream) while piece
+ * p - 1 is evaluated, and because complete row prefixes arrive in order the column hash follows the evaluation piece by
+ * piece on the hash stream.  preenc_rows: this rank's rows, its ranges concatenated in order (NULL: resident from the last
+ * call with the same layout).  Returns once everything is QUEUED; lg_read_root / lg_sync wait.
+ */
+int lg_shard_row_ranges(uint32_t rows, uint32_t world, uint32_t rank, uint32_t pieces, uint32_t* ranges_out /* (row0, nrows) x up to 8 */,
+                        uint32_t* nranges_out);
+int lg_commit_sharded(lg_ctx* ctx, const lg_comm* comm, const uint64_t* preenc_rows, uint32_t pieces);
+/*
+ * Row-relay commit (steps 1-5 of lg_stage_hash_rows; ctx = an ordinary batch-1 context of max(1, this rank's row count)
+ * rows).  col_rows = 4m of the whole proof.  LG_RELAY_CONTIGUOUS: one balanced range per rank.  LG_RELAY_BLOCKS: the rank's
+ * share of each of the four row blocks X, Y, Z, W of preenc_u (mod.rs:516) -- its rows then form a small [X; Y; Z; W]
+ * matrix of their own (the quadratic test's row triples stay on one rank); the relay then has 4 * world hops.
+ * lg_relay_row_ranges: (first row in the column, rows) x up to 4.
+ */
+enum { LG_RELAY_CONTIGUOUS = 0, LG_RELAY_BLOCKS = 1 };
+int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int layout, uint64_t* ranges_out, uint32_t* nranges_out);
+int lg_commit_row_relay(lg_ctx* ctx, const lg_comm* comm, uint64_t col_rows, int layout, const uint64_t* preenc_rows);
+/* Mean milliseconds per stage (HIP events on the library's stream, no host laps) of the sharded commits issued since
+ * lg_profile_enable(ctx, 1), at most the last 16.  Coset-sharded: {interpolate, wait for the last piece of the coefficient
+ * all-gather, evaluate + hash, digest all-gather, tree}; row relay: {encode incl. the first rank's overlapped hash, 0, the
+ * relay = waiting for the previous rank + own hash + hand-over, digest broadcast, tree}. */
+int lg_shard_profile_read(lg_ctx* ctx, float ms_out[5], uint32_t* samples_out);
 
 /*
  * Sub-proof polynomials of a coset-sharded commitment (also valid on an ordinary batch-1 context, where one call serves

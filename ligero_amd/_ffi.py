@@ -24,6 +24,7 @@ SYMBOLS = [
     "lg_upload_constraint_matrix", "lg_linear_constraint_poly_from_seeds", "lg_verifier_linear_sums_from_seed",
     "lg_stage_interpolate", "lg_stage_evaluate_hash", "lg_stage_evaluate_rows", "lg_stage_hash", "lg_stage_hash_rows", "lg_stage_merkle", "lg_device_buffer", "lg_ctx_stream",
     "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
+    "lg_shard_row_ranges", "lg_commit_sharded", "lg_relay_row_ranges", "lg_commit_row_relay", "lg_shard_profile_read",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
 ]
 
@@ -35,6 +36,11 @@ LG_ERR_HIP = -4
 LG_ERR_OOM = -5
 LG_ERR_STATE = -6
 LG_ERR_UNSUPPORTED = -7
+LG_ERR_COMM = -8
+LG_COMM_EXCHANGE_AT_WORLD_1 = 1
+LG_RELAY_CONTIGUOUS, LG_RELAY_BLOCKS = 0, 1
+LG_SHARD_STAGE_NAMES = ("interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle")
+LG_RELAY_STAGE_NAMES = ("encode", "unused", "relay", "digests", "merkle")
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
 LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES, LG_BUF_HSTATE = 0, 1, 2, 3, 4
 LG_HSTATE_BYTES = 80
@@ -118,6 +124,11 @@ def lib():
     L.lg_stage_hash.argtypes = [_vp, _u32]
     L.lg_stage_hash_rows.argtypes = [_vp, _u32, _u32, _u32, ctypes.c_uint64, ctypes.c_uint64]
     L.lg_ctx_stream.argtypes = [_vp, _vp]
+    L.lg_shard_row_ranges.argtypes = [_u32, _u32, _u32, _u32, _vp, _vp]
+    L.lg_commit_sharded.argtypes = [_vp, _vp, _vp, _u32]
+    L.lg_relay_row_ranges.argtypes = [ctypes.c_uint64, _u32, _u32, _int, _vp, _vp]
+    L.lg_commit_row_relay.argtypes = [_vp, _vp, ctypes.c_uint64, _int, _vp]
+    L.lg_shard_profile_read.argtypes = [_vp, _vp, _vp]
     L.lg_stage_merkle.argtypes = [_vp]
     L.lg_device_buffer.argtypes = [_vp, _int, _vp, _vp]
     L.lg_ctx_dims.argtypes = [_vp, _vp, _vp, _vp, _vp]

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/ligero_hip.h"
@@ -124,6 +125,17 @@ struct lg_ctx {
     fr* d_scratch_c = nullptr; size_t scratch_c_elems = 0;  // natural-order output
     uint32_t* d_idx = nullptr; size_t idx_cap = 0;
     uint8_t* d_path_out = nullptr; size_t path_cap = 0;
+    // rows whose message planes (s = 0 mod 8) the interpolation of the staged commit in progress wrote itself (sorted, disjoint):
+    // the evaluation skips those planes for them
+    std::vector<std::pair<uint32_t, uint32_t>> canon_ranges;
+    // lg_commit_sharded: the rows this rank owns are `shard_pieces` ranges, kept compact (piece-major) in d_preenc_alloc
+    uint32_t shard_pieces = 0, shard_world = 0, shard_rank = 0, compact_rows = 0;
+    hipStream_t stream_x = nullptr;        // exchange stream of lg_commit_sharded: the all-gather of piece c + 1 beside the evaluation of piece c
+    static constexpr int kShardStages = 5;
+    static constexpr int kShardProfRing = 16;
+    hipEvent_t ev_shard[kShardProfRing][kShardStages + 1] = {};
+    bool ev_shard_valid = false;
+    uint64_t shard_commits = 0;
     bool committed = false;
     bool staging = false;                  // between lg_stage_interpolate and lg_stage_merkle
     bool profiling = false;
@@ -483,6 +495,7 @@ const char* lg_status_string(int s) {
         case LG_ERR_OOM: return "out of memory";
         case LG_ERR_STATE: return "invalid call order";
         case LG_ERR_UNSUPPORTED: return "unsupported shape";
+        case LG_ERR_COMM: return "communication callback failed";
         default: return "unknown status";
     }
 }
@@ -498,6 +511,7 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->stream_dn) hipStreamSynchronize(c->stream_dn);
     if (c->stream_t) hipStreamSynchronize(c->stream_t);
     if (c->stream_h2) hipStreamSynchronize(c->stream_h2);
+    if (c->stream_x) hipStreamSynchronize(c->stream_x);
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
@@ -528,6 +542,10 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->ev_stage_hash) hipEventDestroy(c->ev_stage_hash);
     for (auto& e : c->ev_leaves_free)
         if (e) hipEventDestroy(e);
+    if (c->ev_shard_valid)
+        for (auto& set : c->ev_shard)
+            for (auto& e : set) hipEventDestroy(e);
+    if (c->stream_x) hipStreamDestroy(c->stream_x);
     if (c->stream_t) hipStreamDestroy(c->stream_t);
     if (c->stream_h2) hipStreamDestroy(c->stream_h2);
     if (c->stream_up) hipStreamDestroy(c->stream_up);
@@ -835,6 +853,7 @@ int lg_profile_enable(lg_ctx* c, int on) {
     }
     c->profiling = on != 0;
     c->prof_commits = 0;
+    c->shard_commits = 0;
     return LG_OK;
 }
 
@@ -1752,6 +1771,17 @@ int lg_subproof_finish(lg_ctx* c, int which, const uint64_t* points, uint64_t* o
 static uint32_t message_planes_mask(const lg_ctx* c) {   // planes s = 0 (mod 8): they hold the canonical message itself
     return all_planes_mask(c) & 0x01010101u;
 }
+static void add_canon_range(lg_ctx* c, uint32_t r0, uint32_t r1) {
+    auto& v = c->canon_ranges;
+    v.emplace_back(r0, r1);
+    std::sort(v.begin(), v.end());
+    size_t w = 0;
+    for (size_t i = 1; i < v.size(); i++) {
+        if (v[i].first <= v[w].second) v[w].second = std::max(v[w].second, v[i].second);
+        else v[++w] = v[i];
+    }
+    v.resize(w + 1);
+}
 
 int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, uint32_t nrows) {
     if (!c) return LG_ERR_BAD_ARG;
@@ -1790,6 +1820,8 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
             if (msg_held & (1u << (8 * cc))) a.canon_mask |= 1u << cc;
     }
     LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+    if (!c->staging) c->canon_ranges.clear();
+    if (msg_held) add_canon_range(c, row0, row0 + nrows);
     // a staged commit starts (or grows by an adjacent row range); what an earlier commitment left in U is void
     if (c->staging && row0 == c->have_row1) c->have_row1 = row0 + nrows;
     else if (c->staging && row0 + nrows == c->have_row0) c->have_row0 = row0;
@@ -1813,24 +1845,31 @@ static int stage_plane_args(lg_ctx* c, uint32_t plane_mask) {
 }
 
 // evaluation of the planes of plane_mask for rows [r0, r1) from LG_BUF_COEFFS.  Rows this context interpolated itself during
-// the staged commit in progress ([have_row0, have_row1)) already have their message planes (lg_stage_interpolate).
+// the staged commit in progress (canon_ranges) already have their message planes (lg_stage_interpolate).
+static int stage_evaluate_launch(lg_ctx* c, uint32_t mask, uint32_t r0, uint32_t r1) {
+    if (r1 <= r0) return LG_OK;
+    lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, c->total_rows * c->ki, r0, r1 - r0, true);
+    a.ncos = 0;
+    for (uint32_t s = 0; s < c->nplanes; s++)
+        if (mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
+    if (a.ncos == 0) return LG_OK;
+    a.chunk_rows = a.rows;
+    LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+    return LG_OK;
+}
 static int stage_evaluate_range(lg_ctx* c, uint32_t plane_mask, uint32_t r0, uint32_t r1) {
     if (r1 <= r0 || plane_mask == 0) return LG_OK;
-    const uint64_t plane = c->total_rows * c->ki;
-    const uint32_t h0 = c->staging ? c->have_row0 : 0, h1 = c->staging ? c->have_row1 : 0;
-    const uint32_t seg[4] = {r0, std::min(r1, std::max(r0, h0)), std::min(r1, std::max(r0, h1)), r1};
-    for (int i = 0; i < 3; i++) {
-        if (seg[i + 1] <= seg[i]) continue;
-        const uint32_t mask = (i == 1) ? (plane_mask & ~message_planes_mask(c)) : plane_mask;
-        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, seg[i], seg[i + 1] - seg[i], true);
-        a.ncos = 0;
-        for (uint32_t s = 0; s < c->nplanes; s++)
-            if (mask & (1u << s)) a.cosets[a.ncos++] = (uint8_t)s;
-        if (a.ncos == 0) continue;
-        a.chunk_rows = a.rows;
-        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
-    }
-    return LG_OK;
+    const uint32_t nomsg = plane_mask & ~message_planes_mask(c);
+    uint32_t at = r0;
+    if (c->staging && nomsg != plane_mask)
+        for (const auto& cr : c->canon_ranges) {
+            const uint32_t a0 = std::max(at, cr.first), a1 = std::min(r1, cr.second);
+            if (a1 <= a0) continue;
+            { const int rc_ = stage_evaluate_launch(c, plane_mask, at, a0); if (rc_ != LG_OK) return rc_; }
+            { const int rc_ = stage_evaluate_launch(c, nomsg, a0, a1); if (rc_ != LG_OK) return rc_; }
+            at = a1;
+        }
+    return stage_evaluate_launch(c, plane_mask, at, r1);
 }
 
 // column hashes of the planes of plane_mask over rows [row0, row0 + nrows) of this context's U, which are rows
@@ -2026,6 +2065,319 @@ int lg_device_buffer(lg_ctx* c, int which, void** dptr_out, size_t* bytes_out) {
         case LG_BUF_HSTATE: *dptr_out = c->d_hstate; *bytes_out = (size_t)c->batch * c->n * LG_HSTATE_BYTES; break;
         default: return LG_ERR_BAD_ARG;
     }
+    return LG_OK;
+}
+
+// ---- one call per commit for a proof sharded over several GPUs: the stages above in one stream-ordered sequence, the exchanges
+// through the caller's callbacks (include/ligero_hip.h: lg_comm).  Nothing here waits on the host.
+static int comm_fail(lg_ctx* c, const char* what, int rc) {
+    snprintf(c->err, sizeof(c->err), "%s: the communication callback returned %d", what, rc);
+    return LG_ERR_COMM;
+}
+static int shard_events(lg_ctx* c, hipEvent_t** ev_out) {
+    *ev_out = nullptr;
+    if (!c->profiling) return LG_OK;
+    if (!c->ev_shard_valid) {
+        for (auto& set : c->ev_shard)
+            for (auto& e : set) LG_HIP(c, hipEventCreate(&e));
+        c->ev_shard_valid = true;
+    }
+    *ev_out = c->ev_shard[c->shard_commits % lg_ctx::kShardProfRing];
+    return LG_OK;
+}
+// ownership rule of lg_commit_sharded: the rows are cut into `pieces` pieces of world * sub rows, rank g owns sub-block g of
+// every piece -- so that piece c of the all-gather is ONE in-place collective on rows [c world sub, (c + 1) world sub) of
+// LG_BUF_COEFFS and complete row prefixes arrive in order (the column hash can follow the evaluation piece by piece)
+static void shard_plan(uint32_t rows, uint32_t world, uint32_t pieces, uint32_t* sub_out, uint32_t* pieces_out) {
+    if (pieces < 1) pieces = 1;
+    if (pieces > (uint32_t)lg_ctx::kMaxChunks) pieces = lg_ctx::kMaxChunks;
+    uint32_t per_piece = (rows + pieces - 1) / pieces;                 // rows per piece before rounding up to whole sub-blocks
+    uint32_t sub = (per_piece + world - 1) / world;
+    if (sub == 0) sub = 1;
+    *sub_out = sub;
+    *pieces_out = (rows + world * sub - 1) / (world * sub);            // pieces that hold at least one row
+}
+
+int lg_shard_row_ranges(uint32_t rows, uint32_t world, uint32_t rank, uint32_t pieces, uint32_t* ranges_out, uint32_t* nranges_out) {
+    if (!ranges_out || !nranges_out || world == 0 || rank >= world || rows == 0) return LG_ERR_BAD_ARG;
+    uint32_t sub, np;
+    shard_plan(rows, world, pieces, &sub, &np);
+    uint32_t n = 0;
+    for (uint32_t p = 0; p < np; p++) {
+        const uint64_t a = (uint64_t)p * world * sub + (uint64_t)rank * sub;
+        const uint64_t b = std::min<uint64_t>(rows, a + sub);
+        if (b > a) { ranges_out[2 * n] = (uint32_t)a; ranges_out[2 * n + 1] = (uint32_t)(b - a); n++; }
+    }
+    *nranges_out = n;
+    return LG_OK;
+}
+
+int lg_commit_sharded(lg_ctx* c, const lg_comm* comm, const uint64_t* preenc_rows, uint32_t pieces) {
+    if (!c || !comm) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1) return LG_ERR_STATE;
+    const uint32_t world = comm->world, rank = comm->rank;
+    if (world == 0 || rank >= world) return LG_ERR_BAD_ARG;
+    const bool exchange = world > 1 || (comm->flags & LG_COMM_EXCHANGE_AT_WORLD_1);
+    if (exchange && !comm->all_gather) return LG_ERR_BAD_ARG;
+    if (c->nplanes % world != 0 || c->own_planes != c->nplanes / world || c->own_plane0 != rank * (c->nplanes / world)) {
+        snprintf(c->err, sizeof(c->err), "lg_commit_sharded: rank %u of %u must hold planes [%u, %u) of %u (lg_ctx_create_sharded); this context holds [%u, %u)", rank, world,
+                 rank * (c->nplanes / world), (rank + 1) * (c->nplanes / world), c->nplanes, c->own_plane0, c->own_plane0 + c->own_planes);
+        return LG_ERR_STATE;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    uint32_t sub, np;
+    shard_plan(c->rows, world, pieces, &sub, &np);
+    const uint32_t piece_rows = world * sub;
+    uint32_t ranges[2 * lg_ctx::kMaxChunks], nranges = 0;
+    lg_shard_row_ranges(c->rows, world, rank, pieces, ranges, &nranges);
+    uint32_t own = 0;
+    for (uint32_t i = 0; i < nranges; i++) own += ranges[2 * i + 1];
+    // earlier work that reads what is about to be rewritten
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    // the coefficient buffer holds np whole pieces (padding rows of the last one are exchanged but never read)
+    if ((uint64_t)np * piece_rows > c->coeff_rows_alloc) {
+        LG_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->stream_x) LG_HIP(c, hipStreamSynchronize(c->stream_x));
+        LG_HIP(c, hipFree(c->d_coeffs));
+        c->d_coeffs = nullptr; c->coeff_rows_alloc = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coeffs), (size_t)np * piece_rows * c->k * sizeof(fr)));
+        c->coeff_rows_alloc = np * piece_rows;
+    }
+    // this rank's message rows, compact and piece-major
+    const bool same_layout = c->shard_pieces == np && c->shard_world == world && c->shard_rank == rank && c->compact_rows == own;
+    if (!preenc_rows && own && !(same_layout && (c->sharded ? c->d_preenc_alloc != nullptr : true))) {
+        snprintf(c->err, sizeof(c->err), "lg_commit_sharded: no resident rows of this layout (pass this rank's %u rows)", own);
+        return LG_ERR_STATE;
+    }
+    fr* compact = nullptr;
+    if (c->sharded) {
+        if (own && (!c->d_preenc_alloc || !same_layout)) {
+            LG_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_preenc_alloc) LG_HIP(c, hipFree(c->d_preenc_alloc));
+            c->d_preenc_alloc = nullptr; c->pre_rows = 0;
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc_alloc), (size_t)own * c->k * sizeof(fr)));
+        }
+        compact = c->d_preenc_alloc;
+        // (a single range keeps lg_stage_interpolate's "rows [pre_row0, pre_row0 + pre_rows) are resident" view of the same buffer)
+        c->pre_row0 = nranges == 1 ? ranges[0] : 0;
+        c->pre_rows = nranges == 1 ? own : 0;
+        c->d_preenc = nranges == 1 ? c->d_preenc_alloc - (size_t)ranges[0] * c->k : nullptr;
+    } else {
+        // an unsharded context (world 1): the matrix has its own full-size buffer; the rows sit at their own positions
+        compact = c->d_preenc;
+    }
+    c->shard_pieces = np; c->shard_world = world; c->shard_rank = rank; c->compact_rows = own;
+    if (preenc_rows && own) LG_HIP(c, hipMemcpyAsync(compact, preenc_rows, (size_t)own * c->k * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    hipEvent_t* ev = nullptr;
+    { const int rc_ = shard_events(c, &ev); if (rc_ != LG_OK) return rc_; }
+    if (ev) LG_HIP(c, hipEventRecord(ev[0], c->stream));
+    if (exchange && np > 1 && !c->stream_x) LG_HIP(c, hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking));
+    // a new staged commit: what an earlier commitment left in U is void
+    c->staging = true; c->committed = false; c->have_planes = 0;
+    c->canon_ranges.clear();
+    c->have_row0 = nranges ? ranges[0] : 0; c->have_row1 = nranges ? ranges[0] + ranges[1] : 0;
+    const uint32_t msg_held = message_planes_mask(c) & own_planes_mask(c);
+    const uint64_t plane = c->total_rows * c->ki;
+    const uint32_t mask = own_planes_mask(c);
+    // 1. interpolate this rank's rows piece by piece; piece p of the all-gather follows on the exchange stream
+    uint32_t compact_off = 0;
+    for (uint32_t i = 0; i < nranges; i++) {
+        const uint32_t r0 = ranges[2 * i], nr = ranges[2 * i + 1], p = r0 / piece_rows;
+        // `in` is indexed by the absolute row like `out`: bias the compact buffer's base accordingly
+        const fr* in = c->sharded ? compact + ((int64_t)compact_off - (int64_t)r0) * (int64_t)c->k : compact;
+        lg::NttArgs a = interp_args(c, in, c->d_coeffs, msg_held ? c->d_u : nullptr, r0, nr);
+        if (msg_held) {
+            a.plane_stride = plane;
+            a.canon_mask = 0;
+            for (uint32_t cc = 0; cc < (1u << c->logo); cc++)
+                if (msg_held & (1u << (8 * cc))) a.canon_mask |= 1u << cc;
+            add_canon_range(c, r0, r0 + nr);
+        }
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, a));
+        compact_off += nr;
+        (void)p;
+    }
+    if (ev) LG_HIP(c, hipEventRecord(ev[1], c->stream));
+    // 2. + 3. the pieces: all-gather (in place on whole pieces of LG_BUF_COEFFS), evaluate, hash -- piece p + 1 is on the wire while
+    // piece p is evaluated, the hash of piece p runs on the hash stream beside the evaluation of piece p + 1
+    hipStream_t xs = (exchange && np > 1) ? c->stream_x : c->stream;
+    if (exchange) {
+        if (xs != c->stream) {
+            LG_HIP(c, hipEventRecord(c->ev_done, c->stream));            // every own row is interpolated
+            LG_HIP(c, hipStreamWaitEvent(xs, c->ev_done, 0));
+        }
+        for (uint32_t p = 0; p < np; p++) {
+            uint8_t* base = reinterpret_cast<uint8_t*>(c->d_coeffs) + (size_t)p * piece_rows * c->k * sizeof(fr);
+            const int rc_ = comm->all_gather(comm->user, base, (uint64_t)sub * c->k * sizeof(fr), static_cast<void*>(xs));
+            if (rc_ != 0) return comm_fail(c, "all-gather of the coefficient rows", rc_);
+            if (xs != c->stream) LG_HIP(c, hipEventRecord(c->ev_up[p], xs));
+        }
+    }
+    for (uint32_t p = 0; p < np; p++) {
+        if (exchange && xs != c->stream) LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up[p], 0));
+        if (ev && p + 1 == np) LG_HIP(c, hipEventRecord(ev[2], c->stream));   // the last piece has arrived
+        const uint32_t r0 = p * piece_rows, r1 = std::min(c->rows, (p + 1) * piece_rows);
+        // (a single piece of a large commit is still cut into row chunks, as lg_stage_evaluate_hash does)
+        Chunk chunks[lg_ctx::kMaxChunks];
+        int nchunks = np > 1 ? 1 : plan_chunks(c, chunks);
+        if (np > 1) chunks[0] = Chunk{0, 1, r0, r1};
+        for (int i = 0; i < nchunks; i++) {
+            { const int rc_ = stage_evaluate_range(c, mask, chunks[i].row_begin, chunks[i].row_end); if (rc_ != LG_OK) return rc_; }
+            LG_HIP(c, hipEventRecord(c->ev_stage_in, c->stream));
+            LG_HIP(c, hipStreamWaitEvent(c->stream_h, c->ev_stage_in, 0));
+            { const int rc_ = stage_hash_launch(c, c->stream_h, mask, chunks[i].row_begin, chunks[i].row_end - chunks[i].row_begin, chunks[i].row_begin, c->rows); if (rc_ != LG_OK) return rc_; }
+            LG_HIP(c, hipEventRecord(c->ev_stage_hash, c->stream_h));
+            c->hash_pending = true;
+        }
+    }
+    c->have_planes |= mask;
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    if (ev) LG_HIP(c, hipEventRecord(ev[3], c->stream));
+    // 4. the digests
+    if (exchange) {
+        void* d = nullptr; size_t bytes = 0;
+        { const int rc_ = lg_stage_digests_pack(c, world, rank, &d, &bytes); if (rc_ != LG_OK) return rc_; }
+        const int rc_ = comm->all_gather(comm->user, d, (uint64_t)bytes, static_cast<void*>(c->stream));
+        if (rc_ != 0) return comm_fail(c, "all-gather of the leaf digests", rc_);
+        { const int rc2 = lg_stage_digests_unpack(c, world); if (rc2 != LG_OK) return rc2; }
+    }
+    if (ev) LG_HIP(c, hipEventRecord(ev[4], c->stream));
+    // 5. the tree
+    { const int rc_ = lg_stage_merkle(c); if (rc_ != LG_OK) return rc_; }
+    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; }
+    return LG_OK;
+}
+
+// Row-relay commit (lg_stage_hash_rows): this context holds the rank's OWN rows -- the ranges of lg_relay_row_ranges, concatenated
+// in column order -- and all coset planes of them.
+int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int layout, uint64_t* ranges_out, uint32_t* nranges_out) {
+    if (!ranges_out || !nranges_out || world == 0 || rank >= world || col_rows == 0) return LG_ERR_BAD_ARG;
+    uint32_t n = 0;
+    if (layout == LG_RELAY_CONTIGUOUS) {
+        const uint64_t a = col_rows * rank / world, b = col_rows * (rank + 1) / world;
+        if (b > a) { ranges_out[0] = a; ranges_out[1] = b - a; n = 1; }
+    } else if (layout == LG_RELAY_BLOCKS) {
+        if (col_rows % 4) return LG_ERR_BAD_ARG;
+        const uint64_t m = col_rows / 4, a = m * rank / world, b = m * (rank + 1) / world;
+        if (b > a)
+            for (uint32_t blk = 0; blk < 4; blk++) { ranges_out[2 * n] = blk * m + a; ranges_out[2 * n + 1] = b - a; n++; }
+    } else {
+        return LG_ERR_BAD_ARG;
+    }
+    *nranges_out = n;
+    return LG_OK;
+}
+
+int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int layout, const uint64_t* preenc_rows) {
+    if (!c || !comm) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1 || c->sharded) return LG_ERR_STATE;
+    const uint32_t world = comm->world, rank = comm->rank;
+    if (world == 0 || rank >= world) return LG_ERR_BAD_ARG;
+    const bool exchange = world > 1;
+    if (exchange && (!comm->send || !comm->recv || !comm->broadcast)) return LG_ERR_BAD_ARG;
+    // the chain: every range of every rank, in column order
+    struct Link { uint64_t pos, n; uint32_t owner, local; };
+    std::vector<Link> chain;
+    uint32_t local_rows = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        uint64_t rg[8]; uint32_t nr = 0;
+        { const int rc_ = lg_relay_row_ranges(col_rows, world, r, layout, rg, &nr); if (rc_ != LG_OK) return rc_; }
+        uint32_t local = 0;
+        for (uint32_t i = 0; i < nr; i++) {
+            chain.push_back(Link{rg[2 * i], rg[2 * i + 1], r, local});
+            local += (uint32_t)rg[2 * i + 1];
+        }
+        if (r == rank) local_rows = local;
+    }
+    std::sort(chain.begin(), chain.end(), [](const Link& a, const Link& b) { return a.pos < b.pos; });
+    if (c->rows != std::max<uint32_t>(1, local_rows)) {
+        snprintf(c->err, sizeof(c->err), "lg_commit_row_relay: rank %u of %u keeps %u of the %llu rows; this context has %u", rank, world, local_rows,
+                 (unsigned long long)col_rows, c->rows);
+        return LG_ERR_STATE;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    hipEvent_t* ev = nullptr;
+    { const int rc_ = shard_events(c, &ev); if (rc_ != LG_OK) return rc_; }
+    if (ev) LG_HIP(c, hipEventRecord(ev[0], c->stream));
+    const uint32_t all = all_planes_mask(c);
+    bool head_done = false;
+    if (local_rows) {
+        { const int rc_ = lg_stage_interpolate(c, preenc_rows, 0, local_rows); if (rc_ != LG_OK) return rc_; }
+        // evaluate in row chunks; the rank that holds the first rows of the columns hashes each chunk as soon as it is evaluated
+        // (on the hash stream, beside the evaluation of the next chunk)
+        const Link* first = nullptr;
+        for (const Link& l : chain)
+            if (l.owner == rank) { first = &l; break; }
+        Chunk chunks[lg_ctx::kMaxChunks];
+        const int planned = plan_chunks(c, chunks);
+        const uint32_t n0 = (uint32_t)first->n, nch = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)planned, n0));
+        const bool head = first->pos == 0;
+        for (uint32_t i = 0; i < nch; i++) {
+            const uint32_t a = (uint32_t)((uint64_t)n0 * i / nch), b = (uint32_t)((uint64_t)n0 * (i + 1) / nch);
+            { const int rc_ = lg_stage_evaluate_rows(c, all, first->local + a, b - a); if (rc_ != LG_OK) return rc_; }
+            if (head) { const int rc_ = lg_stage_hash_rows(c, all, first->local + a, b - a, first->pos + a, col_rows); if (rc_ != LG_OK) return rc_; }
+        }
+        head_done = head;
+        const uint32_t rest0 = first->local + n0;
+        if (local_rows > rest0) { const int rc_ = lg_stage_evaluate_rows(c, all, rest0, local_rows - rest0); if (rc_ != LG_OK) return rc_; }
+    } else {
+        if (c->committed) { c->committed = false; c->have_planes = 0; }
+    }
+    if (ev) LG_HIP(c, hipEventRecord(ev[1], c->stream));
+    if (ev) LG_HIP(c, hipEventRecord(ev[2], c->stream));
+    const size_t state_bytes = (size_t)c->n * LG_HSTATE_BYTES;
+    for (size_t i = 0; i < chain.size(); i++) {
+        const Link& l = chain[i];
+        if (l.owner != rank) continue;
+        if (exchange && i > 0 && chain[i - 1].owner != rank) {
+            { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+            const int rc_ = comm->recv(comm->user, c->d_hstate, state_bytes, chain[i - 1].owner, static_cast<void*>(c->stream));
+            if (rc_ != 0) return comm_fail(c, "receive of the column states", rc_);
+        }
+        if (!(head_done && i == 0)) { const int rc_ = lg_stage_hash_rows(c, all, l.local, (uint32_t)l.n, l.pos, col_rows); if (rc_ != LG_OK) return rc_; }
+        if (exchange && i + 1 < chain.size() && chain[i + 1].owner != rank) {
+            { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+            const int rc_ = comm->send(comm->user, c->d_hstate, state_bytes, chain[i + 1].owner, static_cast<void*>(c->stream));
+            if (rc_ != 0) return comm_fail(c, "send of the column states", rc_);
+        }
+    }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    if (ev) LG_HIP(c, hipEventRecord(ev[3], c->stream));
+    if (exchange || ((comm->flags & LG_COMM_EXCHANGE_AT_WORLD_1) && comm->broadcast)) {
+        { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+        const int rc_ = comm->broadcast(comm->user, c->d_leaves, (uint64_t)c->n * 32, exchange ? chain.back().owner : 0, static_cast<void*>(c->stream));
+        if (rc_ != 0) return comm_fail(c, "broadcast of the leaf digests", rc_);
+    }
+    if (ev) LG_HIP(c, hipEventRecord(ev[4], c->stream));
+    { const int rc_ = lg_stage_merkle(c); if (rc_ != LG_OK) return rc_; }
+    c->have_planes = all;    // every plane of this rank's rows is here (a rank without rows holds the tree only)
+    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; }
+    return LG_OK;
+}
+
+// mean milliseconds per stage of the sharded commits since lg_profile_enable(ctx, 1) (at most the last 16): coset mode
+// {interpolate, wait for the last piece of the coefficient all-gather, evaluate + hash, digest all-gather, tree}; row relay
+// {encode (+ the head's overlapped hash), 0, the relay (waiting for the previous rank, own hash, hand-over), digest broadcast, tree}
+int lg_shard_profile_read(lg_ctx* c, float ms_out[5], uint32_t* samples_out) {
+    if (!c || !ms_out) return LG_ERR_BAD_ARG;
+    if (!c->ev_shard_valid || !c->profiling || c->shard_commits == 0) return LG_ERR_STATE;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint64_t have = std::min<uint64_t>(c->shard_commits, lg_ctx::kShardProfRing);
+    double acc[lg_ctx::kShardStages] = {0, 0, 0, 0, 0};
+    for (uint64_t s = 0; s < have; s++) {
+        hipEvent_t* ev = c->ev_shard[(c->shard_commits - 1 - s) % lg_ctx::kShardProfRing];
+        LG_HIP(c, hipEventSynchronize(ev[lg_ctx::kShardStages]));
+        for (int i = 0; i < lg_ctx::kShardStages; i++) {
+            float ms = 0;
+            LG_HIP(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (int i = 0; i < lg_ctx::kShardStages; i++) ms_out[i] = (float)(acc[i] / (double)have);
+    if (samples_out) *samples_out = (uint32_t)have;
     return LG_OK;
 }
 

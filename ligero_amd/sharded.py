@@ -64,18 +64,135 @@ class _CudaArray:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+_AG = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, _vp)
+_P2P = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp)
+
+
+class _LgComm(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("user", _vp),
+                ("all_gather", _AG), ("send", _P2P), ("recv", _P2P), ("broadcast", _P2P)]
+
+
+class TorchComm:
+    """include/ligero_hip.h `lg_comm` served by torch.distributed (backend "nccl" = RCCL over xGMI): the library calls back with
+    a device pointer and one of ITS streams; the collective is issued with that stream current, so it is ordered with the
+    library's kernels on both sides and nothing waits on the host.  Backends that cannot move device memory point to point
+    (gloo in the tests) get host copies, made on the same stream."""
+
+    def __init__(self, dist, group=None, device: int = 0, exchange_at_world_1: bool = False):
+        self.dist, self.group, self.device = dist, group, device
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.error: Optional[str] = None
+        self._nccl = dist is not None and dist.get_backend(group) == "nccl"
+        self._streams = {}
+        self._cbs = (_AG(self._all_gather), _P2P(self._send), _P2P(self._recv), _P2P(self._broadcast))   # kept alive with the object
+        flags = _ffi.LG_COMM_EXCHANGE_AT_WORLD_1 if (exchange_at_world_1 and dist is not None) else 0
+        if dist is None:
+            self.struct = _LgComm(1, 0, 0, None, _AG(), _P2P(), _P2P(), _P2P())
+        else:
+            self.struct = _LgComm(self.world, self.rank, flags, None, *self._cbs)
+
+    def ptr(self):
+        return ctypes.cast(ctypes.byref(self.struct), _vp)
+
+    def _on(self, stream):
+        import torch
+        key = int(stream or 0)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.ExternalStream(key, device=f"cuda:{self.device}") if key else torch.cuda.default_stream(self.device)
+        return torch.cuda.stream(self._streams[key])
+
+    def _tensor(self, ptr, nbytes):
+        import torch
+        return torch.as_tensor(_CudaArray(int(ptr), int(nbytes)), device=f"cuda:{self.device}")
+
+    def _guard(self, what, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:          # an exception must not unwind through the C caller
+            self.error = f"{what}: {e!r}"
+            return -1
+
+    def _all_gather(self, _user, buf, bytes_per_rank, stream):
+        def go():
+            n = int(bytes_per_rank)
+            with self._on(stream):
+                t = self._tensor(buf, self.world * n)
+                self.dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n], group=self.group)
+        return self._guard("all_gather", go)
+
+    def _send(self, _user, buf, nbytes, dst, stream):
+        def go():
+            with self._on(stream):
+                t = self._tensor(buf, nbytes)
+                self.dist.send(t if self._nccl else t.cpu(), int(dst), group=self.group)
+        return self._guard("send", go)
+
+    def _recv(self, _user, buf, nbytes, src, stream):
+        def go():
+            import torch
+            with self._on(stream):
+                t = self._tensor(buf, nbytes)
+                if self._nccl:
+                    self.dist.recv(t, int(src), group=self.group)
+                else:
+                    h = torch.empty(int(nbytes), dtype=torch.uint8)
+                    self.dist.recv(h, int(src), group=self.group)
+                    t.copy_(h)
+        return self._guard("recv", go)
+
+    def _broadcast(self, _user, buf, nbytes, root, stream):
+        def go():
+            with self._on(stream):
+                t = self._tensor(buf, nbytes)
+                if self._nccl:
+                    self.dist.broadcast(t, int(root), group=self.group)
+                else:
+                    h = t.cpu()
+                    self.dist.broadcast(h, int(root), group=self.group)
+                    if self.rank != int(root):
+                        t.copy_(h)
+        return self._guard("broadcast", go)
+
+
+def shard_row_ranges(rows: int, world: int, rank: int, pieces: int = 1) -> List[Tuple[int, int]]:
+    """[(first row, rows)] of the ranges `rank` owns in the coset-sharded commit, in the order its rows are handed over
+    (lg_shard_row_ranges): the rows are cut into `pieces` pieces of world * sub rows, the rank owns sub-block `rank` of every
+    piece; pieces = 1 is the equal (padded) shard of ceil(rows / world) rows"""
+    pieces = max(1, min(int(pieces), 8))
+    per_piece = -(-rows // pieces)
+    sub = max(1, -(-per_piece // world))
+    out = []
+    for p in range(-(-rows // (world * sub))):
+        a = p * world * sub + rank * sub
+        b = min(rows, a + sub)
+        if b > a:
+            out.append((a, b - a))
+    return out
+
+
+def shard_piece_rows(rows: int, world: int, pieces: int = 1) -> Tuple[int, int]:
+    """(rows per sub-block, pieces that hold a row) of shard_row_ranges' rule"""
+    pieces = max(1, min(int(pieces), 8))
+    sub = max(1, -(-(-(-rows // pieces)) // world))
+    return sub, -(-rows // (world * sub))
+
+
 class HipStageBackend:
     """Staged single-proof commit on this rank's GPU through the C ABI (include/ligero_hip.h:
     lg_stage_interpolate / lg_stage_evaluate_hash / lg_stage_merkle / lg_device_buffer)."""
 
-    def __init__(self, rows: int, k: int, device: int = 0, world: int = 1, rank: int = 0):
+    def __init__(self, rows: int, k: int, device: int = 0, world: int = 1, rank: int = 0, pieces: int = 1):
         """One rank of `world`: the context allocates only this rank's coset planes of U and a coefficient buffer
-        padded to `world` equal row shards (lg_ctx_create_sharded)."""
+        padded to whole exchange pieces of `world` equal sub-blocks (lg_ctx_create_sharded)."""
         from .ligero import LigeroCommitter
         self.rows, self.k, self.n, self.device = rows, k, 8 * k, device
         self.nplanes = 8 if k <= 4096 else 8 * (k // 4096)
         planes = owned_planes(self.nplanes, world, rank)
-        self.coeff_rows = world * padded_shard_rows(rows, world)
+        sub, np_ = shard_piece_rows(rows, world, pieces)
+        self.coeff_rows = max(world * padded_shard_rows(rows, world), np_ * world * sub)
         self.c = LigeroCommitter(rows=rows, k=k, batch=1, device=device, shard=(planes[0], len(planes), self.coeff_rows))
         assert self.c.planes() == (self.nplanes, planes[0], len(planes))
         self._L = _ffi.lib()
@@ -149,65 +266,137 @@ class HipStageBackend:
     def open_columns(self, indices):
         return self.c.open_columns(indices)
 
+    def commit_native(self, comm: TorchComm, preenc_rows: Optional[np.ndarray], pieces: int = 1):
+        """lg_commit_sharded: the whole commit as ONE call, queued on the library's streams; the exchanges come back through
+        `comm`.  Returns nothing: root() waits for the tree."""
+        p = None
+        if preenc_rows is not None:
+            preenc_rows = np.ascontiguousarray(preenc_rows, dtype=np.uint64)
+            p = preenc_rows.ctypes.data_as(_vp)
+        comm.error = None
+        st = self._L.lg_commit_sharded(self.c._ctx, comm.ptr(), p, pieces)
+        if st == _ffi.LG_ERR_COMM and comm.error:
+            raise RuntimeError(f"lg_commit_sharded: {comm.error}")
+        _ffi.check(st, "lg_commit_sharded", self.c._ctx)
+
+    def profile(self, on: bool = True):
+        self.c.profile(on)
+
+    def shard_stage_ms(self) -> Dict[str, float]:
+        out = (ctypes.c_float * 5)()
+        n = ctypes.c_uint32(0)
+        _ffi.check(self._L.lg_shard_profile_read(self.c._ctx, ctypes.cast(out, _vp), ctypes.cast(ctypes.byref(n), _vp)), "lg_shard_profile_read", self.c._ctx)
+        return dict(zip(_ffi.LG_SHARD_STAGE_NAMES, [float(x) for x in out]))
+
     def close(self):
         self.c.close()
 
 
 class CosetShardedCommitter:
     """One proof over `world` ranks.  `backend` does the device work; `dist` is torch.distributed
-    (already initialised) or None for a single process."""
+    (already initialised) or None for a single process.
+
+    Row ownership (shard_row_ranges): with exchange_pieces = 1 rank g interpolates the g-th of `world` equal shards; with
+    exchange_pieces = P the rows are cut into P pieces and rank g owns sub-block g of every piece, so that piece p of the
+    coefficient all-gather is one in-place collective that travels while piece p - 1 is evaluated, and the column hash --
+    which needs the rows in order -- follows the evaluation piece by piece.
+
+    A backend with `commit_native` (HipStageBackend) runs the whole commit as ONE library call (lg_commit_sharded): a
+    stream-ordered sequence with the collectives called back through TorchComm, HIP-event stage times, no host
+    synchronisation in between.  Any other backend (the oracle-backed double of the CPU tests) is driven stage by stage
+    from here with the same ownership rule."""
 
     def __init__(self, backend, dist=None, group=None, collectives_at_world_1: bool = False, exchange_pieces: int = 1):
         """collectives_at_world_1: issue the two all-gathers even in a one-rank group (they are identities then) -- lets a
-        one-GPU box run the exact RCCL calls of the multi-GPU path (bench.py LIGERO_BENCH_FORCE_DIST, tests).
-        exchange_pieces > 1: the coefficient all-gather is cut into that many pieces (piece c = the c-th slice of EVERY rank's
-        shard, so every piece uses all links), issued asynchronously, and the evaluation of piece c runs while piece c + 1
-        is on the wire; the column hash, which needs the rows in order, follows the last piece (commit_pipelined)."""
+        one-GPU box run the exact RCCL calls of the multi-GPU path (bench.py LIGERO_BENCH_FORCE_DIST, tests)."""
         self.be = backend
         self.dist = dist
         self.group = group
-        self.pieces = max(1, int(exchange_pieces))
-        self._piece_buf = [None, None]
         self.force = bool(collectives_at_world_1) and dist is not None
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
         self.planes = owned_planes(backend.nplanes, self.world, self.rank)
+        self.sub_rows, self.pieces = shard_piece_rows(backend.rows, self.world, exchange_pieces)
+        self._asked_pieces = max(1, min(int(exchange_pieces), 8))
         self.shard_rows = padded_shard_rows(backend.rows, self.world)
-        self.stage_ms: Dict[str, float] = {}      # wall time of each stage of the last commit() (each ends in a device sync)
+        self.stage_ms: Dict[str, float] = {}      # per-stage ms of the last commit(s): HIP events (native) or host laps (stage by stage)
         self._digest_buf = None
+        self.native = hasattr(backend, "commit_native")
+        self._comm = TorchComm(dist, group, backend.device, exchange_at_world_1=self.force) if self.native else None
+        self._profiling = False
+
+    def row_ranges(self, rank: Optional[int] = None) -> List[Tuple[int, int]]:
+        """the row ranges this rank hands to commit(), concatenated in this order"""
+        return shard_row_ranges(self.be.rows, self.world, self.rank if rank is None else rank, self._asked_pieces)
 
     def row_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
+        """[begin, end) of the single shard of exchange_pieces = 1"""
+        if self.pieces > 1:
+            raise ValueError("with exchange pieces a rank owns several ranges: row_ranges()")
         return padded_shard_range(self.be.rows, self.world, self.rank if rank is None else rank)
 
+    def piece_plan(self) -> List[Tuple[int, int]]:
+        """[(first row, rows)] of the exchange pieces (whole sub-blocks of every rank; the last one may be short)"""
+        pr = self.world * self.sub_rows
+        return [(p * pr, min(pr, self.be.rows - p * pr)) for p in range(self.pieces)]
+
     def commit(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
-        """preenc_rows_local: this rank's rows [row_range()) of preenc_u (None: they are resident from an earlier
+        """preenc_rows_local: this rank's rows (row_ranges(), concatenated; None: they are resident from an earlier
         commit).  Returns u_root."""
-        if self.pieces > 1 and (self.world > 1 or self.force):
-            return self.commit_pipelined(preenc_rows_local)
+        if self.native:
+            if not self._profiling:
+                self.be.profile(True)
+                self._profiling = True
+            self.be.commit_native(self._comm, preenc_rows_local, self._asked_pieces)
+            root = self.be.root()                       # waits for the tree: the only host wait of the commit
+            self.stage_ms = self.be.shard_stage_ms()
+            return root
+        return self._commit_staged(preenc_rows_local)
+
+    def commit_queued(self, preenc_rows_local: Optional[np.ndarray] = None):
+        """native backends: queue the commit and return at once (bench.py times a stream of them between two fences)"""
+        if not self._profiling:
+            self.be.profile(True)
+            self._profiling = True
+        self.be.commit_native(self._comm, preenc_rows_local, self._asked_pieces)
+
+    def _commit_staged(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
         be, dist = self.be, self.dist
         ms = self.stage_ms = {}
-        r0, r1 = self.row_range()
         t = time.perf_counter()
 
-        def lap(name):
+        def lap(name, add=False):
             nonlocal t
             now = time.perf_counter()
-            ms[name] = (now - t) * 1e3
+            ms[name] = ms.get(name, 0.0) + (now - t) * 1e3 if add else (now - t) * 1e3
             t = now
 
-        be.stage_interpolate(preenc_rows_local, r0, r1 - r0)
+        ranges = self.row_ranges()
+        off = 0
+        for r0, n in ranges:
+            be.stage_interpolate(None if preenc_rows_local is None else preenc_rows_local[off:off + n], r0, n)
+            off += n
         be.sync()
         lap("interpolate")
-        if self.world > 1 or self.force:
-            # equal (padded) shards: ONE in-place all-gather whatever rows % world is
-            coeffs = be.coeffs_bytes()
-            p0 = self.rank * self.shard_rows
-            dist.all_gather_into_tensor(coeffs.view(-1), coeffs[p0:p0 + self.shard_rows].view(-1), group=self.group)
-            self._device_sync(coeffs)
-        lap("allgather_coeffs")
-        be.stage_evaluate_hash(self.planes)
+        ms["allgather_coeffs"] = ms["evaluate_hash"] = 0.0
+        exchange = self.world > 1 or self.force
+        coeffs = be.coeffs_bytes() if exchange else None
+        pr = self.world * self.sub_rows
+        for p, (r0, n) in enumerate(self.piece_plan()):
+            if exchange:
+                block = coeffs[p * pr:(p + 1) * pr]                  # whole piece: `world` equal sub-blocks, this rank's in place
+                dist.all_gather_into_tensor(block.view(-1), block[self.rank * self.sub_rows:(self.rank + 1) * self.sub_rows].view(-1), group=self.group)
+                self._device_sync(coeffs)
+            lap("allgather_coeffs", add=True)
+            if self.pieces > 1:
+                be.stage_evaluate_rows(self.planes, r0, n)
+                lap("evaluate_hash", add=True)
+        if self.pieces > 1:
+            be.stage_hash(self.planes)
+        else:
+            be.stage_evaluate_hash(self.planes)
         be.sync()
-        lap("evaluate_hash")
+        lap("evaluate_hash", add=True)
         return self._digests_and_tree(ms)
 
     def _digests_and_tree(self, ms: Dict[str, float]) -> bytes:
@@ -230,73 +419,6 @@ class CosetShardedCommitter:
         be.sync()
         ms["merkle"] = (time.perf_counter() - t) * 1e3
         return be.root()
-
-    def piece_plan(self) -> List[Tuple[int, int]]:
-        """[(first row inside a shard, rows)] of the exchange pieces: equal slices of the padded shard, the last one short"""
-        per = -(-self.shard_rows // min(self.pieces, max(1, self.shard_rows)))
-        return [(o, min(per, self.shard_rows - o)) for o in range(0, self.shard_rows, per)]
-
-    def commit_pipelined(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
-        """commit() with the coefficient all-gather hidden behind the evaluation.  Piece c of the exchange is rows
-        [o_c, o_c + n_c) of every rank's shard: one all_gather_into_tensor into a staging buffer (two, alternating) and one
-        strided copy into LG_BUF_COEFFS; its rows are then evaluated (lg_stage_evaluate_rows, one call per source shard, padding
-        rows of the last shard skipped) while the next piece is in flight.  stage_ms: `allgather_coeffs` is the time this
-        rank spent WAITING for pieces, `evaluate_hash` the rest of the loop plus the hash."""
-        import torch
-        be, dist = self.be, self.dist
-        ms = self.stage_ms = {}
-        r0, r1 = self.row_range()
-        t = time.perf_counter()
-        be.stage_interpolate(preenc_rows_local, r0, r1 - r0)
-        be.sync()
-        ms["interpolate"] = (time.perf_counter() - t) * 1e3
-        coeffs = be.coeffs_bytes()                                   # [world * shard_rows, k * 32]
-        width = coeffs.shape[1]
-        shards = coeffs.view(self.world, self.shard_rows, width)
-        plan = self.piece_plan()
-        cap = plan[0][1]
-        for i in (0, 1):
-            if self._piece_buf[i] is None or self._piece_buf[i].device != coeffs.device or self._piece_buf[i].shape != (self.world, cap, width):
-                self._piece_buf[i] = torch.empty((self.world, cap, width), dtype=coeffs.dtype, device=coeffs.device)
-
-        def start(c):
-            o, n = plan[c]
-            out = self._piece_buf[c & 1][:, :n, :] if n == cap else self._piece_buf[c & 1].view(-1)[:self.world * n * width].view(self.world, n, width)
-            mine = shards[self.rank, o:o + n, :]
-            return out, dist.all_gather_into_tensor(out.reshape(-1), mine.reshape(-1), group=self.group, async_op=True)
-
-        wait_s = 0.0
-        t_loop = time.perf_counter()
-        pending = start(0)
-        for c, (o, n) in enumerate(plan):
-            out, work = pending
-            tw = time.perf_counter()
-            work.wait()                                              # torch's current stream now follows the collective ...
-            self._stream_sync(coeffs)                                # ... and the host follows that stream (NOT the library's streams,
-            wait_s += time.perf_counter() - tw                       #     where the previous piece may still be being evaluated)
-            # every other rank's slice goes to its place (this rank's own rows are already there)
-            for g in range(self.world):
-                if g != self.rank:
-                    shards[g, o:o + n, :].copy_(out[g])
-            self._stream_sync(coeffs)                                # the library's stream may read them from here on
-            if c + 1 < len(plan):
-                pending = start(c + 1)                               # on the wire while the rows below are evaluated
-            for g in range(self.world):
-                a = g * self.shard_rows + o
-                b = min(a + n, be.rows)                              # the last shard is short: its padding rows are never evaluated
-                if b > a:
-                    be.stage_evaluate_rows(self.planes, a, b - a)
-        be.stage_hash(self.planes)
-        be.sync()
-        ms["allgather_coeffs"] = wait_s * 1e3
-        ms["evaluate_hash"] = (time.perf_counter() - t_loop - wait_s) * 1e3
-        return self._digests_and_tree(ms)
-
-    @staticmethod
-    def _stream_sync(t):
-        if t.is_cuda:
-            import torch
-            torch.cuda.current_stream(t.device).synchronize()
 
     @staticmethod
     def _device_sync(t):
@@ -392,6 +514,30 @@ class HipRelayBackend:
         mask = ((1 << nplanes) - 1) << plane0
         _ffi.check(self._L.lg_stage_hash_rows(self.c._ctx, mask, row0, nrows, col_pos, col_rows), "lg_stage_hash_rows", self.c._ctx)
 
+    def commit_native(self, comm: TorchComm, col_rows: int, layout: str, preenc_rows: Optional[np.ndarray]):
+        """lg_commit_row_relay: the whole commit as ONE call, queued on the library's streams; the hand-over of the column
+        states and the broadcast of the digests come back through `comm`"""
+        p = None
+        if preenc_rows is not None:
+            preenc_rows = np.ascontiguousarray(preenc_rows, dtype=np.uint64)
+            p = preenc_rows.ctypes.data_as(_vp)
+        comm.error = None
+        st = self._L.lg_commit_row_relay(self.c._ctx, comm.ptr(), col_rows, {"contiguous": _ffi.LG_RELAY_CONTIGUOUS, "blocks": _ffi.LG_RELAY_BLOCKS}[layout], p)
+        if st == _ffi.LG_ERR_COMM and comm.error:
+            raise RuntimeError(f"lg_commit_row_relay: {comm.error}")
+        _ffi.check(st, "lg_commit_row_relay", self.c._ctx)
+
+    def profile(self, on: bool = True):
+        self.c.profile(on)
+
+    def shard_stage_ms(self) -> Dict[str, float]:
+        out = (ctypes.c_float * 5)()
+        n = ctypes.c_uint32(0)
+        _ffi.check(self._L.lg_shard_profile_read(self.c._ctx, ctypes.cast(out, _vp), ctypes.cast(ctypes.byref(n), _vp)), "lg_shard_profile_read", self.c._ctx)
+        d = dict(zip(_ffi.LG_RELAY_STAGE_NAMES, [float(x) for x in out]))
+        d.pop("unused")
+        return d
+
     def hstate_bytes(self):
         """[nplanes, ki * LG_HSTATE_BYTES] uint8 view of the parked Blake2s states (settles the hash stream)"""
         return self._buffer(_ffi.LG_BUF_HSTATE).view(self.nplanes, self.ki * _ffi.LG_HSTATE_BYTES)
@@ -464,6 +610,10 @@ class RowRelayCommitter:
         self.stage_ms: Dict[str, float] = {}
         self._stream = self.be.stream() if hasattr(self.be, "stream") else None
         self._nccl = dist is not None and dist.get_backend(group) == "nccl"
+        # one library call per commit (lg_commit_row_relay) where the backend has it; plane groups are driven from here
+        self.native = hasattr(self.be, "commit_native") and self.groups == 1
+        self._comm = TorchComm(dist, group, self.be.device, exchange_at_world_1=self.force) if self.native else None
+        self._profiling = False
 
     def row_ranges(self, rank: Optional[int] = None) -> List[Tuple[int, int]]:
         return relay_row_ranges(self.rows, self.world, self.rank if rank is None else rank, self.layout)
@@ -492,6 +642,11 @@ class RowRelayCommitter:
     def commit(self, preenc_rows_local: Optional[np.ndarray]) -> bytes:
         """preenc_rows_local: this rank's rows (its ranges, concatenated in column order), or None when they are resident from
         an earlier commit.  Returns u_root."""
+        if self.native:
+            self.commit_queued(preenc_rows_local)
+            root = self.be.root()                       # waits for the tree: the only host wait of the commit
+            self.stage_ms = self.be.shard_stage_ms()
+            return root
         import contextlib
         import torch
         be = self.be
@@ -552,6 +707,13 @@ class RowRelayCommitter:
         for (_, a), (name, b) in zip(marks, marks[1:]):
             ms[name] = a.elapsed_time(b) if self._stream is not None else (b - a) * 1e3
         return be.root()
+
+    def commit_queued(self, preenc_rows_local: Optional[np.ndarray] = None):
+        """native backends: queue the commit and return at once"""
+        if not self._profiling:
+            self.be.profile(True)
+            self._profiling = True
+        self.be.commit_native(self._comm, self.rows, self.layout, preenc_rows_local)
 
     def open_columns(self, indices: Sequence[int]):
         """every rank holds ITS ROWS of every column: returns (rows of the columns [t, local_rows, 4] in this rank's own row

@@ -92,3 +92,29 @@ def test_host_dimension_helpers(vectors):
     assert ligero_amd.compute_dimensions(15) == (4, 4)
     for k, t in vectors["calculate_t"].items():
         assert ligero_amd.reed_solomon_parameters(int(k), int(k), 128) == (8 * int(k), t)
+
+
+def test_row_ownership_rules_of_the_library_equal_the_host_layer():
+    """lg_shard_row_ranges / lg_relay_row_ranges (pure host functions of the C ABI: which rows a rank owns in the two
+    multi-GPU modes) against ligero_amd.sharded's statement of the same rules, incl. BASELINE configs[3]'s 20 068 rows on 8 GPUs"""
+    import ctypes
+    import numpy as np
+    from ligero_amd import _ffi
+    from ligero_amd.sharded import relay_row_ranges, shard_row_ranges
+    L = _ffi.lib()
+    vp = ctypes.c_void_p
+    for rows, world in [(20068, 8), (10036, 8), (344, 4), (7, 2), (3, 4), (1, 8), (64, 1)]:
+        for pieces in (1, 2, 3, 4, 8, 50):
+            for rank in range(world):
+                out, n = np.zeros(16, dtype=np.uint32), ctypes.c_uint32(0)
+                assert L.lg_shard_row_ranges(rows, world, rank, pieces, out.ctypes.data_as(vp), ctypes.cast(ctypes.byref(n), vp)) == 0
+                assert [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)] == shard_row_ranges(rows, world, rank, pieces)
+        for layout, code in (("contiguous", _ffi.LG_RELAY_CONTIGUOUS), ("blocks", _ffi.LG_RELAY_BLOCKS)):
+            if layout == "blocks" and rows % 4:
+                continue
+            for rank in range(world):
+                out, n = np.zeros(8, dtype=np.uint64), ctypes.c_uint32(0)
+                assert L.lg_relay_row_ranges(rows, world, rank, code, out.ctypes.data_as(vp), ctypes.cast(ctypes.byref(n), vp)) == 0
+                assert [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)] == relay_row_ranges(rows, world, rank, layout)
+    bad = np.zeros(8, dtype=np.uint64)
+    assert L.lg_relay_row_ranges(10, 2, 0, _ffi.LG_RELAY_BLOCKS, bad.ctypes.data_as(vp), ctypes.cast(ctypes.byref(ctypes.c_uint32(0)), vp)) == _ffi.LG_ERR_BAD_ARG

@@ -26,13 +26,15 @@ def _free_port():
 def _rank_body(rank, world, dist, rows, k, pieces=1):
     from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
     pre = random_mont(515, rows * k).reshape(rows, k, 4)               # same seed on every rank
-    be = HipStageBackend(rows, k, device=0, world=world, rank=rank)     # only this rank's planes of U are allocated
+    be = HipStageBackend(rows, k, device=0, world=world, rank=rank, pieces=pieces)     # only this rank's planes of U are allocated
     try:
         sc = CosetShardedCommitter(be, dist, exchange_pieces=pieces)
-        r0, r1 = sc.row_range()
-        root = sc.commit(pre[r0:r1])
+        assert sc.native                                                       # one lg_commit_sharded call per commit
+        mine = sc.row_ranges()                                                 # one shard, or one sub-block of every exchange piece
+        local = np.concatenate([pre[a:a + n] for a, n in mine]) if mine else None
+        root = sc.commit(local)
         if pieces > 1:
-            assert sc.commit(None) == root                                     # resident rows, staging buffers reused
+            assert sc.commit(None) == root                                     # resident rows
         opened = sc.open_columns([0, 5, 8 * k - 1])
         # a column of a plane the OTHER rank owns must be refused by the C ABI itself, not served from foreign memory
         foreign = ((rank + 1) % world) * (be.nplanes // world)                # first plane of the next rank
@@ -127,10 +129,11 @@ def test_world4_and_world8_on_one_gpu(oracle, world, rows, k):
 
 @pytest.mark.parametrize("world,rows,k,pieces", [(2, 21, 128, 3), (2, 6, 4096, 2), (2, 5, 8192, 2), (4, 10, 128, 4), (8, 23, 128, 2), (8, 9, 8192, 3)])
 def test_pipelined_exchange_on_the_real_backend(oracle, world, rows, k, pieces):
-    """CosetShardedCommitter(exchange_pieces > 1): the coefficient all-gather in pieces (asynchronous, slice c of every rank's
-    shard), lg_stage_evaluate_rows on the rows of a piece while the next one is on the wire, lg_stage_hash after the last --
-    root and owner-served openings equal the oracle's; ragged / short / empty shards, folded k = 8192, a second commit from
-    resident rows.  Worlds 2 and 4: gloo processes; world 8: threads of this process (tests/thread_dist.py)"""
+    """CosetShardedCommitter(exchange_pieces > 1) = lg_commit_sharded(pieces): every rank owns a sub-block of every piece, piece p
+    of the coefficient all-gather is one in-place collective on the library's exchange stream while piece p - 1 is evaluated,
+    and the column hash follows piece by piece on the hash stream -- root and owner-served openings equal the oracle's; ragged /
+    short / empty sub-blocks, folded k = 8192, a second commit from resident rows.  Worlds 2 and 4: gloo processes; world 8:
+    threads of this process (tests/thread_dist.py)"""
     if world <= 4:
         import torch.multiprocessing as mp
         mgr = mp.Manager()
@@ -163,19 +166,27 @@ def _rccl_pipelined_worker(rows, k, pieces, out):
     try:
         from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
         pre = random_mont(617, rows * k).reshape(rows, k, 4)
-        be = HipStageBackend(rows, k, device=0, world=1, rank=0)
+        be = HipStageBackend(rows, k, device=0, world=1, rank=0, pieces=pieces)
         sc = CosetShardedCommitter(be, dist, collectives_at_world_1=True, exchange_pieces=pieces)
         out["root"] = sc.commit(pre)
         out["again"] = sc.commit(None)
         out["plan"] = sc.piece_plan()
+        out["stage_ms"] = dict(sc.stage_ms)
         be.close()
+        # ... and the row relay's identity broadcast of the digests through the same callbacks
+        from ligero_amd.sharded import HipRelayBackend, RowRelayCommitter
+        rc = RowRelayCommitter(lambda local: HipRelayBackend(local, k, device=0), rows, dist, collectives_at_world_1=True)
+        out["relay_root"] = rc.commit(pre)
+        out["relay_native"] = rc.native
+        rc.be.close()
     finally:
         dist.destroy_process_group()
 
 
 def test_pipelined_exchange_over_rccl_at_world_1(oracle):
-    """the asynchronous RCCL all-gathers of the pipelined commit (async_op=True on staging buffers, strided copy into the
-    library's coefficient buffer, evaluation from the library's own stream meanwhile) at world size 1 on this box's GPU"""
+    """lg_commit_sharded's callbacks served by RCCL (torch.distributed "nccl" under the library's own streams, TorchComm): the
+    in-place all-gather of every piece on the exchange stream, the digest all-gather, the row relay's broadcast -- at world
+    size 1 on this box's GPU"""
     import torch.multiprocessing as mp
     rows, k, pieces = 37, 1024, 4
     mgr = mp.Manager()
@@ -187,6 +198,8 @@ def test_pipelined_exchange_over_rccl_at_world_1(oracle):
     pre = random_mont(617, rows * k).reshape(rows, k, 4)
     want = oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
     assert out["root"] == want and out["again"] == want and len(out["plan"]) == 4
+    assert set(out["stage_ms"]) == {"interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle"}
+    assert out["relay_root"] == want and out["relay_native"]
 
 
 def test_partial_commitments_refuse_foreign_data(oracle):

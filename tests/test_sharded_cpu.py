@@ -21,12 +21,13 @@ sys.path.insert(0, ROOT)
 class OracleStageBackend:
     """test double for ligero_amd.sharded.HipStageBackend (same methods), CPU + oracle"""
 
-    def __init__(self, rows, k, world=1):
+    def __init__(self, rows, k, world=1, pieces=1):
         from oracle import binding as orc
-        from ligero_amd.sharded import padded_shard_rows
+        from ligero_amd.sharded import padded_shard_rows, shard_piece_rows
         self.orc = orc
         self.rows, self.k, self.n, self.nplanes = rows, k, 8 * k, 8
-        self.coeff_rows = world * padded_shard_rows(rows, world)          # equal all-gather shards (padding rows stay 0xff)
+        sub, npieces = shard_piece_rows(rows, world, pieces)
+        self.coeff_rows = max(world * padded_shard_rows(rows, world), npieces * world * sub)   # whole exchange pieces (padding rows stay 0xff)
         self.preenc = np.zeros((rows, k, 4), dtype=np.uint64)
         self.coeffs = np.full((self.coeff_rows, k, 4), np.uint64(2**64 - 1), dtype=np.uint64)
         self.leaves = np.zeros((self.n, 32), dtype=np.uint8)
@@ -35,7 +36,8 @@ class OracleStageBackend:
         self._fresh = True
 
     def stage_interpolate(self, preenc_rows, row0, nrows):
-        self.preenc[row0:row0 + nrows] = np.asarray(preenc_rows).reshape(nrows, self.k, 4)
+        if preenc_rows is not None:
+            self.preenc[row0:row0 + nrows] = np.asarray(preenc_rows).reshape(nrows, self.k, 4)
         for r in range(row0, row0 + nrows):
             self.coeffs[r] = self.orc.reed_solomon_interpolate(self.preenc[r], self.k)
 
@@ -212,30 +214,35 @@ def _worker_pieces(rank, world, port, rows, k, pieces, out):
     try:
         from ligero_amd.sharded import CosetShardedCommitter
         pre = random_mont(31, rows * k).reshape(rows, k, 4)
-        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), dist, exchange_pieces=pieces)
-        r0, r1 = sc.row_range()
-        root = sc.commit(pre[r0:r1])
-        again = sc.commit(pre[r0:r1])                                       # the staging buffers are reused
-        out[rank] = (root, again, sc.piece_plan(), sorted(sc.stage_ms))
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world, pieces), dist, exchange_pieces=pieces)
+        mine = sc.row_ranges()
+        local = np.concatenate([pre[a:a + n] for a, n in mine]) if mine else None
+        root = sc.commit(local)
+        again = sc.commit(None)                                             # resident rows
+        out[rank] = (root, again, sc.piece_plan(), sorted(sc.stage_ms), mine)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,rows,k,pieces", [(2, 12, 4, 2), (2, 13, 4, 3), (4, 9, 2, 2), (2, 3, 4, 8)])
 def test_pipelined_exchange_matches_single_process(oracle, world, rows, k, pieces):
-    """exchange_pieces > 1: the coefficient all-gather in pieces (slice c of every shard), issued asynchronously, rows evaluated
-    as they arrive, hash after the last piece -- even, ragged and short last shards, more pieces than shard rows"""
+    """exchange_pieces > 1: every rank owns a sub-block of every piece, so each piece of the coefficient all-gather is one
+    in-place collective on whole rows and complete row prefixes arrive in order -- even, ragged and short last pieces, more
+    pieces than rows per rank"""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_pieces, args=(world, _free_port(), rows, k, pieces, out), nprocs=world, join=True)
     pre = random_mont(31, rows * k).reshape(rows, k, 4)
     ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
-    shard = -(-rows // world)
+    owned = []
     for rank in range(world):
-        root, again, plan, stages = out[rank]
+        root, again, plan, stages, mine = out[rank]
         assert root == ref["root"] and again == ref["root"], rank
-        assert sum(n for _, n in plan) == shard and [o for o, _ in plan] == sorted(o for o, _ in plan) and len(plan) <= pieces
+        assert sum(n for _, n in plan) == rows and [o for o, _ in plan] == sorted(o for o, _ in plan) and len(plan) <= pieces
         assert stages == ["allgather_coeffs", "allgather_digests", "evaluate_hash", "interpolate", "merkle"]
+        assert len(mine) <= len(plan)                                    # at most one sub-block per piece
+        owned += [r for a, n in mine for r in range(a, a + n)]
+    assert sorted(owned) == list(range(rows))                            # every row has exactly one owner
 
 
 def test_pipelined_exchange_on_eight_thread_ranks(oracle):
@@ -245,9 +252,9 @@ def test_pipelined_exchange_on_eight_thread_ranks(oracle):
     pre = random_mont(32, rows * k).reshape(rows, k, 4)
 
     def body(rank, tdist):
-        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world), tdist, exchange_pieces=2)
-        r0, r1 = sc.row_range()
-        return sc.commit(pre[r0:r1])
+        sc = CosetShardedCommitter(OracleStageBackend(rows, k, world, 2), tdist, exchange_pieces=2)
+        mine = sc.row_ranges()
+        return sc.commit(np.concatenate([pre[a:a + n] for a, n in mine]) if mine else None)
 
     ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
     assert all(root == ref["root"] for root in run_ranks(world, body))
@@ -268,3 +275,9 @@ def test_single_process_degenerate(oracle):
     assert [padded_shard_range(5, 4, r) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
     with pytest.raises(ValueError):
         owned_planes(8, 3, 0)
+    # exchange pieces: rank g owns sub-block g of every piece (the rule lg_shard_row_ranges implements in the library)
+    from ligero_amd.sharded import shard_row_ranges
+    assert shard_row_ranges(20068, 8, 0, 1) == [(0, 2509)] and shard_row_ranges(20068, 8, 7, 1) == [(17563, 2505)]
+    assert shard_row_ranges(20068, 8, 3, 4) == [(1884 + p * 5024, 628) for p in range(3)] + [(1884 + 3 * 5024, 628)]
+    assert shard_row_ranges(20068, 8, 7, 4)[-1] == (4396 + 3 * 5024, 20068 - (4396 + 3 * 5024))
+    assert shard_row_ranges(3, 4, 3, 8) == [] and shard_row_ranges(3, 4, 2, 8) == [(2, 1)]
