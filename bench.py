@@ -115,13 +115,10 @@ def usable_cpus() -> int:
     return n
 
 
-def full_prover_rate(device: int, steps: int = 8):
-    """proofs/s of the complete prove() (ligero_amd/host/prover.hpp: commit + three sub-proofs + openings + transcript)
-    on the 64 committed Poseidon witnesses, batch-wide device calls + host threads.  The transcript is the restated
-    test_sponge() -- unpinned against the Rust crates (DESIGN.md 4.8) -- so this is the cost of the same work, not a
-    claim of byte-identical proofs."""
+def poseidon_batch_inputs():
+    """the Poseidon R1CS instance and the 64 committed witnesses (tests/golden/poseidon_witness_batch64.bin): (instance,
+    variable indices, Montgomery values (64, 264, 4))"""
     from ligero_amd import host_pipeline as hp
-    from ligero_amd.prover import LigeroBatchProver
     g = os.path.join(ROOT, "tests", "golden")
     inst = hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(os.path.join(g, "poseidon.r1cs")))
     blob = open(os.path.join(g, "poseidon_witness_batch64.bin"), "rb").read()
@@ -131,7 +128,38 @@ def full_prover_rate(device: int, steps: int = 8):
         for j in range(1, 265):
             v = (int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") << 256) % p      # Montgomery form
             vals[i, j - 1] = [(v >> (64 * l)) & mask for l in range(4)]
-    idx = list(range(1, 265))
+    return inst, list(range(1, 265)), vals
+
+
+def commit_leg(workload, e, st, launches, root, steps, tfile):
+    """one extra shape under the driver's clock: ms per step, dominant-kernel roofline, whole-commit algorithmic rate against the
+    HBM roof and the measured whole-commit HBM traffic over the algorithmic bytes (profiles/pmc_traffic.json)"""
+    r, k_, b_ = WORKLOADS[workload]
+    n_ = 8 * k_
+    dom, srl = roofline_of(workload, st, launches, tfile)
+    gold = golden_large(workload)
+    b_commit, _ = algorithmic_bytes(r, k_, n_, b_)
+    traffic = json.load(open(tfile)).get(workload) if os.path.exists(tfile) else None
+    leg = {"workload": f"{workload}: {b_} x ({r} x {k_} -> {n_})", "steps": steps, "ms_per_step": e / steps * 1e3,
+           "value": steps * b_ * r * n_ / e, "unit": "field-elems/s", "roofline": dom, "stage_rooflines": srl,
+           "valu_roofline": valu_roofline_of(workload, st), "root": root[:32].hex(),
+           "root_matches_golden": (root[:32].hex() == gold["root"]) if gold else None,
+           "commit_algorithmic_bytes": b_commit, "commit_algorithmic_GBs": b_commit * steps / e / 1e9,
+           "commit_roofline_frac": b_commit * steps / e / 1e9 / HBM_PEAK_GBS}
+    if traffic:
+        total = sum(v * (launches if s_ in ("evaluate", "colhash") else 1) for s_, v in traffic.items() if s_ in ("interpolate", "evaluate", "colhash", "merkle"))
+        leg["commit_traffic_bytes"] = total
+        leg["commit_traffic_over_algorithmic"] = total / b_commit
+    return leg
+
+
+def full_prover_rate(device: int, steps: int = 8):
+    """proofs/s of the complete prove() (ligero_amd/host/prover.hpp: commit + three sub-proofs + openings + transcript)
+    on the 64 committed Poseidon witnesses, batch-wide device calls + host threads.  The transcript is the restated
+    test_sponge() -- unpinned against the Rust crates (DESIGN.md 4.8) -- so this is the cost of the same work, not a
+    claim of byte-identical proofs."""
+    from ligero_amd.prover import LigeroBatchProver
+    inst, idx, vals = poseidon_batch_inputs()
     # four batch provers in flight: the host phases of one (transcript on host threads) overlap the device phases of the
     # others; measured on the GPU box (16 usable CPUs): 1 prover 2 600 proofs/s, 4 provers 4 500 proofs/s
     import threading
@@ -257,39 +285,50 @@ def s20_prover_rate(device: int, proofs: int = 2, log_n: int = 20):
             "note": "one proof at a time (single HipLigero prover): host evaluation trace + preenc_u assembly, then device; transcript unpinned"}
 
 
-def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0):
+def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0, min_s: float = 2.0):
     """The oracle (C restatement, reference-equivalent single-thread shape) timed on this
-    host's cores on a bounded sample of the same workload."""
+    host's cores on a bounded sample of the same workload: sized from a calibration call made AFTER a warm-up call (library
+    load, first-touch page faults and table set-up are not per-row costs), never less than `min_s` seconds of work."""
     from oracle import binding as orc        # cpu_baseline leg only: the checker, never the product
     pre = synthetic_preenc(1234, rows * k).reshape(rows, k, 4)
-    # calibrate on a few rows, then size the sample for ~budget_s of single-thread work
-    t0 = time.perf_counter()
     cal_rows = min(rows, 4 if k >= 1024 else 64)
+    orc.encode_commit(pre[:cal_rows], k, n, threads=1, want_u=False)       # warm-up
+    t0 = time.perf_counter()
     orc.encode_commit(pre[:cal_rows], k, n, threads=1, want_u=False)
-    per_row = (time.perf_counter() - t0) / cal_rows
+    per_row = max((time.perf_counter() - t0) / cal_rows, 1e-9)
     if per_row * rows * batch <= budget_s:
         sample_rows, sample_commits = rows, max(1, min(batch, int(budget_s / (per_row * rows))))
     else:
         sample_rows, sample_commits = max(4, min(rows, int(budget_s / per_row)) // 4 * 4), 1
+    elems, dt = 0, 0.0
     t0 = time.perf_counter()
-    for _ in range(sample_commits):
-        orc.encode_commit(pre[:sample_rows], k, n, threads=1, want_u=False)
-    dt = time.perf_counter() - t0
-    elems = sample_commits * sample_rows * n
+    while True:                              # the planned sample, repeated until at least min_s seconds have been measured
+        for _ in range(sample_commits):
+            orc.encode_commit(pre[:sample_rows], k, n, threads=1, want_u=False)
+        elems += sample_commits * sample_rows * n
+        dt = time.perf_counter() - t0
+        if dt >= min_s:
+            break
+    commits_done = elems // (sample_rows * n)
     out = {"value": elems / dt, "unit": "field-elems/s", "cores": 1, "kind": "port",
-           "sample": f"{sample_commits} x ({sample_rows} rows x {k} -> {n}) encode+column-hash+Merkle, serial "
+           "sample": f"{commits_done} x ({sample_rows} rows x {k} -> {n}) encode+column-hash+Merkle, serial "
                      f"reference-shaped C restatement (oracle/ligero_oracle.c), {dt:.1f} s",
            "host_cores_available": os.cpu_count(), "host_cores_usable": usable_cpus()}
     # all-cores variant of the same restatement, reported beside it
     nthr = min(orc.lib().orc_max_threads(), usable_cpus())
     if nthr > 1:
-        reps = max(1, min(sample_commits, 16))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            orc.encode_commit(pre[:sample_rows], k, n, threads=nthr, want_u=False)
-        dt2 = time.perf_counter() - t0
-        out["all_cores"] = {"value": reps * sample_rows * n / dt2, "cores": nthr,
-                            "sample": f"{reps} x ({sample_rows} rows x {k} -> {n}), rows / columns over OpenMP threads, {dt2:.1f} s"}
+        reps = max(1, min(commits_done, 16))
+        orc.encode_commit(pre[:sample_rows], k, n, threads=nthr, want_u=False)   # warm-up: thread pool start
+        done, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(reps):
+                orc.encode_commit(pre[:sample_rows], k, n, threads=nthr, want_u=False)
+            done += reps
+            dt2 = time.perf_counter() - t0
+            if dt2 >= min_s:
+                break
+        out["all_cores"] = {"value": done * sample_rows * n / dt2, "cores": nthr,
+                            "sample": f"{done} x ({sample_rows} rows x {k} -> {n}), rows / columns over OpenMP threads, {dt2:.1f} s"}
     return out
 
 
@@ -368,7 +407,7 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
         out = {
             "workload": f"{workload}: 1 x ({rows} x {k} -> {n}) over {world} GPU(s)",
             "value": steps * rows * n / elapsed, "unit": "field-elems/s", "ms_per_commit": 1e3 * elapsed / steps,
-            "steps": steps, "scaling": "strong", "n_gpus": world, "collective_backend": backend if world > 1 else None,
+            "steps": steps, "scaling": "strong", "n_gpus": world, "collective_backend": backend if dist is not None else None,
             "stage_ms_max_over_ranks": stage, "stage_ms_source": "HIP events on the library's stream (lg_shard_profile_read)",
             "row_shard": list(mine[0]) if mine else None, "planes_per_rank": len(sc.planes),
             "u_bytes_per_rank": len(sc.planes) * rows * (k if k <= 4096 else 4096) * 32,
@@ -387,7 +426,7 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
                 out["pipelined"] = {
                     "exchange_pieces": sp.pieces, "ms_per_commit": 1e3 * pelapsed / steps, "value": steps * rows * n / pelapsed,
                     "stage_ms_max_over_ranks": pstage,
-                    "note": "allgather_coeffs = waiting for the last piece; the exchange ran on its own stream beside the evaluation, the hash piece by piece",
+                    "note": "allgather_coeffs = time the encode stream stood still waiting for pieces; the exchange ran on its own stream beside the evaluation, the hash piece by piece",
                     "root_matches_golden": (proot.hex() == gold["root"]) if gold else None, "root_equals_unpipelined": proot == root,
                 }
                 if pelapsed < best and proot == root:
@@ -422,9 +461,11 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
     return out
 
 
-def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps):
+def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps, witness=None):
     """what a drop-in caller gets: lg_encode_commit from host buffers (PCIe inclusive), root read back; with and without the
-    coefficient rows coming home, pageable and page-locked (lg_host_register)"""
+    coefficient rows coming home, pageable and page-locked (lg_host_register).  witness = (w, gate map) of the SAME matrix:
+    also lg_encode_commit_from_witness -- only the W block crosses PCIe, X / Y / Z are gathered on the device (a1 on the
+    device; its root must equal the host-assembled one)"""
     out = {}
     c = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch, device=device)
     try:
@@ -451,6 +492,27 @@ def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps):
         assert root == root2
         out["bytes_in"] = int(pre.nbytes)
         out["note"] = "lg_encode_commit(host preenc_u -> root [+ host coefficient rows]); PCIe-inclusive, never `value`"
+        if witness is not None:
+            w, (left, right, consts) = witness
+            c.upload_gate_map(left, right, consts)
+
+            def runw():
+                c.encode_commit_from_witness(w)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    _, rw = c.encode_commit_from_witness(w)
+                return (time.perf_counter() - t0) / reps * 1e3, rw
+            fw = {}
+            fw["pageable_root_only"], rw = runw()
+            c.host_register(w)
+            try:
+                fw["page_locked_root_only"], rw2 = runw()
+            finally:
+                c.host_unregister(w)
+            fw["root_equals_host_assembled"] = bool(rw == root and rw2 == root)
+            fw["bytes_in"] = int(w.nbytes)
+            fw["note"] = "lg_encode_commit_from_witness(host w -> root): a quarter of the bytes; X, Y, Z gathered on the device by the circuit's gate map"
+            out["from_witness"] = fw
     finally:
         c.close()
     return out
@@ -721,6 +783,13 @@ def main():
             line["sharded_commit"] = sharded
         if sharded_prove is not None:
             line["sharded_prove"] = sharded_prove
+        if extras:
+            # first of the extra legs, on an otherwise idle host (the prover legs below start thread pools)
+            line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
+            line["vs_cpu_baseline"] = {"ratio": line["value"] / line["cpu_baseline"]["value"],
+                                       "of": "cpu_baseline.value (1-core port of the reference-shaped path); a reported ratio, not the target"}
+            line["vs_baseline_note"] = ("BASELINE.md section 1 holds no published number for this metric (the reference publishes none), so vs_baseline "
+                                        "stays null as the bench contract prescribes; the ratio to the CPU restatement timed in this run is vs_cpu_baseline")
         if extras and args.workload == "poseidon":
             # BASELINE configs[1] as a latency: ONE Poseidon commitment (batch 1), resident input
             one = ligero_amd.LigeroCommitter(rows=rows, k=k, batch=1, device=local_rank)
@@ -739,22 +808,22 @@ def main():
                 one.root()                                                        # waits for the tree: the latency of ONE commitment
             line["single_commit_latency_ms"] = (time.perf_counter() - t1) / 50 * 1e3
             one.close()
-            # what a drop-in caller gets (host buffers in, root [+ coefficients] out): PCIe inclusive, never `value`
-            line["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, local_rank, 10)
+            # what a drop-in caller gets (host buffers in, root [+ coefficients] out): PCIe inclusive, never `value`.  On the 64
+            # committed Poseidon witnesses, so that the same matrix can also go in as w + gate map (a1 on the device)
+            try:
+                pinst, pidx, pvals = poseidon_batch_inputs()
+                pre_real = np.concatenate([pinst.build_preenc_u(pidx, pvals[i])[0] for i in range(batch)])
+                w_real = np.concatenate([pinst.build_w(pidx, pvals[i])[0] for i in range(batch)])
+                line["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre_real, rows, k, batch, local_rank, 10, witness=(w_real, pinst.gate_map()))
+                del pre_real, w_real
+            except Exception as e:
+                line["host_buffer_commit_ms"] = {"error": f"{type(e).__name__}: {e}"}
             # BASELINE configs[2] (the HBM-roofline report shape) under the same clock: 5 commits, root pinned by a golden
             try:
                 pre20 = synthetic_preenc(LARGE_SEED, WORKLOADS["s20"][0] * WORKLOADS["s20"][1]).reshape(-1, WORKLOADS["s20"][1], 4)
                 e20, st20, l20, root20 = resident_run(ligero_amd, torch, None, backend, "s20", pre20, local_rank, 5, 2, 1)
-                r20, k20, _ = WORKLOADS["s20"]
-                d20, srl20 = roofline_of("s20", st20, l20, tfile)
-                gold = golden_large("s20")
-                line["s20"] = {"workload": f"s20: 1 x ({r20} x {k20} -> {8 * k20})", "steps": 5, "ms_per_step": e20 / 5 * 1e3,
-                               "value": 5 * r20 * 8 * k20 / e20, "unit": "field-elems/s", "roofline": d20, "stage_rooflines": srl20,
-                               "valu_roofline": valu_roofline_of("s20", st20), "root": root20[:32].hex(),
-                               "root_matches_golden": (root20[:32].hex() == gold["root"]) if gold else None}
-                hb = host_buffer_commit_ms(ligero_amd, pre20, r20, k20, 1, local_rank, 2)
-                line["s20"]["host_buffer_commit_ms"] = hb
                 del pre20
+                line["s20"] = commit_leg("s20", e20, st20, l20, root20, 5, tfile)
             except Exception as e:
                 line["s20"] = {"error": f"{type(e).__name__}: {e}"}
             # BASELINE configs[3]'s shape on ONE GPU (k = 8192 folded transforms, 16 planes, U = 42 GB resident): 3 commits, golden root
@@ -763,23 +832,25 @@ def main():
                 pre22 = synthetic_preenc(LARGE_SEED, r22 * k22).reshape(-1, k22, 4)
                 e22, st22, l22, root22 = resident_run(ligero_amd, torch, None, backend, "s22", pre22, local_rank, 3, 1, 1)
                 del pre22
-                d22, srl22 = roofline_of("s22", st22, l22, tfile)
-                gold = golden_large("s22")
-                line["s22"] = {"workload": f"s22: 1 x ({r22} x {k22} -> {8 * k22})", "steps": 3, "ms_per_step": e22 / 3 * 1e3,
-                               "value": 3 * r22 * 8 * k22 / e22, "unit": "field-elems/s", "roofline": d22, "stage_rooflines": srl22,
-                               "valu_roofline": valu_roofline_of("s22", st22), "root": root22[:32].hex(),
-                               "root_matches_golden": (root22[:32].hex() == gold["root"]) if gold else None}
+                line["s22"] = commit_leg("s22", e22, st22, l22, root22, 3, tfile)
             except Exception as e:
                 line["s22"] = {"error": f"{type(e).__name__}: {e}"}
             line["full_prover"] = full_prover_rate(local_rank)
+            # the 2^20-constraint R1CS itself: the drop-in entry points on its matrix (host-assembled preenc_u against w + gate map),
+            # then the complete proof
+            try:
+                inst20, idx20, vals20, _setup = repeated_squaring_instance(20)
+                pre20r, _ok = inst20.build_preenc_u(idx20, vals20)
+                w20r, _ok = inst20.build_w(idx20, vals20)
+                r20, k20, _ = WORKLOADS["s20"]
+                line["s20"]["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre20r, r20, k20, 1, local_rank, 2, witness=(w20r, inst20.gate_map()))
+                del pre20r, w20r, inst20
+            except Exception as e:
+                line["s20"]["host_buffer_commit_ms"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 line["s20"]["full_prover_from_r1cs"] = s20_prover_rate(local_rank)
             except Exception as e:
                 line["s20"]["full_prover_from_r1cs"] = {"error": f"{type(e).__name__}: {e}"}
-        if extras:
-            line["cpu_baseline"] = cpu_baseline(rows, k, n, batch)
-            line["vs_cpu_baseline"] = {"ratio": line["value"] / line["cpu_baseline"]["value"],
-                                       "of": "cpu_baseline.value (1-core port of the reference-shaped path); a reported ratio, not the target"}
         emit(line)
     if dist is not None:
         dist.barrier()

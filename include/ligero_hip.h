@@ -106,6 +106,23 @@ void lg_ctx_destroy(lg_ctx* ctx);
  */
 int lg_encode_commit(lg_ctx* ctx, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out);
 /*
+ * a1 ON THE DEVICE: the commit from the solution vector alone.  preenc_u = [X; Y; Z; W] (mod.rs:511-516) is redundant: W is
+ * the vector w of all kept node values (zero padded to m k, mod.rs:483-509), and x[p], y[p] are the operand values of the
+ * Mul gate at position p, z[p] = w[p], all zero where p is no Mul gate (mod.rs:495-503) -- gathers of w by the circuit's
+ * wiring.  So only w crosses PCIe (a quarter of the bytes):
+ *   lg_upload_gate_map             once per circuit: for each of the npos <= m k positions of w, left[p] / right[p] =
+ *                                  LG_GATE_NONE (no Mul gate there), LG_GATE_CONST | c (operand = constants[c]: a constant node
+ *                                  has no position of its own, mod.rs:491) or the operand's position in w.  Batch contexts too.
+ *   lg_encode_commit_from_witness  w: batch * m * k elements (the W block of every proof).  The library gathers X, Y, Z on the
+ *                                  device and commits; w travels in steps that hide behind the encoding of rows already complete
+ *                                  (circuits whose gates refer backwards only; otherwise w is uploaded first).  Outputs and
+ *                                  residency as lg_encode_commit; afterwards LG_BUF_PREENC holds the whole of preenc_u.
+ */
+#define LG_GATE_NONE 0xffffffffu
+#define LG_GATE_CONST 0x80000000u
+int lg_upload_gate_map(lg_ctx* ctx, uint64_t npos, const uint32_t* left, const uint32_t* right, const uint64_t* constants, uint32_t nconst);
+int lg_encode_commit_from_witness(lg_ctx* ctx, const uint64_t* w, uint64_t* coeffs_out, uint8_t* root_out);
+/*
  * lg_encode_commit streams its host buffers: the rows travel over PCIe in chunks while earlier
  * chunks are being encoded, and the coefficient rows travel back the same way.  The overlap needs page-locked host memory -- copies from/to pageable memory
  * block the calling thread, so only the upload overlaps there.  These two pin / unpin a buffer

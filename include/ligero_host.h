@@ -98,6 +98,14 @@ int lgh_build_preenc(const lgh_instance* inst, const uint64_t* node_idx, const u
 int lgh_build_preenc_with_labels(const lgh_instance* inst, const char* const* labels, const uint64_t* values, uint64_t count,
                                  uint64_t* preenc_out, int* all_outputs_one);
 
+/* a1 on the device (include/ligero_hip.h lg_upload_gate_map / lg_encode_commit_from_witness): preenc_u = w + wiring.
+ *   lgh_gate_map   sizes first (left / right / constants NULL): *npos_out = positions of the solution vector, *nconst_out =
+ *                  constants without a position; then the map itself: left[p] / right[p] = 0xffffffff (no Mul gate at p),
+ *                  0x80000000 | c (operand = constants[c]) or the operand's position
+ *   lgh_build_w    the W block alone: m * k elements (w zero padded), same assignment convention as lgh_build_preenc */
+int lgh_gate_map(const lgh_instance* inst, uint64_t* npos_out, uint64_t* nconst_out, uint32_t* left, uint32_t* right, uint64_t* constants);
+int lgh_build_w(const lgh_instance* inst, const uint64_t* node_idx, const uint64_t* values, uint64_t count, uint64_t* w_out, int* all_outputs_one);
+
 /* r_a = A.row_mul(r): r and out have 4 * m * k elements */
 int lgh_a_row_mul(const lgh_instance* inst, const uint64_t* r, uint64_t* out);
 /* COO dump of A (nnz entries each), row-major order */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("LIGERO_HIP_LIB") or os.path.join(_HERE, "lib", "libli
 SYMBOLS = [
     "lg_status_string", "lg_last_error", "lg_abi_version",
     "lg_ctx_create", "lg_ctx_create_batched", "lg_ctx_create_sharded", "lg_ctx_create_field", "lg_ctx_element_words", "lg_ctx_planes", "lg_ctx_destroy",
-    "lg_encode_commit", "lg_host_register", "lg_host_unregister", "lg_upload_preenc", "lg_commit_resident", "lg_sync",
+    "lg_encode_commit", "lg_upload_gate_map", "lg_encode_commit_from_witness", "lg_host_register", "lg_host_unregister", "lg_upload_preenc", "lg_commit_resident", "lg_sync",
     "lg_read_root", "lg_read_coeffs", "lg_read_leaves", "lg_read_nodes", "lg_read_codeword_rows",
     "lg_open_columns", "lg_open_columns_batch",
     "lg_reed_solomon_interpolate", "lg_reed_solomon_evaluate", "lg_reed_solomon",
@@ -44,6 +44,7 @@ LG_RELAY_STAGE_NAMES = ("encode", "unused", "relay", "digests", "merkle")
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")
 LG_BUF_PREENC, LG_BUF_COEFFS, LG_BUF_LEAVES, LG_BUF_NODES, LG_BUF_HSTATE = 0, 1, 2, 3, 4
 LG_HSTATE_BYTES = 80
+LG_GATE_NONE, LG_GATE_CONST = 0xffffffff, 0x80000000
 LG_SUB_INTERLEAVED, LG_SUB_LINEAR, LG_SUB_LINEAR_FROM_SEED, LG_SUB_QUADRATIC = 0, 1, 2, 3
 LG_FIELD_BN254_FR, LG_FIELD_BLS12_377_FQ, LG_FIELD_BN254_FR_GENERIC = 0, 1, 2
 
@@ -93,6 +94,8 @@ def lib():
     L.lg_ctx_destroy.argtypes = [_vp]
     L.lg_ctx_destroy.restype = None
     L.lg_encode_commit.argtypes = [_vp, _vp, _vp, _vp]
+    L.lg_upload_gate_map.argtypes = [_vp, ctypes.c_uint64, _vp, _vp, _vp, _u32]
+    L.lg_encode_commit_from_witness.argtypes = [_vp, _vp, _vp, _vp]
     L.lg_upload_constraint_matrix.argtypes = [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp, _vp]
     L.lg_linear_constraint_poly_from_seeds.argtypes = [_vp, _vp, _vp]
     L.lg_host_register.argtypes = [_vp, _vp, ctypes.c_size_t]

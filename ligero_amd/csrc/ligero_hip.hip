@@ -77,6 +77,10 @@ struct lg_ctx {
     uint32_t* d_a_seg = nullptr; uint32_t a_nseg = 0;       // their segments: [seg_begin | seg_end | heavy_seg_ptr] (challenge_kernels.h)
     fr* d_a_seg_partial = nullptr;                          // [batch][a_nseg]
     uint64_t a_rows = 0, a_nnz = 0; bool a_loaded = false;
+    // gate map of the circuit (lg_upload_gate_map): for every position of the solution vector the sources of x and y
+    uint32_t* d_gate_l = nullptr; uint32_t* d_gate_r = nullptr; fr* d_gate_consts = nullptr;
+    uint64_t gate_npos = 0; uint32_t gate_nconst = 0; bool gate_backward = false;
+    hipEvent_t ev_enc[16] = {};            // lg_encode_commit_from_witness: "rows of encode step i are encoded"
     uint32_t* d_seeds = nullptr;           // [batch][8]
     uint32_t* d_cc_counts = nullptr; size_t cc_counts_cap = 0;
     uint32_t* d_short_flag = nullptr;
@@ -133,9 +137,10 @@ struct lg_ctx {
     hipStream_t stream_x = nullptr;        // exchange stream of lg_commit_sharded: the all-gather of piece c + 1 beside the evaluation of piece c
     static constexpr int kShardStages = 5;
     static constexpr int kShardProfRing = 16;
-    hipEvent_t ev_shard[kShardProfRing][kShardStages + 1] = {};
+    hipEvent_t ev_shard[kShardProfRing][kShardStages + 1 + 2 * kMaxChunks] = {};   // stage marks, then (before, after) of every wait for an exchange piece
     bool ev_shard_valid = false;
     uint64_t shard_commits = 0;
+    uint32_t shard_wait_pairs = 0;         // exchange pieces the profiled sharded commits wait for (0: row relay)
     bool committed = false;
     bool staging = false;                  // between lg_stage_interpolate and lg_stage_merkle
     bool profiling = false;
@@ -344,6 +349,41 @@ __global__ void __launch_bounds__(256) gather_columns_kernel(GatherArgs a) {
     dst[1] = src[1];
 }
 
+// a1 on the device (mod.rs:483-516): x, y, z are functions of w and the circuit's wiring -- x[p] / y[p] = the values of the
+// operands of the Mul gate at position p (a position of w, or a constant that has no position), z[p] = w[p]; zero elsewhere
+struct WitnessGatherArgs {
+    fr* pre;                 // [batch][4 m][k]: blocks X, Y, Z, W; W is read, X / Y / Z are written
+    const uint32_t* left;    // [m k]: kGateNone, kGateConst | index into consts, or a position of w
+    const uint32_t* right;
+    const fr* consts;
+    uint64_t mk;             // m * k
+    uint64_t pos0, pos1;     // positions [pos0, pos1) of every proof
+    uint32_t batch;
+};
+constexpr uint32_t kGateNone = 0xffffffffu, kGateConst = 0x80000000u;
+__global__ void __launch_bounds__(256) witness_gather_kernel(const WitnessGatherArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t span = a.pos1 - a.pos0;
+    if (gid >= span * a.batch) return;
+    const uint64_t pos = a.pos0 + gid % span;
+    fr* base = a.pre + (gid / span) * 4 * a.mk;
+    const fr* w = base + 3 * a.mk;
+    const uint32_t l = a.left[pos], r = a.right[pos];
+    fr x, y, z;
+    if (l == kGateNone) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x.v[i] = 0;
+        y = x; z = x;
+    } else {
+        x = (l & kGateConst) ? fr_load(a.consts + (l & ~kGateConst)) : fr_load(w + l);
+        y = (r & kGateConst) ? fr_load(a.consts + (r & ~kGateConst)) : fr_load(w + r);
+        z = fr_load(w + pos);
+    }
+    fr_store(base + pos, x);
+    fr_store(base + a.mk + pos, y);
+    fr_store(base + 2 * a.mk + pos, z);
+}
+
 // planes (canonical) -> natural column order rows (Montgomery): out[i][np q + s]; k = plane row length
 __global__ void __launch_bounds__(256) planes_to_rows_kernel(const fr* u, uint64_t plane_stride, uint64_t row_base,
                                                             uint32_t nrows, uint32_t k, uint32_t lognp, fr r2, fr* out) {
@@ -515,6 +555,10 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->aux2k) lg_ctx_destroy(c->aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
+    for (void* b : {(void*)c->d_gate_l, (void*)c->d_gate_r, (void*)c->d_gate_consts})
+        if (b) hipFree(b);
+    for (auto& e : c->ev_enc)
+        if (e) hipEventDestroy(e);
     void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_a_seg, c->d_a_seg_partial, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
@@ -1186,6 +1230,212 @@ int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, ui
     // rows stream in (and coefficients out) while earlier rows are being encoded
     const int rc = commit_checked(c, preenc, coeffs_out);
     if (rc != LG_OK) return rc;
+    return lg_read_root(c, root_out);
+}
+
+// ---- a1 on the device: the commit from the solution vector w alone (mod.rs:483-516 on the GPU) ---------------------------------
+static int merkle_launches(lg_ctx* c, hipStream_t ms) {
+    lg::MerkleArgs m;
+    m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
+    uint32_t depth = (uint32_t)c->logn;
+    bool leaf = true;
+    while (depth > 0) {
+        m.in_depth = depth;
+        m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
+        const dim3 grid(c->batch * m.chunks);
+        if (leaf)
+            LG_LAUNCH(c, lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, ms, m);
+        else
+            LG_LAUNCH(c, lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, ms, m);
+        leaf = false;
+        depth = depth > 9 ? depth - 9 : 0;
+    }
+    return LG_OK;
+}
+
+int lg_upload_gate_map(lg_ctx* c, uint64_t npos, const uint32_t* left, const uint32_t* right, const uint64_t* constants, uint32_t nconst) {
+    if (!c || (npos && (!left || !right)) || (nconst && !constants)) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->sharded || (c->rows & 3)) return LG_ERR_STATE;
+    const uint64_t mk = (uint64_t)(c->rows / 4) * c->k;
+    if (npos > mk || nconst >= lg::kGateConst) return LG_ERR_BAD_ARG;
+    bool backward = true;
+    for (uint64_t p = 0; p < npos; p++) {
+        const uint32_t l = left[p], r = right[p];
+        if ((l == lg::kGateNone) != (r == lg::kGateNone)) return LG_ERR_BAD_ARG;
+        if (l == lg::kGateNone) continue;
+        for (uint32_t s : {l, r}) {
+            if (s & lg::kGateConst) { if ((s & ~lg::kGateConst) >= nconst) return LG_ERR_BAD_ARG; }
+            else { if (s >= npos) return LG_ERR_BAD_ARG; if (s >= p) backward = false; }
+        }
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipStreamSynchronize(c->stream));
+    for (void* b : {(void*)c->d_gate_l, (void*)c->d_gate_r, (void*)c->d_gate_consts})
+        if (b) LG_HIP(c, hipFree(b));
+    c->d_gate_l = c->d_gate_r = nullptr; c->d_gate_consts = nullptr; c->gate_npos = 0;
+    // positions past the solution vector (the zero padding up to m k, mod.rs:506-509) are no gates
+    std::vector<uint32_t> pad(mk - npos, lg::kGateNone);
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate_l), mk * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate_r), mk * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate_consts), (nconst ? nconst : 1) * sizeof(fr)));
+    if (npos) {
+        LG_HIP(c, hipMemcpy(c->d_gate_l, left, npos * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_gate_r, right, npos * 4, hipMemcpyHostToDevice));
+    }
+    if (mk > npos) {
+        LG_HIP(c, hipMemcpy(c->d_gate_l + npos, pad.data(), (mk - npos) * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->d_gate_r + npos, pad.data(), (mk - npos) * 4, hipMemcpyHostToDevice));
+    }
+    if (nconst) LG_HIP(c, hipMemcpy(c->d_gate_consts, constants, (size_t)nconst * sizeof(fr), hipMemcpyHostToDevice));
+    c->gate_npos = npos; c->gate_nconst = nconst; c->gate_backward = backward;
+    for (auto& e : c->ev_enc)
+        if (!e) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+    return LG_OK;
+}
+
+// x, y, z of positions [pos0, pos1) of every proof from the W block already in d_preenc
+static int witness_gather(lg_ctx* c, uint64_t pos0, uint64_t pos1) {
+    if (pos1 <= pos0) return LG_OK;
+    lg::WitnessGatherArgs g;
+    g.pre = c->d_preenc; g.left = c->d_gate_l; g.right = c->d_gate_r; g.consts = c->d_gate_consts;
+    g.mk = (uint64_t)(c->rows / 4) * c->k; g.pos0 = pos0; g.pos1 = pos1; g.batch = c->batch;
+    const uint64_t threads = (pos1 - pos0) * c->batch;
+    LG_LAUNCH(c, lg::witness_gather_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, g);
+    return LG_OK;
+}
+
+// The commit (mod.rs:483-551) from w alone.  Only the W block crosses PCIe (a quarter of preenc_u); it travels in row steps,
+// and as soon as step j is there the X, Y, Z rows of the same positions are gathered and the X and Y rows of the step are
+// encoded -- with circuits whose gates refer backwards only, as compiled circuits do, a gate's operands have arrived with or
+// before its own position -- so the transfer hides behind encoding.  A column's Blake2s absorbs the rows in order (X block
+// first): the hash launches are issued in row order on the hash stream, each behind the encode step that produces its rows.
+static int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs) {
+    if (c->sharded) return LG_ERR_STATE;
+    if (!c->d_gate_l) {
+        snprintf(c->err, sizeof(c->err), "lg_encode_commit_from_witness needs the circuit's gate map (lg_upload_gate_map)");
+        return LG_ERR_STATE;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    const uint32_t m = c->rows / 4;
+    const uint64_t mk = (uint64_t)m * c->k, plane = c->total_rows * c->ki;
+    const size_t wbytes = (size_t)c->batch * mk * sizeof(fr);
+    // steps of the W upload (row ranges of the W block = position ranges of all four blocks)
+    uint32_t J = wbytes >= (size_t{16} << 20) ? 4 : (wbytes >= (size_t{2} << 20) ? 2 : 1);
+    if (!c->gate_backward) J = 1;                      // forward references: the whole of w first
+    if (J > m) J = m;
+    // rows of the Z and W blocks: chunks as large commits are cut anyway
+    const uint64_t elems = c->total_rows * c->n;
+    uint32_t CZ = (elems >> 26) >= 1 ? 2 : 1;
+    if (CZ > m) CZ = m;
+    struct Step { uint32_t r0, r1; int upload; uint64_t g0, g1; };   // encode rows [r0, r1) of every proof; before: wait for upload `upload`, gather [g0, g1)
+    std::vector<Step> enc;
+    std::vector<uint32_t> hash_order;                                // indices into enc, in row order
+    std::vector<uint32_t> xs, ys;
+    for (uint32_t j = 0; j < J; j++) {
+        const uint32_t a = (uint32_t)((uint64_t)m * j / J), b = (uint32_t)((uint64_t)m * (j + 1) / J);
+        xs.push_back((uint32_t)enc.size());
+        enc.push_back(Step{a, b, (int)j, (uint64_t)a * c->k, (uint64_t)b * c->k});
+        ys.push_back((uint32_t)enc.size());
+        enc.push_back(Step{m + a, m + b, -1, 0, 0});
+    }
+    for (uint32_t i : xs) hash_order.push_back(i);
+    for (uint32_t i : ys) hash_order.push_back(i);
+    for (uint32_t blk = 2; blk < 4; blk++)
+        for (uint32_t j = 0; j < CZ; j++) {
+            hash_order.push_back((uint32_t)enc.size());
+            enc.push_back(Step{blk * m + (uint32_t)((uint64_t)m * j / CZ), blk * m + (uint32_t)((uint64_t)m * (j + 1) / CZ), -1, 0, 0});
+        }
+    if (enc.size() > 16) return LG_ERR_UNSUPPORTED;
+    hipStream_t hs = c->stream_h;
+    // earlier work on the encode stream may still read d_preenc; the previous commit's tree may still read the leaves
+    LG_HIP(c, hipEventRecord(c->ev_done, c->stream));
+    LG_HIP(c, hipStreamWaitEvent(c->stream_up, c->ev_done, 0));
+    LG_HIP(c, hipStreamWaitEvent(hs, c->ev_done, 0));
+    auto upload = [&](uint32_t j) -> int {
+        const uint32_t a = (uint32_t)((uint64_t)m * j / J), b = (uint32_t)((uint64_t)m * (j + 1) / J);
+        const size_t width = (size_t)(b - a) * c->k * sizeof(fr);
+        LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + ((size_t)3 * m + a) * c->k * sizeof(fr), (size_t)c->rows * c->k * sizeof(fr),
+                                   reinterpret_cast<const uint8_t*>(host_w) + (size_t)a * c->k * sizeof(fr), (size_t)mk * sizeof(fr), width, c->batch,
+                                   hipMemcpyHostToDevice, c->stream_up));
+        LG_HIP(c, hipEventRecord(c->ev_up[j], c->stream_up));
+        return LG_OK;
+    };
+    { const int rc_ = upload(0); if (rc_ != LG_OK) return rc_; }
+    size_t next_hash = 0;
+    std::vector<char> issued(enc.size(), 0);
+    for (size_t i = 0; i < enc.size(); i++) {
+        const Step& st = enc[i];
+        if (st.upload >= 0) {
+            LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up[st.upload], 0));
+            const int rc_ = witness_gather(c, st.g0, st.g1);
+            if (rc_ != LG_OK) return rc_;
+        }
+        const uint32_t nrows = c->batch * (st.r1 - st.r0);
+        lg::NttArgs ia = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, st.r0, nrows);
+        ia.chunk_rows = st.r1 - st.r0;
+        ia.proof_stride = c->rows;
+        ia.plane_stride = plane;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, ia));
+        if (host_coeffs) LG_HIP(c, hipEventRecord(c->ev_coef[i % lg_ctx::kMaxChunks], c->stream));
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, st.r0, nrows, false);
+        a.chunk_rows = st.r1 - st.r0;
+        a.proof_stride = c->rows;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
+        LG_HIP(c, hipEventRecord(c->ev_enc[i], c->stream));
+        issued[i] = 1;
+        // the next step's rows start travelling (issued after this step's kernels: a copy from pageable memory blocks this thread)
+        if (st.upload >= 0 && (uint32_t)st.upload + 1 < J) { const int rc_ = upload((uint32_t)st.upload + 1); if (rc_ != LG_OK) return rc_; }
+        if (host_coeffs) {
+            LG_HIP(c, hipStreamWaitEvent(c->stream_dn, c->ev_coef[i % lg_ctx::kMaxChunks], 0));
+            const size_t pitch = (size_t)c->rows * c->k * sizeof(fr);
+            const size_t off = (size_t)st.r0 * c->k * sizeof(fr), width = (size_t)(st.r1 - st.r0) * c->k * sizeof(fr);
+            LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(host_coeffs) + off, pitch, reinterpret_cast<const uint8_t*>(c->d_coeffs) + off, pitch, width,
+                                       c->batch, hipMemcpyDeviceToHost, c->stream_dn));
+        }
+        // column hashes, in row order, of every step that is encoded by now
+        while (next_hash < hash_order.size() && issued[hash_order[next_hash]]) {
+            const Step& hsr = enc[hash_order[next_hash]];
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_enc[hash_order[next_hash]], 0));
+            lg::ColHashArgs h;
+            memset(&h, 0, sizeof(h));
+            h.u = reinterpret_cast<const uint4*>(c->d_u);
+            h.leaves = c->d_leaves;
+            h.state = c->d_hstate;
+            h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
+            h.proof_begin = 0; h.proof_count = c->batch;
+            h.row_begin = hsr.r0; h.row_end = hsr.r1;
+            h.first = hsr.r0 == 0;
+            h.last = hsr.r1 == c->rows;
+            h.plane_begin = 0; h.plane_count = c->nplanes;
+            h.plane_stride = plane;
+            h.col_pos = hsr.r0; h.col_rows = c->rows;
+            const uint64_t threads = (uint64_t)c->batch * c->n;
+            LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+            next_hash++;
+        }
+    }
+    { const int rc_ = merkle_launches(c, hs); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipEventRecord(c->ev_done, hs));
+    LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    c->committed = true;
+    c->staging = false;
+    c->have_planes = all_planes_mask(c);
+    c->have_row0 = 0; c->have_row1 = c->rows;
+    if (host_coeffs) LG_HIP(c, hipStreamSynchronize(c->stream_dn));
+    return LG_OK;
+}
+
+int lg_encode_commit_from_witness(lg_ctx* c, const uint64_t* w, uint64_t* coeffs_out, uint8_t* root_out) {
+    if (!c || !w || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    const int rc = commit_from_witness(c, w, coeffs_out);
+    if (rc != LG_OK) {
+        if (rc != LG_ERR_STATE) c->committed = false;
+        return rc;
+    }
     return lg_read_root(c, root_out);
 }
 
@@ -2215,9 +2465,12 @@ int lg_commit_sharded(lg_ctx* c, const lg_comm* comm, const uint64_t* preenc_row
             if (xs != c->stream) LG_HIP(c, hipEventRecord(c->ev_up[p], xs));
         }
     }
+    if (ev) LG_HIP(c, hipEventRecord(ev[2], c->stream));
     for (uint32_t p = 0; p < np; p++) {
+        // (the time this stream stands still waiting for piece p is measured by an event on either side of the wait)
+        if (ev) LG_HIP(c, hipEventRecord(ev[lg_ctx::kShardStages + 1 + 2 * p], c->stream));
         if (exchange && xs != c->stream) LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up[p], 0));
-        if (ev && p + 1 == np) LG_HIP(c, hipEventRecord(ev[2], c->stream));   // the last piece has arrived
+        if (ev) LG_HIP(c, hipEventRecord(ev[lg_ctx::kShardStages + 2 + 2 * p], c->stream));
         const uint32_t r0 = p * piece_rows, r1 = std::min(c->rows, (p + 1) * piece_rows);
         // (a single piece of a large commit is still cut into row chunks, as lg_stage_evaluate_hash does)
         Chunk chunks[lg_ctx::kMaxChunks];
@@ -2246,7 +2499,7 @@ int lg_commit_sharded(lg_ctx* c, const lg_comm* comm, const uint64_t* preenc_row
     if (ev) LG_HIP(c, hipEventRecord(ev[4], c->stream));
     // 5. the tree
     { const int rc_ = lg_stage_merkle(c); if (rc_ != LG_OK) return rc_; }
-    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; }
+    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; c->shard_wait_pairs = np; }
     return LG_OK;
 }
 
@@ -2354,7 +2607,7 @@ int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int l
     if (ev) LG_HIP(c, hipEventRecord(ev[4], c->stream));
     { const int rc_ = lg_stage_merkle(c); if (rc_ != LG_OK) return rc_; }
     c->have_planes = all;    // every plane of this rank's rows is here (a rank without rows holds the tree only)
-    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; }
+    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; c->shard_wait_pairs = 0; }
     return LG_OK;
 }
 
@@ -2374,6 +2627,18 @@ int lg_shard_profile_read(lg_ctx* c, float ms_out[5], uint32_t* samples_out) {
             float ms = 0;
             LG_HIP(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             acc[i] += ms;
+        }
+        // coset-sharded commits: the stalls of the encode stream waiting for exchange pieces move from "evaluate + hash" to
+        // "all-gather" (with one piece on the encode stream itself the collective sits between marks 1 and 2 already)
+        if (c->shard_wait_pairs) {
+            double stall = 0;
+            for (uint32_t p = 0; p < c->shard_wait_pairs; p++) {
+                float ms = 0;
+                LG_HIP(c, hipEventElapsedTime(&ms, ev[lg_ctx::kShardStages + 1 + 2 * p], ev[lg_ctx::kShardStages + 2 + 2 * p]));
+                stall += ms;
+            }
+            acc[1] += stall;
+            acc[2] -= stall;
         }
     }
     for (int i = 0; i < lg_ctx::kShardStages; i++) ms_out[i] = (float)(acc[i] / (double)have);

@@ -762,6 +762,42 @@ public:
             pos++;
         }
     }
+    // a1 on the device (include/ligero_hip.h lg_upload_gate_map): preenc_u is w plus wiring.  For every position p of the
+    // solution vector (the kept nodes in node order, mod.rs:483-503) the sources of x[p] and y[p] -- the operands of the Mul
+    // gate sitting there: another position of w, or a constant that has no position (mod.rs:491 keeps only the leading one)
+    struct GateMap {
+        static constexpr uint32_t kNone = 0xffffffffu, kConst = 0x80000000u;
+        std::vector<uint32_t> left, right;
+        std::vector<E> constants;
+    };
+    GateMap gate_map() const {
+        const auto& nodes = circuit.nodes;
+        if (nodes.size() >= GateMap::kConst) throw std::runtime_error("gate map: circuit too large for 31-bit positions");
+        std::vector<uint32_t> src(nodes.size());           // node -> position of w, or kConst | index into constants
+        GateMap g;
+        uint32_t pos = 0;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (nodes[i].kind == Node::Constant && i != 0) {
+                src[i] = GateMap::kConst | (uint32_t)g.constants.size();
+                g.constants.push_back(nodes[i].value);
+            } else {
+                src[i] = pos++;
+            }
+        }
+        if (pos > m * k) throw std::runtime_error("solution vector longer than m * k");
+        g.left.assign(pos, GateMap::kNone);
+        g.right.assign(pos, GateMap::kNone);
+        for (size_t i = 0; i < nodes.size(); i++)
+            if (nodes[i].kind == Node::Mul) {               // (operands may sit after the gate in expression-made circuits)
+                g.left[src[i]] = src[nodes[i].l];
+                g.right[src[i]] = src[nodes[i].r];
+            }
+        return g;
+    }
+    // w alone: the W block of preenc_u, m k elements (zero padded)
+    void build_w_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
+        build_preenc_range_from_formatted(bumped, 3 * m * k, 4 * m * k, out, all_outputs_one, scratch);
+    }
     std::vector<std::vector<E>> build_preenc_u(const std::vector<std::pair<size_t, E>>& var_assignment, bool* all_outputs_one = nullptr) const {
         std::vector<E> flat(4 * m * k);
         build_preenc_into(var_assignment, flat.data(), all_outputs_one);

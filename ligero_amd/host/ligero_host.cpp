@@ -254,6 +254,32 @@ int lgh_build_preenc_with_labels(const lgh_instance* i, const char* const* label
     });
 }
 
+int lgh_gate_map(const lgh_instance* i, uint64_t* npos_out, uint64_t* nconst_out, uint32_t* left, uint32_t* right, uint64_t* constants) {
+    if (!i || !npos_out || !nconst_out) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const auto g = i->inst.gate_map();
+        *npos_out = g.left.size();
+        *nconst_out = g.constants.size();
+        if (left) std::memcpy(left, g.left.data(), g.left.size() * sizeof(uint32_t));
+        if (right) std::memcpy(right, g.right.data(), g.right.size() * sizeof(uint32_t));
+        if (constants && !g.constants.empty()) std::memcpy(constants, g.constants[0].l, g.constants.size() * sizeof(Fr));
+        return LGH_OK;
+    });
+}
+
+int lgh_build_w(const lgh_instance* i, const uint64_t* node_idx, const uint64_t* values, uint64_t count, uint64_t* w_out, int* all_outputs_one) {
+    if (!i || (count && (!node_idx || !values)) || !w_out) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        std::vector<std::pair<size_t, Fr>> vars;
+        vars.reserve(count);
+        for (uint64_t j = 0; j < count; j++) vars.emplace_back(i->inst.bump_index((size_t)node_idx[j]), load_fr(values + 4 * j));
+        bool ok = false;
+        i->inst.build_w_from_formatted(vars, reinterpret_cast<Fr*>(w_out), &ok);
+        if (all_outputs_one) *all_outputs_one = ok ? 1 : 0;
+        return LGH_OK;
+    });
+}
+
 int lgh_a_row_mul(const lgh_instance* i, const uint64_t* r, uint64_t* out) {
     if (!i || !r || !out) return LGH_ERR_BAD_ARG;
     return guarded([&] {

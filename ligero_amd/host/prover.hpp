@@ -146,6 +146,26 @@ inline void upload_constraint_matrix(lg_ctx* ctx, const SparseMatrix& a) {
     if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx) + ")");
 }
 
+// the circuit's wiring -> lg_upload_gate_map; false if the device path cannot take it (then preenc_u is assembled on the host)
+template <class Inst>
+inline bool upload_gate_map(lg_ctx* ctx, const Inst& inst) {
+    try {
+        const auto g = inst.gate_map();
+        const int st = lg_upload_gate_map(ctx, g.left.size(), g.left.data(), g.right.data(), g.constants.empty() ? nullptr : g.constants[0].l,
+                                          (uint32_t)g.constants.size());
+        if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_gate_map (") + lg_last_error(ctx) + ")");
+        return true;
+    } catch (const DeviceError&) {
+        throw;
+    } catch (const std::exception&) {
+        return false;   // (a circuit too large for 31-bit positions)
+    }
+}
+inline bool preenc_on_host() {
+    const char* e = std::getenv("LG_PREENC_ON_HOST");
+    return e && std::atoi(e) != 0;
+}
+
 // CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period")
 inline unsigned usable_cpus() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
@@ -210,6 +230,7 @@ public:
         if constexpr (kDeviceChallenges) {
             try {
                 upload_constraint_matrix(ctx_, inst.a);
+                from_witness_ = upload_gate_map(ctx_, inst);
             } catch (...) {     // a constructor that throws runs no destructor
                 lg_ctx_destroy(ctx_);
                 throw;
@@ -283,16 +304,29 @@ private:
         if constexpr (kDeviceChallenges) {
             if (sharded_) return prove_inner_sharded(formatted_assignment, sponge);
         }
-        if (flat_.empty()) {
-            flat_.resize(4 * m_ * k_);
+        // With the circuit's gate map on the device only w -- the W block, a quarter of preenc_u -- is built and uploaded; x, y, z
+        // are gathered there (lg_encode_commit_from_witness).  LG_PREENC_ON_HOST=1 keeps the whole matrix on the host (A/B, tests).
+        const bool witness_only = from_witness_ && !preenc_on_host();
+        const size_t want = witness_only ? m_ * k_ : 4 * m_ * k_;
+        if (flat_.size() != want) {
+            if (pinned_) lg_host_unregister(ctx_, flat_.data());
+            flat_.assign(want, F::zero());
+            scratch_.buffer_replaced();
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
         PhaseTimer tm;
-        inst_.build_preenc_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_);
-        tm.mark("evaluation trace + preenc_u (host)");
         LigeroProof proof;
-        check(lg_encode_commit(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
-        tm.mark("lg_encode_commit (H2D + commit)");
+        if (witness_only) {
+            inst_.build_w_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_);
+            tm.mark("evaluation trace + w (host)");
+            check(lg_encode_commit_from_witness(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit_from_witness");   // mod.rs:483-551
+            tm.mark("lg_encode_commit_from_witness (H2D of w + gather + commit)");
+        } else {
+            inst_.build_preenc_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_);
+            tm.mark("evaluation trace + preenc_u (host)");
+            check(lg_encode_commit(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit");   // mod.rs:521-551
+            tm.mark("lg_encode_commit (H2D + commit)");
+        }
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
 
         {   // prove_interleaved, mod.rs:646-669
@@ -719,8 +753,9 @@ private:
     size_t m_, k_, n_, t_;
     int logn_ = 0;
     lg_ctx* ctx_ = nullptr;
-    std::vector<Fr> flat_;      // preenc_u of the proof being made (reused between proofs); a sharded prover: its row shard
+    std::vector<Fr> flat_;      // preenc_u (or only its W block, from_witness_) of the proof being made, reused between proofs; a sharded prover: its row shard
     bool pinned_ = false;
+    bool from_witness_ = false; // the circuit's gate map is on the device: commits upload w alone
     std::vector<Fr> cols_stage_;   // opened columns as they come off the device (reused, page-locked)
     bool cols_pinned_ = false;
     typename LigeroInstance::Scratch scratch_;   // trace storage and the "flat_ already holds a preenc_u" note, kept between proofs
@@ -822,9 +857,10 @@ public:
         if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_batched");
         while ((size_t{1} << logn_) < n_) logn_++;
         upload_constraint_matrix(ctx_, inst.a);
+        from_witness_ = upload_gate_map(ctx_, inst) && !preenc_on_host();
         threads_ = threads ? threads : std::max(1u, std::min(usable_cpus(), batch));
         pool_.reset(new WorkerPool(threads_));
-        mat_.resize((size_t)batch_ * 4 * m_ * k_);
+        mat_.resize((size_t)batch_ * (from_witness_ ? 1 : 4) * m_ * k_);
         cols_.resize((size_t)batch_ * t_ * 4 * m_);
         // page-lock the two big staging buffers so the PCIe copies overlap the kernels (lg_encode_commit streams)
         // (each registration is tracked on its own: a buffer must never be freed while still page-locked)
@@ -851,13 +887,25 @@ public:
         proofs.resize(B);
 
         std::vector<PoseidonSponge> sponge(B, PoseidonSponge::test_sponge());
-        parallel_for(B, [&](size_t b) {                                  // x / y / z / w assembly, mod.rs:476-516
-            const auto r = inst_.build_preenc_u(assignments[b]);
-            for (size_t i = 0; i < rows; i++) memcpy(&mat_[b * mat + i * k_], r[i].data(), k_ * sizeof(Fr));
-        });
-        tm.mark("preenc_u (host)");
         std::vector<uint8_t> roots(B * 32);
-        check(lg_encode_commit(ctx_, mat_[0].l, nullptr, roots.data()), "lg_encode_commit");
+        if (from_witness_) {
+            // only w of every proof (the W block: m k elements) is assembled and uploaded; x, y, z are gathered on the device
+            parallel_for(B, [&](size_t b) {
+                std::vector<std::pair<size_t, Fr>> bumped;
+                bumped.reserve(assignments[b].size());
+                for (const auto& v : assignments[b]) bumped.emplace_back(inst_.bump_index(v.first), v.second);
+                inst_.build_w_from_formatted(bumped, &mat_[b * m_ * k_]);
+            });
+            tm.mark("w (host)");
+            check(lg_encode_commit_from_witness(ctx_, mat_[0].l, nullptr, roots.data()), "lg_encode_commit_from_witness");
+        } else {
+            parallel_for(B, [&](size_t b) {                              // x / y / z / w assembly, mod.rs:476-516
+                const auto r = inst_.build_preenc_u(assignments[b]);
+                for (size_t i = 0; i < rows; i++) memcpy(&mat_[b * mat + i * k_], r[i].data(), k_ * sizeof(Fr));
+            });
+            tm.mark("preenc_u (host)");
+            check(lg_encode_commit(ctx_, mat_[0].l, nullptr, roots.data()), "lg_encode_commit");
+        }
         tm.mark("commit (device)");
         // interleaved test
         std::vector<Fr> r_int(B * rows), lc(B * k_);
@@ -968,6 +1016,7 @@ private:
     int logn_ = 0;
     unsigned threads_ = 1;
     bool pinned_mat_ = false, pinned_cols_ = false;
+    bool from_witness_ = false;   // gate map on the device: mat_ holds w of every proof only
     lg_ctx* ctx_ = nullptr;
     std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u
     std::vector<LigeroProof> proofs_;

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libligero_host.so")
 SYMBOLS = [
     "lgh_last_error", "lgh_circuit_new", "lgh_circuit_destroy", "lgh_circuit_num_nodes", "lgh_constant", "lgh_new_variable",
     "lgh_add", "lgh_mul", "lgh_pow", "lgh_minus", "lgh_circuit_from_r1cs", "lgh_circuit_num_outputs", "lgh_circuit_outputs",
-    "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_a_row_mul", "lgh_a_entries",
+    "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_gate_map", "lgh_build_w", "lgh_a_row_mul", "lgh_a_entries",
     "lgh_read_witness", "lgh_chacha_block", "lgh_field_elements_from_seed", "lgh_distinct_indices_from_seed", "lgh_sponge_new", "lgh_sponge_destroy",
     "lgh_sponge_absorb_bytes", "lgh_sponge_absorb_elements", "lgh_sponge_squeeze_bytes", "lgh_sponge_squeeze_elements",
     "lgh_new_variable_with_label", "lgh_get_variable", "lgh_circuit_num_gates", "lgh_pow_bigint", "lgh_indicator", "lgh_scalar_product",
@@ -70,6 +70,8 @@ def lib():
         L.lgh_instance_destroy.restype = None
         L.lgh_instance_info.argtypes = [_vp, _vp]
         L.lgh_build_preenc.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
+        L.lgh_gate_map.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+        L.lgh_build_w.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_build_preenc_with_labels.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_evaluate_multioutput.argtypes = [_vp, _vp, _vp, _u64, _vp, _u64, _vp, _vp]
         L.lgh_a_row_mul.argtypes = [_vp, _vp, _vp]
@@ -327,6 +329,26 @@ class LigeroInstance:
         out = np.empty((self.rows, self.k, 4), dtype=np.uint64)
         ok = _int(0)
         _check(self._L.lgh_build_preenc(self._h, _p(idx), _p(vals), idx.shape[0], _p(out), ctypes.cast(ctypes.byref(ok), _vp)), "prove_inner")
+        return out, bool(ok.value)
+
+    def gate_map(self):
+        """the circuit's wiring for lg_upload_gate_map: (left, right) uint32 arrays over the positions of the solution vector
+        (0xffffffff: no Mul gate; 0x80000000 | c: constants[c]; else a position of w) and the constants (c, 4)"""
+        npos, nconst = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self._L.lgh_gate_map(self._h, ctypes.cast(ctypes.byref(npos), _vp), ctypes.cast(ctypes.byref(nconst), _vp), None, None, None), "gate_map")
+        left = np.empty(npos.value, dtype=np.uint32)
+        right = np.empty(npos.value, dtype=np.uint32)
+        consts = np.empty((nconst.value, 4), dtype=np.uint64)
+        _check(self._L.lgh_gate_map(self._h, ctypes.cast(ctypes.byref(npos), _vp), ctypes.cast(ctypes.byref(nconst), _vp), _p(left), _p(right), _p(consts)), "gate_map")
+        return left, right, consts
+
+    def build_w(self, node_idx: Sequence[int], values_mont: np.ndarray) -> Tuple[np.ndarray, bool]:
+        """the W block of preenc_u alone (mod.rs:483-509: the kept node values, zero padded): ((m, k, 4), all_outputs_one)"""
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(idx.shape[0], 4)
+        out = np.empty((self.m, self.k, 4), dtype=np.uint64)
+        ok = _int(0)
+        _check(self._L.lgh_build_w(self._h, _p(idx), _p(vals), idx.shape[0], _p(out), ctypes.cast(ctypes.byref(ok), _vp)), "prove_inner")
         return out, bool(ok.value)
 
     def build_preenc_u_with_labels(self, labels: Sequence[str], values_mont: np.ndarray) -> Tuple[np.ndarray, bool]:

@@ -148,6 +148,24 @@ class LigeroCommitter:
         self._chk(self._L.lg_encode_commit(self._ctx, _ptr(pre), _ptr(coeffs), _ptr(root)), "lg_encode_commit")
         return coeffs, root.tobytes()
 
+    def upload_gate_map(self, left, right, constants_mont):
+        """lg_upload_gate_map: the circuit's wiring (host_pipeline.LigeroInstance.gate_map()), once per context"""
+        l = np.ascontiguousarray(left, dtype=np.uint32)
+        r = np.ascontiguousarray(right, dtype=np.uint32)
+        c = np.ascontiguousarray(constants_mont, dtype=np.uint64).reshape(-1, 4)
+        self._chk(self._L.lg_upload_gate_map(self._ctx, l.shape[0], _ptr(l), _ptr(r), _ptr(c) if c.shape[0] else None, c.shape[0]), "lg_upload_gate_map")
+
+    def encode_commit_from_witness(self, w, want_coeffs: bool = False, coeffs_out=None):
+        """a1 on the device (mod.rs:483-551): w = the W block of every proof, (batch * m, k, 4); X, Y, Z are gathered on the GPU.
+        Returns (coefficients or None, u_root bytes)."""
+        wm = self._mat(w, self.k, "w")
+        if wm.shape[0] * 4 != self.batch * self.rows:
+            raise ValueError(f"w has {wm.shape[0]} rows, expected {self.batch * self.rows // 4}")
+        coeffs = coeffs_out if coeffs_out is not None else (np.empty((self.batch * self.rows, self.k, 4), dtype=np.uint64) if want_coeffs else None)
+        root = np.empty(32 * self.batch, dtype=np.uint8)
+        self._chk(self._L.lg_encode_commit_from_witness(self._ctx, _ptr(wm), _ptr(coeffs), _ptr(root)), "lg_encode_commit_from_witness")
+        return coeffs, root.tobytes()
+
     def host_register(self, array: np.ndarray):
         """page-lock a host array so that encode_commit can overlap its PCIe copies with the kernels"""
         self._chk(self._L.lg_host_register(self._ctx, _ptr(array), array.nbytes), "lg_host_register")

@@ -257,3 +257,54 @@ def test_repeated_squaring_dimensions_at_baseline_sizes():
         m, k = compute_dimensions(sol)
         nn, t = reed_solomon_parameters(m, k, 128)
         assert (m, k, nn, t) == want
+
+
+def rebuild_preenc_from_w(w_block, left, right, consts, m, k):
+    """what the device's gather does (include/ligero_hip.h lg_encode_commit_from_witness), in numpy: x[p], y[p] = the operands
+    of the Mul gate at position p (a position of w or a constant), z[p] = w[p], zero elsewhere (src/ligero/mod.rs:495-503)"""
+    mk = m * k
+    w = np.ascontiguousarray(w_block).reshape(mk, 4)
+    pre = np.zeros((4, mk, 4), dtype=np.uint64)
+    pre[3] = w
+    gates = np.nonzero(left != 0xffffffff)[0]
+    for blk, src in ((0, left), (1, right)):
+        s = src[gates]
+        is_const = (s & 0x80000000) != 0
+        vals = np.empty((gates.shape[0], 4), dtype=np.uint64)
+        vals[is_const] = consts[(s[is_const] & 0x7fffffff).astype(np.int64)]
+        vals[~is_const] = w[s[~is_const].astype(np.int64)]
+        pre[blk, gates] = vals
+    pre[2, gates] = w[gates]
+    return pre.reshape(4 * m, k, 4)
+
+
+def test_gate_map_and_w_rebuild_preenc_u(hp, oracle, model):
+    """a1 on the device: preenc_u = w + the circuit's wiring.  The gate map (which positions hold Mul gates, where their
+    operands live) and the W block alone must reproduce build_preenc_u -- Poseidon (775 constants without a position) and an
+    expression-made circuit (to_arithmetic_circuit's numbering; the device path's forward-reference case is driven with a
+    hand-made map in tests/test_gpu_witness.py)"""
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+    inst = hp.LigeroInstance(c)
+    w = model.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))
+    vals = oracle.to_mont(oracle.ints_to_limbs(w[1:]))
+    idx = list(range(1, len(w)))
+    pre, ok = inst.build_preenc_u(idx, vals)
+    wblk, ok2 = inst.build_w(idx, vals)
+    assert ok and ok2 and np.array_equal(wblk, pre[3 * inst.m:])
+    left, right, consts = inst.gate_map()
+    assert left.shape[0] == 1 + inst.num_nodes - inst.num_constants == 7013 and consts.shape[0] == inst.num_constants - 1
+    assert int((left != 0xffffffff).sum()) == 3611                               # SURVEY 8d: 3611 Mul nodes
+    assert np.array_equal((left == 0xffffffff), (right == 0xffffffff))
+    assert np.array_equal(rebuild_preenc_from_w(wblk, left, right, consts, inst.m, inst.k), pre)
+    gates = np.nonzero(left != 0xffffffff)[0]
+    for s in (left[gates], right[gates]):                                        # compiled circuits refer backwards only
+        pos = s[(s & 0x80000000) == 0]
+        assert (pos < gates[(s & 0x80000000) == 0]).all()
+    # an expression: x * (x + 3) * y
+    x, y = hp.Expression.variable("x"), hp.Expression.variable("y")
+    circ = ((x * (x + 3)) * y).to_arithmetic_circuit()
+    inst2 = hp.LigeroInstance(circ, [circ.num_nodes() - 1])
+    labels, v = ["x", "y"], np.stack([_mont(oracle, 5), _mont(oracle, 7)])
+    pre2, _ = inst2.build_preenc_u_with_labels(labels, v)
+    l2, r2, c2 = inst2.gate_map()
+    assert np.array_equal(rebuild_preenc_from_w(pre2[3 * inst2.m:], l2, r2, c2, inst2.m, inst2.k), pre2)
