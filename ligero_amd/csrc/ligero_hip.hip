@@ -1307,9 +1307,13 @@ static int witness_gather(lg_ctx* c, uint64_t pos0, uint64_t pos1) {
 
 // The commit (mod.rs:483-551) from w alone.  Only the W block crosses PCIe (a quarter of preenc_u); it travels in row steps,
 // and as soon as step j is there the X, Y, Z rows of the same positions are gathered and the X and Y rows of the step are
-// encoded -- with circuits whose gates refer backwards only, as compiled circuits do, a gate's operands have arrived with or
-// before its own position -- so the transfer hides behind encoding.  A column's Blake2s absorbs the rows in order (X block
-// first): the hash launches are issued in row order on the hash stream, each behind the encode step that produces its rows.
+// encoded (one launch for both blocks) -- with circuits whose gates refer backwards only, as compiled circuits do, a gate's
+// operands have arrived with or before its own position -- so the transfer hides behind encoding.  A column's Blake2s absorbs
+// the rows in order (X block first).  Large commits hash step by step on the hash stream, each launch held back until the NEXT
+// step's evaluation starts: a short kernel (an interpolation) that runs beside a hash launch is stretched to the hash's length
+// -- its workgroups on the CUs the hash occupies get what the older hash waves leave -- while the long evaluations absorb it
+// (measured: rocprofv3 timeline).  Small commits (one chunk in plan_chunks' terms: both kernels issue bound,
+// nothing to gain from running them side by side) hash once at the end on the encode stream.
 static int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs) {
     if (c->sharded) return LG_ERR_STATE;
     if (!c->d_gate_l) {
@@ -1322,40 +1326,64 @@ static int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host
     const uint32_t m = c->rows / 4;
     const uint64_t mk = (uint64_t)m * c->k, plane = c->total_rows * c->ki;
     const size_t wbytes = (size_t)c->batch * mk * sizeof(fr);
-    // steps of the W upload (row ranges of the W block = position ranges of all four blocks)
-    uint32_t J = wbytes >= (size_t{16} << 20) ? 4 : (wbytes >= (size_t{2} << 20) ? 2 : 1);
+    Chunk resident_plan[lg_ctx::kMaxChunks];
+    const bool small = plan_chunks(c, resident_plan) == 1;
+    // Steps of the W upload (row ranges of the W block = position ranges of all four blocks).  The first step's transfer has nothing
+    // to hide behind and the last rows' hash has nothing left to hide it: both ends taper (weights 1, 2, 3, 3, 3 of the upload;
+    // 4, 3, 2, 1 of the W block's rows).  LG_WITNESS_STEPS / LG_WITNESS_TAIL override the counts (experiments).
+    static const int env_steps = [] { const char* e = getenv("LG_WITNESS_STEPS"); return e ? atoi(e) : 0; }();
+    static const int env_tail = [] { const char* e = getenv("LG_WITNESS_TAIL"); return e ? atoi(e) : 0; }();
+    uint32_t J = wbytes >= (size_t{64} << 20) ? 5 : (wbytes >= (size_t{8} << 20) ? 3 : 1);
+    if (env_steps > 0) J = (uint32_t)std::min(env_steps, 5);
     if (!c->gate_backward) J = 1;                      // forward references: the whole of w first
     if (J > m) J = m;
-    // rows of the Z and W blocks: chunks as large commits are cut anyway
-    const uint64_t elems = c->total_rows * c->n;
-    uint32_t CZ = (elems >> 26) >= 1 ? 2 : 1;
+    uint32_t CW = small ? 1 : 4, CZ = small ? 1 : 2;   // rows of the Z and W blocks: chunks as large commits are cut anyway
+    if (env_tail > 0) CW = (uint32_t)std::min(env_tail, 4);
+    if (CW > m) CW = m;
     if (CZ > m) CZ = m;
-    struct Step { uint32_t r0, r1; int upload; uint64_t g0, g1; };   // encode rows [r0, r1) of every proof; before: wait for upload `upload`, gather [g0, g1)
-    std::vector<Step> enc;
-    std::vector<uint32_t> hash_order;                                // indices into enc, in row order
-    std::vector<uint32_t> xs, ys;
-    for (uint32_t j = 0; j < J; j++) {
-        const uint32_t a = (uint32_t)((uint64_t)m * j / J), b = (uint32_t)((uint64_t)m * (j + 1) / J);
-        xs.push_back((uint32_t)enc.size());
-        enc.push_back(Step{a, b, (int)j, (uint64_t)a * c->k, (uint64_t)b * c->k});
-        ys.push_back((uint32_t)enc.size());
-        enc.push_back(Step{m + a, m + b, -1, 0, 0});
-    }
-    for (uint32_t i : xs) hash_order.push_back(i);
-    for (uint32_t i : ys) hash_order.push_back(i);
-    for (uint32_t blk = 2; blk < 4; blk++)
-        for (uint32_t j = 0; j < CZ; j++) {
-            hash_order.push_back((uint32_t)enc.size());
-            enc.push_back(Step{blk * m + (uint32_t)((uint64_t)m * j / CZ), blk * m + (uint32_t)((uint64_t)m * (j + 1) / CZ), -1, 0, 0});
+    auto cuts = [&](uint32_t parts, const uint32_t* weight) {   // row boundaries 0 = b[0] < ... < b[parts] = m by cumulative weight
+        std::vector<uint32_t> bnd(parts + 1, 0);
+        uint64_t total = 0, acc = 0;
+        for (uint32_t i = 0; i < parts; i++) total += weight[i];
+        for (uint32_t i = 0; i < parts; i++) {
+            acc += weight[i];
+            bnd[i + 1] = (i + 1 == parts) ? m : std::max<uint32_t>(bnd[i] + 1, (uint32_t)((uint64_t)m * acc / total));
+            if (bnd[i + 1] > m) bnd[i + 1] = m;
         }
-    if (enc.size() > 16) return LG_ERR_UNSUPPORTED;
-    hipStream_t hs = c->stream_h;
+        return bnd;
+    };
+    static const uint32_t w_up[5][5] = {{1}, {1, 2}, {1, 2, 3}, {1, 2, 3, 3}, {1, 2, 3, 3, 3}};
+    static const uint32_t w_tail[4][4] = {{1}, {2, 1}, {3, 2, 1}, {4, 3, 2, 1}};
+    static const uint32_t w_even[2] = {1, 1};
+    const std::vector<uint32_t> ub = cuts(J, w_up[J - 1]), zb = cuts(CZ, w_even), wb = cuts(CW, w_tail[CW - 1]);
+    // encode steps: rows [r0, r1) of `blocks` consecutive blocks of every proof (blocks = 2: the X and the Y block) in one launch
+    struct Step { uint32_t r0, r1, blocks; int upload; };
+    std::vector<Step> enc;
+    // (a small commit hashes at the end anyway, so nothing is gained by finishing the X block early: every step encodes its rows of
+    // all four blocks -- the Z rows are gathered with the step, the W rows are the upload itself -- and the whole encoding overlaps
+    // the transfer)
+    for (uint32_t j = 0; j < J; j++) enc.push_back(Step{ub[j], ub[j + 1], small ? 4u : 2u, (int)j});
+    if (!small) {
+        for (uint32_t j = 0; j < CZ; j++) enc.push_back(Step{2 * m + zb[j], 2 * m + zb[j + 1], 1, -1});
+        for (uint32_t j = 0; j < CW; j++) enc.push_back(Step{3 * m + wb[j], 3 * m + wb[j + 1], 1, -1});
+    }
+    // hash launches in row order: (rows, index of the encode step that completes them)
+    struct HashStep { uint32_t r0, r1; size_t after; };
+    std::vector<HashStep> hashes;
+    if (small) {
+        hashes.push_back(HashStep{0, c->rows, enc.size() - 1});
+    } else {
+        for (uint32_t j = 0; j < J; j++) hashes.push_back(HashStep{ub[j], ub[j + 1], j});
+        hashes.push_back(HashStep{m, 2 * m, (size_t)J - 1});
+        for (size_t i = J; i < enc.size(); i++) hashes.push_back(HashStep{enc[i].r0, enc[i].r1, i});
+    }
+    hipStream_t hs = small ? c->stream : c->stream_h;
     // earlier work on the encode stream may still read d_preenc; the previous commit's tree may still read the leaves
     LG_HIP(c, hipEventRecord(c->ev_done, c->stream));
     LG_HIP(c, hipStreamWaitEvent(c->stream_up, c->ev_done, 0));
-    LG_HIP(c, hipStreamWaitEvent(hs, c->ev_done, 0));
+    if (!small) LG_HIP(c, hipStreamWaitEvent(hs, c->ev_done, 0));
     auto upload = [&](uint32_t j) -> int {
-        const uint32_t a = (uint32_t)((uint64_t)m * j / J), b = (uint32_t)((uint64_t)m * (j + 1) / J);
+        const uint32_t a = ub[j], b = ub[j + 1];
         const size_t width = (size_t)(b - a) * c->k * sizeof(fr);
         LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + ((size_t)3 * m + a) * c->k * sizeof(fr), (size_t)c->rows * c->k * sizeof(fr),
                                    reinterpret_cast<const uint8_t*>(host_w) + (size_t)a * c->k * sizeof(fr), (size_t)mk * sizeof(fr), width, c->batch,
@@ -1363,63 +1391,89 @@ static int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host
         LG_HIP(c, hipEventRecord(c->ev_up[j], c->stream_up));
         return LG_OK;
     };
+    auto hash_launch = [&](const HashStep& hr) -> int {
+        lg::ColHashArgs h;
+        memset(&h, 0, sizeof(h));
+        h.u = reinterpret_cast<const uint4*>(c->d_u);
+        h.leaves = c->d_leaves;
+        h.state = c->d_hstate;
+        h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
+        h.proof_begin = 0; h.proof_count = c->batch;
+        h.row_begin = hr.r0; h.row_end = hr.r1;
+        h.first = hr.r0 == 0;
+        h.last = hr.r1 == c->rows;
+        h.plane_begin = 0; h.plane_count = c->nplanes;
+        h.plane_stride = plane;
+        h.col_pos = hr.r0; h.col_rows = c->rows;
+        const uint64_t threads = (uint64_t)c->batch * c->n;
+        if (h.first && h.last && threads <= c->quad_hash_max_columns) {   // few columns: four lanes per column (hash_kernels.h)
+            lg::ColHashQuadArgs qa;
+            memset(&qa, 0, sizeof(qa));
+            qa.u = h.u; qa.leaves = h.leaves; qa.rows = h.rows; qa.k = h.k; qa.lognp = h.lognp;
+            qa.proof_begin = 0; qa.proof_count = c->batch; qa.plane_begin = 0; qa.plane_count = c->nplanes;
+            qa.plane_stride = plane;
+            LG_LAUNCH(c, lg::blake2s_columns_quad_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(256), 0, hs, qa);
+        } else {
+            LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+        }
+        return LG_OK;
+    };
     { const int rc_ = upload(0); if (rc_ != LG_OK) return rc_; }
     size_t next_hash = 0;
-    std::vector<char> issued(enc.size(), 0);
     for (size_t i = 0; i < enc.size(); i++) {
         const Step& st = enc[i];
         if (st.upload >= 0) {
             LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up[st.upload], 0));
-            const int rc_ = witness_gather(c, st.g0, st.g1);
+            const int rc_ = witness_gather(c, (uint64_t)st.r0 * c->k, (uint64_t)st.r1 * c->k);
             if (rc_ != LG_OK) return rc_;
         }
-        const uint32_t nrows = c->batch * (st.r1 - st.r0);
+        const uint32_t span = st.r1 - st.r0, nrows = c->batch * st.blocks * span;
         lg::NttArgs ia = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, st.r0, nrows);
-        ia.chunk_rows = st.r1 - st.r0;
+        ia.chunk_rows = span;
         ia.proof_stride = c->rows;
+        ia.blk_count = st.blocks; ia.blk_stride = m;
         ia.plane_stride = plane;
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->stream, ia));
         if (host_coeffs) LG_HIP(c, hipEventRecord(c->ev_coef[i % lg_ctx::kMaxChunks], c->stream));
+        if (!small && next_hash < hashes.size() && hashes[next_hash].after < i) {
+            // the hashes of the rows complete by now start together with the evaluation below
+            LG_HIP(c, hipEventRecord(c->ev_stage_in, c->stream));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_stage_in, 0));
+            while (next_hash < hashes.size() && hashes[next_hash].after < i) {
+                const int rc_ = hash_launch(hashes[next_hash++]);
+                if (rc_ != LG_OK) return rc_;
+            }
+        }
         lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, st.r0, nrows, false);
-        a.chunk_rows = st.r1 - st.r0;
+        a.chunk_rows = span;
         a.proof_stride = c->rows;
+        a.blk_count = st.blocks; a.blk_stride = m;
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->stream, a));
-        LG_HIP(c, hipEventRecord(c->ev_enc[i], c->stream));
-        issued[i] = 1;
         // the next step's rows start travelling (issued after this step's kernels: a copy from pageable memory blocks this thread)
         if (st.upload >= 0 && (uint32_t)st.upload + 1 < J) { const int rc_ = upload((uint32_t)st.upload + 1); if (rc_ != LG_OK) return rc_; }
         if (host_coeffs) {
             LG_HIP(c, hipStreamWaitEvent(c->stream_dn, c->ev_coef[i % lg_ctx::kMaxChunks], 0));
-            const size_t pitch = (size_t)c->rows * c->k * sizeof(fr);
-            const size_t off = (size_t)st.r0 * c->k * sizeof(fr), width = (size_t)(st.r1 - st.r0) * c->k * sizeof(fr);
-            LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(host_coeffs) + off, pitch, reinterpret_cast<const uint8_t*>(c->d_coeffs) + off, pitch, width,
-                                       c->batch, hipMemcpyDeviceToHost, c->stream_dn));
-        }
-        // column hashes, in row order, of every step that is encoded by now
-        while (next_hash < hash_order.size() && issued[hash_order[next_hash]]) {
-            const Step& hsr = enc[hash_order[next_hash]];
-            LG_HIP(c, hipStreamWaitEvent(hs, c->ev_enc[hash_order[next_hash]], 0));
-            lg::ColHashArgs h;
-            memset(&h, 0, sizeof(h));
-            h.u = reinterpret_cast<const uint4*>(c->d_u);
-            h.leaves = c->d_leaves;
-            h.state = c->d_hstate;
-            h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
-            h.proof_begin = 0; h.proof_count = c->batch;
-            h.row_begin = hsr.r0; h.row_end = hsr.r1;
-            h.first = hsr.r0 == 0;
-            h.last = hsr.r1 == c->rows;
-            h.plane_begin = 0; h.plane_count = c->nplanes;
-            h.plane_stride = plane;
-            h.col_pos = hsr.r0; h.col_rows = c->rows;
-            const uint64_t threads = (uint64_t)c->batch * c->n;
-            LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
-            next_hash++;
+            const size_t pitch = (size_t)c->rows * c->k * sizeof(fr), width = (size_t)span * c->k * sizeof(fr);
+            for (uint32_t blk = 0; blk < st.blocks; blk++) {
+                const size_t off = ((size_t)st.r0 + (size_t)blk * m) * c->k * sizeof(fr);
+                LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(host_coeffs) + off, pitch, reinterpret_cast<const uint8_t*>(c->d_coeffs) + off, pitch, width,
+                                           c->batch, hipMemcpyDeviceToHost, c->stream_dn));
+            }
         }
     }
+    if (!small) {
+        LG_HIP(c, hipEventRecord(c->ev_stage_in, c->stream));
+        LG_HIP(c, hipStreamWaitEvent(hs, c->ev_stage_in, 0));
+    }
+    while (next_hash < hashes.size()) {
+        const int rc_ = hash_launch(hashes[next_hash++]);
+        if (rc_ != LG_OK) return rc_;
+    }
     { const int rc_ = merkle_launches(c, hs); if (rc_ != LG_OK) return rc_; }
-    LG_HIP(c, hipEventRecord(c->ev_done, hs));
-    LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    if (!small) {
+        LG_HIP(c, hipEventRecord(c->ev_done, hs));
+        LG_HIP(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    }
     c->committed = true;
     c->staging = false;
     c->have_planes = all_planes_mask(c);

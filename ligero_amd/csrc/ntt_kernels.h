@@ -62,6 +62,8 @@ struct NttArgs {
     uint64_t plane_stride;  // elements between planes (= total_rows * ki)
     uint32_t canon_mask;    // interpolate, O > 1: bit c set = message plane 8 c exists behind canon_out (a coset-sharded context
                             // holds only some of them); ignored for O = 1 (canon_out null or not)
+    uint32_t blk_count;     // > 1: a second level under proof_stride -- run q = r / chunk_rows of the launch is block q % blk_count of
+    uint32_t blk_stride;    // proof q / blk_count, blk_stride rows apart (the same row range of the X and Y blocks of every proof in one launch)
 };
 
 // compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- expanded in the front end, so
@@ -438,7 +440,13 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
         r = w / per_row;
         sel = EVALUATE ? (uint32_t)a.cosets[w % per_row] : (w % per_row);
     }
-    const uint32_t rg = a.row0 + (r / a.chunk_rows) * a.proof_stride + (r % a.chunk_rows);  // row of the matrix
+    uint32_t rg = a.row0 + (r % a.chunk_rows);  // row of the matrix
+    if (a.blk_count > 1) {
+        const uint32_t q = r / a.chunk_rows;
+        rg += (q / a.blk_count) * a.proof_stride + (q % a.blk_count) * a.blk_stride;
+    } else {
+        rg += (r / a.chunk_rows) * a.proof_stride;
+    }
     const size_t row_in = (size_t)rg << (LOGK + LOGO);
     LdsPlanes row;
     row.a = reinterpret_cast<uint4*>(smem);
