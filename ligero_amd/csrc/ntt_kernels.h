@@ -113,40 +113,52 @@ struct LdsPlanes {
 // On return y[m] = sum_q e[q] w_R^(q m) in natural order m, as lazy values with limbs
 // <= 5 * 2^29 and value < 24p (tests/test_limb_bounds.py replays these networks with interval
 // arithmetic).  w8[] holds w_8^1..3 of the transform direction, w8q[] their Barrett quotients.
-template <int LOGR>
+template <int LOGR, int DIR>
 __device__ __forceinline__ void dft_regs(f29 (&e)[1 << LOGR], const f29 (&w8)[3], const f29 (&w8q)[3]);
 
-template <>
-__device__ __forceinline__ void dft_regs<1>(f29 (&e)[2], const f29 (&)[3], const f29 (&)[3]) {
+// product by w_8^(J + 1) of direction DIR (0 forward, 1 inverse): shoup29 with the constant and its quotient in registers,
+// or (LG_W8_SHIFT, an A/B build) wshift29 with the pre-shifted residues as compile-time constants
+template <int DIR, int J>
+__device__ __forceinline__ void mul_w8(f29& x, const f29 (&w8)[3], const f29 (&w8q)[3]) {
+#ifdef LG_W8_SHIFT
+    wshift29<DIR, J>(x, x);
+    (void)w8; (void)w8q;
+#else
+    shoup29(x, x, w8[J], w8q[J]);
+#endif
+}
+
+template <int DIR>
+__device__ __forceinline__ void dft_regs_1(f29 (&e)[2]) {
     bfly29<4, 29>(e[0], e[1]);
 }
-template <>
-__device__ __forceinline__ void dft_regs<2>(f29 (&e)[4], const f29 (&w8)[3], const f29 (&w8q)[3]) {
+template <int DIR>
+__device__ __forceinline__ void dft_regs_2(f29 (&e)[4], const f29 (&w8)[3], const f29 (&w8q)[3]) {
     bfly29<4, 29>(e[0], e[2]);
     bfly29<4, 29>(e[1], e[3]);
-    shoup29(e[3], e[3], w8[1], w8q[1]);
+    mul_w8<DIR, 1>(e[3], w8, w8q);
     bfly29<8, 30>(e[0], e[1]);  // y0, y2
     bfly29<4, 29>(e[2], e[3]);  // y1, y3
     const f29 t = e[1];
     e[1] = e[2];
     e[2] = t;
 }
-template <>
-__device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3], const f29 (&w8q)[3]) {
+template <int DIR>
+__device__ __forceinline__ void dft_regs_3(f29 (&e)[8], const f29 (&w8)[3], const f29 (&w8q)[3]) {
     bfly29<4, 29>(e[0], e[4]);
     bfly29<4, 29>(e[1], e[5]);
     bfly29<4, 29>(e[2], e[6]);
     bfly29<4, 29>(e[3], e[7]);
-    shoup29(e[5], e[5], w8[0], w8q[0]);
+    mul_w8<DIR, 0>(e[5], w8, w8q);
     order29(e[5], e[6]);
-    shoup29(e[6], e[6], w8[1], w8q[1]);
+    mul_w8<DIR, 1>(e[6], w8, w8q);
     order29(e[6], e[7]);
-    shoup29(e[7], e[7], w8[2], w8q[2]);
+    mul_w8<DIR, 2>(e[7], w8, w8q);
     // even outputs: size-4 DFT of the sums e[0..3] (limbs <= 2B, value < 4p)
     bfly29<8, 30>(e[0], e[2]);
     bfly29<8, 30>(e[1], e[3]);
     order29(e[7], e[3]);
-    shoup29(e[3], e[3], w8[1], w8q[1]);
+    mul_w8<DIR, 1>(e[3], w8, w8q);
     norm29(e[0]);
     norm29(e[1]);
     norm29(e[2]);
@@ -156,7 +168,7 @@ __device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3], con
     bfly29<4, 29>(e[4], e[6]);
     bfly29<4, 29>(e[5], e[7]);
     order29(e[3], e[7]);
-    shoup29(e[7], e[7], w8[1], w8q[1]);
+    mul_w8<DIR, 1>(e[7], w8, w8q);
     norm29(e[4]);
     norm29(e[6]);
     bfly29<8, 30>(e[4], e[5]);  // y1, y5
@@ -164,6 +176,12 @@ __device__ __forceinline__ void dft_regs<3>(f29 (&e)[8], const f29 (&w8)[3], con
     // registers now hold (y0, y4, y2, y6, y1, y5, y3, y7)
     const f29 y1 = e[4], y2 = e[2], y3 = e[6], y4 = e[1], y5 = e[5], y6 = e[3];
     e[1] = y1; e[2] = y2; e[3] = y3; e[4] = y4; e[5] = y5; e[6] = y6;
+}
+template <int LOGR, int DIR>
+__device__ __forceinline__ void dft_regs(f29 (&e)[1 << LOGR], const f29 (&w8)[3], const f29 (&w8q)[3]) {
+    if constexpr (LOGR == 1) dft_regs_1<DIR>(e);
+    else if constexpr (LOGR == 2) dft_regs_2<DIR>(e, w8, w8q);
+    else dft_regs_3<DIR>(e, w8, w8q);
 }
 
 // Radix plan: the remainder pass (radix 2 or 4) goes first, all later passes are radix 8.
@@ -360,7 +378,7 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
 #endif
             });
         }
-        dft_regs<LOGR>(e, a.w8, a.w8q);
+        dft_regs<LOGR, EVALUATE ? 0 : 1>(e, a.w8, a.w8q);
         // Constant factors ride on multiplications that happen anyway (the transform is linear):
         //   evaluate: the pre-scale table carries 2^-256, so data leave the ABI's Montgomery form in the
         //     first pass and the last pass only has to reduce -- the codeword is stored canonical;
