@@ -42,13 +42,17 @@ void lgp_prover_destroy(lgp_prover* p);
  * are issued all the same -- the way to run the exact RCCL calls on a one-GPU box.  lgp_verify works on such a prover as on
  * any other.
  */
-enum { LGP_COMM_EXCHANGE_AT_WORLD_1 = 1 };
+enum { LGP_COMM_EXCHANGE_AT_WORLD_1 = 1, LGP_COMM_HAS_STREAM_CALLBACK = 2 };
 typedef struct lgp_comm {
     uint32_t world, rank;
     uint32_t flags;
     void* user;
     int (*all_gather_device)(void* user, void* device_buf, uint64_t bytes_per_rank);
     int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes);
+    /* read only when flags has LGP_COMM_HAS_STREAM_CALLBACK: all_gather_device ORDERED ON `stream` (a hipStream_t of the device
+     * library; include/ligero_hip.h lg_comm::all_gather): enqueue the collective there, do not wait on the host.  The commit
+     * of a sharded proof is then one stream-ordered sequence inside the device library (lg_commit_sharded). */
+    int (*all_gather_device_stream)(void* user, void* device_buf, uint64_t bytes_per_rank, void* stream);
 } lgp_comm;
 int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int device, const lgp_comm* comm);
 

@@ -48,6 +48,7 @@ int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int de
         sc.exchange_at_world_1 = (comm->flags & LGP_COMM_EXCHANGE_AT_WORLD_1) != 0;
         sc.all_gather_device = comm->all_gather_device;
         sc.all_gather_host = comm->all_gather_host;
+        if (comm->flags & LGP_COMM_HAS_STREAM_CALLBACK) sc.all_gather_device_stream = comm->all_gather_device_stream;
         *out = new lgp_prover(inst->inst, device, sc);
         return LGP_OK;
     });

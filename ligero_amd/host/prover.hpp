@@ -25,6 +25,7 @@
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <thread>
@@ -201,6 +202,9 @@ struct ShardComm {
     void* user = nullptr;
     // in-place all-gather on DEVICE memory: device_buf holds `world` blocks of bytes_per_rank, block `rank` is this rank's
     int (*all_gather_device)(void* user, void* device_buf, uint64_t bytes_per_rank) = nullptr;
+    // the same, ORDERED ON A STREAM of the device library (include/ligero_hip.h lg_comm::all_gather): when given, the commit is
+    // one lg_commit_sharded call -- a stream-ordered sequence with no host synchronisation around the two exchanges
+    int (*all_gather_device_stream)(void* user, void* device_buf, uint64_t bytes_per_rank, void* stream) = nullptr;
     // all-gather of equal HOST blocks: recv holds `world` blocks of `bytes`
     int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes) = nullptr;
 };
@@ -406,29 +410,30 @@ private:
             scratch_.buffer_replaced();
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
-        void* d = nullptr;
-        size_t bytes = 0;
-        together("the interpolation of a row shard", [&] {
+        // ONE library call: interpolate the shard, all-gather the coefficient rows, evaluate + hash the own planes, all-gather the
+        // digests, build the tree (lg_commit_sharded).  A host layer that only has the synchronous callback gets the library's stream
+        // drained before each exchange (its callback ends with a device synchronisation of its own).
+        // (the evaluation trace is where a bad assignment fails: its own step, so that every rank learns of it BEFORE any rank enters
+        // the commit's collectives)
+        together("the evaluation trace of a row shard", [&] {
             inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data(), nullptr, &scratch_);
-            check(lg_stage_interpolate(ctx_, own ? flat_[0].l : nullptr, row0_, row1_ - row0_), "lg_stage_interpolate");
-            if (exchange_) {
-                check(lg_device_buffer(ctx_, LG_BUF_COEFFS, &d, &bytes), "lg_device_buffer");
-                check(lg_sync(ctx_), "lg_sync");
-            }
         });
-        if (exchange_) comm_check(comm_.all_gather_device(comm_.user, d, (uint64_t)shard_rows_ * k_ * sizeof(Fr)), "all-gather of the coefficient rows");
-        together("the evaluation of a rank's coset planes", [&] {
-            check(lg_stage_evaluate_hash(ctx_, own_mask_), "lg_stage_evaluate_hash");
-            if (exchange_) {
-                check(lg_stage_digests_pack(ctx_, comm_.world, comm_.rank, &d, &bytes), "lg_stage_digests_pack");
-                check(lg_sync(ctx_), "lg_sync");
-            }
+        together("the sharded commit", [&] {
+            lg_comm lc;
+            std::memset(&lc, 0, sizeof(lc));
+            lc.world = comm_.world; lc.rank = comm_.rank;
+            lc.flags = comm_.exchange_at_world_1 ? LG_COMM_EXCHANGE_AT_WORLD_1 : 0;
+            lc.user = this;
+            lc.all_gather = [](void* self, void* buf, uint64_t bytes_per_rank, void* stream) -> int {
+                auto* me = static_cast<HipLigeroT*>(self);
+                if (me->comm_.all_gather_device_stream) return me->comm_.all_gather_device_stream(me->comm_.user, buf, bytes_per_rank, stream);
+                if (lg_sync(me->ctx_) != LG_OK) return -1;
+                return me->comm_.all_gather_device(me->comm_.user, buf, bytes_per_rank);
+            };
+            const int st = lg_commit_sharded(ctx_, &lc, own ? flat_[0].l : nullptr, 1);
+            if (st == LG_ERR_COMM) throw std::runtime_error(std::string("the host layer's collective failed (") + lg_last_error(ctx_) + ")");
+            check(st, "lg_commit_sharded");
         });
-        if (exchange_) {
-            comm_check(comm_.all_gather_device(comm_.user, d, bytes), "all-gather of the leaf digests");
-            check(lg_stage_digests_unpack(ctx_, comm_.world), "lg_stage_digests_unpack");
-        }
-        check(lg_stage_merkle(ctx_), "lg_stage_merkle");
         check(lg_read_root(ctx_, root.data()), "lg_read_root");
     }
     // the 2k point values of one sub-proof polynomial: this rank's slots from the device, the others' from their owners

@@ -78,7 +78,14 @@ public:
     // eight consecutive blocks at once on 8-lane integer vectors (lane = block): what the compiler turns into
     // AVX2 code where the CPU has it (target_clones picks at load time); same bytes as eight calls of block()
     typedef uint32_t v8u __attribute__((vector_size(32)));
-    __attribute__((target_clones("avx2", "default"))) static void blocks8(const uint32_t key[8], uint64_t counter, uint32_t out[128]) {
+    // (no function multi-versioning under ThreadSanitizer: the IFUNC resolver would run instrumented code before the sanitizer's
+    // runtime exists)
+#if defined(__SANITIZE_THREAD__)
+#define LG_CLONES_AVX2
+#else
+#define LG_CLONES_AVX2 __attribute__((target_clones("avx2", "default")))
+#endif
+    LG_CLONES_AVX2 static void blocks8(const uint32_t key[8], uint64_t counter, uint32_t out[128]) {
         v8u s[16], x[16];
         const uint32_t c4[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
         for (int i = 0; i < 4; i++) s[i] = v8u{c4[i], c4[i], c4[i], c4[i], c4[i], c4[i], c4[i], c4[i]};

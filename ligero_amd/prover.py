@@ -126,11 +126,13 @@ class LigeroProver:
 
 _AG_DEVICE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64)
 _AG_HOST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64)
+_AG_DEVICE_STREAM = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, _vp)
+_LGP_COMM_EXCHANGE_AT_WORLD_1, _LGP_COMM_HAS_STREAM_CALLBACK = 1, 2
 
 
 class _LgpComm(ctypes.Structure):
     _fields_ = [("world", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("user", _vp),
-                ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST)]
+                ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST), ("all_gather_device_stream", _AG_DEVICE_STREAM)]
 
 
 class ShardedLigeroProver(LigeroProver):
@@ -152,13 +154,16 @@ class ShardedLigeroProver(LigeroProver):
         self.comm_error: Optional[str] = None
         self._cb_device = _AG_DEVICE(self._all_gather_device)      # kept alive with the prover
         self._cb_host = _AG_HOST(self._all_gather_host)
+        self._cb_device_stream = _AG_DEVICE_STREAM(self._all_gather_device_stream)
+        self._ext_streams = {}
         super().__init__(instance, device)
 
     def _create(self, instance, device):
         if self.world > 1 or self._force:
-            self._comm = _LgpComm(self.world, self.rank, 1 if self._force else 0, None, self._cb_device, self._cb_host)
+            flags = (_LGP_COMM_EXCHANGE_AT_WORLD_1 if self._force else 0) | _LGP_COMM_HAS_STREAM_CALLBACK
+            self._comm = _LgpComm(self.world, self.rank, flags, None, self._cb_device, self._cb_host, self._cb_device_stream)
         else:
-            self._comm = _LgpComm(1, 0, 0, None, _AG_DEVICE(), _AG_HOST())
+            self._comm = _LgpComm(1, 0, 0, None, _AG_DEVICE(), _AG_HOST(), _AG_DEVICE_STREAM())
         _check(self._L.lgp_sharded_prover_create(ctypes.byref(self._h), instance._h, device, ctypes.cast(ctypes.byref(self._comm), _vp)),
                "lgp_sharded_prover_create")
 
@@ -173,6 +178,23 @@ class ShardedLigeroProver(LigeroProver):
             return 0
         except Exception as e:          # an exception must not unwind through the C++ caller
             self.comm_error = f"all_gather_device: {e!r}"
+            return -1
+
+    def _all_gather_device_stream(self, _user, ptr, bytes_per_rank, stream):
+        """the commit's two exchanges (coefficient rows, leaf digests), issued with the device library's stream current: ordered with
+        its kernels on both sides, no host wait (lg_commit_sharded)"""
+        try:
+            import torch
+            from .sharded import _CudaArray
+            key = int(stream or 0)
+            if key not in self._ext_streams:
+                self._ext_streams[key] = torch.cuda.ExternalStream(key, device=f"cuda:{self._device}") if key else torch.cuda.default_stream(self._device)
+            with torch.cuda.stream(self._ext_streams[key]):
+                buf = torch.as_tensor(_CudaArray(int(ptr), self.world * int(bytes_per_rank)), device=f"cuda:{self._device}")
+                self._dist.all_gather_into_tensor(buf, buf[self.rank * bytes_per_rank:(self.rank + 1) * bytes_per_rank], group=self._group)
+            return 0
+        except Exception as e:
+            self.comm_error = f"all_gather_device_stream: {e!r}"
             return -1
 
     def _all_gather_host(self, _user, send, recv, nbytes):

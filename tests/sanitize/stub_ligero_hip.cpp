@@ -1,0 +1,104 @@
+// RACE-DETECTOR HARNESS ONLY -- not a backend.  A stand-in for libligero_hip.so with the same C ABI (include/ligero_hip.h) whose
+// "device" calls do nothing but fill their outputs with a deterministic function of their inputs, so that the HOST side of the
+// provers -- the thread pool, the per-proof transcript phases, the staging buffers of HipLigeroBatch (ligero_amd/host/prover.hpp) --
+// can run under ThreadSanitizer on a machine without a GPU (tests/test_sanitizers.py).  Proofs made over it are meaningless and are
+// never verified; nothing under ligero_amd/ can load this file.
+#include <cstdint>
+#include <cstring>
+#include <new>
+
+#include "../../include/ligero_hip.h"
+
+struct lg_ctx {
+    uint32_t rows, k, n, batch;
+    uint64_t salt;
+    char err[8];
+};
+static uint64_t mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+static uint64_t digest_of(const void* p, size_t bytes) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (size_t i = 0; i < bytes; i += 997) h = mix(h ^ b[i] ^ (i << 8));
+    return h;
+}
+static void fill(void* out, size_t bytes, uint64_t seed, bool field) {
+    uint64_t* w = static_cast<uint64_t*>(out);
+    for (size_t i = 0; i < bytes / 8; i++) {
+        w[i] = mix(seed + i);
+        if (field && (i & 3) == 3) w[i] &= 0x0fffffffffffffffull;   // a valid (< p) Montgomery representative
+    }
+}
+extern "C" {
+const char* lg_status_string(int) { return "stub"; }
+const char* lg_last_error(const lg_ctx*) { return ""; }
+uint32_t lg_abi_version(void) { return LG_ABI_VERSION; }
+static int make(lg_ctx** out, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+    lg_ctx* c = new (std::nothrow) lg_ctx();
+    if (!c) return LG_ERR_OOM;
+    c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->salt = 1;
+    *out = c;
+    return LG_OK;
+}
+int lg_ctx_create(lg_ctx** out, int, uint32_t rows, uint32_t k, uint32_t n) { return make(out, rows, k, n, 1); }
+int lg_ctx_create_batched(lg_ctx** out, int, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) { return make(out, rows, k, n, batch); }
+int lg_ctx_create_field(lg_ctx** out, int, int, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) { return make(out, rows, k, n, batch); }
+int lg_ctx_create_sharded(lg_ctx** out, int, uint32_t rows, uint32_t k, uint32_t n, uint32_t, uint32_t, uint32_t) { return make(out, rows, k, n, 1); }
+int lg_ctx_planes(const lg_ctx*, uint32_t* a, uint32_t* b, uint32_t* c) { if (a) *a = 8; if (b) *b = 0; if (c) *c = 8; return LG_OK; }
+void lg_ctx_destroy(lg_ctx* c) { delete c; }
+int lg_host_register(lg_ctx*, void*, size_t) { return LG_OK; }
+int lg_host_unregister(lg_ctx*, void*) { return LG_OK; }
+int lg_sync(lg_ctx*) { return LG_OK; }
+int lg_upload_constraint_matrix(lg_ctx*, uint64_t, uint64_t, const uint64_t*, const uint64_t*, const uint64_t*) { return LG_OK; }
+int lg_upload_gate_map(lg_ctx*, uint64_t, const uint32_t*, const uint32_t*, const uint64_t*, uint32_t) { return LG_OK; }
+int lg_encode_commit(lg_ctx* c, const uint64_t* pre, uint64_t* coeffs, uint8_t* root) {
+    const size_t per = (size_t)c->rows * c->k * 32;
+    for (uint32_t b = 0; b < c->batch; b++) fill(root + 32 * b, 32, digest_of(reinterpret_cast<const uint8_t*>(pre) + b * per, per), false);
+    if (coeffs) fill(coeffs, per * c->batch, 7, true);
+    return LG_OK;
+}
+int lg_encode_commit_from_witness(lg_ctx* c, const uint64_t* w, uint64_t* coeffs, uint8_t* root) {
+    const size_t per = (size_t)(c->rows / 4) * c->k * 32;
+    for (uint32_t b = 0; b < c->batch; b++) fill(root + 32 * b, 32, digest_of(reinterpret_cast<const uint8_t*>(w) + b * per, per), false);
+    if (coeffs) fill(coeffs, 4 * per * c->batch, 7, true);
+    return LG_OK;
+}
+int lg_read_root(lg_ctx* c, uint8_t* root) { fill(root, 32 * c->batch, 11, false); return LG_OK; }
+int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
+    for (uint32_t b = 0; b < c->batch; b++) fill(out + (size_t)b * c->k * 4, (size_t)c->k * 32, digest_of(r + (size_t)b * c->rows * 4, (size_t)c->rows * 32), true);
+    return LG_OK;
+}
+int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* ra, uint64_t* out) { fill(out, (size_t)c->batch * 2 * c->k * 32, digest_of(ra, 4096), true); return LG_OK; }
+int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* out) {
+    for (uint32_t b = 0; b < c->batch; b++) fill(out + (size_t)b * 2 * c->k * 4, (size_t)2 * c->k * 32, digest_of(seeds + 32 * b, 32), true);
+    return LG_OK;
+}
+int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* out) {
+    for (uint32_t b = 0; b < c->batch; b++) fill(out + (size_t)b * 2 * c->k * 4, (size_t)2 * c->k * 32, digest_of(r + (size_t)b * (c->rows / 4) * 4, (size_t)(c->rows / 4) * 32), true);
+    return LG_OK;
+}
+static uint32_t log2u(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) l++; return l; }
+int lg_open_columns(lg_ctx* c, uint32_t, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths) {
+    for (uint32_t i = 0; i < t; i++) {
+        fill(cols + (size_t)i * c->rows * 4, (size_t)c->rows * 32, idx[i] + 3, true);
+        fill(sib + 32 * i, 32, idx[i] + 5, false);
+        fill(paths + (size_t)i * (log2u(c->n) - 1) * 32, (size_t)(log2u(c->n) - 1) * 32, idx[i] + 9, false);
+    }
+    return LG_OK;
+}
+int lg_open_columns_batch(lg_ctx* c, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths) {
+    const size_t plen = log2u(c->n) - 1;
+    for (uint32_t b = 0; b < c->batch; b++)
+        lg_open_columns(c, b, idx + (size_t)b * t, t, cols + (size_t)b * t * c->rows * 4, sib + (size_t)b * t * 32, paths + (size_t)b * t * plen * 32);
+    return LG_OK;
+}
+int lg_reed_solomon_interpolate(lg_ctx* c, const uint64_t*, uint32_t nrows, uint64_t* out) { fill(out, (size_t)nrows * c->k * 32, 21, true); return LG_OK; }
+int lg_reed_solomon_evaluate(lg_ctx* c, const uint64_t*, uint32_t nrows, uint64_t* out) { fill(out, (size_t)nrows * c->n * 32, 22, true); return LG_OK; }
+int lg_reed_solomon(lg_ctx* c, const uint64_t*, uint32_t nrows, uint64_t* out) { fill(out, (size_t)nrows * c->n * 32, 23, true); return LG_OK; }
+int lg_verifier_linear_sums_from_seed(lg_ctx*, const uint8_t*, const uint32_t*, uint32_t t, const uint64_t*, uint64_t* sums) { fill(sums, (size_t)t * 32, 31, true); return LG_OK; }
+int lg_subproof_points(lg_ctx* c, int, const void*, uint64_t* out, uint32_t* mask) { fill(out, (size_t)2 * c->k * 32, 41, true); if (mask) *mask = 0xff; return LG_OK; }
+int lg_subproof_finish(lg_ctx* c, int, const uint64_t*, uint64_t* out) { fill(out, (size_t)2 * c->k * 32, 42, true); return LG_OK; }
+int lg_commit_sharded(lg_ctx*, const lg_comm*, const uint64_t*, uint32_t) { return LG_OK; }
+}

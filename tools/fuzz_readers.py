@@ -15,7 +15,7 @@ rng = random.Random(1)
 files = {n: open(os.path.join(G, n), "rb").read() for n in ("cube.r1cs", "poseidon.r1cs", "poseidon_witness.wtns", "poseidon_witness.json", "multiplication.r1cs")}
 d = tempfile.mkdtemp()
 n_ok = n_err = 0
-for it in range(3000):
+for it in range(int(os.environ.get("LG_FUZZ_ITERS", "3000"))):
     name = rng.choice(list(files))
     data = bytearray(files[name])
     mode = rng.randrange(4)
