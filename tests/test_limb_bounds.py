@@ -157,10 +157,11 @@ def test_network_source_matches_model():
     """the model above mirrors dft_regs<3>; if the kernel's sequence of butterflies changes this
     test must be updated with it"""
     src = open(os.path.join(ROOT, "ligero_amd", "csrc", "ntt_kernels.h")).read()
-    body = src[src.index("dft_regs<3>(f29 (&e)[8]"):]
+    body = src[src.index("dft_regs_3(f29 (&e)[8]"):]
     body = body[:body.index("// registers now hold")]
-    ops = re.findall(r"(bfly29<\d+, \d+>\(e\[\d\], e\[\d\]\)|shoup29\(e\[\d\]|norm29\(e\[\d\]\))", body)
-    ops = [o.replace("shoup29", "mul29") for o in ops]
+    # (mul_w8<DIR, J> = the product by w_8^(J + 1): shoup29 in the shipped build, wshift29 in the LG_W8_SHIFT A/B build)
+    ops = re.findall(r"(bfly29<\d+, \d+>\(e\[\d\], e\[\d\]\)|mul_w8<DIR, \d>\(e\[\d\]|norm29\(e\[\d\]\))", body)
+    ops = [re.sub(r"mul_w8<DIR, \d>", "mul29", o) for o in ops]
     expect = ["bfly29<4, 29>(e[0], e[4])", "bfly29<4, 29>(e[1], e[5])", "bfly29<4, 29>(e[2], e[6])", "bfly29<4, 29>(e[3], e[7])",
               "mul29(e[5]", "mul29(e[6]", "mul29(e[7]",
               "bfly29<8, 30>(e[0], e[2])", "bfly29<8, 30>(e[1], e[3])", "mul29(e[3]", "norm29(e[0])", "norm29(e[1])", "norm29(e[2])",
@@ -286,3 +287,55 @@ def test_reduce29_model_exact():
         r = reduce29_model(a)
         assert all(v < B for v in r[:8])
         assert value(r) % P == value(a) % P and value(r) < 2 * P
+
+
+def test_w8shift_table_and_wshift29_model():
+    """ligero_amd/csrc/w8shift_table.h (generated, tools/gen_w8shift.py): the pre-shifted residues of the omega_8 powers, and an exact
+    model of wshift29 (fr29_gfx950.h; the LG_W8_SHIFT A/B build's product by those constants): no column sum overflows 64 bits for
+    the dirtiest operand the butterflies produce, the quotient estimate is floor(sum / p) or one less, the result is < p + p / 2^9"""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location("gen_w8shift", os.path.join(ROOT, "tools", "gen_w8shift.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    table = gen.table()
+    text = open(os.path.join(ROOT, "ligero_amd", "csrc", "w8shift_table.h")).read()
+    words = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", text)]
+    flat = [x for d in table for w in d for row in w for x in row]
+    mu = (1 << 296) // P
+    assert words == flat + [mu & 0xFFFFFFFF, mu >> 32]
+    rho = pow(5, (P - 1) >> 28, P)
+    w8 = pow(rho, 1 << 25, P)
+    rng = random.Random(11)
+    NP = [((1 << 261) - P) >> (29 * i) & M for i in range(9)]
+    for trial in range(400):
+        d, j = rng.randrange(2), rng.randrange(3)
+        w = pow(w8 if d == 0 else pow(w8, P - 2, P), j + 1, P)
+        if trial % 3 == 0:
+            a = [6 << 29] * 8 + [(1 << 29) - 1]                                   # the dirtiest operand shoup29's contract allows
+        else:
+            a = [rng.randrange(0, 6 << 29) for _ in range(8)] + [rng.randrange(0, 1 << 29)]
+        col = [sum(a[i] * table[d][j][c][i] for i in range(9)) for c in range(9)]
+        assert max(col) < 2**64
+        carry, lo = 0, []
+        for c in range(8):
+            t = col[c] + carry
+            assert t < 2**64
+            lo.append(t & M)
+            carry = t >> 29
+        T = col[8] + carry
+        assert T < 2**57
+        q = (T * mu) >> 64
+        total = sum(l << (29 * i) for i, l in enumerate(lo)) + (T << 232)
+        assert total == sum(a[i] * ((w << (29 * i)) % P) for i in range(9))
+        assert total // P - 1 <= q <= total // P
+        acc, out = 0, []
+        q0, q1 = q & M, q >> 29
+        for c in range(9):
+            acc += lo[c] if c < 8 else (T & M)
+            acc += q0 * NP[c] + (q1 * NP[c - 1] if c > 0 else 0)
+            assert acc < 2**64
+            out.append(acc & M)
+            acc >>= 29
+        r = sum(l << (29 * i) for i, l in enumerate(out))
+        assert r % P == (sum(x << (29 * i) for i, x in enumerate(a)) * w) % P and r < P + (P >> 9)
