@@ -78,12 +78,20 @@ def algorithmic_bytes(rows: int, k: int, n: int, batch: int):
 
 def multiplier_instr_per_element(k: int):
     """v_mad_u64_u32 / v_mul_lo_u32 instructions the evaluate kernel executes per output element
-    (ligero_amd/csrc/ntt_kernels.h, k <= 4096): shoup29 = 143, reduce29 = 10, Montgomery dot<2> = 261"""
+    (ligero_amd/csrc/ntt_kernels.h): shoup29 = 143, reduce29 = 10, Montgomery dot<2> = 261, dot<4> = 423"""
     lg = k.bit_length() - 1
-    if lg < 4 or lg > 12:
+    if lg < 4 or lg > 14:
         return None
-    rem = lg % 3
-    first = {0: (8 + 5 + 7) * 143 / 8 + 10 / 8, 1: 261.0, 2: (4 + 1 + 3) * 143 / 4 + 10 / 4}[rem]
+    if lg > 12:
+        # k = 8192, 16384: O = 2, 4 folded 4096-point transforms; the load stage is a Montgomery dot product of O terms
+        # (mul29_dot<O>: 81 O + 90 + 9) in place of the pre-scale product, the radix-8 passes are those of k = 4096
+        o = 1 << (lg - 12)
+        first = (81 * o + 99) + (5 + 7) * 143 / 8 + 10 / 8
+        lg = 12
+        rem = 0
+    else:
+        rem = lg % 3
+        first = {0: (8 + 5 + 7) * 143 / 8 + 10 / 8, 1: 261.0, 2: (4 + 1 + 3) * 143 / 4 + 10 / 4}[rem]
     npass8 = (lg - (rem or 3)) // 3            # radix-8 passes after the first one; the last of them only reduces
     return first + (npass8 - 1) * ((12 * 143 + 10) / 8) + (5 * 143 + 8 * 10) / 8
 

@@ -449,7 +449,31 @@ __global__ void __launch_bounds__(NttPlan<LOGK>::kWgThreads, 2) ntt_rows_kernel(
         const uint32_t full = (a.rows / 8) * 8 * per_row;  // items of complete groups of 8 rows
         if (w < full) {
             const uint32_t x = w & 7, i = w >> 3;              // i-th item of XCD class x
-            w = (8 * (i / per_row) + x) * per_row + (i % per_row);
+            if constexpr (EVALUATE && LOGO > 0) {
+                // Folded sizes: the pre-scale table of ONE plane is k * 36 B = 295 KB at k = 8192 and a row has 14 computed planes:
+                // 4.1 MB of table per row against 4 MB of L2 per XCD -- with the planes of a row back to back the table thrashes
+                // (measured at S22: 5.6 GB of HBM reads per evaluate launch for 0.66 GB of coefficient rows).  So the XCD takes its
+                // rows in passes over a GROUP of planes whose tables (~2 MB) stay in L2 for all its rows, at the price of fetching
+                // every coefficient row once per group (256 KB, the smaller of the two): two groups of 7 planes at k = 8192 --
+                // 1.4 GB of reads per launch and 2.4 % off the S22 commit; four groups: 3.0 GB and slower
+                // (profiles/r03_ab_fold_plane_groups.log).  k = 16 384 (28 planes of 590 KB): eight groups.
+#ifndef LG_FOLD_PLANE_GROUPS
+#define LG_FOLD_PLANE_GROUPS (LOGO == 1 ? 2 : 8)
+#endif
+                constexpr uint32_t H = LG_FOLD_PLANE_GROUPS;
+                const uint32_t J = a.rows / 8;                             // rows of this XCD class
+                const uint32_t ph = (per_row + H - 1) / H;                 // planes per group (the last group may be shorter)
+                uint32_t h = 0, base = 0, cnt = ph < per_row ? ph : per_row;
+                while (i >= base + J * cnt) {
+                    base += J * cnt;
+                    h++;
+                    cnt = per_row - h * ph < ph ? per_row - h * ph : ph;
+                }
+                const uint32_t ii = i - base;
+                w = (8 * (ii / cnt) + x) * per_row + h * ph + (ii % cnt);
+            } else {
+                w = (8 * (i / per_row) + x) * per_row + (i % per_row);
+            }
         }
     }
     const bool active = w < total;
