@@ -5,8 +5,9 @@
 //! APIs the reference itself uses.  If a signature has drifted, the fix is local to the wrapper impls below -- the
 //! recorded quantities are what matters.
 //!
-//! Cases: `multiplication` (circom/multiplication.r1cs, a 4-wire circuit) and `poseidon` (the reference's
-//! test_poseidon, src/ligero/tests.rs:364-415).
+//! Cases: `multiplication` (circom/multiplication.r1cs, a 4-wire circuit), `poseidon` (the reference's
+//! test_poseidon, src/ligero/tests.rs:364-415) and `bls12_377_curve` (test_prove_and_verify_bls12_377, tests.rs:186-193, on
+//! the G1 generator: the second element type, ark_bls12_377::Fq -- pins its FFT domain and 48-byte serialisation).
 use std::borrow::Borrow;
 use std::str::FromStr;
 use std::sync::Mutex;
@@ -92,6 +93,45 @@ impl CRHScheme for RecColHasher {
             l.col_hash_output.push(hex::encode(&out));
         });
         Ok(out)
+    }
+}
+
+/// The same recorder for ANY field (the BLS12-377 Fq case below): elements are logged with their own serialised width
+/// (48 bytes for Fq), so the dump also pins that field's FFT domain -- U[0..2][j] depends on the 2-adic root arkworks
+/// derives from the multiplicative generator -- and its serialisation.
+pub struct RecColHasherG<F: PrimeField>(std::marker::PhantomData<F>);
+impl<F: PrimeField> CRHScheme for RecColHasherG<F> {
+    type Input = Vec<F>;
+    type Output = Vec<u8>;
+    type Parameters = ();
+    fn setup<R: Rng>(_: &mut R) -> Result<(), Error> {
+        Ok(())
+    }
+    fn evaluate<T: Borrow<Vec<F>>>(p: &(), input: T) -> Result<Vec<u8>, Error> {
+        let col: &Vec<F> = input.borrow();
+        let out = <FieldToBytesColHasher<F, Blake2s256> as CRHScheme>::evaluate(p, col.clone())?;
+        let mut ser = Vec::new();
+        ark_serialize::CanonicalSerialize::serialize_compressed(col, &mut ser).unwrap();
+        assert_eq!(<Blake2s256 as blake2::Digest>::digest(&ser).to_vec(), out);
+        with_log(|l| {
+            l.col_hash_input_sha256.push(hex::encode(Sha2::digest(&ser)));
+            l.col_hash_input_len.push(col.len());
+            l.col_hash_first_elems.push(col.iter().take(2).map(|x| hex::encode(x.into_bigint().to_bytes_le())).collect());
+            l.col_hash_output.push(hex::encode(&out));
+        });
+        Ok(out)
+    }
+}
+pub struct RecParamsG;
+impl<F: PrimeField> LigeroMTParams<RecMerkleParams, RecColHasherG<F>> for RecParamsG {
+    fn leaf_hash_param(&self) -> &() {
+        &()
+    }
+    fn two_to_one_hash_param(&self) -> &() {
+        &()
+    }
+    fn col_hash_params(&self) -> &() {
+        &()
     }
 }
 
@@ -195,6 +235,36 @@ fn run_case(name: &str, r1cs: &str, wasm: &str, witness: Vec<Fr>) -> Case {
     Case { name: name.into(), witness: witness.iter().map(fr_hex).collect(), num_nodes, prove: prove_log, verify: verify_log, verified }
 }
 
+/// src/ligero/tests.rs:186-193 (test_prove_and_verify_bls12_377) on a FIXED point, the G1 generator, with the circuit of
+/// src/arithmetic_circuit/tests.rs:17-33 rebuilt through the public builder API (the generator there is pub(crate)).
+/// The sponge is the plain test_sponge::<Fq>() (the Fq transcript is not recorded: the commitment-level facts -- domain,
+/// serialisation width, hashes, tree -- are what this case pins).
+fn run_bls12_377_case() -> Case {
+    use ark_bls12_377::{Fq, G1Affine};
+    use ark_ec::AffineRepr;
+    let g = G1Affine::generator();
+    let (x, y) = (g.x().unwrap(), g.y().unwrap());
+    let mut circuit = ArithmeticCircuit::<Fq>::new();
+    let one = circuit.constant(Fq::from(1u64));
+    let xn = circuit.new_variable_with_label("x");
+    let yn = circuit.new_variable_with_label("y");
+    let y_squared = circuit.pow(yn, 2);
+    let minus_y_squared = circuit.minus(y_squared);
+    let x_cubed = circuit.pow(xn, 3);
+    circuit.add_nodes([x_cubed, one, minus_y_squared, one]);
+    let num_nodes = circuit.num_nodes();
+    let output = circuit.last();
+    let ligero = LigeroCircuit::new(circuit, vec![output], DEFAULT_SECURITY_LEVEL);
+    let sponge: PoseidonSponge<Fq> = test_sponge();
+    *LOG.lock().unwrap() = Some(Log::default());
+    let proof = ligero.prove::<RecMerkleParams, RecColHasherG<Fq>, RecParamsG>(vec![(1, x), (2, y)], &RecParamsG, &mut sponge.clone());
+    let prove_log = LOG.lock().unwrap().replace(Log::default()).unwrap();
+    let verified = ligero.verify::<RecMerkleParams, RecColHasherG<Fq>, RecParamsG>(proof, &RecParamsG, &mut sponge.clone());
+    let verify_log = LOG.lock().unwrap().take().unwrap();
+    let hex48 = |v: &Fq| hex::encode(v.into_bigint().to_bytes_le());
+    Case { name: "bls12_377_curve".into(), witness: vec![hex48(&Fq::from(1u64)), hex48(&x), hex48(&y)], num_nodes, prove: prove_log, verify: verify_log, verified }
+}
+
 #[test]
 fn pin_dump() {
     // src/ligero/tests.rs:375-381
@@ -208,6 +278,7 @@ fn pin_dump() {
     let cases = vec![
         run_case("multiplication", "circom/multiplication.r1cs", "circom/multiplication.wasm", mult_witness),
         run_case("poseidon", "circom/poseidon/poseidon.r1cs", "circom/poseidon/poseidon_js/poseidon.wasm", poseidon_witness),
+        run_bls12_377_case(),
     ];
     for c in &cases {
         assert!(c.verified, "{}: the reference rejected its own proof", c.name);

@@ -6,7 +6,8 @@ commitment and the sub-proof polynomials.  The GPU path is tied to the oracle by
 
     python tests/golden/compare_rust_dump.py [tests/golden/rust_dump.json]
 
-What is compared, per case (multiplication, poseidon), each named after the upstream behaviour it pins:
+What is compared, per case (multiplication, poseidon; bls12_377_curve: the commitment-level items only, over ark_bls12_377::Fq),
+each named after the upstream behaviour it pins:
   * column hash (mod.rs:536-542): for every column j of U, sha256 of serialize_compressed(column) [the u64-LE length prefix +
     32-byte LE canonical elements], its first two elements, and the Blake2s-256 digest
   * Merkle tree (mod.rs:544-551): the multiset of two-to-one calls -- bottom level `evaluate` on LE64(32) || digest pairs
@@ -127,12 +128,82 @@ def expected_case(name: str):
     return exp
 
 
+# the BLS12-377 G1 generator (the fixed point rust-shim's third case proves the curve equation for)
+BLS_GX = 0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef
+BLS_GY = 0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6
+
+
+def expected_bls12_377_case():
+    """test_prove_and_verify_bls12_377 (src/ligero/tests.rs:186-193) on the G1 generator, commitment-level facts only, from the
+    generic-field model (oracle/model_field.py): the circuit of src/arithmetic_circuit/tests.rs:17-48 evaluated by hand --
+    nodes 0: 1, 1: x, 2: y, 3: y*y, 4: const -1, 5: (-1)*y^2, 6: x*x, 7: x^2*x, 8: +1, 9: +node5, 10: +1; the constant at node 4
+    takes no position (mod.rs:491), so w has 10 entries; (m, k, n, t) = (4, 4, 32, 32)"""
+    from oracle import model_field as mf
+    fq = mf.BLS12_377_FQ
+    p, x, y = fq.p, BLS_GX, BLS_GY
+    y2, x2 = y * y % p, x * x % p
+    x3 = x2 * x % p
+    n8 = (x3 + 1) % p
+    n9 = (n8 + (p - y2)) % p
+    w = [1, x, y, y2, (p - y2) % p, x2, x3, n8, n9, (n9 + 1) % p]
+    assert w[-1] == 1
+    mul = {3: (y, y), 4: (p - 1, y2), 5: (x, x), 6: (x2, x)}           # position -> operands
+    m = k = 4
+    blocks = [[0] * (m * k) for _ in range(4)]
+    for pos, v in enumerate(w):
+        blocks[3][pos] = v
+        if pos in mul:
+            blocks[0][pos], blocks[1][pos], blocks[2][pos] = mul[pos][0], mul[pos][1], v
+    pre = [blk[r * k:(r + 1) * k] for blk in blocks for r in range(m)]
+    coeffs, u, leaves, nodes, root = fq.encode_commit(pre, k, 8 * k)
+    rows, n = 4 * m, 8 * k
+    cols = []
+    for j in range(n):
+        col = [u[i][j] for i in range(rows)]
+        ser = rows.to_bytes(8, "little") + b"".join(v.to_bytes(48, "little") for v in col)
+        cols.append((hashlib.sha256(ser).hexdigest(), rows, [v.to_bytes(48, "little").hex() for v in col[:2]], leaves[j].hex()))
+    calls = set()
+    pre32 = (32).to_bytes(8, "little")
+    first_leaf_parent = n // 2 - 1
+    for i in range(n // 2):
+        calls.add(("evaluate", (pre32 + leaves[2 * i]).hex(), (pre32 + leaves[2 * i + 1]).hex(), nodes[first_leaf_parent + i].hex()))
+    for i in range(first_leaf_parent):
+        calls.add(("compress", nodes[2 * i + 1].hex(), nodes[2 * i + 2].hex(), nodes[i].hex()))
+    return {"dims": (m, k, n, n), "num_nodes": 11, "witness": [v.to_bytes(48, "little").hex() for v in (1, x, y)], "commit_cols": cols,
+            "two_to_one": calls, "root": root.hex()}
+
+
+def compare_bls12_377(case):
+    """the Fq case: domain (through U), 48-byte serialisation, column hashes, tree; the Fq transcript is not recorded"""
+    exp = expected_bls12_377_case()
+    name = case["name"]
+    m, k, n, t = exp["dims"]
+    assert case["verified"], f"{name}: the reference rejected its own proof"
+    assert case["num_nodes"] == exp["num_nodes"], f"{name}: node count of the curve-equation circuit (arithmetic_circuit/tests.rs:37-48)"
+    assert case["witness"] == exp["witness"], f"{name}: not the G1 generator / not 48-byte little-endian elements"
+    pl = case["prove"]
+    assert len(pl["col_hash_output"]) == n
+    for j in range(n):
+        sha, ln, first, out = exp["commit_cols"][j]
+        assert pl["col_hash_input_len"][j] == ln, f"{name}: column {j} has {pl['col_hash_input_len'][j]} elements, 4m = {ln}"
+        assert pl["col_hash_first_elems"][j] == first, (f"{name}: U[0..2][{j}] differs: ark_bls12_377::Fq's FFT domain -- the 2-adic root derived from "
+                                                        "the multiplicative generator (15 here) -- or the dimensions (m, k) = (4, 4)")
+        assert pl["col_hash_input_sha256"][j] == sha, f"{name}: serialize_compressed(column {j}) differs: 48-byte elements / u64 length prefix"
+        assert pl["col_hash_output"][j] == out, f"{name}: Blake2s-256 of column {j} differs"
+    missing = exp["two_to_one"] - {tuple(x) for x in pl["two_to_one"]}
+    assert not missing, f"{name}: {len(missing)} two-to-one calls of the tree differ"
+    return f"{name}: m={m} k={k} n={n}: {n} column hashes over 48-byte elements, {len(exp['two_to_one'])} tree nodes -- identical; root {exp['root']}"
+
+
 def compare(dump_path: str):
     """raises AssertionError naming the first upstream behaviour that differs"""
     cases = json.load(open(dump_path))
     report = []
     for case in cases:
         name = case["name"]
+        if name == "bls12_377_curve":
+            report.append(compare_bls12_377(case))
+            continue
         exp = expected_case(name)
         m, k, n, t = exp["dims"]
         assert case["verified"], f"{name}: the reference rejected its own proof"
