@@ -335,10 +335,13 @@ int lg_commit_sharded(lg_ctx* ctx, const lg_comm* comm, const uint64_t* preenc_r
  * share of each of the four row blocks X, Y, Z, W of preenc_u (mod.rs:516) -- its rows then form a small [X; Y; Z; W]
  * matrix of their own (the quadratic test's row triples stay on one rank); the relay then has 4 * world hops.
  * lg_relay_row_ranges: (first row in the column, rows) x up to 4.
+ * plane_groups P (0 = chosen by the library; contiguous layout only): every hop is cut into P runs of planes, rank g works on
+ * group c while rank g + 1 works on group c - 1 -- G + P - 1 steps instead of G, each over n / P columns, which pays once a
+ * group is small enough for the four-lanes-per-column hash kernel (<= 32 768 columns).
  */
 enum { LG_RELAY_CONTIGUOUS = 0, LG_RELAY_BLOCKS = 1 };
 int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int layout, uint64_t* ranges_out, uint32_t* nranges_out);
-int lg_commit_row_relay(lg_ctx* ctx, const lg_comm* comm, uint64_t col_rows, int layout, const uint64_t* preenc_rows);
+int lg_commit_row_relay(lg_ctx* ctx, const lg_comm* comm, uint64_t col_rows, int layout, uint32_t plane_groups, const uint64_t* preenc_rows);
 /* Mean milliseconds per stage (HIP events on the library's stream, no host laps) of the sharded commits issued since
  * lg_profile_enable(ctx, 1), at most the last 16.  Coset-sharded: {interpolate, wait for the last piece of the coefficient
  * all-gather, evaluate + hash, digest all-gather, tree}; row relay: {encode incl. the first rank's overlapped hash, 0, the

@@ -130,7 +130,7 @@ def lib():
     L.lg_shard_row_ranges.argtypes = [_u32, _u32, _u32, _u32, _vp, _vp]
     L.lg_commit_sharded.argtypes = [_vp, _vp, _vp, _u32]
     L.lg_relay_row_ranges.argtypes = [ctypes.c_uint64, _u32, _u32, _int, _vp, _vp]
-    L.lg_commit_row_relay.argtypes = [_vp, _vp, ctypes.c_uint64, _int, _vp]
+    L.lg_commit_row_relay.argtypes = [_vp, _vp, ctypes.c_uint64, _int, _u32, _vp]
     L.lg_shard_profile_read.argtypes = [_vp, _vp, _vp]
     L.lg_stage_merkle.argtypes = [_vp]
     L.lg_device_buffer.argtypes = [_vp, _int, _vp, _vp]

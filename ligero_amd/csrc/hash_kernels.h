@@ -235,10 +235,18 @@ constexpr int kQuadStrideWords = 44;  // two slots + pad: 44 c mod 32 is distinc
 struct ColHashQuadArgs {
     const uint4* u;         // coset planes, canonical integers, 2 x uint4 per element
     uint8_t* leaves;        // [batch][n][32]
-    uint32_t rows, k, lognp;
+    uint32_t rows, k, lognp;   // rows: rows per proof of THIS matrix (addressing)
     uint32_t proof_begin, proof_count;
     uint32_t plane_begin, plane_count;
     uint64_t plane_stride;  // elements
+    // Row ranges (round 3), with the same parked state as the one-lane kernel (kColStateVec uint4 per column): rows
+    // [row_begin, row_end) are absorbed; they are rows [col_pos, ...) of columns of col_rows rows.  col_pos must be EVEN and,
+    // unless `last`, so must the number of rows (the host falls back to the one-lane kernel otherwise).  A whole-column launch
+    // is row_begin = 0, row_end = rows, col_pos = 0, col_rows = rows, first = last = 1.
+    uint4* state;
+    uint32_t row_begin, row_end;
+    uint32_t first, last;
+    uint64_t col_pos, col_rows;
 };
 
 static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const ColHashQuadArgs a) {
@@ -252,7 +260,8 @@ static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const 
     const uint32_t s = a.plane_begin + (uint32_t)((cc / a.k) % a.plane_count);
     const uint32_t b = a.proof_begin + (uint32_t)((cc / a.k) / a.plane_count);
     // lane l fetches 16 bytes: rows (2 blk + l / 2), half (l % 2)
-    const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + (lane >> 1)) * a.k + q) + (lane & 1);
+    const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + a.row_begin + (lane >> 1)) * a.k + q) + (lane & 1);
+    uint32_t* st = reinterpret_cast<uint32_t*>(a.state + kColStateVec * ((((uint64_t)b << a.lognp) + s) * a.k + q));
     const uint64_t step = 4 * (uint64_t)a.k;               // two rows, in uint4
     uint32_t* slot0 = lds + quad * kQuadStrideWords;
     // loop-invariant LDS addresses of this lane's message words (slot 0; slot 1 = + kQuadSlotWords words)
@@ -263,10 +272,13 @@ static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const 
         for (int j = 0; j < 4; j++) mw[r][j] = slot0 + 2 + kB2sQuadSigma.w[r][lane][j];
     const uint32_t iv_lo = kB2sIv[lane], iv_hi = kB2sIv[4 + lane];
     uint32_t h_lo = iv_lo ^ (lane == 0 ? 0x01010020u : 0u), h_hi = iv_hi;
+    if (!a.first && active) { h_lo = st[lane]; h_hi = st[4 + lane]; }     // resume: lane l holds h[l] and h[4 + l]
 
-    const uint32_t rows = a.rows;
-    const uint32_t nblk = (rows & 1) ? (rows + 1) / 2 : rows / 2 + 1;   // rows even: the last block holds only the 8 carried bytes
-    const uint64_t total_len = 8 + 32 * (uint64_t)rows;
+    const uint32_t rows = a.row_end - a.row_begin;
+    // finalising launch: rows even -> one more block with only the 8 carried bytes; otherwise whole blocks of two rows
+    const uint32_t nblk = a.last ? ((rows & 1) ? (rows + 1) / 2 : rows / 2 + 1) : rows / 2;
+    const uint64_t total_len = 8 + 32 * a.col_rows;
+    const uint64_t blk0 = a.col_pos >> 1;                                   // blocks compressed before this launch
     auto fetch = [&](uint32_t blk) -> uint4 {
         const uint32_t row = 2 * blk + (lane >> 1);
         return (active && row < rows) ? p[(uint64_t)blk * step] : make_uint4(0, 0, 0, 0);
@@ -281,14 +293,17 @@ static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const 
             other[3] = v.w;
         }
     };
-    if (lane == 0) { slot0[2] = rows; slot0[3] = 0; }      // LE64(rows): serialize_compressed length prefix of Vec<F>
+    if (lane == 0) {
+        if (a.first) { slot0[2] = (uint32_t)a.col_rows; slot0[3] = (uint32_t)(a.col_rows >> 32); }   // LE64(rows): serialize_compressed length prefix of Vec<F>
+        else if (active) { slot0[2] = st[8]; slot0[3] = st[9]; }                                     // the 8 bytes carried over from the last row absorbed
+    }
     uint4 cur = fetch(0);
     stage(0, cur);
     uint4 nxt = fetch(1);
     auto block = [&](uint32_t blk, auto slot_c) {
         constexpr int so = decltype(slot_c)::value * kQuadSlotWords;   // compile-time slot: the 40 reads use immediate offsets
-        const bool last = blk + 1 == nblk;
-        const uint64_t t = last ? total_len : 64 * (uint64_t)(blk + 1);
+        const bool last = a.last && blk + 1 == nblk;
+        const uint64_t t = last ? total_len : 64 * (blk0 + blk + 1);
         uint32_t va = h_lo, vb = h_hi, vc = iv_lo;
         const uint32_t tw = lane == 0 ? (uint32_t)t : (lane == 1 ? (uint32_t)(t >> 32) : ((lane == 2 && last) ? 0xffffffffu : 0u));
         uint32_t vd = iv_hi ^ tw;
@@ -335,7 +350,7 @@ static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const 
         // undo the last diagonal rotation and feed forward: h[l] ^= v[l] ^ v[8 + l], h[4 + l] ^= v[4 + l] ^ v[12 + l]
         h_lo ^= quad_rot<kQuadRot1>(va) ^ quad_rot<kQuadRot3>(vc);
         h_hi ^= vb ^ quad_rot<kQuadRot2>(vd);
-        if (!last) {
+        if (blk + 1 < nblk) {
             quad_lds_order();
             stage(blk + 1, nxt);
             nxt = fetch(blk + 2);
@@ -346,6 +361,18 @@ static __global__ void __launch_bounds__(256) blake2s_columns_quad_kernel(const 
         if (blk + 1 < nblk) block(blk + 1, std::integral_constant<int, 1>{});
     }
     if (!active) return;
+    if (!a.last) {
+        // park: h[l] / h[4 + l] from lane l, the 8 carried bytes (staged into the slot the next block would have used) from lane 0
+        st[lane] = h_lo;
+        st[4 + lane] = h_hi;
+        quad_lds_order();
+        if (lane == 0) {
+            const uint32_t* nx = slot0 + (nblk & 1) * kQuadSlotWords;
+            st[8] = nx[2];
+            st[9] = nx[3];
+        }
+        return;
+    }
     uint32_t* out = reinterpret_cast<uint32_t*>(a.leaves + 32 * ((((uint64_t)b * a.k + q) << a.lognp) + s));
     out[lane] = h_lo;
     out[4 + lane] = h_hi;

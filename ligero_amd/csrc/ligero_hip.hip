@@ -465,6 +465,23 @@ static int grow(lg_ctx* c, fr** p, size_t* cap, size_t need) {
     return LG_OK;
 }
 
+// the four-lanes-per-column kernel's view of a column-hash launch (same rows, same parked state)
+static lg::ColHashQuadArgs quad_args_of(const lg::ColHashArgs& h) {
+    lg::ColHashQuadArgs qa;
+    memset(&qa, 0, sizeof(qa));
+    qa.u = h.u; qa.leaves = h.leaves; qa.rows = h.rows; qa.k = h.k; qa.lognp = h.lognp;
+    qa.proof_begin = h.proof_begin; qa.proof_count = h.proof_count; qa.plane_begin = h.plane_begin; qa.plane_count = h.plane_count;
+    qa.plane_stride = h.plane_stride;
+    qa.state = h.state; qa.row_begin = h.row_begin; qa.row_end = h.row_end; qa.first = h.first; qa.last = h.last;
+    qa.col_pos = h.col_pos; qa.col_rows = h.col_rows;
+    return qa;
+}
+// ... which needs an even position in the column and, unless it finalises, an even number of rows (whole 64-byte blocks)
+static bool quad_can_take(const lg::ColHashArgs& h) {
+    const uint32_t nrows = h.row_end - h.row_begin;
+    return (h.col_pos & 1) == 0 && nrows > 0 && (h.last || (nrows & 1) == 0);
+}
+
 // The commit is pipelined over row chunks on two streams: while the encode stream evaluates
 // chunk c+1, the hash stream absorbs chunk c into the per-column Blake2s states.  The column
 // hash is latency bound (one sequential chain per column, only n columns), so it fills issue
@@ -1050,11 +1067,7 @@ static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeff
         if (h.first && h.last && threads <= c->quad_hash_max_columns) {
             // few columns (a single small proof): the one-lane-per-column kernel would be one latency chain per SIMD;
             // four lanes per column shorten the chain (hash_kernels.h)
-            lg::ColHashQuadArgs qa;
-            memset(&qa, 0, sizeof(qa));
-            qa.u = h.u; qa.leaves = h.leaves; qa.rows = h.rows; qa.k = h.k; qa.lognp = h.lognp;
-            qa.proof_begin = h.proof_begin; qa.proof_count = h.proof_count; qa.plane_begin = 0; qa.plane_count = c->nplanes;
-            qa.plane_stride = plane;
+            const lg::ColHashQuadArgs qa = quad_args_of(h);
             hipLaunchKernelGGL(lg::blake2s_columns_quad_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(256), 0, hs, qa);
         } else {
             hipLaunchKernelGGL(lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
@@ -1407,11 +1420,7 @@ static int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host
         h.col_pos = hr.r0; h.col_rows = c->rows;
         const uint64_t threads = (uint64_t)c->batch * c->n;
         if (h.first && h.last && threads <= c->quad_hash_max_columns) {   // few columns: four lanes per column (hash_kernels.h)
-            lg::ColHashQuadArgs qa;
-            memset(&qa, 0, sizeof(qa));
-            qa.u = h.u; qa.leaves = h.leaves; qa.rows = h.rows; qa.k = h.k; qa.lognp = h.lognp;
-            qa.proof_begin = 0; qa.proof_count = c->batch; qa.plane_begin = 0; qa.plane_count = c->nplanes;
-            qa.plane_stride = plane;
+            const lg::ColHashQuadArgs qa = quad_args_of(h);
             LG_LAUNCH(c, lg::blake2s_columns_quad_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(256), 0, hs, qa);
         } else {
             LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
@@ -2198,7 +2207,14 @@ static int stage_hash_launch(lg_ctx* c, hipStream_t hs, uint32_t plane_mask, uin
         h.plane_stride = plane;
         h.col_pos = col_pos; h.col_rows = col_rows;
         const uint64_t threads = (uint64_t)h.plane_count * c->ki;
-        LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+        // few columns (a rank's planes of a coset-sharded proof: n / G of them): the one-lane kernel would be a latency chain on a
+        // fraction of the SIMDs; four lanes per column shorten it, now also across row ranges (the parked state is the same)
+        if (threads <= c->quad_hash_max_columns && quad_can_take(h)) {
+            const lg::ColHashQuadArgs qa = quad_args_of(h);
+            LG_LAUNCH(c, lg::blake2s_columns_quad_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(256), 0, hs, qa);
+        } else {
+            LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+        }
         s = e2 + 1;
     }
     return LG_OK;
@@ -2577,7 +2593,7 @@ int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int la
     return LG_OK;
 }
 
-int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int layout, const uint64_t* preenc_rows) {
+int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int layout, uint32_t plane_groups, const uint64_t* preenc_rows) {
     if (!c || !comm) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;
     if (c->batch != 1 || c->sharded) return LG_ERR_STATE;
@@ -2635,20 +2651,38 @@ int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int l
     }
     if (ev) LG_HIP(c, hipEventRecord(ev[1], c->stream));
     if (ev) LG_HIP(c, hipEventRecord(ev[2], c->stream));
-    const size_t state_bytes = (size_t)c->n * LG_HSTATE_BYTES;
+    // Plane groups: every hop is cut into P runs of planes and rank g works on group c while rank g + 1 works on group c - 1.  With
+    // n / P <= 32 768 columns per launch the four-lanes-per-column kernel takes the hash (a shorter chain per block), which is what
+    // makes the (G + P - 1) steps cheaper than G steps over all columns -- measured per rank at S22: 2.26 ms for all 65 536
+    // columns in one launch, 1.53 / 1.13 ms per group of 32 768 / 16 384 (tools/chain_probe.py).  0 = choose by the size of the
+    // group.  The block layout's chain wraps around (rank G - 1 hands back to rank 0), where a rank would have to send and receive
+    // in the same step: one group there.
+    uint32_t P = plane_groups;
+    const bool auto_groups = P == 0;
+    if (auto_groups) P = world <= 2 ? 1 : (world <= 4 ? 2 : 4);
+    if (layout != LG_RELAY_CONTIGUOUS) P = 1;
+    while (P & (P - 1)) P &= P - 1;                       // a power of two (the planes are)
+    while (P > 1 && (P > c->nplanes || (auto_groups && (c->n / P) < 8192))) P >>= 1;
+    if (P < 1) P = 1;
+    const uint32_t per = c->nplanes / P;
+    const size_t group_bytes = (size_t)per * c->ki * LG_HSTATE_BYTES;
     for (size_t i = 0; i < chain.size(); i++) {
         const Link& l = chain[i];
         if (l.owner != rank) continue;
-        if (exchange && i > 0 && chain[i - 1].owner != rank) {
-            { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
-            const int rc_ = comm->recv(comm->user, c->d_hstate, state_bytes, chain[i - 1].owner, static_cast<void*>(c->stream));
-            if (rc_ != 0) return comm_fail(c, "receive of the column states", rc_);
-        }
-        if (!(head_done && i == 0)) { const int rc_ = lg_stage_hash_rows(c, all, l.local, (uint32_t)l.n, l.pos, col_rows); if (rc_ != LG_OK) return rc_; }
-        if (exchange && i + 1 < chain.size() && chain[i + 1].owner != rank) {
-            { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
-            const int rc_ = comm->send(comm->user, c->d_hstate, state_bytes, chain[i + 1].owner, static_cast<void*>(c->stream));
-            if (rc_ != 0) return comm_fail(c, "send of the column states", rc_);
+        for (uint32_t g = 0; g < P; g++) {
+            uint8_t* gstate = reinterpret_cast<uint8_t*>(c->d_hstate) + (size_t)g * group_bytes;
+            const uint32_t gmask = (per >= 32 ? 0xffffffffu : ((1u << per) - 1u)) << (g * per);
+            if (exchange && i > 0 && chain[i - 1].owner != rank) {
+                { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+                const int rc_ = comm->recv(comm->user, gstate, group_bytes, chain[i - 1].owner, static_cast<void*>(c->stream));
+                if (rc_ != 0) return comm_fail(c, "receive of the column states", rc_);
+            }
+            if (!(head_done && i == 0)) { const int rc_ = lg_stage_hash_rows(c, gmask, l.local, (uint32_t)l.n, l.pos, col_rows); if (rc_ != LG_OK) return rc_; }
+            if (exchange && i + 1 < chain.size() && chain[i + 1].owner != rank) {
+                { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+                const int rc_ = comm->send(comm->user, gstate, group_bytes, chain[i + 1].owner, static_cast<void*>(c->stream));
+                if (rc_ != 0) return comm_fail(c, "send of the column states", rc_);
+            }
         }
     }
     { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }

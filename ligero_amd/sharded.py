@@ -514,7 +514,7 @@ class HipRelayBackend:
         mask = ((1 << nplanes) - 1) << plane0
         _ffi.check(self._L.lg_stage_hash_rows(self.c._ctx, mask, row0, nrows, col_pos, col_rows), "lg_stage_hash_rows", self.c._ctx)
 
-    def commit_native(self, comm: TorchComm, col_rows: int, layout: str, preenc_rows: Optional[np.ndarray]):
+    def commit_native(self, comm: TorchComm, col_rows: int, layout: str, preenc_rows: Optional[np.ndarray], plane_groups: int = 0):
         """lg_commit_row_relay: the whole commit as ONE call, queued on the library's streams; the hand-over of the column
         states and the broadcast of the digests come back through `comm`"""
         p = None
@@ -522,7 +522,8 @@ class HipRelayBackend:
             preenc_rows = np.ascontiguousarray(preenc_rows, dtype=np.uint64)
             p = preenc_rows.ctypes.data_as(_vp)
         comm.error = None
-        st = self._L.lg_commit_row_relay(self.c._ctx, comm.ptr(), col_rows, {"contiguous": _ffi.LG_RELAY_CONTIGUOUS, "blocks": _ffi.LG_RELAY_BLOCKS}[layout], p)
+        st = self._L.lg_commit_row_relay(self.c._ctx, comm.ptr(), col_rows, {"contiguous": _ffi.LG_RELAY_CONTIGUOUS, "blocks": _ffi.LG_RELAY_BLOCKS}[layout],
+                                         plane_groups, p)
         if st == _ffi.LG_ERR_COMM and comm.error:
             raise RuntimeError(f"lg_commit_row_relay: {comm.error}")
         _ffi.check(st, "lg_commit_row_relay", self.c._ctx)
@@ -583,12 +584,13 @@ class RowRelayCommitter:
     coset-sharded mode.  The rank with the last rows broadcasts the n digests and every rank builds the tree.
 
     `make_backend(local_rows)` builds this rank's backend (HipRelayBackend; the CPU tests inject an oracle-backed double).
-    plane_groups P > 1 cuts every hop into P runs of planes: rank g works on group c while rank g + 1 works on group c - 1.
-    That pays only if a hash launch over fewer columns is faster -- on MI355X it is not (one lane per column, one wave per SIMD
-    at most: a latency chain whose length does not depend on the number of columns) -- so the default is 1.
+    plane_groups P > 1 cuts every hop into P runs of planes: rank g works on group c while rank g + 1 works on group c - 1 --
+    G + P - 1 steps instead of G.  With one lane per column a launch over fewer columns is no faster (a latency chain whose length
+    does not depend on their number), but a group of <= 32 768 columns goes to the four-lanes-per-column kernel, which is (DESIGN.md
+    section 7): 0 = let the library choose by world size and group size (native backends; the stage-by-stage path takes it as 1).
     layout: relay_row_ranges()."""
 
-    def __init__(self, make_backend, rows: int, dist=None, group=None, plane_groups: int = 1, layout: str = "contiguous",
+    def __init__(self, make_backend, rows: int, dist=None, group=None, plane_groups: int = 0, layout: str = "contiguous",
                  collectives_at_world_1: bool = False):
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group) if dist is not None else 1
@@ -598,7 +600,8 @@ class RowRelayCommitter:
         self.mine = [(pos, n, local) for pos, n, r, local in self.chain if r == self.rank]
         self.local_rows = sum(n for _, n, _ in self.mine)
         self.be = make_backend(self.local_rows)
-        self.groups = max(1, min(int(plane_groups), self.be.nplanes))
+        self.asked_groups = int(plane_groups)
+        self.groups = max(1, min(self.asked_groups, self.be.nplanes))
         while self.be.nplanes % self.groups:
             self.groups -= 1
         if layout != "contiguous":
@@ -610,8 +613,8 @@ class RowRelayCommitter:
         self.stage_ms: Dict[str, float] = {}
         self._stream = self.be.stream() if hasattr(self.be, "stream") else None
         self._nccl = dist is not None and dist.get_backend(group) == "nccl"
-        # one library call per commit (lg_commit_row_relay) where the backend has it; plane groups are driven from here
-        self.native = hasattr(self.be, "commit_native") and self.groups == 1
+        # one library call per commit (lg_commit_row_relay) where the backend has it
+        self.native = hasattr(self.be, "commit_native")
         self._comm = TorchComm(dist, group, self.be.device, exchange_at_world_1=self.force) if self.native else None
         self._profiling = False
 
@@ -713,7 +716,7 @@ class RowRelayCommitter:
         if not self._profiling:
             self.be.profile(True)
             self._profiling = True
-        self.be.commit_native(self._comm, self.rows, self.layout, preenc_rows_local)
+        self.be.commit_native(self._comm, self.rows, self.layout, preenc_rows_local, self.asked_groups)
 
     def open_columns(self, indices: Sequence[int]):
         """every rank holds ITS ROWS of every column: returns (rows of the columns [t, local_rows, 4] in this rank's own row

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential sweep (GPU library vs the oracle) over shapes the fixed test cases do not name:
-random rows / k / batch, random data incl. field corners, both commit entry points, openings, sub-proof polynomials.
+random rows / k / batch, random data incl. field corners, both commit entry points, openings, sub-proof polynomials, the commit from w
+alone (random wirings), the row relay and the coset-sharded commit over several contexts.
     python tests/parity_sweep.py [seconds] [seed]
 Collected by pytest through tests/test_gpu_parity_sweep.py (fixed seed, bounded time); as a script it sweeps for as long
 as asked with a time-derived seed.  Lives under tests/ because it uses the oracle."""
@@ -31,8 +32,30 @@ def sweep(budget: float, seed: int) -> int:
             batch = 1
         seed = int(rng.integers(1 << 30))
         pre = random_mont(seed, batch * rows * k).reshape(batch * rows, k, 4)
+        # a quarter of the cases are matrices with the STRUCTURE of preenc_u: a random wiring on random w (a1 on the device, round 3)
+        wiring = None
+        if rng.integers(4) == 0:
+            from test_host_pipeline import rebuild_preenc_from_w
+            m, mk = rows // 4, (rows // 4) * k
+            npos = max(2, mk - int(rng.integers(0, min(mk - 1, 5))))
+            left = np.full(npos, 0xffffffff, dtype=np.uint32)
+            right = left.copy()
+            gates = np.sort(rng.choice(np.arange(1, npos), size=max(1, (npos - 1) // 3), replace=False))
+            forward = bool(rng.integers(4) == 0)
+            consts = random_mont(seed + 11, 3).reshape(3, 4)
+            for side in (left, right):
+                src = (rng.random(gates.shape[0]) * (npos if forward else gates)).astype(np.uint32)
+                use_const = rng.random(gates.shape[0]) < 0.15
+                src[use_const] = 0x80000000 | rng.integers(0, 3, size=int(use_const.sum())).astype(np.uint32)
+                side[gates] = src
+            w = np.zeros((batch, mk, 4), dtype=np.uint64)
+            w[:, :npos] = random_mont(seed + 12, batch * npos).reshape(batch, npos, 4)
+            for _ in range(8):                       # corner values go into w (the matrix is a function of it)
+                w[int(rng.integers(batch)), int(rng.integers(npos))] = [0, 0, 0, 0] if rng.integers(2) else P_LIMBS - np.array([1, 0, 0, 0], dtype=np.uint64)
+            pre = np.concatenate([rebuild_preenc_from_w(w[b], left, right, consts, m, k) for b in range(batch)])
+            wiring = (w.reshape(batch * m, k, 4), left, right, consts)
         # sprinkle corner values: 0, 1 (Montgomery one is in random_mont's range anyway), p - 1
-        for _ in range(8):
+        for _ in range(0 if wiring is not None else 8):
             i, j = int(rng.integers(batch * rows)), int(rng.integers(k))
             pre[i, j] = [0, 0, 0, 0] if rng.integers(2) else P_LIMBS - np.array([1, 0, 0, 0], dtype=np.uint64)
         force = int(rng.choice([0, 0, 2, 3]))
@@ -80,6 +103,37 @@ def sweep(budget: float, seed: int) -> int:
                 for b in range(batch):
                     want = oracle.quadratic_constraint_poly(coeffs[b * rows:(b + 1) * rows], r[b])
                     assert np.array_equal(got[b], want), ("quad", rows, k, batch, b, seed)
+            if wiring is not None:
+                # the same commitment from w alone: X, Y, Z gathered on the device, the upload in steps (lg_encode_commit_from_witness)
+                with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as cw:
+                    cw.upload_gate_map(wiring[1], wiring[2], wiring[3])
+                    wco, wroots = cw.encode_commit_from_witness(wiring[0], want_coeffs=True)
+                    assert wroots == roots and np.array_equal(wco, coeffs), ("from witness", rows, k, batch, seed)
+                    assert np.array_equal(cw.leaves(), c.leaves()), ("from witness leaves", rows, k, batch, seed)
+            if batch == 1 and rng.integers(3) == 0:
+                # the same proof ROW-sharded over 2 .. 5 contexts with the Blake2s states of the columns handed on (row relay, round 3):
+                # both layouts, ragged and empty shards, odd boundaries; root, and every rank's rows of the opened columns
+                from ligero_amd.sharded import HipRelayBackend, relay_chain
+                from sharded_inprocess import relay_commit
+                world = int(rng.integers(2, 6))
+                layout = "blocks" if rng.integers(2) else "contiguous"
+                chain = relay_chain(rows, world, layout)
+                local = [sum(n for _, n, o, _ in chain if o == r) for r in range(world)]
+                rbes = [HipRelayBackend(local[r], k, device=0) for r in range(world)]
+                try:
+                    assert all(rt == roots[:32] for rt in relay_commit(rbes, chain, pre, rows)), ("relay root", rows, k, world, layout, seed)
+                    tc, ts, tp = c.open_columns(idx)
+                    merged = np.empty_like(tc)
+                    for r, be in enumerate(rbes):
+                        gc, gs, gp = be.open_columns(idx)
+                        assert np.array_equal(gs, ts) and np.array_equal(gp, tp), ("relay paths", rows, k, world, layout, seed)
+                        for pos, n, o, loc in chain:
+                            if o == r:
+                                merged[:, pos:pos + n] = gc[:, loc:loc + n]
+                    assert np.array_equal(merged, tc), ("relay columns", rows, k, world, layout, seed)
+                finally:
+                    for be in rbes:
+                        be.close()
             if batch == 1 and k <= 8192 and rng.integers(4) == 0:
                 # the same proof coset-sharded over 2 / 4 / 8 contexts (one process, exchanges as device copies): root, owner-served
                 # openings, and the three sub-proof polynomials from the plane owners' point values

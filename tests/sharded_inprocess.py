@@ -55,3 +55,34 @@ def merge_points(points_and_masks, nplanes):
         if s in owner:
             out[j] = points_and_masks[owner[s]][0][j]
     return out, owner
+
+
+def relay_commit(backends, chain, pre, rows):
+    """the row-relay commit (ligero_amd.sharded.RowRelayCommitter) over several HipRelayBackend contexts of ONE process: every
+    hop of the column states and the broadcast of the digests as a device copy.  chain: relay_chain(rows, world, layout)."""
+    import torch
+    for r, be in enumerate(backends):
+        mine = [(pos, n) for pos, n, owner, _ in chain if owner == r]
+        if be.local_rows:
+            be.stage_interpolate(np.concatenate([pre[a:a + n] for a, n in mine]), 0, be.local_rows)
+            be.stage_evaluate_rows(0, be.local_rows)
+            be.sync()
+    prev = None
+    for pos, n, owner, local in chain:
+        be = backends[owner]
+        if prev is not None and prev is not be:
+            prev.sync()
+            be.hstate_bytes().copy_(prev.hstate_bytes())
+            torch.cuda.synchronize()
+        be.stage_hash_rows(0, be.nplanes, local, n, pos, rows)
+        prev = be
+    prev.sync()
+    roots = []
+    for be in backends:
+        if be is not prev:
+            be.leaves_bytes().copy_(prev.leaves_bytes())
+            torch.cuda.synchronize()
+        be.stage_merkle()
+        be.sync()
+        roots.append(be.root())
+    return roots

@@ -162,7 +162,8 @@ def _s22_worker(rank, world, port, out):
         import bench
         from ligero_amd.sharded import HipRelayBackend, RowRelayCommitter
         rows, k = 20068, 8192
-        rc = RowRelayCommitter(lambda local: HipRelayBackend(local, k, device=0), rows, dist)
+        # (four plane groups: 16 384 columns per hop and launch -- the four-lanes-per-column kernel with its state parked and resumed)
+        rc = RowRelayCommitter(lambda local: HipRelayBackend(local, k, device=0), rows, dist, plane_groups=4)
         try:
             (a, n), = rc.row_ranges()
             root = rc.commit(bench.shard_rows_of_seeded_matrix(bench.LARGE_SEED, k, a, a + n))

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""What one rank of an 8-GPU S22 commit would spend in the column hash, measured on ONE GPU (the launches are the ones the sharded
+paths issue; only their concurrency with the other ranks is missing):
+  row relay   : all 65 536 columns, rows / 8 rows        (lg_stage_hash_rows on a context of the rank's own rows)
+  coset mode  : 2 of 16 planes = 8 192 columns, all rows (lg_stage_hash on a context that holds those planes)
+and the same for 1, 2, 4 plane groups of the relay (is a launch over fewer columns faster?).  HIP-event timing through torch on the
+library's stream."""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from ligero_amd import _ffi  # noqa: E402
+from ligero_amd.sharded import HipRelayBackend, HipStageBackend  # noqa: E402
+
+rows, k = 20068, 8192
+G = 8
+L = _ffi.lib()
+
+
+def timed(fn, sync, reps=3):
+    fn(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+# ---- relay: a rank's own rows, all planes
+local = rows // G
+be = HipRelayBackend(local, k)
+pre = bench.shard_rows_of_seeded_matrix(bench.LARGE_SEED, k, 0, local)
+be.stage_interpolate(pre, 0, local)
+be.stage_evaluate_rows(0, local)
+be.sync()
+t_enc = timed(lambda: (be.stage_interpolate(None, 0, local), be.stage_evaluate_rows(0, local)), be.sync)
+print(f"relay rank: interpolate + evaluate {local} rows x 16 planes: {t_enc:.2f} ms")
+for groups in (1, 2, 4, 16):
+    per = be.nplanes // groups
+    def go():
+        for g in range(groups):
+            be.stage_hash_rows(g * per, per, 0, local, 2 * (rows // G // 2) * 3, rows)      # a middle rank: resume and park
+    print(f"relay rank: hash {local} rows, all 65536 columns in {groups:2d} plane group(s): {timed(go, be.sync):.2f} ms"
+          f"  ({timed(lambda: be.stage_hash_rows(0, per, 0, local, 2 * (rows // G // 2) * 3, rows), be.sync):.2f} ms per group)")
+be.close()
+
+# ---- coset: 2 planes, all rows (needs the coefficient rows of all rows: interpolate them here)
+sb = HipStageBackend(rows, k, device=0, world=G, rank=3)
+full = bench.synthetic_preenc(bench.LARGE_SEED, rows * k).reshape(rows, k, 4)
+sb.stage_interpolate(full, 0, rows)
+del full
+planes = list(range(6, 8))
+sb.stage_evaluate_rows(planes, 0, rows)
+sb.sync()
+print(f"coset rank: evaluate 2 planes x {rows} rows: {timed(lambda: sb.stage_evaluate_rows(planes, 0, rows), sb.sync):.2f} ms")
+print(f"coset rank: hash 8192 columns x {rows} rows (one lane per column): {timed(lambda: sb.stage_hash(planes), sb.sync):.2f} ms")
+print(f"coset rank: evaluate + hash, chunk-pipelined (lg_stage_evaluate_hash): {timed(lambda: sb.stage_evaluate_hash(planes), sb.sync):.2f} ms")
+sb.close()
