@@ -42,7 +42,7 @@ void lgp_prover_destroy(lgp_prover* p);
  * are issued all the same -- the way to run the exact RCCL calls on a one-GPU box.  lgp_verify works on such a prover as on
  * any other.
  */
-enum { LGP_COMM_EXCHANGE_AT_WORLD_1 = 1, LGP_COMM_HAS_STREAM_CALLBACK = 2 };
+enum { LGP_COMM_EXCHANGE_AT_WORLD_1 = 1, LGP_COMM_HAS_STREAM_CALLBACK = 2, LGP_COMM_ROW_RELAY = 4 };
 typedef struct lgp_comm {
     uint32_t world, rank;
     uint32_t flags;
@@ -53,6 +53,14 @@ typedef struct lgp_comm {
      * library; include/ligero_hip.h lg_comm::all_gather): enqueue the collective there, do not wait on the host.  The commit
      * of a sharded proof is then one stream-ordered sequence inside the device library (lg_commit_sharded). */
     int (*all_gather_device_stream)(void* user, void* device_buf, uint64_t bytes_per_rank, void* stream);
+    /* read only when flags has LGP_COMM_ROW_RELAY: the proof runs on the ROW RELAY instead: every rank
+     * keeps its share of the rows of each of the X, Y, Z, W blocks end to end, the columns' Blake2s states travel from rank to
+     * rank (send / recv), the last rank broadcasts the digests -- the three stream-ordered calls of include/ligero_hip.h
+     * lg_comm -- every sub-proof point is the sum of per-rank partial sums (all_gather_host + a local add: balanced over all
+     * ranks, each holds its columns of A), opened columns come back as row pieces.  The proof is the same proof. */
+    int (*send_stream)(void* user, const void* device_buf, uint64_t bytes, uint32_t dst, void* stream);
+    int (*recv_stream)(void* user, void* device_buf, uint64_t bytes, uint32_t src, void* stream);
+    int (*broadcast_stream)(void* user, void* device_buf, uint64_t bytes, uint32_t root, void* stream);
 } lgp_comm;
 int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int device, const lgp_comm* comm);
 

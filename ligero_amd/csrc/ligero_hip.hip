@@ -1763,10 +1763,13 @@ static int linear_ra_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t* per_o
     int rc = linear_buffers(c, &per, &nch);
     if (rc != LG_OK) return rc;
     *per_out = per; *nch_out = nch;
-    const uint64_t n = (uint64_t)c->rows * c->k;      // 4 m k challenges per proof
-    if (n > 0x7fffffffull) return LG_ERR_UNSUPPORTED;
+    const uint64_t n = (uint64_t)c->rows * c->k;      // entries of r_a per proof = columns of A this context holds
+    // entries of r_linear = rows of A.  The reference's A is square (4mk x 4mk); a context that holds only a row shard of the proof's
+    // matrix (row relay, blocks layout) holds the matching COLUMNS of A and still needs every challenge
+    const uint64_t rlen = c->a_rows;
+    if (n > 0x7fffffffull || rlen > 0x7fffffffull) return LG_ERR_UNSUPPORTED;
     // 75.6 % of the 32-byte chunks are accepted; 1.5 chunks per element leaves > 50 standard deviations of margin
-    const uint32_t blocks = (uint32_t)((n * 3 + 3) / 4 + 64), wgs = (blocks + 255) / 256;
+    const uint32_t blocks = (uint32_t)((rlen * 3 + 3) / 4 + 64), wgs = (blocks + 255) / 256;
     if (!c->d_seeds) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_seeds), (size_t)c->batch * 32));
     if (!c->d_short_flag) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_short_flag), 4));
     if (c->cc_counts_cap < (size_t)c->batch * wgs) {
@@ -1775,18 +1778,18 @@ static int linear_ra_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t* per_o
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_cc_counts), (size_t)c->batch * wgs * 4));
         c->cc_counts_cap = (size_t)c->batch * wgs;
     }
-    rc = grow(c, &c->d_rlin, &c->rlin_elems, (size_t)c->batch * n);
+    rc = grow(c, &c->d_rlin, &c->rlin_elems, (size_t)c->batch * rlen);
     if (rc != LG_OK) return rc;
     LG_HIP(c, hipMemcpyAsync(c->d_seeds, seeds, (size_t)c->batch * 32, hipMemcpyHostToDevice, c->stream));
     LG_HIP(c, hipMemsetAsync(c->d_short_flag, 0, 4, c->stream));
     lg::ChaChaArgs a;
     a.seeds = c->d_seeds; a.out = c->d_rlin; a.counts = c->d_cc_counts; a.short_flag = c->d_short_flag;
-    a.n = (uint32_t)n; a.blocks = blocks; a.wgs = wgs;
+    a.n = (uint32_t)rlen; a.blocks = blocks; a.wgs = wgs;
     LG_LAUNCH(c, lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
     LG_LAUNCH(c, lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->stream, a);
     lg::SparseRowMulArgs m;
     m.col_ptr = c->d_a_colptr; m.ent_row = c->d_a_row; m.ent_val = c->d_a_val;
-    m.r = c->d_rlin; m.out = c->d_scratch_a; m.heavy = c->d_a_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)n;
+    m.r = c->d_rlin; m.out = c->d_scratch_a; m.heavy = c->d_a_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)rlen;
     LG_LAUNCH(c, lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->stream, m);
     if (c->a_nheavy) {
         lg::HeavySegArgs h;

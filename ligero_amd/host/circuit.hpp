@@ -677,15 +677,36 @@ public:
     // shard one rank of a coset-sharded proof uploads (elem = row * k; the trace is still evaluated in full)
     void build_preenc_range_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, size_t elem_begin, size_t elem_end, E* out,
                                            bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
+        build_preenc_ranges_from_formatted(bumped, {{elem_begin, elem_end}}, out, all_outputs_one, scratch);
+    }
+    // ... or several element ranges at once (one evaluation of the trace), written back to back into out[0 ..): the rows one rank
+    // of a row-relay proof keeps in the blocks layout -- its share of each of the X, Y, Z, W blocks
+    void build_preenc_ranges_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, const std::vector<std::pair<size_t, size_t>>& ranges, E* out,
+                                            bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
         const size_t mk = m * k;
-        if (elem_end > 4 * mk || elem_begin > elem_end) throw std::runtime_error("build_preenc: element range outside the 4m x k matrix");
+        size_t total = 0;
+        std::vector<size_t> out_off;
+        for (size_t i = 0; i < ranges.size(); i++) {
+            if (ranges[i].second > 4 * mk || ranges[i].first > ranges[i].second || (i && ranges[i].first < ranges[i - 1].second))
+                throw std::runtime_error("build_preenc: element ranges outside the 4m x k matrix or out of order");
+            out_off.push_back(total);
+            total += ranges[i].second - ranges[i].first;
+        }
+        const size_t elem_begin = ranges.empty() ? 0 : ranges.front().first, elem_end = ranges.size() == 1 ? ranges.front().second : elem_begin + total;
+        const bool single = ranges.size() == 1;
+        // flat index of the matrix -> index into out, or npos
+        auto locate = [&](size_t flat) -> size_t {
+            for (size_t i = 0; i < ranges.size(); i++)
+                if (flat >= ranges[i].first && flat < ranges[i].second) return out_off[i] + (flat - ranges[i].first);
+            return ~size_t{0};
+        };
         typename ArithmeticCircuitT<E>::Trace local;
         typename ArithmeticCircuitT<E>::Trace& trace = scratch ? scratch->trace : local;
         // the all-zero limbs are the field's zero.  WHICH elements get a value depends on the circuit alone, so a buffer that
         // already holds an earlier preenc_u of this instance (same range) needs no second pass over its 1.3 GB
-        const bool zeroed = scratch && scratch->filled == out && scratch->filled_begin == elem_begin && scratch->filled_end == elem_end;
-        if (!zeroed) std::memset(static_cast<void*>(out), 0, (elem_end - elem_begin) * sizeof(E));
-        if (scratch) { scratch->filled = out; scratch->filled_begin = elem_begin; scratch->filled_end = elem_end; }
+        const bool zeroed = single && scratch && scratch->filled == out && scratch->filled_begin == elem_begin && scratch->filled_end == elem_end;
+        if (!zeroed) std::memset(static_cast<void*>(out), 0, total * sizeof(E));
+        if (scratch) { scratch->filled = single ? out : nullptr; scratch->filled_begin = elem_begin; scratch->filled_end = elem_end; }
         if (!prog_.kind.empty()) {
             // One pass over the compact program: evaluate node i and drop its value(s) into x / y / z / w at once.  (The
             // node structs are 88 bytes each; walking 5 M of them twice -- trace, then assembly -- was memory-bound.)
@@ -700,10 +721,11 @@ public:
                 val[v.first] = v.second;
                 set[v.first] = 1;
             }
-            const bool whole = elem_begin == 0 && elem_end == 4 * mk;
+            const bool whole = single && elem_begin == 0 && elem_end == 4 * mk;
             auto put = [&](size_t flat, const E& v) {
                 if (whole) out[flat] = v;
-                else if (flat >= elem_begin && flat < elem_end) out[flat - elem_begin] = v;
+                else if (single) { if (flat >= elem_begin && flat < elem_end) out[flat - elem_begin] = v; }
+                else { const size_t at = locate(flat); if (at != ~size_t{0}) out[at] = v; }
             };
             size_t pos = 0, ci = 0;
             for (size_t i = 0; i < nn; i++) {
@@ -750,7 +772,8 @@ public:
                 if (!F::eq(sol[o], F::one())) *all_outputs_one = false;
         }
         auto put = [&](size_t flat, const E& v) {
-            if (flat >= elem_begin && flat < elem_end) out[flat - elem_begin] = v;
+            const size_t at = locate(flat);
+            if (at != ~size_t{0}) out[at] = v;
         };
         size_t pos = 0;
         for (size_t i = 0; i < circuit.nodes.size(); i++) {

@@ -49,6 +49,10 @@ int lgp_sharded_prover_create(lgp_prover** out, const lgh_instance* inst, int de
         sc.all_gather_device = comm->all_gather_device;
         sc.all_gather_host = comm->all_gather_host;
         if (comm->flags & LGP_COMM_HAS_STREAM_CALLBACK) sc.all_gather_device_stream = comm->all_gather_device_stream;
+        if (comm->flags & LGP_COMM_ROW_RELAY) {
+            sc.row_relay = true;
+            sc.send_stream = comm->send_stream; sc.recv_stream = comm->recv_stream; sc.broadcast_stream = comm->broadcast_stream;
+        }
         *out = new lgp_prover(inst->inst, device, sc);
         return LGP_OK;
     });

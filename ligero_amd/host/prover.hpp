@@ -207,6 +207,12 @@ struct ShardComm {
     int (*all_gather_device_stream)(void* user, void* device_buf, uint64_t bytes_per_rank, void* stream) = nullptr;
     // all-gather of equal HOST blocks: recv holds `world` blocks of `bytes`
     int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes) = nullptr;
+    // ROW RELAY: rows sharded end to end in the blocks layout, the columns' Blake2s states handed from
+    // rank to rank.  Needs the three stream-ordered point-to-point / broadcast calls of include/ligero_hip.h lg_comm.
+    bool row_relay = false;
+    int (*send_stream)(void* user, const void* device_buf, uint64_t bytes, uint32_t dst, void* stream) = nullptr;
+    int (*recv_stream)(void* user, void* device_buf, uint64_t bytes, uint32_t src, void* stream) = nullptr;
+    int (*broadcast_stream)(void* user, void* device_buf, uint64_t bytes, uint32_t root, void* stream) = nullptr;
 };
 
 // E = Fr: the tuned BN254 device path, linear-test challenges generated on the device.  Any other element type (the
@@ -248,8 +254,12 @@ public:
         static_assert(kDeviceChallenges, "sharded proofs run on the tuned BN254 device path");
         if (comm.world == 0 || comm.rank >= comm.world) throw std::runtime_error("ShardComm: rank outside the world");
         exchange_ = comm.world > 1 || comm.exchange_at_world_1;
-        if (exchange_ && (!comm.all_gather_device || !comm.all_gather_host)) throw std::runtime_error("ShardComm: both all-gathers are needed");
+        if (exchange_ && !comm.row_relay && (!comm.all_gather_device || !comm.all_gather_host)) throw std::runtime_error("ShardComm: both all-gathers are needed");
         sharded_ = true;
+        if (comm.row_relay) {
+            init_relay(inst, device);
+            return;
+        }
         const uint32_t rows = (uint32_t)(4 * m_);
         nplanes_ = k_ <= 4096 ? 8 : (uint32_t)(8 * (k_ / 4096));       // the library's plane rule (include/ligero_hip.h); checked below
         if (nplanes_ % comm.world != 0)
@@ -517,41 +527,194 @@ private:
         if (xchg_recv_pinned_) lg_host_unregister(ctx_, xchg_recv_.data());
         xchg_send_pinned_ = xchg_recv_pinned_ = false;
     }
+
+    // ================================================================ the same proof on the ROW RELAY
+    // Rank g keeps rows [lo_g, hi_g) of each of the four blocks X, Y, Z, W (the library's LG_RELAY_BLOCKS rule): its context is
+    // an ordinary one over a small [X; Y; Z; W] matrix of 4 (hi_g - lo_g) rows, with the matching COLUMNS of the constraint
+    // matrix A.  Every sub-proof point is a sum over ALL rows, so each rank computes the partial sum over ITS rows for every slot
+    // (lg_subproof_points on its context), the partials are all-gathered and added -- balanced over all ranks.  Opened columns
+    // come back as row pieces.
+    void init_relay(const LigeroInstance& inst, int device) {
+        relay_ = true;
+        const bool need = comm_.world > 1;
+        if (need && (!comm_.send_stream || !comm_.recv_stream || !comm_.broadcast_stream || !comm_.all_gather_host))
+            throw std::runtime_error("ShardComm: the row relay needs send / recv / broadcast on a stream and the host all-gather");
+        relay_lo_.resize(comm_.world + 1);
+        for (uint32_t r = 0; r <= comm_.world; r++) relay_lo_[r] = (uint32_t)((uint64_t)m_ * r / comm_.world);   // = lg_relay_row_ranges
+        mg_ = relay_lo_[comm_.rank + 1] - relay_lo_[comm_.rank];
+        mg_max_ = 0;
+        for (uint32_t r = 0; r < comm_.world; r++) mg_max_ = std::max(mg_max_, relay_lo_[r + 1] - relay_lo_[r]);
+        const int st = lg_ctx_create(&ctx_, device, std::max<uint32_t>(1, 4 * mg_), (uint32_t)k_, (uint32_t)n_);
+        if (st != LG_OK) throw DeviceError(st, "lg_ctx_create (row relay)");
+        logn_ = 0;
+        while ((size_t{1} << logn_) < n_) logn_++;
+        if (mg_ == 0) return;
+        try {
+            // the columns of A that belong to this rank's rows: column c = (block b, row i of the block, position j in the row)
+            const size_t mk = m_ * k_, lo = relay_lo_[comm_.rank], hi = relay_lo_[comm_.rank + 1];
+            std::vector<uint64_t> rows, cols;
+            std::vector<Fr> vals;
+            for (size_t r = 0; r < inst.a.num_rows(); r++)
+                for (const auto& e : inst.a.row(r)) {
+                    const size_t b = e.second / mk, i = (e.second % mk) / k_, j = e.second % k_;
+                    if (i < lo || i >= hi) continue;
+                    rows.push_back(r);
+                    cols.push_back((b * mg_ + (i - lo)) * k_ + j);
+                    vals.push_back(e.first);
+                }
+            const int st2 = lg_upload_constraint_matrix(ctx_, inst.a.num_rows(), rows.size(), rows.data(), cols.data(), vals.empty() ? nullptr : vals[0].l);
+            if (st2 != LG_OK) throw DeviceError(st2, std::string("lg_upload_constraint_matrix (") + lg_last_error(ctx_) + ")");
+        } catch (...) {
+            lg_ctx_destroy(ctx_);
+            throw;
+        }
+    }
+    void relay_commit(const std::vector<std::pair<size_t, E>>& formatted_assignment, Digest& root) {
+        const size_t own = (size_t)4 * mg_ * k_;
+        if (flat_.size() != std::max<size_t>(own, 1)) {
+            if (pinned_) lg_host_unregister(ctx_, flat_.data());
+            flat_.assign(std::max<size_t>(own, 1), F::zero());
+            scratch_.buffer_replaced();
+            pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
+        }
+        together("the evaluation trace of a rank's rows", [&] {
+            std::vector<std::pair<size_t, size_t>> ranges;
+            if (mg_)
+                for (size_t b = 0; b < 4; b++) ranges.emplace_back((b * m_ + relay_lo_[comm_.rank]) * k_, (b * m_ + relay_lo_[comm_.rank + 1]) * k_);
+            if (ranges.empty()) ranges.emplace_back(0, 0);                    // (a rank without rows still evaluates the trace: it must fail like the others)
+            inst_.build_preenc_ranges_from_formatted(formatted_assignment, ranges, flat_.data(), nullptr, &scratch_);
+        });
+        together("the row-relay commit", [&] {
+            lg_comm lc;
+            std::memset(&lc, 0, sizeof(lc));
+            lc.world = comm_.world; lc.rank = comm_.rank;
+            lc.flags = comm_.exchange_at_world_1 ? LG_COMM_EXCHANGE_AT_WORLD_1 : 0;
+            lc.user = this;
+            lc.send = [](void* self, const void* buf, uint64_t bytes, uint32_t dst, void* stream) -> int {
+                auto* me = static_cast<HipLigeroT*>(self);
+                return me->comm_.send_stream(me->comm_.user, buf, bytes, dst, stream);
+            };
+            lc.recv = [](void* self, void* buf, uint64_t bytes, uint32_t src, void* stream) -> int {
+                auto* me = static_cast<HipLigeroT*>(self);
+                return me->comm_.recv_stream(me->comm_.user, buf, bytes, src, stream);
+            };
+            lc.broadcast = [](void* self, void* buf, uint64_t bytes, uint32_t root_rank, void* stream) -> int {
+                auto* me = static_cast<HipLigeroT*>(self);
+                return me->comm_.broadcast_stream(me->comm_.user, buf, bytes, root_rank, stream);
+            };
+            if (!comm_.broadcast_stream) lc.broadcast = nullptr;
+            const int st = lg_commit_row_relay(ctx_, &lc, 4 * m_, LG_RELAY_BLOCKS, 1, mg_ ? flat_[0].l : nullptr);
+            if (st == LG_ERR_COMM) throw std::runtime_error(std::string("the host layer's collective failed (") + lg_last_error(ctx_) + ")");
+            check(st, "lg_commit_row_relay");
+        });
+        check(lg_read_root(ctx_, root.data()), "lg_read_root");
+    }
+    // a sub-proof polynomial from per-rank PARTIAL point sums: this rank's rows, every slot
+    std::vector<Fr> relay_poly(int which, const void* challenge) {
+        std::vector<Fr> mine(2 * k_, F::zero());
+        together("a sub-proof's partial point sums", [&] {
+            if (mg_ == 0) return;
+            const uint32_t lo = relay_lo_[comm_.rank], hi = relay_lo_[comm_.rank + 1];
+            const Fr* ch = static_cast<const Fr*>(challenge);
+            std::vector<Fr> local;
+            const void* arg = challenge;
+            if (which == LG_SUB_INTERLEAVED) {                        // r has 4m entries: this rank's rows of each block
+                for (size_t b = 0; b < 4; b++) local.insert(local.end(), ch + b * m_ + lo, ch + b * m_ + hi);
+                arg = local.data();
+            } else if (which == LG_SUB_QUADRATIC) {                   // r has m entries: this rank's triples
+                local.assign(ch + lo, ch + hi);
+                arg = local.data();
+            }
+            check(lg_subproof_points(ctx_, which, arg, mine[0].l, nullptr), "lg_subproof_points");
+        });
+        std::vector<Fr> total = mine;
+        if (comm_.world > 1) {
+            std::vector<Fr> all((size_t)comm_.world * 2 * k_);
+            comm_check(comm_.all_gather_host(comm_.user, mine.data(), all.data(), 2 * k_ * sizeof(Fr)), "all-gather of the partial point sums");
+            for (size_t j = 0; j < 2 * k_; j++) {
+                Fr acc = F::zero();
+                for (uint32_t r = 0; r < comm_.world; r++) acc = F::add(acc, all[(size_t)r * 2 * k_ + j]);
+                total[j] = acc;
+            }
+        }
+        std::vector<Fr> out(which == LG_SUB_INTERLEAVED ? k_ : 2 * k_);
+        check(lg_subproof_finish(ctx_, which, total[0].l, out[0].l), "lg_subproof_finish");
+        return out;
+    }
+    // mod.rs:935-955: every rank opens ALL t columns on its own rows; the row pieces are all-gathered (equal blocks of the
+    // largest shard) and put together in row order; the paths come from the replicated tree
+    OpenedColumns relay_open_columns(PoseidonSponge& sponge) {
+        const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
+        const size_t t = indices.size(), plen = (size_t)logn_ - 1, local_rows = std::max<size_t>(1, (size_t)4 * mg_);
+        std::vector<uint32_t> idx(indices.begin(), indices.end());
+        const size_t piece = t * (size_t)4 * mg_max_ * sizeof(Fr);            // a rank's block of the exchange
+        reserve_exchange(std::max<size_t>(piece, t * local_rows * sizeof(Fr)) + 1);
+        std::vector<uint8_t> sib(t * 32), paths(t * plen * 32 + 1);
+        together("the opening of a rank's rows", [&] {
+            check(lg_open_columns(ctx_, 0, idx.data(), (uint32_t)t, reinterpret_cast<uint64_t*>(xchg_send_.data()), sib.data(), paths.data()), "lg_open_columns");
+        });
+        const uint8_t* blocks = xchg_send_.data();
+        size_t block = 0;
+        if (comm_.world > 1) {
+            block = xchg_send_.size();
+            comm_check(comm_.all_gather_host(comm_.user, xchg_send_.data(), xchg_recv_.data(), block), "all-gather of the opened rows");
+            blocks = xchg_recv_.data();
+        }
+        OpenedColumns out;
+        for (size_t c = 0; c < t; c++) {
+            std::vector<Fr> col(4 * m_);
+            for (uint32_t r = 0; r < comm_.world; r++) {
+                const size_t lo = relay_lo_[r], mg = relay_lo_[r + 1] - lo;
+                if (mg == 0) continue;
+                const Fr* src = reinterpret_cast<const Fr*>(blocks + (size_t)r * block) + c * (4 * mg);   // [t][4 mg] of rank r
+                for (size_t b = 0; b < 4; b++) memcpy(static_cast<void*>(&col[b * m_ + lo]), src + b * mg, mg * sizeof(Fr));
+            }
+            out.columns.push_back(std::move(col));
+            MerklePath mp;
+            mp.leaf_index = indices[c];
+            memcpy(mp.leaf_sibling_hash.data(), &sib[32 * c], 32);
+            mp.auth_path.resize(plen);
+            for (size_t l = 0; l < plen; l++) memcpy(mp.auth_path[l].data(), &paths[32 * (c * plen + l)], 32);
+            out.paths.push_back(std::move(mp));
+        }
+        return out;
+    }
     LigeroProof prove_inner_sharded(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {
         PhaseTimer tm;
         LigeroProof proof;
-        sharded_commit(formatted_assignment, proof.u_root);                                           // mod.rs:521-551
+        if (relay_) relay_commit(formatted_assignment, proof.u_root);
+        else sharded_commit(formatted_assignment, proof.u_root);                                      // mod.rs:521-551
         tm.mark("sharded: trace + row shard + commit");
         sponge.absorb_bytes(proof.u_root.data(), 32);                                                  // mod.rs:560
         {   // prove_interleaved, mod.rs:646-669
             const std::vector<Fr> r = get_field_elements_from_prng<E>(4 * m_, sponge.squeeze_seed());
-            proof.interleaved_proof.preenc_u_lc = sharded_poly(LG_SUB_INTERLEAVED, r[0].l);
+            proof.interleaved_proof.preenc_u_lc = relay_ ? relay_poly(LG_SUB_INTERLEAVED, r[0].l) : sharded_poly(LG_SUB_INTERLEAVED, r[0].l);
             tm.mark("sharded: interleaved points + finish");
             sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
             tm.mark("sharded: sponge absorbs k elements");
-            proof.interleaved_proof.open = sharded_open_columns(sponge);
+            proof.interleaved_proof.open = relay_ ? relay_open_columns(sponge) : sharded_open_columns(sponge);
             tm.mark("sharded: open_columns");
         }
         {   // prove_linear_constraints, mod.rs:712-747
             const std::array<uint8_t, 32> seed = sponge.squeeze_seed();
-            std::vector<Fr> poly = sharded_poly(LG_SUB_LINEAR_FROM_SEED, seed.data());
+            std::vector<Fr> poly = relay_ ? relay_poly(LG_SUB_LINEAR_FROM_SEED, seed.data()) : sharded_poly(LG_SUB_LINEAR_FROM_SEED, seed.data());
             tm.mark("sharded: linear points + finish");
             trim_zeros(poly);
             proof.linear_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
             tm.mark("sharded: sponge absorbs 2k elements");
-            proof.linear_constraints_proof.open = sharded_open_columns(sponge);
+            proof.linear_constraints_proof.open = relay_ ? relay_open_columns(sponge) : sharded_open_columns(sponge);
             tm.mark("sharded: open_columns");
         }
         {   // prove_quadratic_constraints, mod.rs:832-859
             const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
-            std::vector<Fr> poly = sharded_poly(LG_SUB_QUADRATIC, r[0].l);
+            std::vector<Fr> poly = relay_ ? relay_poly(LG_SUB_QUADRATIC, r[0].l) : sharded_poly(LG_SUB_QUADRATIC, r[0].l);
             tm.mark("sharded: quadratic points + finish");
             trim_zeros(poly);
             proof.quadratic_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
             tm.mark("sharded: sponge absorbs 2k elements");
-            proof.quadratic_constraints_proof.open = sharded_open_columns(sponge);
+            proof.quadratic_constraints_proof.open = relay_ ? relay_open_columns(sponge) : sharded_open_columns(sponge);
             tm.mark("sharded: open_columns");
         }
         return proof;
@@ -663,7 +826,13 @@ private:
         const std::vector<Fr> r_a = inst_.a.row_mul(r_linear);
         // r_polys = small_domain.ifft of every k-chunk of r_a (mod.rs:773-781)
         std::vector<Fr> r_polys(4 * m_ * k_);
-        check(lg_reed_solomon_interpolate(ctx_, r_a[0].l, (uint32_t)(4 * m_), r_polys[0].l), "lg_reed_solomon_interpolate");
+        {   // (a row-relay rank's context is sized for its own rows: feed it what it takes)
+            const size_t cap = relay_ ? std::max<size_t>(1, (size_t)4 * mg_) : 4 * m_;
+            for (size_t i0 = 0; i0 < 4 * m_; i0 += cap) {
+                const size_t nr = std::min(cap, 4 * m_ - i0);
+                check(lg_reed_solomon_interpolate(ctx_, r_a[i0 * k_].l, (uint32_t)nr, r_polys[i0 * k_].l), "lg_reed_solomon_interpolate");
+            }
+        }
         if (!p.polynomial.empty() && p.polynomial.size() - 1 >= 2 * k_ - 1) return false;      // degree check, mod.rs:783
         std::vector<Fr> q = p.polynomial;
         q.resize(2 * k_, fr_zero());
@@ -677,7 +846,7 @@ private:
         // host never holds more than ~256 MB of encodings (the reference materialises all 4m x n of them)
         const size_t nopen = p.open.columns.size();
         std::vector<Fr> acc(nopen, fr_zero());
-        const size_t chunk = std::max<size_t>(1, std::min<size_t>(4 * m_, (size_t{256} << 20) / (n_ * sizeof(Fr))));
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(relay_ ? std::max<size_t>(1, (size_t)4 * mg_) : 4 * m_, (size_t{256} << 20) / (n_ * sizeof(Fr))));
         std::vector<Fr> r_evals(chunk * n_);
         for (size_t i0 = 0; i0 < 4 * m_; i0 += chunk) {
             const size_t rows = std::min(chunk, 4 * m_ - i0);
@@ -770,6 +939,9 @@ private:
     std::vector<uint8_t> xchg_send_, xchg_recv_;   // opened-columns exchange (reserve_exchange)
     bool xchg_send_pinned_ = false, xchg_recv_pinned_ = false;
     uint32_t nplanes_ = 0, planes_per_rank_ = 0, shard_rows_ = 0, row0_ = 0, row1_ = 0, own_mask_ = 0;
+    bool relay_ = false;                    // row relay: this rank's rows of each block are [relay_lo_[rank], relay_lo_[rank + 1])
+    std::vector<uint32_t> relay_lo_;
+    uint32_t mg_ = 0, mg_max_ = 0;
 };
 using HipLigero = HipLigeroT<Fr>;
 

@@ -127,12 +127,14 @@ class LigeroProver:
 _AG_DEVICE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64)
 _AG_HOST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64)
 _AG_DEVICE_STREAM = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, _vp)
-_LGP_COMM_EXCHANGE_AT_WORLD_1, _LGP_COMM_HAS_STREAM_CALLBACK = 1, 2
+_LGP_COMM_EXCHANGE_AT_WORLD_1, _LGP_COMM_HAS_STREAM_CALLBACK, _LGP_COMM_ROW_RELAY = 1, 2, 4
+_P2P = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp)
 
 
 class _LgpComm(ctypes.Structure):
     _fields_ = [("world", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("user", _vp),
-                ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST), ("all_gather_device_stream", _AG_DEVICE_STREAM)]
+                ("all_gather_device", _AG_DEVICE), ("all_gather_host", _AG_HOST), ("all_gather_device_stream", _AG_DEVICE_STREAM),
+                ("send_stream", _P2P), ("recv_stream", _P2P), ("broadcast_stream", _P2P)]
 
 
 class ShardedLigeroProver(LigeroProver):
@@ -144,9 +146,14 @@ class ShardedLigeroProver(LigeroProver):
     the host all-gather (sub-proof points, opened columns) through pinned staging on the same backend (plain CPU tensors
     under gloo)."""
 
-    def __init__(self, instance: LigeroInstance, dist=None, group=None, device: int = 0, collectives_at_world_1: bool = False):
+    def __init__(self, instance: LigeroInstance, dist=None, group=None, device: int = 0, collectives_at_world_1: bool = False, mode: str = "coset"):
         """collectives_at_world_1: issue the (identity) all-gathers in a one-rank group too -- the exact RCCL calls of the
-        multi-GPU path on a one-GPU box (tests, bench.py)"""
+        multi-GPU path on a one-GPU box (tests, bench.py).  mode: "coset" (row shard -> all-gather of the coefficient rows -> each
+        rank its coset planes; sub-proof points from the plane owners) or "relay" (rows end to end, the columns' hash states
+        handed from rank to rank; sub-proof points as sums of per-rank partial sums) -- the same proof either way."""
+        if mode not in ("coset", "relay"):
+            raise ValueError(f"unknown mode {mode!r}")
+        self.mode = mode
         self._dist, self._group, self._device = dist, group, device
         self._force = bool(collectives_at_world_1) and dist is not None
         self.world = dist.get_world_size(group) if dist is not None else 1
@@ -161,9 +168,16 @@ class ShardedLigeroProver(LigeroProver):
     def _create(self, instance, device):
         if self.world > 1 or self._force:
             flags = (_LGP_COMM_EXCHANGE_AT_WORLD_1 if self._force else 0) | _LGP_COMM_HAS_STREAM_CALLBACK
-            self._comm = _LgpComm(self.world, self.rank, flags, None, self._cb_device, self._cb_host, self._cb_device_stream)
+            p2p = (_P2P(), _P2P(), _P2P())
+            if self.mode == "relay":
+                from .sharded import TorchComm
+                self._torch_comm = TorchComm(self._dist, self._group, device, exchange_at_world_1=self._force)    # serves send / recv / broadcast
+                p2p = (ctypes.cast(self._torch_comm._cbs[1], _P2P), ctypes.cast(self._torch_comm._cbs[2], _P2P), ctypes.cast(self._torch_comm._cbs[3], _P2P))
+                flags |= _LGP_COMM_ROW_RELAY
+            self._comm = _LgpComm(self.world, self.rank, flags, None, self._cb_device, self._cb_host, self._cb_device_stream, *p2p)
         else:
-            self._comm = _LgpComm(1, 0, 0, None, _AG_DEVICE(), _AG_HOST(), _AG_DEVICE_STREAM())
+            flags = _LGP_COMM_ROW_RELAY if self.mode == "relay" else 0
+            self._comm = _LgpComm(1, 0, flags, None, _AG_DEVICE(), _AG_HOST(), _AG_DEVICE_STREAM(), _P2P(), _P2P(), _P2P())
         _check(self._L.lgp_sharded_prover_create(ctypes.byref(self._h), instance._h, device, ctypes.cast(ctypes.byref(self._comm), _vp)),
                "lgp_sharded_prover_create")
 

@@ -44,11 +44,11 @@ def _small_case():
     return hp.LigeroInstance(c, outs), ["x", "y"], np.stack([hp.fr_mont(3), hp.fr_mont(4)])
 
 
-def _rank_body(rank, world, dist, which):
+def _rank_body(rank, world, dist, which, mode="coset"):
     from ligero_amd.prover import LigeroProver, ShardedLigeroProver, proofs_equal
     inst, names, vals = _poseidon_case() if which == "poseidon" else _small_case()
     by_label = isinstance(names[0], str)
-    with ShardedLigeroProver(inst, dist, device=0) as sp:
+    with ShardedLigeroProver(inst, dist, device=0, mode=mode) as sp:
         proof = sp.prove_with_labels(names, vals) if by_label else sp.prove(names, vals)
         again = sp.prove_with_labels(names, vals) if by_label else sp.prove(names, vals)        # the context is reused
         accepted_by_sharded = sp.verify(proof)
@@ -68,7 +68,7 @@ def _rank_body(rank, world, dist, which):
     return res
 
 
-def _worker(rank, world, port, which, out):
+def _worker(rank, world, port, which, out, mode="coset"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -76,21 +76,24 @@ def _worker(rank, world, port, which, out):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out[rank] = _rank_body(rank, world, dist, which)
+        out[rank] = _rank_body(rank, world, dist, which, mode)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("which,world", [("poseidon", 2), ("poseidon", 4), ("small", 8)])
-def test_sharded_proof_equals_the_single_gpu_proof(which, world):
+# mode "relay" (round 3): rows end to end in the blocks layout, hash states handed on, sub-proof points = sums of per-rank partial
+# sums, opened columns as row pieces -- the SAME proof, field for field; m = 86 over 4 ranks and m = 4 over 8 (four ranks without rows)
+@pytest.mark.parametrize("which,world,mode", [("poseidon", 2, "coset"), ("poseidon", 4, "coset"), ("small", 8, "coset"),
+                                              ("poseidon", 2, "relay"), ("poseidon", 4, "relay"), ("small", 8, "relay")])
+def test_sharded_proof_equals_the_single_gpu_proof(which, world, mode):
     if world <= 4:                         # real gloo process groups; the GPU box admits at most six processes on its card,
         import torch.multiprocessing as mp
         mgr = mp.Manager()
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), which, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), which, out, mode), nprocs=world, join=True)
     else:                                  # so world 8 is eight sharded provers on eight threads of this process (tests/thread_dist.py)
         from thread_dist import run_ranks
-        out = dict(enumerate(run_ranks(world, lambda rank, dist: _rank_body(rank, world, dist, which))))
+        out = dict(enumerate(run_ranks(world, lambda rank, dist: _rank_body(rank, world, dist, which, mode))))
     assert set(out.keys()) == set(range(world))
     last = out[world - 1]
     assert last["equal"], "the sharded proof differs from the single-GPU proof"
@@ -116,9 +119,13 @@ def _rccl_worker(out):
         inst, idx, vals = _poseidon_case()
         with ShardedLigeroProver(inst, dist, device=0, collectives_at_world_1=True) as sp, LigeroProver(inst) as single:
             proof = sp.prove(idx, vals)
-            out["equal"] = proofs_equal(proof, single.prove(idx, vals))
+            ref = single.prove(idx, vals)
+            out["equal"] = proofs_equal(proof, ref)
             out["accepted"] = single.verify(proof)
             out["error"] = sp.comm_error
+            with ShardedLigeroProver(inst, dist, device=0, collectives_at_world_1=True, mode="relay") as rp:   # the relay's identity broadcast
+                out["relay_equal"] = proofs_equal(rp.prove(idx, vals), ref)
+                out["relay_error"] = rp.comm_error
     finally:
         dist.destroy_process_group()
 
@@ -134,6 +141,7 @@ def test_sharded_prover_over_rccl_at_world_1():
     p.join(300)
     assert p.exitcode == 0
     assert out["error"] is None and out["equal"] and out["accepted"]
+    assert out["relay_error"] is None and out["relay_equal"]
 
 
 def _failing_worker(rank, world, port, out):
