@@ -194,6 +194,10 @@ int lg_linear_constraint_poly(lg_ctx* ctx, const uint64_t* r_a, uint64_t* coeffs
  *   lg_upload_constraint_matrix            self.a (mod.rs:202, built by generate_matrices, mod.rs:296-433) as COO triplets
  *                                          (row, column, Montgomery value); columns < rows * k; duplicates are summed, as
  *                                          SparseMatrix::row_mul does (src/matrices/mod.rs:100-110).  Once per context.
+ *                                          num_rows is the matrix's row count = the length of r_linear (4mk in the reference: A is
+ *                                          square); a context that holds only a row shard of the proof's matrix (row relay, blocks
+ *                                          layout) uploads the COLUMNS of A that belong to its rows, renumbered, with the same
+ *                                          num_rows -- every rank draws the whole r_linear.
  *   lg_linear_constraint_poly_from_seeds   seeds: batch * 32 bytes, the value of sponge.squeeze_bytes(32) at mod.rs:719 for each
  *                                          proof.  r_linear = get_field_elements_from_prng(4mk, seed) (src/utils.rs:23-29:
  *                                          ChaCha20Rng + F::rand rejection sampling) is generated on the device, r_a =

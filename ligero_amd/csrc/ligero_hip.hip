@@ -80,7 +80,6 @@ struct lg_ctx {
     // gate map of the circuit (lg_upload_gate_map): for every position of the solution vector the sources of x and y
     uint32_t* d_gate_l = nullptr; uint32_t* d_gate_r = nullptr; fr* d_gate_consts = nullptr;
     uint64_t gate_npos = 0; uint32_t gate_nconst = 0; bool gate_backward = false;
-    hipEvent_t ev_enc[16] = {};            // lg_encode_commit_from_witness: "rows of encode step i are encoded"
     uint32_t* d_seeds = nullptr;           // [batch][8]
     uint32_t* d_cc_counts = nullptr; size_t cc_counts_cap = 0;
     uint32_t* d_short_flag = nullptr;
@@ -574,8 +573,6 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->gf) gf_destroy(c->gf);
     for (void* b : {(void*)c->d_gate_l, (void*)c->d_gate_r, (void*)c->d_gate_consts})
         if (b) hipFree(b);
-    for (auto& e : c->ev_enc)
-        if (e) hipEventDestroy(e);
     void* bufs2[] = {c->d_digest_xchg, c->d_sub_partial, c->d_sub_q, c->d_sub_r, c->d_a_colptr, c->d_a_row, c->d_a_val, c->d_a_heavy, c->d_a_seg, c->d_a_seg_partial, c->d_seeds, c->d_cc_counts, c->d_short_flag, c->d_rlin};
     for (void* b : bufs2)
         if (b) hipFree(b);
@@ -1302,8 +1299,6 @@ int lg_upload_gate_map(lg_ctx* c, uint64_t npos, const uint32_t* left, const uin
     }
     if (nconst) LG_HIP(c, hipMemcpy(c->d_gate_consts, constants, (size_t)nconst * sizeof(fr), hipMemcpyHostToDevice));
     c->gate_npos = npos; c->gate_nconst = nconst; c->gate_backward = backward;
-    for (auto& e : c->ev_enc)
-        if (!e) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
     return LG_OK;
 }
 
