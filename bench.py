@@ -745,6 +745,7 @@ def main():
                       "config": {"workload": f"{args.workload}: {batch} x ({rows} x {k} -> {n}) per GPU per step", "rows": rows, "k": k, "n": n,
                                  "batch_per_gpu": batch, "parallelism": f"independent proofs x{world}"},
                       "stage_ms": {s_: stage[s_] for s_ in ("interpolate", "evaluate", "colhash", "merkle")}, "root0": root[:32].hex(),
+                      "roofline": roofline_of(args.workload, stage, launches, tfile)[0],
                       "sharded_commit": partial.get("sharded_commit", {"error": "the extra sharded legs did not finish in time; headline only"}),
                       "sharded_legs_note": "a sharded leg did not finish in time: what had completed is reported"})
             os._exit(3)          # non-zero on every rank (the partial line above is still usable)

@@ -207,8 +207,13 @@ __device__ __forceinline__ void fr_store_stream(fr* p, const fr& a) {
     lg_u32x4 lo, hi;
     lo.x = a.v[0]; lo.y = a.v[1]; lo.z = a.v[2]; lo.w = a.v[3];
     hi.x = a.v[4]; hi.y = a.v[5]; hi.z = a.v[6]; hi.w = a.v[7];
+#ifdef LG_PLAIN_STORES
+    *q = lo;
+    q[1] = hi;
+#else
     __builtin_nontemporal_store(lo, q);
     __builtin_nontemporal_store(hi, q + 1);
+#endif
 }
 
 }  // namespace lg

@@ -117,7 +117,7 @@ struct lg_ctx {
     uint8_t* d_tw_fwd = nullptr;    // butterfly twiddles of the size-ki transform, pass order (lg::pass_tw_offset)
     uint8_t* d_tw_inv = nullptr;    // same for the inverse transform
     uint8_t* d_coset_tw = nullptr;  // [plane s < 8 O][d < k] = omega_n^(s d)
-    uint8_t* d_fold_inv = nullptr;  // O > 1: [h < O][d < k] = omega_k^(-h d)
+    uint8_t* d_fold_inv = nullptr;  // O = 2: omega_k^-d, d < ki (with quotients); O = 4: [h < O][d < k] = omega_k^(-h d) / k
     uint8_t* d_first2 = nullptr;    // log2 k = 1 (mod 3): coefficients of the dot-product radix-2 first pass (ntt_kernels.h)
     uint32_t n_pass_tw = 0;
     lg::f29 w8_fwd[3], w8_inv[3], w8q_fwd[3], w8q_inv[3], one29, oneq29, scale29, invk29, invkq29;
@@ -407,8 +407,12 @@ static lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon
     memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.canon_out = canon_out;
     a.tw = planes_q_of(c->d_tw_inv, c->n_pass_tw ? c->n_pass_tw : 1);
-    a.coset_tw.w = planes_of(c->d_fold_inv, (size_t)c->k << c->logo);
-    a.coset_tw.q = a.coset_tw.w;  // unused: the fold is a Montgomery dot product
+    if (c->logo == 1) {
+        a.coset_tw = planes_q_of(c->d_fold_inv, c->ki);  // the odd half's factors of the radix-2 fold
+    } else {
+        a.coset_tw.w = planes_of(c->d_fold_inv, (size_t)c->k << c->logo);
+        a.coset_tw.q = a.coset_tw.w;  // unused: the fold is a Montgomery dot product
+    }
     a.first2 = a.coset_tw.w;      // unused
     for (int i = 0; i < 3; i++) { a.w8[i] = c->w8_inv[i]; a.w8q[i] = c->w8q_inv[i]; }
     a.one = c->one29;
@@ -721,8 +725,8 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
                 const int logsub = logs - logr;
                 if (logsub > 0) {
                     const size_t off = (size_t)lg::pass_tw_offset(c->logki, logs);
-                    // without an outer fold the inverse transform's 1/k rides on the first pass' twiddles
-                    const bool scaled = (logs == c->logki) && c->logo == 0;
+                    // the inverse transform's 1/k rides on the first pass' twiddles (outer fold of 4: on the fold table instead)
+                    const bool scaled = (logs == c->logki) && c->logo <= 1;
                     for (uint32_t m = 1; m < (1u << logr); m++)
                         for (uint32_t i0 = 0; i0 < (1u << logsub); i0++) {
                             const uint32_t e = (i0 * m) << (c->logki - logs);
@@ -779,8 +783,15 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_first2), ft.size()));
             LG_HIP(c, hipMemcpy(c->d_first2, ft.data(), ft.size(), hipMemcpyHostToDevice));
         }
-        // outer-fold factors of the inverse transform [h][d] = wk^(-h d mod k)
-        {
+        // outer fold of the inverse transform.  Radix 2 (k = 8192) is a butterfly in the load stage: wk^-d, d < ki, for its
+        // odd half.  Radix 4: dot-product factors [h][d] = wk^(-h d mod k) / k.
+        if (c->logo == 1) {
+            const size_t cnt = c->ki;
+            std::vector<uint8_t> ft(cnt * 72);
+            for (uint32_t d = 0; d < c->ki; d++) fill_planes_q(ft, cnt, d, pk_inv[d]);
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_fold_inv), ft.size()));
+            LG_HIP(c, hipMemcpy(c->d_fold_inv, ft.data(), ft.size(), hipMemcpyHostToDevice));
+        } else {
             const size_t cnt = (size_t)k << c->logo;
             std::vector<uint8_t> ft(cnt * 36);
             for (uint32_t h = 0; h < (1u << c->logo); h++)

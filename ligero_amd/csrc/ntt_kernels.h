@@ -43,7 +43,8 @@ struct NttArgs {
                          // value + Barrett quotient (shoup29); root = omega_ki^-1 (interpolate) or omega_ki (evaluate)
     Tw29q coset_tw;      // evaluate, O = 1: [plane s][d < k] = omega_n^(s d), the pre-scale of coefficient d (plain +
                          // quotient); O > 1: the same * 2^261 (Montgomery dot product, .q unused);
-                         // interpolate with O > 1: [h < O][d < k] = omega_k^(-h d) * 2^261 (.q unused)
+                         // interpolate with O = 2: [d < ki] = omega_k^-d, plain + quotient (the odd half of the radix-2 fold);
+                         // O = 4: [h < O][d < k] = omega_k^(-h d) / k * 2^261 (.q unused)
     Tw29 first2;         // evaluate, k = 2 (mod 8 stages: log2 k = 1 mod 3), O = 1: the radix-2 first pass as two dot
                          // products, [plane s][4][i0 < k/2] = pre(i0), pre(i0 + k/2), pre(i0) w^i0, -pre(i0 + k/2) w^i0,
                          // all * 2^261 (mul29_dot)
@@ -353,6 +354,25 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
                     }
                 }
             });
+        } else if constexpr (FIRST && !EVALUATE && LOGO == 1) {
+            // outer radix 2 of an interpolation, as a butterfly: output 2 j + h of the size-2ki inverse transform is output j of
+            // the size-ki one over (x[d] + x[d + ki]) for h = 0 and (x[d] - x[d + ki]) w_k^-d for h = 1 -- no product and one
+            // product per element where the dot product below has two and a reduction.  1/k rides on this pass' twiddles as it
+            // does without a fold.  (h is the same for the whole workgroup: the branch does not diverge.)
+            static_for<0, R>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int d = base + (q << LOGSUB);
+                const f29 x0 = unpack29(fr_load(gin + d)), x1 = unpack29(fr_load(gin + d + K));
+                if (sel == 0) {
+                    add29(e[q], x0, x1);
+                    norm29_strict(e[q]);  // limbs back below 2^29 (value < 2p): what the butterfly network's biases assume
+                } else {
+                    const f29 g = tw29_load(pre_tw.w, (size_t)d), gq = tw29_load(pre_tw.q, (size_t)d);
+                    sub29<4, 29>(e[q], x0, x1);
+                    if constexpr (q > 0) order29(e[q - 1], e[q]);
+                    shoup29(e[q], e[q], g, gq);
+                }
+            });
         } else if constexpr (FIRST) {
             // outer radix folded into the load: e[q] = sum_c x[d + c ki] * f^(d + c ki)
             static_for<0, R>([&](auto qc) {
@@ -383,9 +403,9 @@ __device__ __forceinline__ void dif_pass(const LdsPlanes& row, int slot_base, in
         //   evaluate: the pre-scale table carries 2^-256, so data leave the ABI's Montgomery form in the
         //     first pass and the last pass only has to reduce -- the codeword is stored canonical;
         //   interpolate: 1/k sits in the first pass (its twiddles are pre-scaled, output 0 is multiplied
-        //     explicitly; with an outer fold it is in the fold table), so the last pass only reduces.
+        //     explicitly; with an outer fold of 4 it is in the fold table), so the last pass only reduces.
         if constexpr (LOGSUB > 0) {
-            if constexpr (FIRST && !EVALUATE && LOGO == 0)
+            if constexpr (FIRST && !EVALUATE && LOGO <= 1)
                 shoup29(e[0], e[0], a.invk, a.invkq);
             else
                 reduce29(e[0], e[0]);  // output 0 has no twiddle: a partial reduction instead of a product by one

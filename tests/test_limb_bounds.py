@@ -153,6 +153,22 @@ def test_butterfly_networks_stay_in_range():
             reduce(o)
 
 
+def test_radix2_fold_of_the_interpolation_stays_in_range():
+    """ntt_kernels.h, load stage of the k = 8192 interpolation: x0 + x1 of two unpacked ABI elements (canonical, limbs < 2^29)
+    is carried back to strict limbs and is then an N operand; x0 - x1 + 4p goes through a product"""
+    x = Lazy(M, P >> 232, 1)
+    s = add(x, x)
+    assert s.val <= 2 and (s.val * P) >> 232 <= N().top     # after norm29_strict: limbs < 2^29, top limb = value >> 232
+    outs = dft8([N() for _ in range(8)])                      # ... which is what the network is checked with
+    for o in outs:
+        mul(o)
+    mul(sub(x, x, 4, 29))
+    src = open(os.path.join(ROOT, "ligero_amd", "csrc", "ntt_kernels.h")).read()
+    body = src[src.index("FIRST && !EVALUATE && LOGO == 1"):]
+    body = body[:body.index("} else if constexpr (FIRST)")]
+    assert "norm29_strict(e[q])" in body and "sub29<4, 29>(e[q], x0, x1)" in body
+
+
 def test_network_source_matches_model():
     """the model above mirrors dft_regs<3>; if the kernel's sequence of butterflies changes this
     test must be updated with it"""
