@@ -2282,7 +2282,8 @@ int lg_stage_evaluate_rows(lg_ctx* c, uint32_t plane_mask, uint32_t row0, uint32
 int lg_stage_hash_rows(lg_ctx* c, uint32_t plane_mask, uint32_t row0, uint32_t nrows, uint64_t col_pos, uint64_t col_rows) {
     if (!c) return LG_ERR_BAD_ARG;
     { const int rc_ = stage_plane_args(c, plane_mask); if (rc_ != LG_OK) return rc_; }
-    if ((uint64_t)row0 + nrows > c->rows || nrows == 0 || col_pos + nrows > col_rows) return LG_ERR_BAD_ARG;
+    // (the column's byte length 8 + 32 col_rows is a 64-bit Blake2s counter)
+    if ((uint64_t)row0 + nrows > c->rows || nrows == 0 || col_rows > (1ull << 58) || col_pos > col_rows || nrows > col_rows - col_pos) return LG_ERR_BAD_ARG;
     if (c->committed) { c->committed = false; c->have_planes = 0; }
     if (plane_mask == 0) return LG_OK;
     LG_HIP(c, hipSetDevice(c->device));

@@ -185,3 +185,41 @@ def test_full_size_s22_at_world2_equals_the_golden_root():
     for rank in range(2):
         assert out[rank][0] == gold["root"], rank
     print("s22 row-relay at world 2 (one GPU, gloo):", out[0][1], out[1][1])
+
+
+def test_error_behaviour_of_the_relay_entry_points():
+    """bad ranges, a wrong row count for the rank, missing callbacks: a status, never a launch (include/ligero_hip.h)"""
+    import ctypes
+    from ligero_amd import _ffi
+    from ligero_amd.sharded import HipRelayBackend, _LgComm
+    L = _ffi.lib()
+    be = HipRelayBackend(6, 128)
+    try:
+        ctx = be.c._ctx
+        allp = (1 << be.nplanes) - 1
+        be.stage_interpolate(random_mont(1, 6 * 128).reshape(6, 128, 4), 0, 6)
+        be.stage_evaluate_rows(0, 6)
+        B = _ffi.LG_ERR_BAD_ARG
+        assert L.lg_stage_hash_rows(ctx, allp, 0, 0, 0, 6) == B                      # no rows
+        assert L.lg_stage_hash_rows(ctx, allp, 4, 3, 0, 6) == B                      # rows [4, 7) of 6
+        assert L.lg_stage_hash_rows(ctx, allp, 0, 6, 1, 6) == B                      # positions [1, 7) of a 6-row column
+        assert L.lg_stage_hash_rows(ctx, allp, 0, 6, 2**64 - 3, 6) == B              # (no wrap-around of col_pos + nrows)
+        assert L.lg_stage_hash_rows(ctx, allp, 0, 6, 0, 2**59) == B                  # longer than Blake2s' byte counter
+        assert L.lg_stage_hash_rows(ctx, 1 << be.nplanes, 0, 6, 0, 6) == B           # a plane that does not exist
+        assert L.lg_stage_hash_rows(None, allp, 0, 6, 0, 6) == B
+        # the one-call commit: this context has 6 rows, rank 0 of 2 over 20 rows keeps 10
+        comm = _LgComm(world=2, rank=0, flags=0, user=None)
+        assert L.lg_commit_row_relay(ctx, ctypes.byref(comm), 20, _ffi.LG_RELAY_CONTIGUOUS, 0, None) == B      # world 2 without callbacks
+        one = _LgComm(world=1, rank=0, flags=0, user=None)
+        assert L.lg_commit_row_relay(ctx, ctypes.byref(one), 20, _ffi.LG_RELAY_CONTIGUOUS, 0, None) == _ffi.LG_ERR_STATE
+        assert b"keeps 20 of the 20 rows" in L.lg_last_error(ctx)
+        assert L.lg_commit_row_relay(ctx, ctypes.byref(one), 6, 7, 0, None) == B                                  # no such layout
+        bad = _LgComm(world=2, rank=2, flags=0, user=None)
+        assert L.lg_commit_row_relay(ctx, ctypes.byref(bad), 6, _ffi.LG_RELAY_CONTIGUOUS, 0, None) == B
+        assert L.lg_commit_row_relay(ctx, None, 6, _ffi.LG_RELAY_CONTIGUOUS, 0, None) == B
+        # ... and the context still works afterwards
+        be.stage_hash_rows(0, be.nplanes, 0, 6, 0, 6)
+        be.stage_merkle()
+        assert len(be.root()) == 32
+    finally:
+        be.close()
