@@ -222,8 +222,9 @@ int lg_verifier_linear_sums_from_seed(lg_ctx* ctx, const uint8_t* seed, const ui
 
 /*
  * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU
- * (DESIGN.md section 7).  The exchanges between the stages are the caller's (RCCL all-gather on the
- * device buffers below); there is no collective inside the library.
+ * (DESIGN.md section 7).  With these stage calls the exchanges between the stages are the caller's (RCCL all-gather on the
+ * device buffers below); lg_commit_sharded / lg_commit_row_relay further down queue the same stages as ONE call and ask for the
+ * exchanges through the lg_comm callbacks.  Either way the library links no communication library.
  *   1. lg_stage_interpolate   rows [row0, row0+nrows): upload (preenc_rows may be NULL if the rows
  *                             are already in LG_BUF_PREENC) and interpolate -> LG_BUF_COEFFS rows
  *   2. (caller) all-gather LG_BUF_COEFFS rows
