@@ -328,7 +328,8 @@ enum { LG_COMM_EXCHANGE_AT_WORLD_1 = 1 };
  * every piece (lg_shard_row_ranges; pieces = 1: equal shards of ceil(rows / world) rows) -- so piece p of the coefficient
  * all-gather is ONE in-place collective on whole rows of LG_BUF_COEFFS, it is on the wire (on a second stream) while piece
  * p - 1 is evaluated, and because complete row prefixes arrive in order the column hash follows the evaluation piece by
- * piece on the hash stream.  preenc_rows: this rank's rows, its ranges concatenated in order (NULL: resident from the last
+ * piece on the hash stream (with pieces > 1 the sub-blocks are an even number of rows, so every piece starts on an even row).
+ * preenc_rows: this rank's rows, its ranges concatenated in order (NULL: resident from the last
  * call with the same layout).  Returns once everything is QUEUED; lg_read_root / lg_sync wait.
  */
 int lg_shard_row_ranges(uint32_t rows, uint32_t world, uint32_t rank, uint32_t pieces, uint32_t* ranges_out /* (row0, nrows) x up to 8 */,
@@ -336,7 +337,9 @@ int lg_shard_row_ranges(uint32_t rows, uint32_t world, uint32_t rank, uint32_t p
 int lg_commit_sharded(lg_ctx* ctx, const lg_comm* comm, const uint64_t* preenc_rows, uint32_t pieces);
 /*
  * Row-relay commit (steps 1-5 of lg_stage_hash_rows; ctx = an ordinary batch-1 context of max(1, this rank's row count)
- * rows).  col_rows = 4m of the whole proof.  LG_RELAY_CONTIGUOUS: one balanced range per rank.  LG_RELAY_BLOCKS: the rank's
+ * rows).  col_rows = 4m of the whole proof.  LG_RELAY_CONTIGUOUS: one balanced range per rank, every boundary on an EVEN row
+ * (two rows share a 64-byte Blake2s block: the four-lanes-per-column kernel resumes a column at block boundaries only; the last
+ * rank takes an odd last row).  LG_RELAY_BLOCKS: the rank's
  * share of each of the four row blocks X, Y, Z, W of preenc_u (mod.rs:516) -- its rows then form a small [X; Y; Z; W]
  * matrix of their own (the quadratic test's row triples stay on one rank); the relay then has 4 * world hops.
  * lg_relay_row_ranges: (first row in the column, rows) x up to 4.

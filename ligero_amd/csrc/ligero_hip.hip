@@ -2424,6 +2424,9 @@ static void shard_plan(uint32_t rows, uint32_t world, uint32_t pieces, uint32_t*
     uint32_t per_piece = (rows + pieces - 1) / pieces;                 // rows per piece before rounding up to whole sub-blocks
     uint32_t sub = (per_piece + world - 1) / world;
     if (sub == 0) sub = 1;
+    // pieces start on even rows: a piece is hashed on its own and two rows share a Blake2s block (the four-lanes-per-column kernel
+    // resumes at block boundaries only)
+    if (pieces > 1 && (sub & 1)) sub++;
     *sub_out = sub;
     *pieces_out = (rows + world * sub - 1) / (world * sub);            // pieces that hold at least one row
 }
@@ -2589,7 +2592,10 @@ int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int la
     if (!ranges_out || !nranges_out || world == 0 || rank >= world || col_rows == 0) return LG_ERR_BAD_ARG;
     uint32_t n = 0;
     if (layout == LG_RELAY_CONTIGUOUS) {
-        const uint64_t a = col_rows * rank / world, b = col_rows * (rank + 1) / world;
+        // balanced, every boundary on an even row (two rows share a Blake2s block: the four-lanes-per-column kernel hands a column
+        // over at block boundaries only); the last rank takes the odd row
+        const uint64_t half = col_rows / 2;
+        const uint64_t a = 2 * (half * rank / world), b = rank + 1 == world ? col_rows : 2 * (half * (rank + 1) / world);
         if (b > a) { ranges_out[0] = a; ranges_out[1] = b - a; n = 1; }
     } else if (layout == LG_RELAY_BLOCKS) {
         if (col_rows % 4) return LG_ERR_BAD_ARG;
@@ -2649,7 +2655,9 @@ int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int l
         const uint32_t n0 = (uint32_t)first->n, nch = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)planned, n0));
         const bool head = first->pos == 0;
         for (uint32_t i = 0; i < nch; i++) {
-            const uint32_t a = (uint32_t)((uint64_t)n0 * i / nch), b = (uint32_t)((uint64_t)n0 * (i + 1) / nch);
+            // (even cuts, as plan_chunks makes them)
+            const uint32_t a = i == 0 ? 0 : 2 * (uint32_t)((uint64_t)(n0 / 2) * i / nch), b = i + 1 == nch ? n0 : 2 * (uint32_t)((uint64_t)(n0 / 2) * (i + 1) / nch);
+            if (b <= a) continue;
             { const int rc_ = lg_stage_evaluate_rows(c, all, first->local + a, b - a); if (rc_ != LG_OK) return rc_; }
             if (head) { const int rc_ = lg_stage_hash_rows(c, all, first->local + a, b - a, first->pos + a, col_rows); if (rc_ != LG_OK) return rc_; }
         }

@@ -161,9 +161,7 @@ def shard_row_ranges(rows: int, world: int, rank: int, pieces: int = 1) -> List[
     """[(first row, rows)] of the ranges `rank` owns in the coset-sharded commit, in the order its rows are handed over
     (lg_shard_row_ranges): the rows are cut into `pieces` pieces of world * sub rows, the rank owns sub-block `rank` of every
     piece; pieces = 1 is the equal (padded) shard of ceil(rows / world) rows"""
-    pieces = max(1, min(int(pieces), 8))
-    per_piece = -(-rows // pieces)
-    sub = max(1, -(-per_piece // world))
+    sub, _ = shard_piece_rows(rows, world, pieces)
     out = []
     for p in range(-(-rows // (world * sub))):
         a = p * world * sub + rank * sub
@@ -177,6 +175,8 @@ def shard_piece_rows(rows: int, world: int, pieces: int = 1) -> Tuple[int, int]:
     """(rows per sub-block, pieces that hold a row) of shard_row_ranges' rule"""
     pieces = max(1, min(int(pieces), 8))
     sub = max(1, -(-(-(-rows // pieces)) // world))
+    if pieces > 1 and sub & 1:
+        sub += 1                 # pieces start on even rows (two rows share a Blake2s block)
     return sub, -(-rows // (world * sub))
 
 
@@ -440,11 +440,14 @@ class CosetShardedCommitter:
 # ---------------------------------------------------------------------------------------------- row-relay mode
 def relay_row_ranges(rows: int, world: int, rank: int, layout: str = "contiguous") -> List[Tuple[int, int]]:
     """[(first row in the column, rows)] this rank keeps in row-relay mode, in column order (empty ranges dropped).
-    "contiguous": one balanced range per rank.  "blocks": the rank's share of each of the four row blocks X, Y, Z, W of
+    "contiguous": one balanced range per rank, cut on even rows.  "blocks": the rank's share of each of the four row blocks X, Y, Z, W of
     preenc_u (mod.rs:516; rows = 4m) -- its rows then form a small [X; Y; Z; W] matrix of their own, which is what the
     quadratic test's row triples (x_i, y_i, z_i) need to stay on one rank."""
     if layout == "contiguous":
-        a, b = shard_range(rows, world, rank)
+        # balanced, boundaries on even rows (two rows share a Blake2s block); the last rank takes the odd row
+        half = rows // 2
+        a = 2 * (half * rank // world)
+        b = rows if rank + 1 == world else 2 * (half * (rank + 1) // world)
         return [(a, b - a)] if b > a else []
     if layout != "blocks":
         raise ValueError(f"unknown relay layout {layout!r}")

@@ -163,12 +163,15 @@ def test_row_ownership_and_chain():
     from ligero_amd.sharded import relay_chain, relay_row_ranges
     # BASELINE configs[3]: 20 068 rows on 8 GPUs
     r = [relay_row_ranges(20068, 8, g) for g in range(8)]
-    assert r[0] == [(0, 2508)] and r[7] == [(17559, 2509)] and sum(n for x in r for _, n in x) == 20068
+    assert r[0] == [(0, 2508)] and r[7] == [(17558, 2510)] and sum(n for x in r for _, n in x) == 20068
+    assert all(a % 2 == 0 for x in r for a, _ in x)                      # hand-overs at Blake2s block boundaries
+    assert max(n for x in r for _, n in x) - min(n for x in r for _, n in x) <= 2
+    assert relay_row_ranges(20067, 4, 3) == [(15048, 5019)]              # the last rank takes the odd row
     b = [relay_row_ranges(20068, 8, g, "blocks") for g in range(8)]
     assert b[0] == [(0, 627), (5017, 627), (10034, 627), (15051, 627)] and b[7][3] == (15051 + 4389, 628)
     chain = relay_chain(20068, 8, "blocks")
     assert len(chain) == 32 and [c[2] for c in chain[:9]] == [0, 1, 2, 3, 4, 5, 6, 7, 0]
-    assert relay_row_ranges(3, 4, 3) == [(2, 1)] and relay_row_ranges(3, 4, 0) == []     # fewer rows than ranks: rank 0 keeps none
+    assert relay_row_ranges(3, 4, 3) == [(0, 3)] and relay_row_ranges(3, 4, 0) == []     # fewer row pairs than ranks: the first ranks keep none
     with pytest.raises(ValueError):
         relay_row_ranges(10, 2, 0, "blocks")
 

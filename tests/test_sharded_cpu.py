@@ -280,4 +280,4 @@ def test_single_process_degenerate(oracle):
     assert shard_row_ranges(20068, 8, 0, 1) == [(0, 2509)] and shard_row_ranges(20068, 8, 7, 1) == [(17563, 2505)]
     assert shard_row_ranges(20068, 8, 3, 4) == [(1884 + p * 5024, 628) for p in range(3)] + [(1884 + 3 * 5024, 628)]
     assert shard_row_ranges(20068, 8, 7, 4)[-1] == (4396 + 3 * 5024, 20068 - (4396 + 3 * 5024))
-    assert shard_row_ranges(3, 4, 3, 8) == [] and shard_row_ranges(3, 4, 2, 8) == [(2, 1)]
+    assert shard_row_ranges(3, 4, 3, 8) == [] and shard_row_ranges(3, 4, 1, 8) == [(2, 1)]      # sub-blocks are even when there are pieces

@@ -48,6 +48,9 @@ for groups in (1, 2, 4, 16):
             be.stage_hash_rows(g * per, per, 0, local, 2 * (rows // G // 2) * 3, rows)      # a middle rank: resume and park
     print(f"relay rank: hash {local} rows, all 65536 columns in {groups:2d} plane group(s): {timed(go, be.sync):.2f} ms"
           f"  ({timed(lambda: be.stage_hash_rows(0, per, 0, local, 2 * (rows // G // 2) * 3, rows), be.sync):.2f} ms per group)")
+per = be.nplanes // 4
+print(f"relay rank: one group of 4 planes resumed at an ODD row (the hand-over inside a Blake2s block: one lane per column): "
+      f"{timed(lambda: be.stage_hash_rows(0, per, 0, local, 5017, rows), be.sync):.2f} ms -- why lg_relay_row_ranges cuts on even rows")
 be.close()
 
 # ---- coset: 2 planes, all rows (needs the coefficient rows of all rows: interpolate them here)
