@@ -62,6 +62,6 @@ planes = list(range(6, 8))
 sb.stage_evaluate_rows(planes, 0, rows)
 sb.sync()
 print(f"coset rank: evaluate 2 planes x {rows} rows: {timed(lambda: sb.stage_evaluate_rows(planes, 0, rows), sb.sync):.2f} ms")
-print(f"coset rank: hash 8192 columns x {rows} rows (one lane per column): {timed(lambda: sb.stage_hash(planes), sb.sync):.2f} ms")
+print(f"coset rank: hash 8192 columns x {rows} rows (four lanes per column, state carried): {timed(lambda: sb.stage_hash(planes), sb.sync):.2f} ms")
 print(f"coset rank: evaluate + hash, chunk-pipelined (lg_stage_evaluate_hash): {timed(lambda: sb.stage_evaluate_hash(planes), sb.sync):.2f} ms")
 sb.close()
