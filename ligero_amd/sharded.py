@@ -107,6 +107,10 @@ class TorchComm:
         import torch
         return torch.as_tensor(_CudaArray(int(ptr), int(nbytes)), device=f"cuda:{self.device}")
 
+    def _global(self, r) -> int:
+        """torch.distributed's point-to-point and broadcast calls name peers by their rank in the WORLD; lg_comm speaks group ranks"""
+        return int(r) if self.group is None else self.dist.get_global_rank(self.group, int(r))
+
     def _guard(self, what, fn):
         try:
             fn()
@@ -127,7 +131,7 @@ class TorchComm:
         def go():
             with self._on(stream):
                 t = self._tensor(buf, nbytes)
-                self.dist.send(t if self._nccl else t.cpu(), int(dst), group=self.group)
+                self.dist.send(t if self._nccl else t.cpu(), self._global(dst), group=self.group)
         return self._guard("send", go)
 
     def _recv(self, _user, buf, nbytes, src, stream):
@@ -136,10 +140,10 @@ class TorchComm:
             with self._on(stream):
                 t = self._tensor(buf, nbytes)
                 if self._nccl:
-                    self.dist.recv(t, int(src), group=self.group)
+                    self.dist.recv(t, self._global(src), group=self.group)
                 else:
                     h = torch.empty(int(nbytes), dtype=torch.uint8)
-                    self.dist.recv(h, int(src), group=self.group)
+                    self.dist.recv(h, self._global(src), group=self.group)
                     t.copy_(h)
         return self._guard("recv", go)
 
@@ -148,10 +152,10 @@ class TorchComm:
             with self._on(stream):
                 t = self._tensor(buf, nbytes)
                 if self._nccl:
-                    self.dist.broadcast(t, int(root), group=self.group)
+                    self.dist.broadcast(t, self._global(root), group=self.group)
                 else:
                     h = t.cpu()
-                    self.dist.broadcast(h, int(root), group=self.group)
+                    self.dist.broadcast(h, self._global(root), group=self.group)
                     if self.rank != int(root):
                         t.copy_(h)
         return self._guard("broadcast", go)
@@ -624,24 +628,28 @@ class RowRelayCommitter:
     def row_ranges(self, rank: Optional[int] = None) -> List[Tuple[int, int]]:
         return relay_row_ranges(self.rows, self.world, self.rank if rank is None else rank, self.layout)
 
-    # -- the three transfers; device tensors go through RCCL as they are, any other backend gets host copies
+    # -- the three transfers; device tensors go through RCCL as they are, any other backend gets host copies.  (Peers are group
+    # ranks here; torch.distributed names them by their rank in the world.)
+    def _global(self, r: int) -> int:
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
     def _send(self, t, dst):
-        self.dist.send(t if self._nccl or not t.is_cuda else t.cpu(), dst, group=self.group)
+        self.dist.send(t if self._nccl or not t.is_cuda else t.cpu(), self._global(dst), group=self.group)
 
     def _recv(self, t, src):
         if self._nccl or not t.is_cuda:
-            self.dist.recv(t, src, group=self.group)
+            self.dist.recv(t, self._global(src), group=self.group)
         else:
             h = t.cpu()
-            self.dist.recv(h, src, group=self.group)
+            self.dist.recv(h, self._global(src), group=self.group)
             t.copy_(h)
 
     def _broadcast(self, t, src):
         if self._nccl or not t.is_cuda:
-            self.dist.broadcast(t, src, group=self.group)
+            self.dist.broadcast(t, self._global(src), group=self.group)
         else:
             h = t.cpu()
-            self.dist.broadcast(h, src, group=self.group)
+            self.dist.broadcast(h, self._global(src), group=self.group)
             if self.rank != src:
                 t.copy_(h)
 

@@ -118,6 +118,32 @@ def _worker(rank, world, port, rows, k, layout, groups, out):
         dist.destroy_process_group()
 
 
+def _subgroup_worker(rank, world, port, rows, k, out):
+    """a relay over the sub-group {1, 2} of a three-process world: group ranks 0, 1 are world ranks 1, 2"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group([1, 2])                                      # (every process calls new_group)
+        if rank == 0:
+            return
+        from ligero_amd.sharded import RowRelayCommitter
+        pre = random_mont(4243, rows * k).reshape(rows, k, 4)
+        rc = RowRelayCommitter(lambda local: OracleRelayBackend(local, k), rows, dist, group=grp)
+        out[rank] = (rc.commit(_local_rows(pre, rc.row_ranges())), rc.rank, rc.world)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_relay_over_a_subgroup_names_its_peers_by_world_rank(oracle):
+    rows, k = 10, 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), rows, k, out), nprocs=3, join=True)
+    want = oracle.encode_commit(random_mont(4243, rows * k).reshape(rows, k, 4), k, 8 * k, want_u=False)["root"]
+    assert dict(out) == {1: (want, 0, 2), 2: (want, 1, 2)}
+
+
 def _check(oracle, out, world, rows, k, layout):
     from ligero_amd.sharded import RowRelayCommitter, relay_chain
     pre = random_mont(4243, rows * k).reshape(rows, k, 4)
