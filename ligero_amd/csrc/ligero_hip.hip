@@ -139,7 +139,7 @@ struct lg_ctx {
     hipEvent_t ev_shard[kShardProfRing][kShardStages + 1 + 2 * kMaxChunks] = {};   // stage marks, then (before, after) of every wait for an exchange piece
     bool ev_shard_valid = false;
     uint64_t shard_commits = 0;
-    uint32_t shard_wait_pairs = 0;         // exchange pieces the profiled sharded commits wait for (0: row relay)
+    uint32_t shard_wait_pairs[kShardProfRing] = {};   // per profiled commit: exchange pieces it waited for (0: row relay)
     bool committed = false;
     bool staging = false;                  // between lg_stage_interpolate and lg_stage_merkle
     bool profiling = false;
@@ -2582,7 +2582,7 @@ int lg_commit_sharded(lg_ctx* c, const lg_comm* comm, const uint64_t* preenc_row
     if (ev) LG_HIP(c, hipEventRecord(ev[4], c->stream));
     // 5. the tree
     { const int rc_ = lg_stage_merkle(c); if (rc_ != LG_OK) return rc_; }
-    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; c->shard_wait_pairs = np; }
+    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_wait_pairs[c->shard_commits % lg_ctx::kShardProfRing] = np; c->shard_commits++; }
     return LG_OK;
 }
 
@@ -2713,7 +2713,7 @@ int lg_commit_row_relay(lg_ctx* c, const lg_comm* comm, uint64_t col_rows, int l
     if (ev) LG_HIP(c, hipEventRecord(ev[4], c->stream));
     { const int rc_ = lg_stage_merkle(c); if (rc_ != LG_OK) return rc_; }
     c->have_planes = all;    // every plane of this rank's rows is here (a rank without rows holds the tree only)
-    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_commits++; c->shard_wait_pairs = 0; }
+    if (ev) { LG_HIP(c, hipEventRecord(ev[5], c->stream)); c->shard_wait_pairs[c->shard_commits % lg_ctx::kShardProfRing] = 0; c->shard_commits++; }
     return LG_OK;
 }
 
@@ -2736,9 +2736,11 @@ int lg_shard_profile_read(lg_ctx* c, float ms_out[5], uint32_t* samples_out) {
         }
         // coset-sharded commits: the stalls of the encode stream waiting for exchange pieces move from "evaluate + hash" to
         // "all-gather" (with one piece on the encode stream itself the collective sits between marks 1 and 2 already)
-        if (c->shard_wait_pairs) {
+        // (commits with different numbers of pieces may share the ring: each entry knows its own)
+        const uint32_t pairs = c->shard_wait_pairs[(c->shard_commits - 1 - s) % lg_ctx::kShardProfRing];
+        if (pairs) {
             double stall = 0;
-            for (uint32_t p = 0; p < c->shard_wait_pairs; p++) {
+            for (uint32_t p = 0; p < pairs; p++) {
                 float ms = 0;
                 LG_HIP(c, hipEventElapsedTime(&ms, ev[lg_ctx::kShardStages + 1 + 2 * p], ev[lg_ctx::kShardStages + 2 + 2 * p]));
                 stall += ms;

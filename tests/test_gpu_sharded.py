@@ -329,3 +329,21 @@ def test_contexts_on_two_devices_in_one_process(oracle):
     for dev in (0, 1):
         with ligero_amd.LigeroCommitter(rows=rows, k=k, device=dev) as c:
             assert c.encode_commit(pre, want_coeffs=False)[1] == want
+
+
+def test_stage_times_of_commits_with_different_piece_counts_on_one_context(oracle):
+    """the HIP-event ring of lg_shard_profile_read holds commits made with one exchange piece and with four side by side (found by
+    tools/soak_sharded.py: the reader took the latest commit's piece count for every entry)"""
+    from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
+    rows, k = 40, 256
+    pre = random_mont(31, rows * k).reshape(rows, k, 4)
+    want = oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
+    be = HipStageBackend(rows, k, device=0, world=1, rank=0, pieces=4)
+    try:
+        one, four = CosetShardedCommitter(be, None), CosetShardedCommitter(be, None, exchange_pieces=4)
+        for cm in (one, four, one, four):
+            assert cm.commit(pre) == want
+            assert set(cm.stage_ms) == {"interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle"}
+            assert all(v >= 0 for v in cm.stage_ms.values())
+    finally:
+        be.close()
