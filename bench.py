@@ -657,6 +657,8 @@ def main():
 
     import torch
     import ligero_amd
+    from ligero_amd.sharded import cap_host_threads
+    cap_host_threads()      # torch's intra-op pool follows the core count, not the container's CPU quota (see its docstring)
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")

@@ -167,7 +167,8 @@ inline bool preenc_on_host() {
     return e && std::atoi(e) != 0;
 }
 
-// CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period")
+// CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period") and shared with
+// the other ranks a launcher started on this box (LOCAL_WORLD_SIZE, as torch.distributed.run exports it)
 inline unsigned usable_cpus() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -177,6 +178,10 @@ inline unsigned usable_cpus() {
             if (q >= 1 && q < n) n = q;
         }
         fclose(f);
+    }
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) {
+        const long v = atol(lw);
+        if (v > 1) n = std::max(1u, n / (unsigned)v);
     }
     return n;
 }
@@ -468,7 +473,9 @@ private:
     // mod.rs:935-955: column j is opened by the rank that holds plane j mod np; fixed-size blocks (the most any rank opens) go
     // through one host all-gather, and every rank assembles the openings in index order
     OpenedColumns sharded_open_columns(PoseidonSponge& sponge) {
+        PhaseTimer otm;
         const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
+        otm.mark("    open: indices");
         const size_t t = indices.size(), rows = 4 * m_, plen = (size_t)logn_ - 1;
         auto owner_of = [&](uint64_t j) { return (uint32_t)((j % nplanes_) / planes_per_rank_); };
         std::vector<uint32_t> count(comm_.world, 0);
@@ -479,6 +486,7 @@ private:
         const size_t col_bytes = rows * sizeof(Fr);
         const size_t block = std::max<size_t>(most * (col_bytes + 32 + plen * 32), 1) + 1;
         reserve_exchange(block);
+        otm.mark("    open: exchange buffers");
         uint8_t* mine = xchg_send_.data();
         std::vector<uint32_t> idx;
         for (uint64_t j : indices)
@@ -489,11 +497,13 @@ private:
                                   mine + most * (col_bytes + 32)),
                   "lg_open_columns");
         });
+        otm.mark("    open: lg_open_columns + status");
         const uint8_t* blocks = mine;
         if (exchange_) {
             comm_check(comm_.all_gather_host(comm_.user, mine, xchg_recv_.data(), block), "all-gather of the opened columns");
             blocks = xchg_recv_.data();
         }
+        otm.mark("    open: all-gather of the blocks");
         OpenedColumns out;
         std::vector<uint32_t> next(comm_.world, 0);
         for (size_t c = 0; c < t; c++) {

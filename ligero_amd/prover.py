@@ -154,6 +154,9 @@ class ShardedLigeroProver(LigeroProver):
         if mode not in ("coset", "relay"):
             raise ValueError(f"unknown mode {mode!r}")
         self.mode = mode
+        if dist is not None:
+            from .sharded import cap_host_threads
+            cap_host_threads()          # torch's intra-op pool against the container's CPU quota (sharded.py)
         self._dist, self._group, self._device = dist, group, device
         self._force = bool(collectives_at_world_1) and dist is not None
         self.world = dist.get_world_size(group) if dist is not None else 1

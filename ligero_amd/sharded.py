@@ -33,6 +33,34 @@ from . import _ffi
 _vp = ctypes.c_void_p
 
 
+def usable_cpus() -> int:
+    """CPUs this process may use: os.cpu_count() capped by a cgroup v2 quota (/sys/fs/cgroup/cpu.max)"""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cap_host_threads() -> int:
+    """torch sizes its intra-op (OpenMP) pool from the machine's core count, not from the CPU quota of the container.  On a box that
+    shows 256 cores and grants 16, one host-side copy of a megabyte -- the staging of a gloo collective, a `.clone()` of an
+    exchange block -- wakes 128 spinning workers, the quota of the 100 ms scheduler period is gone in a few milliseconds and the
+    kernel stops the WHOLE process until the next period: measured, a sharded Poseidon proof over two gloo ranks took 0.4-1.4 s
+    instead of 7 ms (tools/sharded_prove_probe.py).  Called by everything here that talks to torch.distributed: lowers
+    (never raises) torch's thread count to the quota divided by the ranks sharing the box.  Returns the count in force."""
+    import os
+    import torch
+    share = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    if torch.get_num_threads() > share:
+        torch.set_num_threads(share)
+    return torch.get_num_threads()
+
+
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     """contiguous, balanced [begin, end) of `total` items for `rank` (proofs in throughput mode)"""
     return (total * rank) // world, (total * (rank + 1)) // world
@@ -80,6 +108,8 @@ class TorchComm:
     (gloo in the tests) get host copies, made on the same stream."""
 
     def __init__(self, dist, group=None, device: int = 0, exchange_at_world_1: bool = False):
+        if dist is not None:
+            cap_host_threads()
         self.dist, self.group, self.device = dist, group, device
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
@@ -313,6 +343,8 @@ class CosetShardedCommitter:
     def __init__(self, backend, dist=None, group=None, collectives_at_world_1: bool = False, exchange_pieces: int = 1):
         """collectives_at_world_1: issue the two all-gathers even in a one-rank group (they are identities then) -- lets a
         one-GPU box run the exact RCCL calls of the multi-GPU path (bench.py LIGERO_BENCH_FORCE_DIST, tests)."""
+        if dist is not None:
+            cap_host_threads()
         self.be = backend
         self.dist = dist
         self.group = group
@@ -599,6 +631,8 @@ class RowRelayCommitter:
 
     def __init__(self, make_backend, rows: int, dist=None, group=None, plane_groups: int = 0, layout: str = "contiguous",
                  collectives_at_world_1: bool = False):
+        if dist is not None:
+            cap_host_threads()
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0

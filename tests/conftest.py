@@ -11,6 +11,15 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# torch's intra-op pool follows the machine's core count, not the container's CPU quota: host-side tensor copies in the gloo and
+# thread-rank tests would otherwise run the process into the scheduler's throttle (ligero_amd/sharded.py cap_host_threads).
+# Spawned rank processes import this module with their test module, so the cap holds there too.
+try:
+    from ligero_amd.sharded import cap_host_threads
+    cap_host_threads()
+except Exception:                                  # the CPU-only suite must collect without the HIP library
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -82,6 +82,7 @@ def _worker(rank, world, port, rows, k, layout, groups, out):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -156,6 +157,7 @@ def _s22_worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

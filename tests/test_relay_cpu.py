@@ -111,6 +111,7 @@ def _rank_body(rank, d, rows, k, layout, groups, seed=4243):
 def _worker(rank, world, port, rows, k, layout, groups, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out[rank] = _rank_body(rank, dist, rows, k, layout, groups)
@@ -122,6 +123,7 @@ def _subgroup_worker(rank, world, port, rows, k, out):
     """a relay over the sub-group {1, 2} of a three-process world: group ranks 0, 1 are world ranks 1, 2"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         grp = dist.new_group([1, 2])                                      # (every process calls new_group)

@@ -110,6 +110,7 @@ def _free_port():
 def _worker(rank, world, port, rows, k, batch, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ligero_amd.sharded import CosetShardedCommitter, ShardedBatchCommitter, shard_range
@@ -151,6 +152,7 @@ def test_world2_gloo_matches_single_process(oracle, rows, k):
 def _worker_n(rank, world, port, rows, k, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ligero_amd.sharded import CosetShardedCommitter
@@ -210,6 +212,7 @@ def test_thread_ranks_equal_the_gloo_group(oracle):
 def _worker_pieces(rank, world, port, rows, k, pieces, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))      # the ranks share this box's CPU quota (cap_host_threads)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ligero_amd.sharded import CosetShardedCommitter
