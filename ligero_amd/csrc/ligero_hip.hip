@@ -2493,10 +2493,13 @@ int lg_commit_sharded(lg_ctx* c, const lg_comm* comm, const uint64_t* preenc_row
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc_alloc), (size_t)own * c->k * sizeof(fr)));
         }
         compact = c->d_preenc_alloc;
-        // (a single range keeps lg_stage_interpolate's "rows [pre_row0, pre_row0 + pre_rows) are resident" view of the same buffer)
-        c->pre_row0 = nranges == 1 ? ranges[0] : 0;
-        c->pre_rows = nranges == 1 ? own : 0;
-        c->d_preenc = nranges == 1 ? c->d_preenc_alloc - (size_t)ranges[0] * c->k : nullptr;
+        // (ranges that follow one another -- a single range, or one rank owning every sub-block -- keep lg_stage_interpolate's "rows
+        // [pre_row0, pre_row0 + pre_rows) are resident" view of the same buffer: the compact order is then the matrix order)
+        bool one_run = nranges >= 1;
+        for (uint32_t i = 1; i < nranges; i++) one_run = one_run && ranges[2 * i] == ranges[2 * (i - 1)] + ranges[2 * (i - 1) + 1];
+        c->pre_row0 = one_run ? ranges[0] : 0;
+        c->pre_rows = one_run ? own : 0;
+        c->d_preenc = one_run ? c->d_preenc_alloc - (size_t)ranges[0] * c->k : nullptr;
     } else {
         // an unsharded context (world 1): the matrix has its own full-size buffer; the rows sit at their own positions
         compact = c->d_preenc;
@@ -2510,7 +2513,12 @@ int lg_commit_sharded(lg_ctx* c, const lg_comm* comm, const uint64_t* preenc_row
     // a new staged commit: what an earlier commitment left in U is void
     c->staging = true; c->committed = false; c->have_planes = 0;
     c->canon_ranges.clear();
-    c->have_row0 = nranges ? ranges[0] : 0; c->have_row1 = nranges ? ranges[0] + ranges[1] : 0;
+    // the message rows this context holds as ONE run of the matrix: all of its ranges if they follow one another (one rank: the
+    // whole matrix), else none -- the entry points that read preenc_u rows (lg_interleaved_row_mul, lg_commit_resident) index them
+    // by matrix row, which a compact buffer of scattered ranges does not support
+    bool rows_one_run = nranges >= 1;
+    for (uint32_t i = 1; i < nranges; i++) rows_one_run = rows_one_run && ranges[2 * i] == ranges[2 * (i - 1)] + ranges[2 * (i - 1) + 1];
+    c->have_row0 = rows_one_run ? ranges[0] : 0; c->have_row1 = rows_one_run ? ranges[0] + own : 0;
     const uint32_t msg_held = message_planes_mask(c) & own_planes_mask(c);
     const uint64_t plane = c->total_rows * c->ki;
     const uint32_t mask = own_planes_mask(c);

@@ -348,3 +348,30 @@ def test_stage_times_of_commits_with_different_piece_counts_on_one_context(oracl
             assert all(v >= 0 for v in cm.stage_ms.values())
     finally:
         be.close()
+
+
+def test_one_rank_commit_in_pieces_holds_every_message_row(oracle):
+    """lg_commit_sharded at world 1 with several pieces: the rank's ranges are adjacent and cover the matrix, so the entry points
+    that need every row of preenc_u work afterwards (found by tools/fuzz_api_sequences.py: only the first range was counted)"""
+    from ligero_amd.sharded import CosetShardedCommitter, HipStageBackend
+    rows, k = 24, 64
+    pre = random_mont(77, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k, want_u=False)
+    be = HipStageBackend(rows, k, device=0, world=1, rank=0, pieces=3)
+    try:
+        cm = CosetShardedCommitter(be, None, exchange_pieces=3)
+        assert len(cm.row_ranges()) == 3
+        assert cm.commit(pre) == ref["root"]
+        r = random_mont(78, rows).reshape(rows, 4)
+        got = be.c.interleaved_row_mul(r)
+        with ligero_amd_committer(rows, k) as plain:
+            plain.encode_commit(pre, want_coeffs=False)
+            assert np.array_equal(got, plain.interleaved_row_mul(r))
+        assert cm.commit(None) == ref["root"]                               # resident rows, same layout
+    finally:
+        be.close()
+
+
+def ligero_amd_committer(rows, k):
+    import ligero_amd
+    return ligero_amd.LigeroCommitter(rows=rows, k=k)
