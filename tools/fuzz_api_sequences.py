@@ -7,7 +7,9 @@ row product).  Every answer is compared with what a FRESH context gives for the 
 after: state carried from one entry-point family into the next -- which rows and planes the context believes it holds, parked hash
 states, pending asynchronous hash / tree work, the canonical message copy.
 
-    python tools/fuzz_api_sequences.py <seconds> [rows=24] [k=64] [seed=1]        (rows = 4 m)
+    python tools/fuzz_api_sequences.py <seconds> [rows=24] [k=64] [seed=1] [batch=1]        (rows = 4 m)
+
+batch > 1: the three entry points that take a batch (resident, host buffers, from `w`), the reads per proof and for the whole batch.
 """
 import ctypes
 import os
@@ -30,6 +32,7 @@ def main():
     rows = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     k = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     assert rows % 4 == 0
     rng = np.random.default_rng(seed)
     n, m = 8 * k, rows // 4
@@ -40,40 +43,52 @@ def main():
     right[gates] = rng.integers(m * k, size=gates.size)
 
     def matrix():
-        a = rng.integers(0, 2**62, size=(4, m * k, 4), dtype=np.uint64)
+        a = rng.integers(0, 2**62, size=(batch, 4, m * k, 4), dtype=np.uint64)
         a[..., 3] &= np.uint64((1 << 60) - 1)
-        a[:3] = 0
-        w = a[3]
-        a[0][gates], a[1][gates], a[2][gates] = w[left[gates]], w[right[gates]], w[gates]
-        return a.reshape(rows, k, 4), np.ascontiguousarray(w).reshape(m, k, 4)
+        a[:, :3] = 0
+        w = a[:, 3]
+        a[:, 0][:, gates], a[:, 1][:, gates], a[:, 2][:, gates] = w[:, left[gates]], w[:, right[gates]], w[:, gates]
+        return a.reshape(batch * rows, k, 4), np.ascontiguousarray(w).reshape(batch * m, k, 4)
 
     mats = [matrix(), matrix()]
     idx = sorted(set(int(x) for x in rng.integers(n, size=9)) | {0, n - 1})
-    r_quad = rng.integers(0, 2**62, size=(m, 4), dtype=np.uint64)
-    r_int = rng.integers(0, 2**62, size=(rows, 4), dtype=np.uint64)
+    r_quad = rng.integers(0, 2**62, size=(batch * m, 4), dtype=np.uint64)
+    r_int = rng.integers(0, 2**62, size=(batch * rows, 4), dtype=np.uint64)
+    bidx = np.stack([np.array(idx, dtype=np.uint32)[rng.permutation(len(idx))] for _ in range(batch)])      # per-proof order
     want = []
     for pre, _ in mats:                                       # the plain path on a fresh context
-        with ligero_amd.LigeroCommitter(rows=rows, k=k) as c:
+        with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
             coeffs, root = c.encode_commit(pre)
-            want.append({"root": root, "coeffs": coeffs, "leaves": c.leaves().copy(), "open": c.open_columns(idx),
+            want.append({"root": root, "coeffs": coeffs, "leaves": c.leaves().copy(), "open": c.open_columns(idx, proof=batch - 1),
+                         "openb": c.open_columns_batch(bidx),
                          "quad": c.quadratic_constraint_poly(r_quad) if 4 <= k <= 8192 else None, "int": c.interleaved_row_mul(r_int)})
+    trace = open(os.environ["LG_FUZZ_TRACE"], "w") if os.environ.get("LG_FUZZ_TRACE") else None
     L = _ffi.lib()
-    be = HipRelayBackend(rows, k)
-    c = be.c
+    be = HipRelayBackend(rows, k) if batch == 1 else None
+    c = be.c if be is not None else ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch)
     comm = TorchComm(None)
     c.upload_gate_map(left, right, np.zeros((0, 4), dtype=np.uint64))
-    allp = be.nplanes
+    allp = 8 if k <= 4096 else 8 * (k // 4096)
     counts = {}
 
+    def note(what):
+        if trace is not None:
+            trace.write(f"    {what}\n")
+            trace.flush()
+
     def resident(i):
+        note("upload")
         c.upload(mats[i][0])
         for _ in range(int(rng.integers(1, 4))):
+            note("commit_resident")
             c.commit_resident()
 
     def host(i):
+        note("encode_commit")
         c.encode_commit(mats[i][0], want_coeffs=bool(rng.integers(2)))
 
     def witness(i):
+        note("encode_commit_from_witness")
         c.encode_commit_from_witness(mats[i][1])
 
     def staged_all(i):
@@ -105,28 +120,33 @@ def main():
     def relay(i):
         be.commit_native(comm, rows, "contiguous", mats[i][0], plane_groups=int(rng.choice([0, 1, 2])))
 
-    ops = [resident, host, witness, staged_all, staged_rows, sharded, relay]
+    ops = [resident, host, witness, staged_all, staged_rows, sharded, relay] if batch == 1 else [resident, host, witness]
 
     def check(i, what):
         wnt = want[i]
-        reads = rng.integers(2, size=6)
-        assert be.root() == wnt["root"], (what, "root")
+        reads = rng.integers(2, size=7)
+        note(f"check {list(map(int, reads))}")
+        assert c.root() == wnt["root"], (what, "root")
+        note("root ok")
         if reads[0]:
             assert np.array_equal(c.leaves(), wnt["leaves"]), (what, "leaves")
         if reads[1]:
             assert np.array_equal(c.coeffs(), wnt["coeffs"]), (what, "coeffs")
         if reads[2]:
-            got = c.open_columns(idx)
+            got = c.open_columns(idx, proof=batch - 1)
             assert all(np.array_equal(a, b) for a, b in zip(got, wnt["open"])), (what, "openings")
+        if reads[6]:
+            got = c.open_columns_batch(bidx)
+            assert all(np.array_equal(a, b) for a, b in zip(got, wnt["openb"])), (what, "batch openings")
         if reads[3] and wnt["quad"] is not None:              # (the size-2k extraction serves 4 <= k <= 8192)
             assert np.array_equal(c.quadratic_constraint_poly(r_quad), wnt["quad"]), (what, "quadratic polynomial")
         if reads[4]:
             assert np.array_equal(c.interleaved_row_mul(r_int), wnt["int"]), (what, "interleaved row product")
+        note("reads ok")
         if reads[5]:
             c.commit_resident()                               # ... and the matrix is still the resident one
-            assert be.root() == wnt["root"], (what, "resident commit afterwards")
+            assert c.root() == wnt["root"], (what, "resident commit afterwards")
 
-    trace = open(os.environ["LG_FUZZ_TRACE"], "w") if os.environ.get("LG_FUZZ_TRACE") else None
     if trace is not None:
         import faulthandler
         faulthandler.dump_traceback_later(seconds + 30, exit=True)     # a hang ends with the Python stack of the blocking call
@@ -151,8 +171,8 @@ def main():
                 t_mark = time.time()
                 print(f"  ... {total} commits", flush=True)
     finally:
-        be.close()
-    print(f"api sequence fuzz ({rows} x {k}, seed {seed}): {total} commits through {len(ops)} entry-point families on one context "
+        (be if be is not None else c).close()
+    print(f"api sequence fuzz ({batch} x {rows} x {k}, seed {seed}): {total} commits through {len(ops)} entry-point families on one context "
           f"({', '.join(f'{k_} {v}' for k_, v in sorted(counts.items()))}), every read equal to a fresh context's")
 
 
