@@ -54,12 +54,22 @@ def main():
     idx = sorted(set(int(x) for x in rng.integers(n, size=9)) | {0, n - 1})
     r_quad = rng.integers(0, 2**62, size=(batch * m, 4), dtype=np.uint64)
     r_int = rng.integers(0, 2**62, size=(batch * rows, 4), dtype=np.uint64)
+    small = rows * k <= 1 << 16                              # the linear test's explicit challenge is rows * k elements per proof
+    r_a = rng.integers(0, 2**62, size=(batch * rows, k, 4), dtype=np.uint64) if small else None
+    ncols = rows * k
+    a_ri = np.concatenate([np.arange(ncols), np.arange(0, ncols, 7)]).astype(np.uint64)
+    a_ci = np.concatenate([np.arange(ncols), (np.arange(0, ncols, 7) * 5 + 3) % ncols]).astype(np.uint64)
+    a_vals = rng.integers(0, 2**62, size=(a_ri.shape[0], 4), dtype=np.uint64)
+    seeds = bytes(int(x) for x in rng.integers(256, size=32 * batch))
     bidx = np.stack([np.array(idx, dtype=np.uint32)[rng.permutation(len(idx))] for _ in range(batch)])      # per-proof order
     want = []
     for pre, _ in mats:                                       # the plain path on a fresh context
         with ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch) as c:
             coeffs, root = c.encode_commit(pre)
-            want.append({"root": root, "coeffs": coeffs, "leaves": c.leaves().copy(), "open": c.open_columns(idx, proof=batch - 1),
+            c.upload_constraint_matrix(ncols, a_ri, a_ci, a_vals)
+            want.append({"lin": c.linear_constraint_poly(r_a) if small and 4 <= k <= 8192 else None,
+                         "seed": c.linear_constraint_poly_from_seeds(seeds) if 4 <= k <= 8192 else None,
+                         "root": root, "coeffs": coeffs, "leaves": c.leaves().copy(), "open": c.open_columns(idx, proof=batch - 1),
                          "openb": c.open_columns_batch(bidx),
                          "quad": c.quadratic_constraint_poly(r_quad) if 4 <= k <= 8192 else None, "int": c.interleaved_row_mul(r_int)})
     trace = open(os.environ["LG_FUZZ_TRACE"], "w") if os.environ.get("LG_FUZZ_TRACE") else None
@@ -68,6 +78,7 @@ def main():
     c = be.c if be is not None else ligero_amd.LigeroCommitter(rows=rows, k=k, batch=batch)
     comm = TorchComm(None)
     c.upload_gate_map(left, right, np.zeros((0, 4), dtype=np.uint64))
+    c.upload_constraint_matrix(ncols, a_ri, a_ci, a_vals)
     allp = 8 if k <= 4096 else 8 * (k // 4096)
     counts = {}
 
@@ -124,7 +135,7 @@ def main():
 
     def check(i, what):
         wnt = want[i]
-        reads = rng.integers(2, size=7)
+        reads = rng.integers(2, size=9)
         note(f"check {list(map(int, reads))}")
         assert c.root() == wnt["root"], (what, "root")
         note("root ok")
@@ -142,6 +153,10 @@ def main():
             assert np.array_equal(c.quadratic_constraint_poly(r_quad), wnt["quad"]), (what, "quadratic polynomial")
         if reads[4]:
             assert np.array_equal(c.interleaved_row_mul(r_int), wnt["int"]), (what, "interleaved row product")
+        if reads[7] and wnt["lin"] is not None:
+            assert np.array_equal(c.linear_constraint_poly(r_a), wnt["lin"]), (what, "linear polynomial")
+        if reads[8] and wnt["seed"] is not None:
+            assert np.array_equal(c.linear_constraint_poly_from_seeds(seeds), wnt["seed"]), (what, "linear polynomial from seeds")
         note("reads ok")
         if reads[5]:
             c.commit_resident()                               # ... and the matrix is still the resident one
