@@ -4,7 +4,9 @@ of this process, the Poseidon fixture proved over and over, alternating between 
 different matrices, commitments and proofs); every proof must equal the first proof of the same witness field for field, on every
 rank, and the first ones must equal the single-GPU prover's.
 
-    python tools/soak_sharded_prover.py <seconds> [world=4]
+    python tools/soak_sharded_prover.py <seconds> [world=4] [poseidon|s18|s20]
+
+s18 / s20: the synthetic 2^18- / 2^20-constraint repeated-squaring R1CS (BASELINE configs[2]) instead of the Poseidon fixture.
 """
 import os
 import sys
@@ -26,10 +28,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    circ = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
-    inst = hp.LigeroInstance(circ)
-    w = hp.read_witness(os.path.join(GOLDEN, "poseidon_witness.json"))
-    idx, good = list(range(1, w.shape[0])), w[1:]
+    case = sys.argv[3] if len(sys.argv) > 3 else "poseidon"
+    if case == "poseidon":
+        circ = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+        inst = hp.LigeroInstance(circ)
+        w = hp.read_witness(os.path.join(GOLDEN, "poseidon_witness.json"))
+        idx, good = list(range(1, w.shape[0])), w[1:]
+    else:
+        import bench
+        inst, idx, good, _ = bench.repeated_squaring_instance(int(case[1:]))
+        good = np.ascontiguousarray(good)
     bad = good.copy()
     bad[0, 0] ^= np.uint64(1)
     wit = [good, bad]
@@ -59,7 +67,7 @@ def main():
 
     out = run_ranks(world, body, timeout=max(300, int(seconds) + 180))
     for mode, n in out[0].items():
-        print(f"soak sharded prover, {mode}: world {world}, Poseidon fixture: {n} proofs per rank after the first two, all equal to the single-GPU proofs")
+        print(f"soak sharded prover, {mode}: world {world}, {case}: {n} proofs per rank after the first two, all equal to the single-GPU proofs")
 
 
 if __name__ == "__main__":
