@@ -112,7 +112,8 @@ def device_copy_gbs(torch, nbytes: int = 1 << 30, reps: int = 5) -> float:
 
 
 def usable_cpus() -> int:
-    """CPUs this process may use: os.cpu_count() capped by a cgroup v2 quota (the GPU boxes give 16 of 256)"""
+    """CPUs this process may use: os.cpu_count() capped by a cgroup v2 quota (the GPU boxes give 16 of 256), divided by the ranks
+    a launcher started on this box (LOCAL_WORLD_SIZE)"""
     n = os.cpu_count() or 1
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -120,7 +121,7 @@ def usable_cpus() -> int:
             n = max(1, min(n, -(-int(quota) // int(period))))
     except (OSError, ValueError):
         pass
-    return n
+    return max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))      # the ranks of one box share it
 
 
 def poseidon_batch_inputs():
@@ -193,7 +194,7 @@ def full_prover_rate(device: int, steps: int = 8):
         for bp in provers:
             bp.close()
     n = nprov * 64 * steps
-    return {"value": n / dt, "unit": "proofs/s", "ms_per_64_proofs": dt / (nprov * steps) * 1e3, "concurrent_batch_provers": nprov,
+    return {"value": n / dt, "unit": "proofs/s", "proofs": n, "seconds": dt, "ms_per_64_proofs": dt / (nprov * steps) * 1e3, "concurrent_batch_provers": nprov,
             "host_threads_each": threads, "host_cpus_usable": usable_cpus(),
             "note": "full prove() incl. transcript on host threads; host bound; transcript unpinned vs the Rust crates"}
 
@@ -733,6 +734,24 @@ def main():
     # (default 300) rank 0 prints the line without the extra legs and every rank leaves.
     watchdog = None
     partial = {}
+    # BASELINE's other target, proofs/s at 1 / 2 / 4 / 8 GPUs: every rank proves batches of the 64 committed Poseidon witnesses on its own
+    # GPU and its share of the host cores (no collective inside: weak scaling); total proofs over the slowest rank's time
+    multi_prover = None
+    if dist is not None and args.workload == "poseidon" and not args.no_cpu_baseline:
+        try:
+            dist.barrier()
+            fp = full_prover_rate(local_rank, steps=4)
+            dev_ = "cuda" if backend == "nccl" else "cpu"
+            tot = torch.tensor([float(fp["proofs"])], dtype=torch.float64, device=dev_)
+            slow = torch.tensor([float(fp["seconds"])], dtype=torch.float64, device=dev_)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(slow, op=dist.ReduceOp.MAX)
+            multi_prover = {"value": float(tot.item()) / float(slow.item()), "unit": "proofs/s", "n_gpus": world, "scaling": "weak",
+                            "proofs": int(tot.item()), "seconds_slowest_rank": float(slow.item()), "rank0": fp,
+                            "note": "complete prove() per proof, independent batches per rank; host bound; transcript unpinned vs the Rust crates"}
+        except Exception as e:
+            multi_prover = {"error": f"{type(e).__name__}: {e}"}
+        partial["full_prover"] = multi_prover
     if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
         import threading
 
@@ -748,6 +767,7 @@ def main():
                                  "batch_per_gpu": batch, "parallelism": f"independent proofs x{world}"},
                       "stage_ms": {s_: stage[s_] for s_ in ("interpolate", "evaluate", "colhash", "merkle")}, "root0": root[:32].hex(),
                       "roofline": roofline_of(args.workload, stage, launches, tfile)[0],
+                      "full_prover": partial.get("full_prover"),
                       "sharded_commit": partial.get("sharded_commit", {"error": "the extra sharded legs did not finish in time; headline only"}),
                       "sharded_legs_note": "a sharded leg did not finish in time: what had completed is reported"})
             os._exit(3)          # non-zero on every rank (the partial line above is still usable)
@@ -812,6 +832,8 @@ def main():
         vr = valu_roofline_of(args.workload, stage)
         if vr:
             line["valu_roofline"] = vr
+        if multi_prover is not None:
+            line["full_prover"] = multi_prover
         if sharded is not None:
             line["sharded_commit"] = sharded
         if sharded_prove is not None:
