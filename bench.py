@@ -738,19 +738,23 @@ def main():
     # GPU and its share of the host cores (no collective inside: weak scaling); total proofs over the slowest rank's time
     multi_prover = None
     if dist is not None and args.workload == "poseidon" and not args.no_cpu_baseline:
-        try:
-            dist.barrier()
+        dist.barrier()
+        try:                                        # (local work only inside the try: every rank must reach the reductions below)
             fp = full_prover_rate(local_rank, steps=4)
-            dev_ = "cuda" if backend == "nccl" else "cpu"
-            tot = torch.tensor([float(fp["proofs"])], dtype=torch.float64, device=dev_)
-            slow = torch.tensor([float(fp["seconds"])], dtype=torch.float64, device=dev_)
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            dist.all_reduce(slow, op=dist.ReduceOp.MAX)
-            multi_prover = {"value": float(tot.item()) / float(slow.item()), "unit": "proofs/s", "n_gpus": world, "scaling": "weak",
-                            "proofs": int(tot.item()), "seconds_slowest_rank": float(slow.item()), "rank0": fp,
-                            "note": "complete prove() per proof, independent batches per rank; host bound; transcript unpinned vs the Rust crates"}
         except Exception as e:
-            multi_prover = {"error": f"{type(e).__name__}: {e}"}
+            fp = {"error": f"{type(e).__name__}: {e}", "proofs": 0, "seconds": 0.0}
+        dev_ = "cuda" if backend == "nccl" else "cpu"
+        tot = torch.tensor([float(fp["proofs"]), 1.0 if "error" in fp else 0.0], dtype=torch.float64, device=dev_)
+        slow = torch.tensor([float(fp["seconds"])], dtype=torch.float64, device=dev_)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(slow, op=dist.ReduceOp.MAX)
+        failed = int(tot[1].item())
+        if failed or float(slow.item()) <= 0:
+            multi_prover = {"error": f"the prover leg failed on {failed} rank(s)", "rank0": fp}
+        else:
+            multi_prover = {"value": float(tot[0].item()) / float(slow.item()), "unit": "proofs/s", "n_gpus": world, "scaling": "weak",
+                            "proofs": int(tot[0].item()), "seconds_slowest_rank": float(slow.item()), "rank0": fp,
+                            "note": "complete prove() per proof, independent batches per rank; host bound; transcript unpinned vs the Rust crates"}
         partial["full_prover"] = multi_prover
     if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
         import threading
