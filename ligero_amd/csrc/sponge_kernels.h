@@ -1,0 +1,329 @@
+// Fiat-Shamir on the device for MANY proofs in flight: one lane per proof.
+//
+//   PoseidonSponge (width 3 = rate 2 + capacity 1; test_sponge(): 8 full + 31 partial rounds, alpha = 17)
+//     absorb(&Vec<u8>)   src/ligero/mod.rs:560     the Merkle root
+//     absorb(&Vec<F>)    src/ligero/mod.rs:660, 738, 850   preenc_u_lc, the two constraint polynomials
+//     squeeze_bytes(32)  src/ligero/mod.rs:653, 719, 839, 941   ChaCha20 seeds
+//   get_distinct_indices_from_prng   src/utils.rs:31-55
+//
+// The same restatement as ligero_amd/host/transcript.hpp (PARITY UNPINNED against the Rust crates, see there); the tests
+// compare the two bit for bit.  Why it exists: a proof's transcript is a chain of 326 permutations (275 field products each)
+// that nothing in the protocol lets run in parallel, and in throughput mode it was the host that ran it -- proofs/s followed
+// the host's cores, not the GPUs.  One lane per proof makes a batch of B proofs B / 64 waves: a negligible
+// share of the chip's issue slots, at the price of latency (tools/microbench9.hip), which batches in flight hide.
+//
+// Arithmetic: the 9 x 29-bit limbs of fr29_gfx950.h with its Montgomery product (radix 2^261).  The state is kept as
+// x * 2^261 mod p; elements cross in the ABI's x * 2^256 form (one product by 2^266 on the way in, by 2^256 on the way out).
+// Values stay below 2p between rounds (one product or one reduce29 per element and round), limbs 0..7 below 2^29.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "challenge_kernels.h"
+#include "fr29_gfx950.h"
+#include "fr_gfx950.h"
+
+namespace lg {
+
+// 2^266, 2^256, 2^522 mod p in 29-bit limbs (tests/test_limb_bounds.py re-derives them)
+__device__ __forceinline__ constexpr uint32_t kC266(int i) {
+    constexpr uint32_t T[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+    return T[i];
+}
+__device__ __forceinline__ constexpr uint32_t kC256(int i) {
+    constexpr uint32_t T[9] = {0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+    return T[i];
+}
+__device__ __forceinline__ constexpr uint32_t kC522(int i) {
+    constexpr uint32_t T[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
+    return T[i];
+}
+__device__ __forceinline__ constexpr uint32_t kOne29(int i) { return i == 0 ? 1u : 0u; }
+template <uint32_t (*C)(int)>
+__device__ __forceinline__ f29 const29() {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = C(i);
+    return r;
+}
+
+// Poseidon parameters as the kernels read them: round constants as 29-bit limbs of ark * 2^261 mod p, [round][3][9] words
+// (the kernel copies them into LDS: every round starts with them, and a global load per round would sit on the chain).
+// mds == nullptr: the additions-only matrix of test_sponge() [[1,0,1],[1,1,0],[0,1,1]]; otherwise [3][3][9] words of
+// mds * 2^261 mod p.
+struct PoseidonParams {
+    const uint32_t* ark;
+    const uint32_t* mds;
+    uint32_t full_rounds, partial_rounds;
+};
+
+// x^17: four squarings and one product.  x: limbs 0..7 < 2^29, value < 8p.  Result < 1.1p, limbs 0..7 < 2^29.
+__device__ __forceinline__ void sbox17(f29& x) {
+    f29 y;
+    mul29(y, x, x);
+    mul29(y, y, y);
+    mul29(y, y, y);
+    mul29(y, y, y);
+    mul29(x, y, x);
+}
+
+// one permutation; s[j]: limbs 0..7 < 2^29, value < 2p on entry and on exit.  TEST_MDS: the additions-only matrix (P.mds unused).
+template <bool TEST_MDS>
+__device__ __forceinline__ void poseidon_permute(f29 (&s)[3], const PoseidonParams& P) {
+    const uint32_t half = P.full_rounds / 2, rounds = P.full_rounds + P.partial_rounds;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t* ark = P.ark + 27 * r;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) s[j].v[i] += ark[9 * j + i];   // < 3p, limbs < 2^30
+            norm29_strict(s[j]);
+        }
+        const bool full = r < half || r >= half + P.partial_rounds;
+        sbox17(s[0]);
+        if (full) {
+            sbox17(s[1]);
+            sbox17(s[2]);
+        }
+        f29 n[3];
+        if constexpr (TEST_MDS) {
+            add29(n[0], s[0], s[2]);
+            add29(n[1], s[0], s[1]);
+            add29(n[2], s[1], s[2]);
+        } else {
+            // (each row spelled out: left as a loop the compiler indexes n[] dynamically, i.e. through scratch memory)
+            auto mds_row = [&](f29& out, int row) {
+                f29 t, c;
+#pragma unroll
+                for (int col = 0; col < 3; col++) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) c.v[i] = P.mds[9 * (3 * row + col) + i];
+                    mul29(t, s[col], c);
+                    if (col == 0) out = t; else add29(out, out, t);
+                }
+            };
+            mds_row(n[0], 0);
+            mds_row(n[1], 1);
+            mds_row(n[2], 2);
+        }
+        // < 6p with limbs < 2^31: one partial reduction each brings them back below 2p with clean limbs
+#pragma unroll
+        for (int j = 0; j < 3; j++) reduce29(s[j], n[j]);
+    }
+}
+
+// ---- per-proof sponge state in device memory: 32 words per proof
+//   [0, 27)  the three state elements (x * 2^261 mod p, limbs 0..7 < 2^29, value < 2p)
+//   [27]     DuplexSpongeMode: 0 absorbing, 1 squeezing      [28]  next_absorb_index / next_squeeze_index
+constexpr uint32_t kSpongeWords = 32;
+
+// What one launch does for every proof (lane), in this order:
+//   1. absorb `count` elements            -- absorb(&Vec<F>) -- or, kind = kAbsorbDigest, one 32-byte string -- absorb(&Vec<u8>)
+//   2. nsqueeze times squeeze_bytes(32)   -> seeds[j][proof][8 words]
+struct SpongeArgs {
+    uint32_t* state;         // [batch][kSpongeWords]
+    PoseidonParams P;
+    const fr* src;           // kAbsorbElems: element i of proof b at src[b * src_proof + i] (ABI Montgomery words)
+    const uint8_t* digests;  // kAbsorbDigest: 32 bytes of proof b at digests + b * digest_stride
+    uint64_t src_proof, digest_stride;
+    uint32_t* lens_out;      // optional: the number of elements absorbed per proof (the trimmed polynomial's length)
+    uint32_t* seeds;         // [nsqueeze][batch][8]
+    uint32_t batch, count, kind, trim, nsqueeze, reset;
+};
+enum { kAbsorbNone = 0, kAbsorbElems = 1, kAbsorbDigest = 2 };
+
+__device__ __forceinline__ bool fr_is_zero_words(const fr& x) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= x.v[i];
+    return o == 0;
+}
+
+// element i of the 40-byte string LE64(32) || digest packed 31 bytes per field element (little endian): canonical words
+__device__ __forceinline__ fr digest_element(const uint32_t (&rw)[8], uint32_t i) {
+    fr e;
+    if (i == 0) {
+        e.v[0] = 32u; e.v[1] = 0u;
+        e.v[2] = rw[0]; e.v[3] = rw[1]; e.v[4] = rw[2]; e.v[5] = rw[3]; e.v[6] = rw[4];
+        e.v[7] = rw[5] & 0x00ffffffu;
+    } else {
+        e.v[0] = (rw[5] >> 24) | (rw[6] << 8);
+        e.v[1] = (rw[6] >> 24) | (rw[7] << 8);
+        e.v[2] = rw[7] >> 24;
+        e.v[3] = e.v[4] = e.v[5] = e.v[6] = e.v[7] = 0u;
+    }
+    return e;
+}
+
+constexpr uint32_t kSpongeMaxRounds = 96;
+template <bool TEST_MDS>
+__global__ void __launch_bounds__(64) sponge_kernel(const SpongeArgs a) {
+    __shared__ uint32_t ark_lds[27 * kSpongeMaxRounds];
+    {
+        const uint32_t words = 27 * (a.P.full_rounds + a.P.partial_rounds);
+        for (uint32_t i = threadIdx.x; i < words; i += 64) ark_lds[i] = a.P.ark[i];
+        __syncthreads();
+    }
+    const PoseidonParams P{ark_lds, a.P.mds, a.P.full_rounds, a.P.partial_rounds};
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < a.batch;
+    const uint32_t bb = live ? b : 0;
+    uint32_t* st = a.state + (uint64_t)bb * kSpongeWords;
+    f29 s[3];
+    uint32_t squeezing, idx;
+    if (a.reset) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 9; i++) s[j].v[i] = 0;
+        squeezing = 0; idx = 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 9; i++) s[j].v[i] = st[9 * j + i];
+        squeezing = st[27]; idx = st[28];
+    }
+    // what this lane absorbs
+    uint32_t len = 0;
+    uint32_t rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const fr* src = a.src + (uint64_t)bb * a.src_proof;
+    if (a.kind == kAbsorbDigest) {
+        const uint32_t* d = reinterpret_cast<const uint32_t*>(a.digests + (uint64_t)bb * a.digest_stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) rw[i] = d[i];
+        len = 2;
+    } else if (a.kind == kAbsorbElems) {
+        len = a.count;
+        if (a.trim)   // DensePolynomial::from_coefficients_vec: trailing zero coefficients are not part of the polynomial
+            while (len > 0 && fr_is_zero_words(fr_load(src + (len - 1)))) len--;
+        if (a.lens_out && live) a.lens_out[b] = len;
+    }
+    // the duplex state machine of PoseidonSponge (absorb / squeeze_native_field_elements), every lane on its own, with ONE
+    // permutation site: a lane runs until its next step needs a permutation, the wave permutes, the lane goes on
+    uint32_t phase = live ? 0u : 4u;   // 0 absorb: first step, 1 absorb: chunks, 2 squeeze j: first step, 3 squeeze j: emit, 4 done
+    uint32_t pos = 0, start = 0, j = 0;
+    bool need_perm = false;
+    for (;;) {
+        if (need_perm) {
+            poseidon_permute<TEST_MDS>(s, P);
+            need_perm = false;
+        }
+        while (!need_perm && phase != 4u) {
+            if (phase == 0u) {
+                if (len == 0) { phase = 2u; continue; }
+                if (squeezing || idx == 2u) { start = 0; need_perm = true; } else { start = idx; }
+                phase = 1u;
+            } else if (phase == 1u) {
+                const uint32_t left = len - pos, room = 2u - start, cnt = left < room ? left : room;
+                for (uint32_t i = 0; i < cnt; i++) {
+                    f29 e, x;
+                    if (a.kind == kAbsorbDigest) {
+                        x = unpack29(digest_element(rw, pos + i));
+                        mul29(e, x, const29<kC522>());        // canonical -> x * 2^261
+                    } else {
+                        x = unpack29(fr_load(src + pos + i));
+                        mul29(e, x, const29<kC266>());        // x * 2^256 -> x * 2^261
+                    }
+                    const uint32_t t = start + i;             // rate slot 0 / 1 = state element 1 / 2
+#pragma unroll
+                    for (int l = 0; l < 9; l++) {
+                        s[1].v[l] += (t == 0u) ? e.v[l] : 0u;
+                        s[2].v[l] += (t == 0u) ? 0u : e.v[l];
+                    }
+                }
+                // (< 2p + 1.1p: below the 8p the S-box takes; limbs are re-normalised by the next round's first step)
+                if (start + left <= 2u) {
+                    squeezing = 0; idx = start + left; phase = 2u;
+                } else {
+                    pos += cnt; start = 0; need_perm = true;
+                }
+            } else if (phase == 2u) {
+                if (j == a.nsqueeze) { phase = 4u; continue; }
+                if (!squeezing || idx == 2u) { start = 0; need_perm = true; } else { start = idx; }
+                phase = 3u;
+            } else {   // phase 3: squeeze_bytes(32) = two elements, the low 31 little-endian bytes of each, truncated to 32
+                f29 c0, c1;
+                // squeeze_internal from `start`: elements state[1 + start], then (start = 1: no permutation in between, as upstream) state[1]
+                f29 q0, q1;
+#pragma unroll
+                for (int l = 0; l < 9; l++) {   // (limb-wise selects: a select of whole structs sends the state through scratch memory)
+                    q0.v[l] = start == 0u ? s[1].v[l] : s[2].v[l];
+                    q1.v[l] = start == 0u ? s[2].v[l] : s[1].v[l];
+                }
+                mul29(c0, q0, const29<kOne29>());
+                mul29(c1, q1, const29<kOne29>());
+                const fr e0 = pack29_reduced(c0), e1 = pack29_reduced(c1);
+                uint32_t* out = a.seeds + ((uint64_t)j * a.batch + b) * 8;
+#pragma unroll
+                for (int i = 0; i < 7; i++) out[i] = e0.v[i];
+                out[7] = (e0.v[7] & 0x00ffffffu) | (e1.v[0] << 24);
+                squeezing = 1; idx = start == 0u ? 2u : 1u;
+                j++; phase = 2u;
+            }
+        }
+        if (!__any(need_perm)) break;
+    }
+    if (live) {
+        // limbs may be dirty after a final absorb: store them normalised
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            norm29_strict(s[jj]);
+#pragma unroll
+            for (int i = 0; i < 9; i++) st[9 * jj + i] = s[jj].v[i];
+        }
+        st[27] = squeezing; st[28] = idx;
+    }
+}
+
+// ---- get_distinct_indices_from_prng(n, t, seed) (src/utils.rs:31-55): rand 0.8 gen_range(0..n) on u64 draws of ChaCha20 until
+// min(t, n - t) distinct values are in the set; the result is the set, or its complement when t > n / 2, ascending.  One lane
+// per proof; the set is a bitmap of n bits per proof in device memory.
+struct IndexArgs {
+    const uint32_t* seeds;   // [batch][8]
+    uint32_t* bitmap;        // [batch][n / 32 (at least 1)] scratch, zeroed by the kernel
+    uint32_t* idx_out;       // [batch][t] ascending
+    uint32_t batch, n, t;
+};
+__global__ void __launch_bounds__(64) distinct_indices_kernel(const IndexArgs a) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.batch) return;
+    const uint32_t words = a.n >= 32 ? a.n / 32 : 1;
+    uint32_t* bm = a.bitmap + (uint64_t)b * words;
+    for (uint32_t w = 0; w < words; w++) bm[w] = 0;
+    const uint32_t to_select = a.t < a.n - a.t ? a.t : a.n - a.t;
+    const uint64_t n64 = a.n;
+    const uint64_t zone = (n64 << __clzll(n64)) - 1;
+    uint32_t have = 0;
+    uint64_t counter = 0;
+    while (have < to_select) {
+        uint32_t x[16];
+        chacha20_block(a.seeds + 8 * (uint64_t)b, counter++, x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (have < to_select) {
+                const uint64_t v = (uint64_t)x[2 * i] | ((uint64_t)x[2 * i + 1] << 32);
+                const uint64_t lo = v * n64, hi = __umul64hi(v, n64);
+                if (lo <= zone) {   // otherwise the draw is rejected (UniformInt::sample_single)
+                    const uint32_t s = (uint32_t)hi, bit = 1u << (s & 31);
+                    const uint32_t w = bm[s >> 5];
+                    if (!(w & bit)) { bm[s >> 5] = w | bit; have++; }
+                }
+            }
+        }
+    }
+    uint32_t* out = a.idx_out + (uint64_t)b * a.t;
+    const bool complement = to_select != a.t;
+    uint32_t o = 0;
+    for (uint32_t w = 0; w < words && o < a.t; w++) {
+        uint32_t m = complement ? ~bm[w] : bm[w];
+        if (a.n < 32) m &= (1u << a.n) - 1u;
+        while (m && o < a.t) {
+            const uint32_t l = __builtin_ctz(m);
+            out[o++] = 32 * w + l;
+            m &= m - 1;
+        }
+    }
+}
+
+}  // namespace lg
