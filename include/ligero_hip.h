@@ -53,7 +53,7 @@ const char* lg_status_string(int status);
 const char* lg_last_error(const lg_ctx* ctx);
 /* ABI version of this header: bumped on any incompatible change. */
 uint32_t lg_abi_version(void);
-#define LG_ABI_VERSION 3u
+#define LG_ABI_VERSION 4u
 
 /*
  * Context for `batch` independent commitments of identical shape (batch = 1 for
@@ -221,6 +221,49 @@ int lg_verifier_linear_sums_from_seed(lg_ctx* ctx, const uint8_t* seed, const ui
                                       uint64_t* sums_out);
 
 /*
+ * ---- Throughput mode with the Fiat-Shamir transcript ON THE DEVICE ----
+ * prove_inner (src/ligero/mod.rs:457-578) for every proof of a batched context as ONE stream-ordered sequence: the commit
+ * from w (lg_encode_commit_from_witness' path), then absorb(u_root) / squeeze_bytes / get_field_elements_from_prng /
+ * get_distinct_indices_from_prng / absorb(polynomial) (mod.rs:560, 653-660, 719-738, 839-850, 941; src/utils.rs:23-55) on the
+ * device, one lane per proof, between the sub-proof kernels and the openings -- no host round trip inside a proof, so
+ * proofs/s follows the GPU (and PCIe), not the host's cores.  The host's part is w (the evaluation trace) before, nothing after.
+ *
+ *   lg_prover_setup        once per context, after lg_upload_constraint_matrix and lg_upload_gate_map: the sponge's
+ *                          parameters (PoseidonConfig: rate 2, capacity 1; alpha must be 17; elements as Montgomery words)
+ *                          and t, the number of columns every sub-proof opens.
+ *   lg_prover_layout       where the pieces of a batch of proofs land in the caller's buffer (byte offsets; arrays are
+ *                          proof-major: roots [batch][32], preenc_u_lc [batch][k], the polynomials [batch][2k] with their
+ *                          lengths AFTER DensePolynomial's trimming of trailing zeros in poly_lens [2][batch] (linear,
+ *                          quadratic); per sub-proof o = 0 interleaved, 1 linear, 2 quadratic: idx [batch][t] (ascending),
+ *                          columns [batch][t][rows] Montgomery words, siblings [batch][t][32], paths [batch][t][path_len][32]
+ *                          root side first).  The field layout of LigeroProof (src/ligero/types.rs:29-46) item for item.
+ *   lg_prove_batch_queue   queues the whole batch and returns; w = [batch][m k] elements (the W block of every proof, as for
+ *                          lg_encode_commit_from_witness) in host memory, proofs_out = total_bytes of host memory.  Page-lock
+ *                          both (lg_host_register) or the copies block the calling thread.  Neither buffer may be touched
+ *                          until lg_prove_batch_wait returns; one batch per context is in flight at a time (several contexts
+ *                          overlap: a proof's transcript is a latency chain of ~40 ms that other contexts' work hides).
+ *   lg_prove_batch_wait    blocks until the proofs are in proofs_out.
+ * The transcript restates the same unpinned crates as ligero_amd/host/transcript.hpp; the proofs equal the host-transcript
+ * provers' field for field.
+ */
+typedef struct lg_sponge_params {
+    uint32_t full_rounds, partial_rounds;
+    uint64_t alpha;
+    const uint64_t* ark;   /* [full_rounds + partial_rounds][3][4] */
+    const uint64_t* mds;   /* [3][3][4] */
+} lg_sponge_params;
+typedef struct lg_proof_layout {
+    uint64_t total_bytes;
+    uint64_t off_roots, off_lc, off_linear_poly, off_quadratic_poly, off_poly_lens, off_status;
+    uint64_t off_idx[3], off_columns[3], off_siblings[3], off_paths[3];
+    uint32_t batch, k, rows, t, path_len;
+} lg_proof_layout;
+int lg_prover_setup(lg_ctx* ctx, const lg_sponge_params* sponge, uint32_t t);
+int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
+int lg_prove_batch_queue(lg_ctx* ctx, const uint64_t* w, void* proofs_out);
+int lg_prove_batch_wait(lg_ctx* ctx, const void* proofs_out);
+
+/*
  * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU
  * (DESIGN.md section 7).  With these stage calls the exchanges between the stages are the caller's (RCCL all-gather on the
  * device buffers below); lg_commit_sharded / lg_commit_row_relay further down queue the same stages as ONE call and ask for the
@@ -282,11 +325,15 @@ int lg_stage_merkle(lg_ctx* ctx);
  * (8 after an even number of rows, 40 after an odd one), padded; plane-major, so the states of a run of planes are contiguous */
 typedef enum lg_buffer { LG_BUF_PREENC = 0, LG_BUF_COEFFS = 1, LG_BUF_LEAVES = 2, LG_BUF_NODES = 3, LG_BUF_HSTATE = 4 } lg_buffer;
 #define LG_HSTATE_BYTES 80u
-/* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers).  Asking for LG_BUF_PREENC of an
- * unsharded context hands the whole matrix to the caller: every row counts as present afterwards (fill it, then
- * lg_commit_resident).  LG_BUF_LEAVES / LG_BUF_NODES name the buffers of the CURRENT commitment: overlapped single-chunk
- * commits rotate through a ring of them, so the pointers are valid until the next commit on this context. */
+/* Raw device pointer and size of a resident buffer (for collectives / zero-copy producers).  The call changes no state.
+ * LG_BUF_LEAVES / LG_BUF_NODES name the buffers of the CURRENT commitment: overlapped single-chunk commits rotate through a
+ * ring of them, so the pointers are valid until the next commit on this context. */
 int lg_device_buffer(lg_ctx* ctx, int which, void** dptr_out, size_t* bytes_out);
+/* A zero-copy producer wrote EVERY row of LG_BUF_PREENC (ordered before whatever it calls next on this context): the rows
+ * count as present, lg_commit_resident / lg_interleaved_row_mul may read them.  A fresh context holds no row -- until this
+ * call, lg_upload_preenc or a commit from host buffers, lg_commit_resident returns LG_ERR_STATE instead of committing to
+ * uninitialised memory.  LG_ERR_STATE on a sharded context and while a staged commit is in progress. */
+int lg_preenc_mark_filled(lg_ctx* ctx);
 /* The HIP stream (hipStream_t) every call of this context is ordered on.  Work the caller enqueues on it -- a collective on
  * the buffers above -- is ordered with the library's own: no host synchronisation is needed around an exchange. */
 int lg_ctx_stream(lg_ctx* ctx, void** stream_out);

@@ -10,6 +10,7 @@
 
 #include <stdint.h>
 
+#include "ligero_hip.h"
 #include "ligero_host.h"
 
 #ifdef __cplusplus
@@ -80,6 +81,14 @@ void lgp_proof_destroy(lgp_proof* proof);
  * proofs_out receives `batch` handles, each identical to what lgp_prove gives for that assignment.
  */
 int lgp_batch_prover_create(lgp_batch_prover** out, const lgh_instance* inst, uint32_t batch, int device, uint32_t threads);
+/* flags = LGP_BATCH_DEVICE_TRANSCRIPT: the transcript runs on the device as well (include/ligero_hip.h lg_prove_batch_queue):
+ * the host only assembles w, so proofs/s no longer follows the host's cores; the proofs are the same.  lgp_prove_batch with
+ * proofs_out = NULL then leaves the batch in page-locked memory the prover owns -- lgp_batch_proof_arena gives its base and
+ * layout (lg_proof_layout), valid until the next lgp_prove_batch -- and lgp_batch_proof(index) copies one proof out of it into
+ * a handle on first use. */
+enum { LGP_BATCH_DEVICE_TRANSCRIPT = 1 };
+int lgp_batch_prover_create_ex(lgp_batch_prover** out, const lgh_instance* inst, uint32_t batch, int device, uint32_t threads, uint32_t flags);
+int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_proof_layout* layout_out);
 void lgp_batch_prover_destroy(lgp_batch_prover* p);
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p);
 int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out);

@@ -26,6 +26,7 @@ SYMBOLS = [
     "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
     "lg_shard_row_ranges", "lg_commit_sharded", "lg_relay_row_ranges", "lg_commit_row_relay", "lg_shard_profile_read",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
+    "lg_preenc_mark_filled", "lg_prover_setup", "lg_prover_layout", "lg_prove_batch_queue", "lg_prove_batch_wait",
 ]
 
 LG_OK = 0
@@ -138,6 +139,11 @@ def lib():
     L.lg_ctx_pipeline_chunks.argtypes = [_vp, _vp]
     L.lg_profile_enable.argtypes = [_vp, _int]
     L.lg_profile_read.argtypes = [_vp, _vp, _vp]
+    L.lg_preenc_mark_filled.argtypes = [_vp]
+    L.lg_prover_setup.argtypes = [_vp, _vp, _u32]
+    L.lg_prover_layout.argtypes = [_vp, _vp]
+    L.lg_prove_batch_queue.argtypes = [_vp, _vp, _vp]
+    L.lg_prove_batch_wait.argtypes = [_vp, _vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("lg_abi_version", "lg_ctx_element_words"):

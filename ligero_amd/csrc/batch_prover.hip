@@ -1,0 +1,291 @@
+// Throughput mode with the Fiat-Shamir transcript on the device.
+//
+// prove_inner (src/ligero/mod.rs:457-578) for every proof of a batch as ONE stream-ordered sequence -- no host round trip
+// between the commitment and the last opening:
+//
+//   commit from w                      mod.rs:483-551    witness.hip
+//   absorb(u_root)                     mod.rs:560        sponge_kernel (one lane per proof)
+//   squeeze -> r_interleaved           mod.rs:653-656    sponge_kernel, chacha_*_kernel (utils.rs:23-29 on the device)
+//   preenc_u.row_mul(r)                mod.rs:658        interleaved_on_device
+//   absorb(lc); squeeze -> indices     mod.rs:660, 941   sponge_kernel, distinct_indices_kernel (utils.rs:31-55)
+//   open_columns                       mod.rs:944-952    gather_columns_launch -> staging -> page-locked host memory
+//   squeeze -> r_linear, A.row_mul, p  mod.rs:719-736    linear_from_device_seeds
+//   absorb(p); squeeze; open           mod.rs:738, 941
+//   squeeze -> r_quadratic, p_0        mod.rs:839-848    quadratic_on_device
+//   absorb(p_0); squeeze; open         mod.rs:850, 941
+//
+// The host's part of a proof is then w itself (the evaluation trace) and nothing after it; the proofs land in the caller's
+// (page-locked) memory in the flat layout lg_prover_layout describes, where a host proof object can point at them.
+// Same transcript as ligero_amd/host/transcript.hpp (PARITY UNPINNED against the Rust crates, see there): the proofs equal
+// the host-transcript provers' field for field (tests/test_gpu_prover.py).
+#include "lg_context.h"
+#include "challenge_kernels.h"
+#include "sponge_kernels.h"
+
+struct lg_batch_prover_state {
+    uint32_t t = 0, plen = 0;
+    uint32_t full_rounds = 0, partial_rounds = 0;
+    uint32_t* d_ark = nullptr;      // [rounds][3][9]
+    uint32_t* d_mds = nullptr;      // [3][3][9]; null: the additions-only matrix of test_sponge()
+    uint32_t* d_state = nullptr;    // [batch][lg::kSpongeWords]
+    uint32_t* d_seeds = nullptr;    // [2][batch][8]: what one sponge launch squeezes
+    uint32_t* d_bitmap = nullptr;   // [batch][n / 32]
+    uint32_t* d_idx = nullptr;      // [3][batch][t]
+    uint32_t* d_lens = nullptr;     // [2][batch]: trimmed lengths of the linear / quadratic polynomial
+    fr* d_cols[3] = {nullptr, nullptr, nullptr};        // [batch][t][rows] opened columns of the three sub-proofs
+    uint8_t* d_paths[3] = {nullptr, nullptr, nullptr};  // [batch][t][32] sibling digests, then [batch][t][plen][32] paths
+    hipEvent_t ev_gathered[3] = {nullptr, nullptr, nullptr};   // on the encode stream: staging o is complete
+    hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr};     // on the copy stream: staging o has left for the host
+    hipEvent_t ev_done = nullptr;                              // everything of the batch is in host memory
+    bool copied_valid = false, queued = false;
+    lg_proof_layout layout;
+};
+
+static void bp_free(lg_ctx* c) {
+    lg_batch_prover_state* b = c->bp;
+    if (!b) return;
+    for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_idx, (void*)b->d_lens})
+        if (p) (void)hipFree(p);
+    for (int o = 0; o < 3; o++) {
+        if (b->d_cols[o]) (void)hipFree(b->d_cols[o]);
+        if (b->d_paths[o]) (void)hipFree(b->d_paths[o]);
+        if (b->ev_gathered[o]) (void)hipEventDestroy(b->ev_gathered[o]);
+        if (b->ev_copied[o]) (void)hipEventDestroy(b->ev_copied[o]);
+    }
+    if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+    delete b;
+    c->bp = nullptr;
+}
+// (context.hip calls this from lg_ctx_destroy, after the streams have drained)
+void batch_prover_release(lg_ctx* c) { bp_free(c); }
+
+static uint64_t align64(uint64_t x) { return (x + 63) & ~uint64_t{63}; }
+
+static int chacha_elements(lg_ctx* c, const uint32_t* d_seeds, fr* d_out, uint32_t n) {
+    // 75.6 % of the 32-byte chunks are accepted; 1.5 chunks per element + 64 blocks leaves > 50 standard deviations of margin
+    const uint32_t blocks = (uint32_t)(((uint64_t)n * 3 + 3) / 4 + 64), wgs = (blocks + 255) / 256;
+    if (c->chal.counts_cap < (size_t)c->batch * wgs) {
+        if (c->chal.d_counts) LG_HIP(c, hipFree(c->chal.d_counts));
+        c->chal.d_counts = nullptr; c->chal.counts_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_counts), (size_t)c->batch * wgs * 4));
+        c->chal.counts_cap = (size_t)c->batch * wgs;
+    }
+    lg::ChaChaArgs a;
+    a.seeds = d_seeds; a.out = d_out; a.counts = c->chal.d_counts; a.short_flag = c->chal.d_short_flag;
+    a.n = n; a.blocks = blocks; a.wgs = wgs;
+    LG_LAUNCH(c, lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
+    LG_LAUNCH(c, lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
+    return LG_OK;
+}
+
+static int sponge_launch(lg_ctx* c, const lg::SpongeArgs& a) {
+    const dim3 grid((c->batch + 63) / 64);
+    if (c->bp->d_mds)
+        LG_LAUNCH(c, lg::sponge_kernel<false>, grid, dim3(64), 0, c->st.main, a);
+    else
+        LG_LAUNCH(c, lg::sponge_kernel<true>, grid, dim3(64), 0, c->st.main, a);
+    return LG_OK;
+}
+
+extern "C" {
+
+int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
+    if (!c || !sp || !sp->ark || !sp->mds) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->shard.on || (c->rows & 3)) return LG_ERR_STATE;
+    if (sp->alpha != 17 || sp->full_rounds == 0 || (sp->full_rounds & 1) || sp->full_rounds + sp->partial_rounds > lg::kSpongeMaxRounds) {
+        snprintf(c->err, sizeof(c->err), "lg_prover_setup: the device sponge takes alpha = 17, an even number of full rounds and at most %u rounds", lg::kSpongeMaxRounds);
+        return LG_ERR_UNSUPPORTED;
+    }
+    if (t == 0 || t > c->n) return LG_ERR_BAD_ARG;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    bp_free(c);
+    lg_batch_prover_state* b = new (std::nothrow) lg_batch_prover_state();
+    if (!b) return LG_ERR_OOM;
+    c->bp = b;
+    auto body = [&]() -> int {
+        b->t = t; b->plen = (uint32_t)c->logn - 1;
+        b->full_rounds = sp->full_rounds; b->partial_rounds = sp->partial_rounds;
+        const uint32_t rounds = sp->full_rounds + sp->partial_rounds;
+        auto fr_at = [](const uint64_t* base, size_t i) { lg_host::Fr x; memcpy(x.l, base + 4 * i, 32); return x; };
+        std::vector<uint32_t> ark(27 * (size_t)rounds);
+        for (size_t i = 0; i < (size_t)rounds * 3; i++) {
+            const lg::f29 v = to_f29(fr_at(sp->ark, i));
+            memcpy(&ark[9 * i], v.v, 36);
+        }
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_ark), ark.size() * 4));
+        LG_HIP(c, hipMemcpy(b->d_ark, ark.data(), ark.size() * 4, hipMemcpyHostToDevice));
+        // the matrix of test_sponge() is additions only: [[1,0,1],[1,1,0],[0,1,1]]
+        static const int test_mds[9] = {1, 0, 1, 1, 1, 0, 0, 1, 1};
+        bool is_test = true;
+        for (int i = 0; i < 9; i++) {
+            const lg_host::Fr x = fr_at(sp->mds, i), want = test_mds[i] ? lg_host::kOneMont : lg_host::Fr{{0, 0, 0, 0}};
+            is_test = is_test && memcmp(x.l, want.l, 32) == 0;
+        }
+        if (!is_test) {
+            std::vector<uint32_t> mds(81);
+            for (int i = 0; i < 9; i++) {
+                const lg::f29 v = to_f29(fr_at(sp->mds, i));
+                memcpy(&mds[9 * i], v.v, 36);
+            }
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_mds), mds.size() * 4));
+            LG_HIP(c, hipMemcpy(b->d_mds, mds.data(), mds.size() * 4, hipMemcpyHostToDevice));
+        }
+        const size_t B = c->batch;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_state), B * lg::kSpongeWords * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_seeds), 2 * B * 32));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_bitmap), B * (c->n >= 32 ? c->n / 32 : 1) * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_idx), 3 * B * t * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_lens), 2 * B * 4));
+        for (int o = 0; o < 3; o++) {
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_cols[o]), B * t * c->rows * sizeof(fr)));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_paths[o]), B * t * (b->plen + 1) * 32));
+            LG_HIP(c, hipEventCreateWithFlags(&b->ev_gathered[o], hipEventDisableTiming));
+            LG_HIP(c, hipEventCreateWithFlags(&b->ev_copied[o], hipEventDisableTiming));
+        }
+        LG_HIP(c, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
+        // everything the sub-proof calls would otherwise grow on first use (a buffer that grows under a challenge already written
+        // into it would lose it): row-sum partials, the challenge vector, the seeds and the candidate counters
+        {
+            const uint32_t per = std::max<uint32_t>(32, c->rows / 256), nch = (c->rows + per - 1) / per;
+            const int rc_ = sub_buffers(c, B * nch * 2 * c->k, c->total_rows);
+            if (rc_ != LG_OK) return rc_;
+        }
+        if (!c->chal.d_seeds) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_seeds), B * 32));
+        if (!c->chal.d_short_flag) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_short_flag), 4));
+        { const int rc_ = sub_aux2k(c); if (rc_ != LG_OK) return rc_; }
+        // the flat layout of a batch of proofs in host memory
+        lg_proof_layout& L = b->layout;
+        memset(&L, 0, sizeof(L));
+        L.batch = c->batch; L.k = c->k; L.rows = c->rows; L.t = t; L.path_len = b->plen;
+        uint64_t off = 0;
+        auto take = [&](uint64_t bytes) { const uint64_t at = off; off = align64(off + bytes); return at; };
+        L.off_roots = take(B * 32);
+        L.off_lc = take(B * c->k * 32);
+        L.off_linear_poly = take(B * 2 * c->k * 32);
+        L.off_quadratic_poly = take(B * 2 * c->k * 32);
+        L.off_poly_lens = take(2 * B * 4);
+        L.off_status = take(64);
+        for (int o = 0; o < 3; o++) {
+            L.off_idx[o] = take(B * t * 4);
+            L.off_columns[o] = take(B * t * (uint64_t)c->rows * 32);
+            L.off_siblings[o] = take(B * t * 32);
+            L.off_paths[o] = take(B * t * (uint64_t)b->plen * 32);
+        }
+        L.total_bytes = off;
+        return LG_OK;
+    };
+    const int rc = body();
+    if (rc != LG_OK) bp_free(c);
+    return rc;
+}
+
+int lg_prover_layout(const lg_ctx* c, lg_proof_layout* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (!c->bp) return LG_ERR_STATE;
+    *out = c->bp->layout;
+    return LG_OK;
+}
+
+int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
+    if (!c || !w || !proofs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    lg_batch_prover_state* b = c->bp;
+    if (!b || !c->amat.loaded || !c->gate.loaded) {
+        snprintf(c->err, sizeof(c->err), "lg_prove_batch_queue needs lg_prover_setup, the constraint matrix and the gate map");
+        return LG_ERR_STATE;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    const lg_proof_layout& L = b->layout;
+    uint8_t* out = static_cast<uint8_t*>(proofs_out);
+    const uint32_t B = c->batch, m = c->rows / 4, t = b->t;
+    hipStream_t s = c->st.main;
+    b->queued = true;
+    int rc = LG_OK;
+    // 0. the candidate-stream flag of the three challenge draws of this batch
+    LG_HIP(c, hipMemsetAsync(c->chal.d_short_flag, 0, 4, s));
+    // 1. the commitment (mod.rs:483-551)
+    rc = commit_from_witness(c, w, nullptr);
+    if (rc != LG_OK) { if (rc != LG_ERR_STATE) c->held.drop(); return rc; }
+    LG_HIP(c, hipMemcpy2DAsync(out + L.off_roots, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, B, hipMemcpyDeviceToHost, s));
+    lg::SpongeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.state = b->d_state; sa.P = lg::PoseidonParams{b->d_ark, b->d_mds, b->full_rounds, b->partial_rounds};
+    sa.seeds = b->d_seeds; sa.batch = B;
+    const uint32_t* seed0 = b->d_seeds;
+    const uint32_t* seed1 = b->d_seeds + (size_t)B * 8;
+    // 2. absorb(u_root); squeeze the interleaved test's seed (mod.rs:560, 653)
+    sa.kind = lg::kAbsorbDigest; sa.digests = c->d_nodes; sa.digest_stride = (uint64_t)(c->n - 1) * 32; sa.nsqueeze = 1; sa.reset = 1;
+    if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
+    // 3. r_interleaved (4m elements per proof), preenc_u.row_mul(r) (mod.rs:654-658)
+    if ((rc = chacha_elements(c, seed0, c->sub.d_r, c->rows)) != LG_OK) return rc;
+    if ((rc = interleaved_on_device(c)) != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(out + L.off_lc, c->sub.d_q, (size_t)B * c->k * sizeof(fr), hipMemcpyDeviceToHost, s));
+    // the three openings share one routine: indices from a seed, the gather into staging, the copies home on the copy stream
+    auto open = [&](int o, const uint32_t* d_seed) -> int {
+        uint32_t* d_idx = b->d_idx + (size_t)o * B * t;
+        lg::IndexArgs ia{d_seed, b->d_bitmap, d_idx, B, c->n, t};
+        LG_LAUNCH(c, lg::distinct_indices_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ia);
+        if (b->copied_valid) LG_HIP(c, hipStreamWaitEvent(s, b->ev_copied[o], 0));   // the previous batch's copy out of this staging
+        uint8_t* d_sib = b->d_paths[o];
+        uint8_t* d_paths = b->d_paths[o] + (size_t)B * t * 32;
+        { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+        { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, b->d_cols[o], d_sib, d_paths); if (rc_ != LG_OK) return rc_; }
+        LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
+        LG_HIP(c, hipStreamWaitEvent(c->st.dn, b->ev_gathered[o], 0));
+        LG_HIP(c, hipMemcpyAsync(out + L.off_columns[o], b->d_cols[o], (size_t)B * t * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->st.dn));
+        LG_HIP(c, hipMemcpyAsync(out + L.off_siblings[o], d_sib, (size_t)B * t * 32, hipMemcpyDeviceToHost, c->st.dn));
+        if (b->plen) LG_HIP(c, hipMemcpyAsync(out + L.off_paths[o], d_paths, (size_t)B * t * b->plen * 32, hipMemcpyDeviceToHost, c->st.dn));
+        LG_HIP(c, hipMemcpyAsync(out + L.off_idx[o], d_idx, (size_t)B * t * 4, hipMemcpyDeviceToHost, c->st.dn));
+        LG_HIP(c, hipEventRecord(b->ev_copied[o], c->st.dn));
+        return LG_OK;
+    };
+    // 4. absorb(preenc_u_lc); squeeze the opening's seed, then the linear test's (mod.rs:660, 941, 719)
+    sa.kind = lg::kAbsorbElems; sa.src = c->sub.d_q; sa.src_proof = c->k; sa.count = c->k; sa.trim = 0; sa.lens_out = nullptr; sa.nsqueeze = 2; sa.reset = 0;
+    if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
+    if ((rc = open(0, seed0)) != LG_OK) return rc;
+    // 5. r_linear, r_a = A.row_mul(r_linear), the polynomial (mod.rs:720-736)
+    LG_HIP(c, hipMemcpyAsync(c->chal.d_seeds, seed1, (size_t)B * 32, hipMemcpyDeviceToDevice, s));
+    if ((rc = linear_from_device_seeds(c)) != LG_OK) return rc;
+    const fr* d_poly = c->sub.aux2k->d_coeffs;
+    LG_HIP(c, hipMemcpyAsync(out + L.off_linear_poly, d_poly, (size_t)B * 2 * c->k * sizeof(fr), hipMemcpyDeviceToHost, s));
+    // 6. absorb(polynomial); squeeze the opening's seed, then the quadratic test's (mod.rs:738, 941, 839)
+    sa.src = d_poly; sa.src_proof = 2 * (uint64_t)c->k; sa.count = 2 * c->k; sa.trim = 1; sa.lens_out = b->d_lens; sa.nsqueeze = 2;
+    if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
+    if ((rc = open(1, seed0)) != LG_OK) return rc;
+    // 7. r_quadratic (m elements per proof), p_0 (mod.rs:840-848)
+    if ((rc = chacha_elements(c, seed1, c->sub.d_r, m)) != LG_OK) return rc;
+    if ((rc = quadratic_on_device(c)) != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(out + L.off_quadratic_poly, d_poly, (size_t)B * 2 * c->k * sizeof(fr), hipMemcpyDeviceToHost, s));
+    // 8. absorb(p_0); squeeze the last opening's seed (mod.rs:850, 941)
+    sa.lens_out = b->d_lens + B; sa.nsqueeze = 1;
+    if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
+    if ((rc = open(2, seed0)) != LG_OK) return rc;
+    b->copied_valid = true;
+    LG_HIP(c, hipMemcpyAsync(out + L.off_poly_lens, b->d_lens, (size_t)2 * B * 4, hipMemcpyDeviceToHost, s));
+    LG_HIP(c, hipMemcpyAsync(out + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToHost, s));
+    // "done" = the encode stream's own copies and the copy stream's
+    LG_HIP(c, hipEventRecord(c->evt.done, s));
+    LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->evt.done, 0));
+    LG_HIP(c, hipEventRecord(b->ev_done, c->st.dn));
+    return LG_OK;
+}
+
+int lg_prove_batch_wait(lg_ctx* c, const void* proofs_out) {
+    if (!c || !proofs_out) return LG_ERR_BAD_ARG;
+    lg_batch_prover_state* b = c->bp;
+    if (!b || !b->queued) return LG_ERR_STATE;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipEventSynchronize(b->ev_done));
+    uint32_t flag = 0;
+    memcpy(&flag, static_cast<const uint8_t*>(proofs_out) + b->layout.off_status, 4);
+    if (flag) {
+        snprintf(c->err, sizeof(c->err), "ChaCha candidate stream too short for a challenge vector of this batch");
+        return LG_ERR_STATE;
+    }
+    return LG_OK;
+}
+
+}  // extern "C"

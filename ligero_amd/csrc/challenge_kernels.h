@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t wg_accept_prefix(bool a0, bool a1, uint32_t&
     return total;
 }
 
-__global__ void __launch_bounds__(256) chacha_count_kernel(ChaChaArgs a) {
+static __global__ void __launch_bounds__(256) chacha_count_kernel(ChaChaArgs a) {
     const uint32_t proof = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
     uint32_t x[16];
     fr e;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) chacha_count_kernel(ChaChaArgs a) {
     if (threadIdx.x == 0) a.counts[(uint64_t)proof * a.wgs + blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(256) chacha_scatter_kernel(ChaChaArgs a) {
+static __global__ void __launch_bounds__(256) chacha_scatter_kernel(ChaChaArgs a) {
     __shared__ uint32_t part[256];
     const uint32_t proof = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
     // accepted chunks in the workgroups before this one
@@ -152,7 +152,7 @@ __device__ __forceinline__ void sparse_accumulate(const SparseRowMulArgs& a, con
     fr_mul_lazy(t, fr_load(r + row), fr_load(a.ent_val + e));
     fr_add_lazy(acc, acc, t);
 }
-__global__ void __launch_bounds__(256) sparse_row_mul_kernel(SparseRowMulArgs a) {
+static __global__ void __launch_bounds__(256) sparse_row_mul_kernel(SparseRowMulArgs a) {
     const uint32_t col = blockIdx.x * 256 + threadIdx.x, proof = blockIdx.y;
     if (col >= a.cols) return;
     const uint32_t e0 = a.col_ptr[col], e1 = a.col_ptr[col + 1];
@@ -192,7 +192,7 @@ __device__ __forceinline__ fr block_sum(fr acc, fr* part) {
     }
     return part[0];
 }
-__global__ void __launch_bounds__(256) sparse_row_mul_heavy_segments_kernel(HeavySegArgs a) {
+static __global__ void __launch_bounds__(256) sparse_row_mul_heavy_segments_kernel(HeavySegArgs a) {
     __shared__ fr part[256];
     const uint32_t seg = blockIdx.x, proof = blockIdx.y;
     const fr* r = a.m.r + (uint64_t)proof * a.m.rows_in;
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) sparse_row_mul_heavy_segments_kernel(Heav
     const fr total = block_sum(acc, part);
     if (threadIdx.x == 0) fr_store(a.seg_partial + (uint64_t)proof * a.nseg + seg, total);
 }
-__global__ void __launch_bounds__(256) sparse_row_mul_heavy_finish_kernel(HeavySegArgs a) {
+static __global__ void __launch_bounds__(256) sparse_row_mul_heavy_finish_kernel(HeavySegArgs a) {
     __shared__ fr part[256];
     const uint32_t h = blockIdx.x, proof = blockIdx.y;
     const fr* partial = a.seg_partial + (uint64_t)proof * a.nseg;

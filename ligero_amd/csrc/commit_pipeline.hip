@@ -1,0 +1,339 @@
+// The commit (src/ligero/mod.rs:521-551) on the device: interpolate -> evaluate -> column hashes -> Merkle tree, resident
+// (lg_commit_resident) or streamed from host buffers (lg_encode_commit), pipelined over row chunks on two streams.
+#include "lg_context.h"
+
+// the four-lanes-per-column kernel's view of a column-hash launch (same rows, same parked state)
+static lg::ColHashQuadArgs quad_args_of(const lg::ColHashArgs& h) {
+    lg::ColHashQuadArgs qa;
+    memset(&qa, 0, sizeof(qa));
+    qa.u = h.u; qa.leaves = h.leaves; qa.rows = h.rows; qa.k = h.k; qa.lognp = h.lognp;
+    qa.proof_begin = h.proof_begin; qa.proof_count = h.proof_count; qa.plane_begin = h.plane_begin; qa.plane_count = h.plane_count;
+    qa.plane_stride = h.plane_stride;
+    qa.state = h.state; qa.row_begin = h.row_begin; qa.row_end = h.row_end; qa.first = h.first; qa.last = h.last;
+    qa.col_pos = h.col_pos; qa.col_rows = h.col_rows;
+    return qa;
+}
+// ... which needs an even position in the column and, unless it finalises, an even number of rows (whole 64-byte blocks)
+static bool quad_can_take(const lg::ColHashArgs& h) {
+    const uint32_t nrows = h.row_end - h.row_begin;
+    return (h.col_pos & 1) == 0 && nrows > 0 && (h.last || (nrows & 1) == 0);
+}
+
+int colhash_launch(lg_ctx* c, hipStream_t hs, const lg::ColHashArgs& h, bool allow_quad) {
+    const uint64_t threads = (uint64_t)h.proof_count * h.plane_count * h.k;
+    if (allow_quad && threads <= c->quad_hash_max_columns && quad_can_take(h)) {
+        // few columns (a single small proof, a rank's planes of a sharded one): the one-lane-per-column kernel would be one latency
+        // chain per SIMD; four lanes per column shorten the chain (hash_kernels.h)
+        const lg::ColHashQuadArgs qa = quad_args_of(h);
+        LG_LAUNCH(c, lg::blake2s_columns_quad_kernel, dim3((uint32_t)((threads + 63) / 64)), dim3(256), 0, hs, qa);
+    } else {
+        LG_LAUNCH(c, lg::blake2s_columns_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, hs, h);
+    }
+    return LG_OK;
+}
+
+// The commit is pipelined over row chunks on two streams: while the encode stream evaluates
+// chunk c+1, the hash stream absorbs chunk c into the per-column Blake2s states.  The column
+// hash is latency bound (one sequential chain per column, only n columns), so it fills issue
+// slots the NTT kernel leaves idle instead of extending the critical path.
+int plan_chunks(const lg_ctx* c, Chunk* out, bool from_host) {
+    int n = 0;
+    // a chunk must be big enough (>= 2^25 codeword elements, a few ms of encoding) for the extra
+    // launches and cross-stream waits to pay; small commits run as one chunk
+    const uint64_t elems = c->total_rows * c->n;
+    uint32_t want = c->force_chunks ? c->force_chunks : (uint32_t)(elems >> 25);
+    if (from_host && !c->force_chunks) {
+        // streamed input: the PCIe copy of chunk c+1 hides behind the encoding of chunk c, which pays
+        // from ~16 MiB of input per chunk; at least 4 chunks so that the exposed first copy is short
+        const uint64_t bytes = c->total_rows * c->k * sizeof(fr);
+        const uint32_t up = bytes >= (64ull << 20) ? 8 : (bytes >= (16ull << 20) ? 4 : 1);
+        if (up > want) want = up;
+    }
+    if (want > (uint32_t)lg_ctx::kMaxChunks) want = lg_ctx::kMaxChunks;
+    if (want <= 1) {
+        out[0] = Chunk{0, c->batch, 0, c->rows};
+        return 1;
+    }
+    // Row ranges, each covering the same rows of EVERY proof of the batch: the hash kernel keeps all
+    // batch * n column chains busy in every chunk and only their length shrinks.  (Splitting a batch
+    // by proofs instead halves the number of chains per launch but not their length, which is what a
+    // latency-bound kernel's duration follows: measured 1.35 ms vs 1.19 ms unsplit on the Poseidon
+    // batch.)  Boundaries on even rows: a Blake2s block holds two rows.
+    uint32_t parts = want;
+    const uint32_t pairs = c->rows / 2;
+    if (parts > pairs) parts = pairs;
+    if (parts <= 1) {
+        out[0] = Chunk{0, c->batch, 0, c->rows};
+        return 1;
+    }
+    // The hash of the LAST chunk has nothing left to hide behind, so the chunks taper: weights 4, 4, ..., 4, 3, 1
+    // (the exposed tail is 1/(4 parts - 4) of the hash instead of 1/parts).  LG_CHUNK_TAPER=0: equal chunks.
+    static const bool taper = [] { const char* e = getenv("LG_CHUNK_TAPER"); return !e || atoi(e) != 0; }();
+    std::vector<uint32_t> w(parts, 4);
+    if (taper && parts >= 4 && pairs >= 8 * parts) { w[parts - 2] = 3; w[parts - 1] = 1; }   // (3,2,1 / 2,1 tails measured the same)
+    uint64_t total = 0, acc = 0;
+    for (uint32_t x : w) total += x;
+    uint32_t r0 = 0;
+    for (uint32_t i = 0; i < parts; i++) {
+        acc += w[i];
+        uint32_t r1 = (i + 1 == parts) ? c->rows : 2 * (uint32_t)((uint64_t)pairs * acc / total);
+        if (r1 <= r0) r1 = r0 + 2;
+        out[n++] = Chunk{0, c->batch, r0, r1};
+        r0 = r1;
+    }
+    return n;
+}
+// Single-chunk commits build their Merkle tree on the second stream and do NOT make the encode stream wait for
+// it: the tree is latency bound (a few workgroups, ten dependent SHA-256 levels, 0.075 ms on the Poseidon batch)
+// and the next commit's interpolation and evaluation do not touch the leaves, so in a stream of commits the tree
+// hides behind them.  Everything that reads or rewrites leaves / nodes calls settle_tree() first.
+int settle_tree(lg_ctx* c) {
+    if (c->held.tree_pending) {
+        LG_HIP(c, hipStreamWaitEvent(c->st.main, c->evt.tree, 0));
+        c->held.tree_pending = false;
+    }
+    return LG_OK;
+}
+
+// the same for staged column hashes queued on the hash stream (lg_stage_hash_rows)
+int settle_hash(lg_ctx* c) {
+    if (c->held.hash_pending) {
+        LG_HIP(c, hipStreamWaitEvent(c->st.main, c->evt.stage_hash, 0));
+        c->held.hash_pending = false;
+    }
+    return LG_OK;
+}
+// The commit (mod.rs:521-551).  host_pre == nullptr: the matrix is resident in d_preenc.  Otherwise the
+// rows are streamed from host memory chunk by chunk (same row range of every proof: one strided copy),
+// so that the PCIe transfer of chunk c+1 overlaps the encoding of chunk c; host_coeffs (optional)
+// receives the coefficient rows the same way in the other direction.
+static int commit_core(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeffs) {
+    if (c->shard.on) {
+        snprintf(c->err, sizeof(c->err), "a sharded context holds planes [%u, %u) only: use the lg_stage_* calls", c->shard.plane0, c->shard.plane0 + c->shard.planes);
+        return LG_ERR_STATE;
+    }
+    if (!host_pre) {
+        const int rc_ = need_all_message_rows(c, "lg_commit_resident");
+        if (rc_ != LG_OK) return rc_;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    const uint64_t plane = c->total_rows * c->ki;
+    const bool streamed = host_pre != nullptr;
+    const bool prof = c->prof.on && c->prof.ev_valid && !streamed;
+    hipEvent_t* ev = c->prof.ev[c->prof.commits % lg_ctx::kProfRing];
+    Chunk chunks[lg_ctx::kMaxChunks];
+    const int nchunks = plan_chunks(c, chunks, streamed);
+    // one chunk: the hash of THIS commit has nothing of its own to hide behind; it is put beside the NEXT commit's encoding
+    // (async_hash) -- or, with that off, everything stays on the encode stream (no cross-stream waits)
+    const bool async_hash = c->ring.async_hash && c->ring.async_tree && nchunks == 1;
+    // (three deep: consecutive overlapped commits alternate between the two hash streams, so two column-hash chains run at once)
+    hipStream_t hs = (nchunks > 1 || async_hash) ? ((async_hash && c->ring.depth == 3 && ((c->ring.seq + 1) & 1)) ? c->st.hash2 : c->st.hash) : c->st.main;
+    if (async_hash) {
+        // this commit encodes into the other U buffer; the hash that last read it (two commits ago) must be done.  The slot's three
+        // buffers are allocated on first use, each checked on its own, and the context only moves to the slot once all three exist:
+        // a failed allocation leaves the previous commitment and the ring position as they were
+        const int par = (c->ring.slot + 1) % c->ring.depth;
+        if (!c->ring.u[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->ring.u[par]), (size_t)c->nplanes * plane * sizeof(fr)));
+        if (!c->ring.leaves[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->ring.leaves[par]), (size_t)c->batch * c->n * 32));
+        if (!c->ring.nodes[par]) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->ring.nodes[par]), (size_t)c->batch * (c->n - 1) * 32));
+        c->ring.slot = par;
+        c->ring.seq++;
+        c->d_u = c->ring.u[par];
+        LG_HIP(c, hipStreamWaitEvent(c->st.main, c->ring.ev_hash_free[par], 0));   // (never recorded = no-op)
+        // ... and hashes into the other leaf buffer / builds the other tree (readers use c->d_leaves / c->d_nodes: this commitment's)
+        // what an earlier commitment left queued against the buffers about to become "current" is covered below: the hash waits
+        // for the tree that last read leaves[par]; read-backs of the previous commitment were issued on the encode stream
+        c->d_leaves = c->ring.leaves[par];
+        c->d_nodes = c->ring.nodes[par];
+    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[0], c->st.main));
+    if (streamed) {
+        // copies go on their own stream and the encode stream picks the chunks up by event.  Copy c+1 is
+        // issued after the kernels of chunk c: a copy from pageable memory blocks the calling thread, and
+        // this order lets the device work through chunk c meanwhile
+        LG_HIP(c, hipEventRecord(c->evt.done, c->st.main));            // earlier work on the encode stream may still read d_preenc
+        LG_HIP(c, hipStreamWaitEvent(c->st.up, c->evt.done, 0));
+    } else {
+        // rows -> coefficients (mod.rs:521-526) in one launch; also emits the canonical message = coset plane 0
+        // (with an outer fold the canonical message planes 8c are written by the same kernel: every input is loaded by
+        // the O workgroups of its row anyway, and a separate pass over the matrix cost 3.5 ms of S22's 94)
+        lg::NttArgs a = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, 0, (uint32_t)c->total_rows);
+        a.plane_stride = plane;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->st.main, a));
+    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[1], c->st.main));
+    auto upload_chunk = [&](int i) -> int {
+        const Chunk& ch = chunks[i];
+        const size_t pitch = (size_t)c->rows * c->k * sizeof(fr);    // one proof
+        const size_t off = (size_t)ch.row_begin * c->k * sizeof(fr), width = (size_t)(ch.row_end - ch.row_begin) * c->k * sizeof(fr);
+        LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + off, pitch, reinterpret_cast<const uint8_t*>(host_pre) + off, pitch,
+                                   width, c->batch, hipMemcpyHostToDevice, c->st.up));
+        LG_HIP(c, hipEventRecord(c->evt.up[i], c->st.up));
+        return LG_OK;
+    };
+    if (streamed) {
+        const int rc = upload_chunk(0);
+        if (rc != LG_OK) return rc;
+    }
+    for (int i = 0; i < nchunks; i++) {
+        const Chunk& ch = chunks[i];
+        // coefficients -> cosets 1..7 of the order-n domain (mod.rs:528-533)
+        const uint32_t row0 = ch.proof_begin * c->rows + ch.row_begin;
+        const uint32_t nrows = ch.proof_count * (ch.row_end - ch.row_begin);
+        if (streamed) {
+            LG_HIP(c, hipStreamWaitEvent(c->st.main, c->evt.up[i], 0));
+            lg::NttArgs ia = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, row0, nrows);
+            ia.chunk_rows = ch.row_end - ch.row_begin;
+            ia.proof_stride = c->rows;
+            ia.plane_stride = plane;
+            LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->st.main, ia));
+            if (host_coeffs) LG_HIP(c, hipEventRecord(c->evt.coef[i], c->st.main));
+        }
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, row0, nrows, false);
+        a.chunk_rows = ch.row_end - ch.row_begin;  // rows [row_begin, row_end) of each proof
+        a.proof_stride = c->rows;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->st.main, a));
+        if (prof && i + 1 == nchunks) LG_HIP(c, hipEventRecord(ev[2], c->st.main));
+        // column hashes (mod.rs:536-542) of the rows just encoded, on the hash stream
+        if (nchunks > 1) {
+            LG_HIP(c, hipEventRecord(c->evt.chunk[i], c->st.main));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->evt.chunk[i], 0));
+        }
+        if (async_hash) {
+            // the hash waits for this encoding, and for the tree (two commits ago, on the tree stream) that read the leaf buffer it is
+            // about to rewrite; the previous commit's tree reads the OTHER buffer and runs beside this hash
+            LG_HIP(c, hipEventRecord(c->evt.hashed, c->st.main));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->evt.hashed, 0));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->ring.ev_leaves_free[c->ring.slot], 0));   // (never recorded = no-op)
+            // (a tree that an earlier, differently scheduled commit left reading either buffer ran on stream_h -- stream order -- or on
+            // the encode stream, before the event just waited for)
+        } else if (i == 0) {   // the previous commit's tree may still be reading the leaves this hash is about to rewrite
+            const int rc = settle_tree(c);
+            if (rc != LG_OK) return rc;
+            if (nchunks > 1) LG_HIP(c, hipStreamWaitEvent(hs, c->evt.tree, 0));   // (ev_tree: completed or never recorded = no-op)
+        }
+        if (prof && i == 0) LG_HIP(c, hipEventRecord(ev[3], hs));
+        lg::ColHashArgs h;
+        memset(&h, 0, sizeof(h));
+        h.u = reinterpret_cast<const uint4*>(c->d_u);
+        h.leaves = c->d_leaves;
+        h.state = c->d_hstate;
+        h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
+        h.proof_begin = ch.proof_begin; h.proof_count = ch.proof_count;
+        h.row_begin = ch.row_begin; h.row_end = ch.row_end;
+        h.first = ch.row_begin == 0;
+        h.last = ch.row_end == c->rows;
+        h.plane_begin = 0; h.plane_count = c->nplanes;
+        h.plane_stride = plane;
+        h.col_pos = h.row_begin; h.col_rows = c->rows;
+        // (only a whole-column launch of few columns takes the four-lanes-per-column kernel here)
+        { const int rc_ = colhash_launch(c, hs, h, h.first && h.last); if (rc_ != LG_OK) return rc_; }
+        if (streamed && i + 1 < nchunks) {
+            const int rc = upload_chunk(i + 1);
+            if (rc != LG_OK) return rc;
+        }
+        if (streamed && host_coeffs) {
+            // coefficient rows of this chunk go home while its cosets are being evaluated (issued after
+            // the kernels for the same reason as the uploads: a copy to pageable memory blocks this thread)
+            LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->evt.coef[i], 0));
+            const size_t pitch = (size_t)c->rows * c->k * sizeof(fr);
+            const size_t off = (size_t)ch.row_begin * c->k * sizeof(fr), width = (size_t)(ch.row_end - ch.row_begin) * c->k * sizeof(fr);
+            LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(host_coeffs) + off, pitch, reinterpret_cast<const uint8_t*>(c->d_coeffs) + off, pitch,
+                                       width, c->batch, hipMemcpyDeviceToHost, c->st.dn));
+        }
+    }
+    if (prof) LG_HIP(c, hipEventRecord(ev[4], hs));
+    if (async_hash) LG_HIP(c, hipEventRecord(c->ring.ev_hash_free[c->ring.slot], hs));
+    const bool async_tree = c->ring.async_tree && nchunks == 1;
+    // with the hash overlap on, the tree goes to its own stream (it follows this hash by event; the next commit's hash, on
+    // stream_h, does not queue behind it)
+    hipStream_t ms = async_hash ? c->st.tree : (async_tree ? c->st.hash : hs);
+    if (async_hash) {
+        LG_HIP(c, hipStreamWaitEvent(ms, c->ring.ev_hash_free[c->ring.slot], 0));   // recorded just above: this commit's hash is done
+    } else if (async_tree) {
+        LG_HIP(c, hipEventRecord(c->evt.hashed, c->st.main));
+        LG_HIP(c, hipStreamWaitEvent(c->st.hash, c->evt.hashed, 0));
+    }
+    // Merkle tree (mod.rs:544-551): nine levels per launch
+    {
+        lg::MerkleArgs m;
+        m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
+        uint32_t depth = (uint32_t)c->logn;
+        bool leaf = true;
+        while (depth > 0) {
+            m.in_depth = depth;
+            m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
+            const dim3 grid(c->batch * m.chunks);
+            if (leaf)
+                LG_LAUNCH(c, lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, ms, m);
+            else
+                LG_LAUNCH(c, lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, ms, m);
+            leaf = false;
+            depth = depth > 9 ? depth - 9 : 0;
+        }
+        LG_HIP(c, hipGetLastError());
+    }
+    if (prof) {
+        LG_HIP(c, hipEventRecord(ev[5], ms));
+        c->prof.commits++;
+    }
+    if (async_hash) LG_HIP(c, hipEventRecord(c->ring.ev_leaves_free[c->ring.slot], ms));
+    if (async_tree) {
+        LG_HIP(c, hipEventRecord(c->evt.tree, ms));
+        c->held.tree_pending = true;
+    }
+    // everything issued later on the encode stream (read-backs, the next commit) sees the tree
+    if (nchunks > 1) {
+        LG_HIP(c, hipEventRecord(c->evt.done, hs));
+        LG_HIP(c, hipStreamWaitEvent(c->st.main, c->evt.done, 0));
+    }
+    c->held.complete(all_planes_mask(c), c->rows);
+    if (streamed && host_coeffs) LG_HIP(c, hipStreamSynchronize(c->st.dn));
+    return LG_OK;
+}
+
+// a commit that fails half way leaves no commitment behind (the buffers may be partly rewritten)
+static int commit_checked(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_coeffs) {
+    const int rc = commit_core(c, host_pre, host_coeffs);
+    if (rc != LG_OK && rc != LG_ERR_STATE) c->held.drop();
+    return rc;
+}
+extern "C" {
+
+int lg_commit_resident(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_commit(c->gf, nullptr, nullptr); }
+    return commit_checked(c, nullptr, nullptr);
+}
+
+int lg_encode_commit(lg_ctx* c, const uint64_t* preenc, uint64_t* coeffs_out, uint8_t* root_out) {
+    if (!c || !preenc || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); const int rc_ = gf_commit(c->gf, preenc, coeffs_out); return rc_ != LG_OK ? rc_ : gf_read_root(c->gf, root_out); }
+    // rows stream in (and coefficients out) while earlier rows are being encoded
+    const int rc = commit_checked(c, preenc, coeffs_out);
+    if (rc != LG_OK) return rc;
+    return lg_read_root(c, root_out);
+}
+
+}  // extern "C"
+
+// ---- a1 on the device: the commit from the solution vector w alone (mod.rs:483-516 on the GPU) ---------------------------------
+int merkle_launches(lg_ctx* c, hipStream_t ms) {
+    lg::MerkleArgs m;
+    m.leaves = c->d_leaves; m.nodes = c->d_nodes; m.n = c->n; m.logn = (uint32_t)c->logn; m.batch = c->batch;
+    uint32_t depth = (uint32_t)c->logn;
+    bool leaf = true;
+    while (depth > 0) {
+        m.in_depth = depth;
+        m.chunks = depth > 9 ? (1u << (depth - 9)) : 1u;
+        const dim3 grid(c->batch * m.chunks);
+        if (leaf)
+            LG_LAUNCH(c, lg::merkle_subtree_kernel<true>, grid, dim3(256), 0, ms, m);
+        else
+            LG_LAUNCH(c, lg::merkle_subtree_kernel<false>, grid, dim3(256), 0, ms, m);
+        leaf = false;
+        depth = depth > 9 ? depth - 9 : 0;
+    }
+    return LG_OK;
+}

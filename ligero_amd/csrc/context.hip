@@ -1,0 +1,482 @@
+// Context of the MI355X Ligero encode-and-commit library (include/ligero_hip.h): creation with the domain tables
+// (small_domain / large_domain of src/ligero/mod.rs:204-211), destruction, dimension queries, synchronisation, read-backs,
+// stage profiling.  gfx950 only; there is no CPU fallback anywhere in this library.
+#include "lg_context.h"
+
+// ----------------------------------------------------------------------------- ABI
+extern "C" {
+
+const char* lg_status_string(int s) {
+    switch (s) {
+        case LG_OK: return "ok";
+        case LG_ERR_BAD_ARG: return "bad argument";
+        case LG_ERR_BAD_DIMS: return "bad dimensions";
+        case LG_ERR_NO_DEVICE: return "no such HIP device";
+        case LG_ERR_HIP: return "HIP runtime error";
+        case LG_ERR_OOM: return "out of memory";
+        case LG_ERR_STATE: return "invalid call order";
+        case LG_ERR_UNSUPPORTED: return "unsupported shape";
+        case LG_ERR_COMM: return "communication callback failed";
+        default: return "unknown status";
+    }
+}
+const char* lg_last_error(const lg_ctx* c) { return c ? c->err : ""; }
+uint32_t lg_abi_version(void) { return LG_ABI_VERSION; }
+
+void lg_ctx_destroy(lg_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->st.main) hipStreamSynchronize(c->st.main);
+    if (c->st.hash) hipStreamSynchronize(c->st.hash);
+    if (c->st.up) hipStreamSynchronize(c->st.up);
+    if (c->st.dn) hipStreamSynchronize(c->st.dn);
+    if (c->st.tree) hipStreamSynchronize(c->st.tree);
+    if (c->st.hash2) hipStreamSynchronize(c->st.hash2);
+    if (c->st.xchg) hipStreamSynchronize(c->st.xchg);
+    batch_prover_release(c);
+    if (c->sub.aux2k) lg_ctx_destroy(c->sub.aux2k);
+    hipSetDevice(c->device);
+    if (c->gf) gf_destroy(c->gf);
+    for (void* b : {(void*)c->gate.d_left, (void*)c->gate.d_right, (void*)c->gate.d_consts})
+        if (b) hipFree(b);
+    void* bufs2[] = {c->shard.d_digest_xchg, c->sub.d_partial, c->sub.d_q, c->sub.d_r, c->amat.d_colptr, c->amat.d_row, c->amat.d_val, c->amat.d_heavy, c->amat.d_seg, c->amat.d_seg_partial, c->chal.d_seeds, c->chal.d_counts, c->chal.d_short_flag, c->chal.d_rlin};
+    for (void* b : bufs2)
+        if (b) hipFree(b);
+    void* bufs[] = {c->shard.on ? c->shard.d_preenc_alloc : c->d_preenc, c->d_coeffs, c->d_u_alloc, c->ring.leaves[0], c->ring.nodes[0], c->ring.leaves[1], c->ring.nodes[1], c->ring.leaves[2], c->ring.nodes[2], c->tab.d_tw_fwd, c->tab.d_tw_inv, c->tab.d_coset_tw, c->tab.d_fold_inv, c->tab.d_first2,
+                    c->scr.a, c->scr.b, c->scr.c, c->scr.d_idx, c->scr.d_path, c->d_hstate};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    if (c->prof.ev_valid)
+        for (auto& set : c->prof.ev)
+            for (auto& e : set) hipEventDestroy(e);
+    for (auto& e : c->evt.chunk)
+        if (e) hipEventDestroy(e);
+    for (auto& e : c->evt.up)
+        if (e) hipEventDestroy(e);
+    for (auto& e : c->evt.coef)
+        if (e) hipEventDestroy(e);
+    if (c->evt.done) hipEventDestroy(c->evt.done);
+    if (c->ring.u[1]) hipFree(c->ring.u[1]);
+    if (c->ring.u[2]) hipFree(c->ring.u[2]);
+    for (auto& e : c->ring.ev_hash_free)
+        if (e) hipEventDestroy(e);
+    if (c->evt.hashed) hipEventDestroy(c->evt.hashed);
+    if (c->evt.tree) hipEventDestroy(c->evt.tree);
+    if (c->evt.stage_in) hipEventDestroy(c->evt.stage_in);
+    if (c->evt.stage_hash) hipEventDestroy(c->evt.stage_hash);
+    for (auto& e : c->ring.ev_leaves_free)
+        if (e) hipEventDestroy(e);
+    if (c->shard.ev_valid)
+        for (auto& set : c->shard.ev)
+            for (auto& e : set) hipEventDestroy(e);
+    if (c->st.xchg) hipStreamDestroy(c->st.xchg);
+    if (c->st.tree) hipStreamDestroy(c->st.tree);
+    if (c->st.hash2) hipStreamDestroy(c->st.hash2);
+    if (c->st.up) hipStreamDestroy(c->st.up);
+    if (c->st.dn) hipStreamDestroy(c->st.dn);
+    if (c->st.hash) hipStreamDestroy(c->st.hash);
+    if (c->st.main) hipStreamDestroy(c->st.main);
+    delete c;
+}
+
+}  // extern "C"
+struct ShardSpec {
+    uint32_t plane_begin, plane_count, coeff_rows_alloc;
+};
+static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch, const ShardSpec* shard) {
+    if (!out) return LG_ERR_BAD_ARG;
+    *out = nullptr;
+    const int logk = ilog2_exact(k), logn = ilog2_exact(n);
+    if (rows == 0 || batch == 0 || logk < 1 || logn < 0 || n != 8 * (uint64_t)k || logn > lg_host::kTwoAdicity) return LG_ERR_BAD_DIMS;
+    if (logk > 14) return LG_ERR_UNSUPPORTED;
+    if ((uint64_t)rows * batch > 0xffffffffull / 8) return LG_ERR_BAD_DIMS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LG_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return LG_ERR_NO_DEVICE;
+    lg_ctx* c = new (std::nothrow) lg_ctx();
+    if (!c) return LG_ERR_OOM;
+    c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
+    c->total_rows = (uint64_t)rows * batch;
+    // whole rows stay in LDS up to k = 4096 (one workgroup per CU, 188 VGPRs: the column-hash
+    // waves of the commit pipeline still fit beside it); larger k folds an outer radix 2 or 4
+    c->logki = logk <= 12 ? logk : 12;
+    c->logo = logk - c->logki;
+    c->ki = 1u << c->logki;
+    c->nplanes = 8u << c->logo;
+    c->lognp = 3 + c->logo;
+    if (const char* fc = getenv("LG_FORCE_CHUNKS")) c->force_chunks = (uint32_t)atoi(fc);
+    if (const char* qm = getenv("LG_HASH_QUAD_MAX_COLUMNS")) c->quad_hash_max_columns = strtoull(qm, nullptr, 0);
+    c->shard.plane0 = 0; c->shard.planes = c->nplanes; c->shard.coeff_rows_alloc = (uint32_t)c->total_rows;
+    if (shard) {
+        if (batch != 1 || shard->plane_count == 0 || (uint64_t)shard->plane_begin + shard->plane_count > c->nplanes ||
+            shard->coeff_rows_alloc < rows) {
+            delete c;
+            return LG_ERR_BAD_ARG;
+        }
+        c->shard.on = true;
+        c->shard.plane0 = shard->plane_begin; c->shard.planes = shard->plane_count; c->shard.coeff_rows_alloc = shard->coeff_rows_alloc;
+    }
+    int rc = LG_OK;
+    auto body = [&]() -> int {
+        LG_HIP(c, hipSetDevice(device));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.main, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.hash, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.up, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.dn, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.tree, hipStreamNonBlocking));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.hash2, hipStreamNonBlocking));
+        for (auto& e : c->ring.ev_leaves_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        for (auto& e : c->evt.chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        for (auto& e : c->evt.up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        for (auto& e : c->evt.coef) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->evt.done, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->evt.hashed, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->evt.tree, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->evt.stage_in, lg_event_flags()));
+        LG_HIP(c, hipEventCreateWithFlags(&c->evt.stage_hash, lg_event_flags()));
+        if (const char* e = getenv("LG_ASYNC_TREE")) c->ring.async_tree = atoi(e) != 0;
+        if (const char* e = getenv("LG_ASYNC_HASH")) c->ring.async_hash = atoi(e) != 0;
+        for (auto& e : c->ring.ev_hash_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_hstate), (size_t)batch * n * sizeof(uint4) * lg::kColStateVec));
+        const size_t mat = (size_t)c->total_rows * k;
+        // sharded: the message rows arrive shard by shard (lg_stage_interpolate allocates what it is given), the
+        // coefficient buffer is padded so that equal all-gather shards fit, and only the owned planes of U exist
+        if (!c->shard.on) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_preenc), mat * sizeof(fr)));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_coeffs), (size_t)c->shard.coeff_rows_alloc * k * sizeof(fr)));
+        {
+            const size_t plane = (size_t)c->total_rows * c->ki;
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_u_alloc), (size_t)c->shard.planes * plane * sizeof(fr)));
+            c->d_u = c->d_u_alloc - (size_t)c->shard.plane0 * plane;   // never dereferenced outside the owned planes
+            c->ring.u[0] = c->d_u_alloc;
+            // a third ring slot costs one more U: only where U is small, i.e. where a commit is latency-bound (LG_RING_DEPTH overrides)
+            c->ring.depth = ((size_t)c->nplanes * plane * sizeof(fr) <= (size_t{64} << 20)) ? 3 : 2;
+            if (const char* rd = getenv("LG_RING_DEPTH")) { const int v = atoi(rd); if (v == 2 || v == 3) c->ring.depth = v; }
+        }
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_leaves), (size_t)batch * n * 32));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_nodes), (size_t)batch * (n - 1) * 32));
+        c->ring.leaves[0] = c->d_leaves;
+        c->ring.nodes[0] = c->d_nodes;
+        // (no message row is present until lg_upload_preenc, a commit from host buffers or from w, or a zero-copy producer's
+        // lg_preenc_mark_filled: lg_commit_resident on a fresh context is LG_ERR_STATE, not a commitment to uninitialised memory)
+        // domain tables: large_domain (size n) generator wn; small_domain generator wk = wn^8 (mod.rs:89, 204-211)
+        using namespace lg_host;
+        const Fr wn = domain_generator(logn);
+        const Fr wk = domain_generator(logk);
+        const Fr wk_inv = inverse(wk);
+        std::vector<Fr> pn(n), pki(c->ki), pki_inv(c->ki), pk_inv(k);  // powers of wn, w_ki, w_ki^-1, wk^-1
+        {
+            Fr a = kOneMont;
+            for (uint32_t e = 0; e < n; e++) { pn[e] = a; a = mul(a, wn); }
+            const Fr wki = pow_u64(wk, 1ull << c->logo), wki_inv = pow_u64(wk_inv, 1ull << c->logo);
+            a = kOneMont;
+            Fr b = kOneMont;
+            for (uint32_t e = 0; e < c->ki; e++) { pki[e] = a; pki_inv[e] = b; a = mul(a, wki); b = mul(b, wki_inv); }
+            a = kOneMont;
+            for (uint32_t e = 0; e < k; e++) { pk_inv[e] = a; a = mul(a, wk_inv); }
+        }
+        const Fr inv_k = inverse(to_mont(Fr{{k, 0, 0, 0}}));
+        // butterfly twiddles in pass order
+        c->tab.n_pass_tw = (uint32_t)lg::pass_tw_total(c->logki);
+        {
+            const size_t cnt = c->tab.n_pass_tw ? c->tab.n_pass_tw : 1;
+            std::vector<uint8_t> tf(cnt * 72), ti(cnt * 72);
+            int logs = c->logki, logr = (c->logki < 3) ? c->logki : ((c->logki % 3) ? (c->logki % 3) : 3);
+            while (logs > 0) {
+                const int logsub = logs - logr;
+                if (logsub > 0) {
+                    const size_t off = (size_t)lg::pass_tw_offset(c->logki, logs);
+                    // the inverse transform's 1/k rides on the first pass' twiddles (outer fold of 4: on the fold table instead)
+                    const bool scaled = (logs == c->logki) && c->logo <= 1;
+                    for (uint32_t m = 1; m < (1u << logr); m++)
+                        for (uint32_t i0 = 0; i0 < (1u << logsub); i0++) {
+                            const uint32_t e = (i0 * m) << (c->logki - logs);
+                            fill_planes_q(tf, cnt, off + ((size_t)(m - 1) << logsub) + i0, pki[e]);
+                            fill_planes_q(ti, cnt, off + ((size_t)(m - 1) << logsub) + i0, scaled ? mul(pki_inv[e], inv_k) : pki_inv[e]);
+                        }
+                }
+                logs -= logr;
+                logr = 3;
+            }
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->tab.d_tw_fwd), tf.size()));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->tab.d_tw_inv), ti.size()));
+            LG_HIP(c, hipMemcpy(c->tab.d_tw_fwd, tf.data(), tf.size(), hipMemcpyHostToDevice));
+            LG_HIP(c, hipMemcpy(c->tab.d_tw_inv, ti.data(), ti.size(), hipMemcpyHostToDevice));
+        }
+        // pre-scale table [plane][d] = wn^(s d mod n)
+        {
+            const size_t cnt = (size_t)c->nplanes * k;
+            // O = 1: plain values + quotients (shoup29); O > 1: Montgomery operands of the fold's dot product
+            std::vector<uint8_t> ct(cnt * (c->logo == 0 ? 72 : 36));
+            for (uint32_t sp = 0; sp < c->nplanes; sp++)
+                for (uint32_t d = 0; d < k; d++) {
+                    // times 2^-256: the evaluation leaves the ABI's Montgomery form with its first product
+                    const Fr w = from_mont(pn[((uint64_t)sp * d) & (n - 1)]);
+                    if (c->logo == 0)
+                        fill_planes_q(ct, cnt, (size_t)sp * k + d, w);
+                    else
+                        fill_planes(ct, cnt, (size_t)sp * k + d, to_f29(w));
+                }
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->tab.d_coset_tw), ct.size()));
+            LG_HIP(c, hipMemcpy(c->tab.d_coset_tw, ct.data(), ct.size(), hipMemcpyHostToDevice));
+        }
+        // dot-product coefficients of the radix-2 first pass (k = 2, 16, 128, 1024): [plane][4][i0 < k/2]
+        if (c->logo == 0 && logk % 3 == 1 && logk > 1) {
+            const uint32_t half = k / 2;
+            const size_t cnt = (size_t)c->nplanes * 2 * k;
+            std::vector<uint8_t> ft(cnt * 36);
+            std::vector<Fr> pk(half);  // wk^i0
+            Fr a = kOneMont;
+            for (uint32_t i = 0; i < half; i++) { pk[i] = a; a = mul(a, wk); }
+            for (uint32_t sp = 0; sp < c->nplanes; sp++)
+                for (uint32_t i0 = 0; i0 < half; i0++) {
+                    const Fr pre0 = pn[((uint64_t)sp * i0) & (n - 1)], pre1 = pn[((uint64_t)sp * (i0 + half)) & (n - 1)];
+                    const Fr c10 = mul(pre0, pk[i0]), t = mul(pre1, pk[i0]);
+                    const Fr zero = {{0, 0, 0, 0}};
+                    const Fr c11 = (t.l[0] | t.l[1] | t.l[2] | t.l[3]) ? sub_raw(kP, t) : zero;
+                    const size_t base = (size_t)sp * 4 * half + i0;
+                    // all four carry 2^-256 (see the pre-scale table)
+                    fill_planes(ft, cnt, base, to_f29(from_mont(pre0)));
+                    fill_planes(ft, cnt, base + half, to_f29(from_mont(pre1)));
+                    fill_planes(ft, cnt, base + 2 * (size_t)half, to_f29(from_mont(c10)));
+                    fill_planes(ft, cnt, base + 3 * (size_t)half, to_f29(from_mont(c11)));
+                }
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->tab.d_first2), ft.size()));
+            LG_HIP(c, hipMemcpy(c->tab.d_first2, ft.data(), ft.size(), hipMemcpyHostToDevice));
+        }
+        // outer fold of the inverse transform.  Radix 2 (k = 8192) is a butterfly in the load stage: wk^-d, d < ki, for its
+        // odd half.  Radix 4: dot-product factors [h][d] = wk^(-h d mod k) / k.
+        if (c->logo == 1) {
+            const size_t cnt = c->ki;
+            std::vector<uint8_t> ft(cnt * 72);
+            for (uint32_t d = 0; d < c->ki; d++) fill_planes_q(ft, cnt, d, pk_inv[d]);
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->tab.d_fold_inv), ft.size()));
+            LG_HIP(c, hipMemcpy(c->tab.d_fold_inv, ft.data(), ft.size(), hipMemcpyHostToDevice));
+        } else {
+            const size_t cnt = (size_t)k << c->logo;
+            std::vector<uint8_t> ft(cnt * 36);
+            for (uint32_t h = 0; h < (1u << c->logo); h++)
+                for (uint32_t d = 0; d < k; d++) fill_planes(ft, cnt, (size_t)h * k + d, to_f29(mul(pk_inv[((uint64_t)h * d) & (k - 1)], inv_k)));
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->tab.d_fold_inv), ft.size()));
+            LG_HIP(c, hipMemcpy(c->tab.d_fold_inv, ft.data(), ft.size(), hipMemcpyHostToDevice));
+        }
+        const Fr w8 = domain_generator(3), w8i = inverse(w8);
+        Fr p = w8, pi = w8i;
+        for (int i = 0; i < 3; i++) {
+            c->tab.w8_fwd[i] = to_f29_plain(p);
+            c->tab.w8_inv[i] = to_f29_plain(pi);
+            c->tab.w8q_fwd[i] = to_f29_quot(p);
+            c->tab.w8q_inv[i] = to_f29_quot(pi);
+            p = mul(p, w8);
+            pi = mul(pi, w8i);
+        }
+        c->tab.one29 = to_f29_plain(kOneMont);
+        c->tab.oneq29 = to_f29_quot(kOneMont);
+        c->tab.scale29 = to_f29(inv_k);
+        c->tab.invk29 = to_f29_plain(inv_k);
+        c->tab.invkq29 = to_f29_quot(inv_k);
+        c->tab.r2 = to_dev(kR2);
+        c->tab.r3 = to_dev(mul(kR2, kR2));  // R^2 (*) R^2 = R^4 / R = R^3
+        return LG_OK;
+    };
+    rc = body();
+    if (rc != LG_OK) {
+        lg_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LG_OK;
+}
+extern "C" {
+
+int lg_ctx_create_batched(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+    return ctx_create_impl(out, device, rows, k, n, batch, nullptr);
+}
+int lg_ctx_create(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n) {
+    return ctx_create_impl(out, device, rows, k, n, 1, nullptr);
+}
+int lg_ctx_create_sharded(lg_ctx** out, int device, uint32_t rows, uint32_t k, uint32_t n, uint32_t plane_begin, uint32_t plane_count,
+                          uint32_t coeff_rows_alloc) {
+    const ShardSpec sp = {plane_begin, plane_count, coeff_rows_alloc ? coeff_rows_alloc : rows};
+    return ctx_create_impl(out, device, rows, k, n, 1, &sp);
+}
+int lg_ctx_create_field(lg_ctx** out, int device, int field, uint32_t rows, uint32_t k, uint32_t n, uint32_t batch) {
+    if (field == LG_FIELD_BN254_FR) return ctx_create_impl(out, device, rows, k, n, batch, nullptr);
+    if (!out) return LG_ERR_BAD_ARG;
+    *out = nullptr;
+    if (field != LG_FIELD_BLS12_377_FQ && field != LG_FIELD_BN254_FR_GENERIC) return LG_ERR_BAD_ARG;
+    const int logk = ilog2_exact(k), logn = ilog2_exact(n);
+    if (rows == 0 || batch == 0 || logk < 1 || logn < 0 || n != 8 * (uint64_t)k) return LG_ERR_BAD_DIMS;
+    if ((uint64_t)rows * batch > 0xffffffffull / 8) return LG_ERR_BAD_DIMS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LG_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return LG_ERR_NO_DEVICE;
+    lg_ctx* c = new (std::nothrow) lg_ctx();
+    if (!c) return LG_ERR_OOM;
+    c->device = device; c->rows = rows; c->k = k; c->n = n; c->batch = batch; c->logk = logk; c->logn = logn;
+    c->total_rows = (uint64_t)rows * batch;
+    c->ki = k; c->logki = logk; c->nplanes = 8; c->shard.planes = 8; c->shard.coeff_rows_alloc = (uint32_t)c->total_rows;
+    auto body = [&]() -> int {
+        LG_HIP(c, hipSetDevice(device));
+        LG_HIP(c, hipStreamCreateWithFlags(&c->st.main, hipStreamNonBlocking));
+        return gf_create(&c->gf, field, rows, k, n, batch, c->st.main, c->err, sizeof(c->err));
+    };
+    const int rc = body();
+    if (rc != LG_OK) {
+        lg_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LG_OK;
+}
+uint32_t lg_ctx_element_words(const lg_ctx* c) { return c ? (c->gf ? gf_element_words64(c->gf) : 4u) : 0u; }
+int lg_ctx_planes(const lg_ctx* c, uint32_t* nplanes, uint32_t* plane_begin, uint32_t* plane_count) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (nplanes) *nplanes = c->nplanes;
+    if (plane_begin) *plane_begin = c->shard.plane0;
+    if (plane_count) *plane_count = c->shard.planes;
+    return LG_OK;
+}
+
+int lg_ctx_stream(lg_ctx* c, void** stream_out) {
+    if (!c || !stream_out) return LG_ERR_BAD_ARG;
+    *stream_out = static_cast<void*>(c->st.main);
+    return LG_OK;
+}
+
+int lg_ctx_dims(const lg_ctx* c, uint32_t* rows, uint32_t* k, uint32_t* n, uint32_t* batch) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (rows) *rows = c->rows;
+    if (k) *k = c->k;
+    if (n) *n = c->n;
+    if (batch) *batch = c->batch;
+    return LG_OK;
+}
+
+int lg_ctx_pipeline_chunks(const lg_ctx* c, uint32_t* chunks_out) {
+    if (!c || !chunks_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { *chunks_out = 1; return LG_OK; }
+    Chunk chunks[lg_ctx::kMaxChunks];
+    *chunks_out = (uint32_t)plan_chunks(c, chunks);
+    return LG_OK;
+}
+
+int lg_upload_preenc(lg_ctx* c, const uint64_t* preenc) {
+    if (!c || !preenc) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_upload(c->gf, preenc); }
+    if (c->shard.on) return LG_ERR_STATE;   // a sharded context takes its row shard through lg_stage_interpolate
+    LG_HIP(c, hipSetDevice(c->device));
+    c->held.row0 = 0; c->held.row1 = c->rows;
+    LG_HIP(c, hipMemcpyAsync(c->d_preenc, preenc, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+    return LG_OK;
+}
+
+int lg_preenc_mark_filled(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->shard.on || c->held.staging) return LG_ERR_STATE;   // a sharded context holds row shards; a staged commit is in progress
+    c->held.row0 = 0; c->held.row1 = c->rows;
+    return LG_OK;
+}
+
+int lg_profile_enable(lg_ctx* c, int on) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    LG_HIP(c, hipSetDevice(c->device));
+    if (on && !c->prof.ev_valid) {
+        for (auto& set : c->prof.ev)
+            for (auto& e : set) LG_HIP(c, hipEventCreate(&e));
+        c->prof.ev_valid = true;
+    }
+    c->prof.on = on != 0;
+    c->prof.commits = 0;
+    c->shard.commits = 0;
+    return LG_OK;
+}
+int lg_host_register(lg_ctx* c, void* ptr, size_t bytes) {
+    if (!c || !ptr || bytes == 0) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return LG_OK;
+}
+int lg_host_unregister(lg_ctx* c, void* ptr) {
+    if (!c || !ptr) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipHostUnregister(ptr));
+    return LG_OK;
+}
+
+int lg_profile_read(lg_ctx* c, float ms_out[LG_STAGE_COUNT], uint32_t* samples_out) {
+    if (!c || !ms_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (!c->prof.ev_valid || !c->prof.on || c->prof.commits == 0) return LG_ERR_STATE;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint64_t have = c->prof.commits < lg_ctx::kProfRing ? c->prof.commits : lg_ctx::kProfRing;
+    double acc[LG_STAGE_COUNT] = {0, 0, 0, 0};
+    static const int from[LG_STAGE_COUNT] = {0, 1, 3, 4}, to[LG_STAGE_COUNT] = {1, 2, 4, 5};
+    for (uint64_t s = 0; s < have; s++) {
+        hipEvent_t* ev = c->prof.ev[(c->prof.commits - 1 - s) % lg_ctx::kProfRing];
+        LG_HIP(c, hipEventSynchronize(ev[5]));
+        LG_HIP(c, hipEventSynchronize(ev[2]));
+        for (int i = 0; i < LG_STAGE_COUNT; i++) {
+            float ms = 0;
+            LG_HIP(c, hipEventElapsedTime(&ms, ev[from[i]], ev[to[i]]));
+            acc[i] += ms;
+        }
+    }
+    for (int i = 0; i < LG_STAGE_COUNT; i++) ms_out[i] = (float)(acc[i] / (double)have);
+    if (samples_out) *samples_out = (uint32_t)have;
+    return LG_OK;
+}
+
+int lg_sync(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_sync(c->gf); }
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    return LG_OK;
+}
+
+}  // extern "C"
+
+int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes) {
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->st.main));
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    return LG_OK;
+}
+
+extern "C" {
+
+int lg_read_root(lg_ctx* c, uint8_t* root_out) {
+    if (!c || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_root(c->gf, root_out) : LG_ERR_STATE; }
+    if (!c->held.committed) return LG_ERR_STATE;
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipMemcpy2DAsync(root_out, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, c->batch, hipMemcpyDeviceToHost, c->st.main));
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    return LG_OK;
+}
+int lg_read_coeffs(lg_ctx* c, uint64_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_coeffs(c->gf, out) : LG_ERR_STATE; }
+    if (!c->held.committed) return LG_ERR_STATE;
+    return read_back(c, out, c->d_coeffs, (size_t)c->total_rows * c->k * sizeof(fr));
+}
+int lg_read_leaves(lg_ctx* c, uint8_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_leaves(c->gf, out) : LG_ERR_STATE; }
+    if (!c->held.committed) return LG_ERR_STATE;
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    return read_back(c, out, c->d_leaves, (size_t)c->batch * c->n * 32);
+}
+int lg_read_nodes(lg_ctx* c, uint8_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_committed(c->gf) ? gf_read_nodes(c->gf, out) : LG_ERR_STATE; }
+    if (!c->held.committed) return LG_ERR_STATE;
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    return read_back(c, out, c->d_nodes, (size_t)c->batch * (c->n - 1) * 32);
+}
+}  // extern "C"

@@ -1,4 +1,4 @@
-// Host side of the generic-field path (generic_kernels.h): interface used by the C ABI implementation in ligero_hip.hip.
+// Host side of the generic-field path (generic_kernels.h): interface used by the translation units behind the C ABI (lg_context.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -1,0 +1,434 @@
+// Internal header of libligero_hip.so: the context behind the opaque lg_ctx of include/ligero_hip.h and what the
+// translation units of the library share.  Nothing here is part of the ABI.
+//
+//   context.hip          create / destroy, domain tables, reads, profiling
+//   commit_pipeline.hip  the commit (src/ligero/mod.rs:521-551): resident and from host buffers; column-hash and tree launches
+//   witness.hip          a1 on the device: the commit from the solution vector w alone (mod.rs:483-551)
+//   openings.hip         open_columns (mod.rs:935-955), codeword rows, the row operators reed_solomon* (mod.rs:998-1012)
+//   subproof.hip         the three sub-proof polynomials, the linear test's challenges, the verifier's column sums
+//   staged_sharded.hip   one proof over several GPUs: staged calls, lg_commit_sharded, lg_commit_row_relay
+//   batch_prover.hip     throughput mode with the transcript on the device (sponge_kernels.h)
+//
+// The context is a set of sub-structs, each with one concern; the state that decides what a call may read -- which planes
+// and message rows of the resident buffers belong to the current commitment -- lives in ONE of them (Held) and changes
+// through its methods only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <utility>
+#include <vector>
+
+// the library is built with -fvisibility=hidden: only what the public header declares is exported
+#pragma GCC visibility push(default)
+#include "../../include/ligero_hip.h"
+#pragma GCC visibility pop
+#include "fr29_gfx950.h"
+#include "fr_gfx950.h"
+#include "generic_path.h"
+#include "hash_kernels.h"
+#include "host_fr.h"
+#include "ntt_launch.h"
+
+using lg::fr;
+
+struct lg_ctx {
+    int device = 0;
+    uint32_t rows = 0, k = 0, n = 0, batch = 1;
+    int logk = 0, logn = 0;
+    // k = O * ki: transforms are done as O-way folded size-ki transforms (ntt_kernels.h); the
+    // codeword lives in 8 O planes of [total_rows][ki], column j = (8 O) q + s <-> plane s, slot q
+    int logki = 0, logo = 0, lognp = 3;
+    uint32_t ki = 0, nplanes = 8;
+    uint64_t total_rows = 0;  // batch * rows
+    static constexpr int kMaxChunks = 8;
+    static constexpr int kRing = 3;
+    static constexpr int kShardStages = 5;
+    static constexpr int kShardProfRing = 16;
+    static constexpr int kProfRing = 64;                 // commits remembered by the profiler
+
+    struct Streams {
+        hipStream_t main = nullptr;   // encode stream; every public call is ordered on it
+        hipStream_t hash = nullptr;   // column-hash / Merkle stream of the commit pipeline
+        hipStream_t hash2 = nullptr;  // second hash stream (ring.depth == 3)
+        hipStream_t tree = nullptr;   // the tree of overlapped single-chunk commits
+        hipStream_t up = nullptr;     // host -> device copies of lg_encode_commit's row chunks
+        hipStream_t dn = nullptr;     // device -> host copies of the coefficient rows
+        hipStream_t xchg = nullptr;   // exchange stream of lg_commit_sharded: the all-gather of piece c + 1 beside the evaluation of piece c
+    } st;
+
+    struct Events {
+        hipEvent_t chunk[kMaxChunks] = {};  // "rows of chunk c are encoded"
+        hipEvent_t up[kMaxChunks] = {};     // "rows of chunk c have arrived from the host"
+        hipEvent_t coef[kMaxChunks] = {};   // "rows of chunk c are interpolated"
+        hipEvent_t done = nullptr;          // "tree of this commit is complete"
+        hipEvent_t hashed = nullptr, tree = nullptr;   // single-chunk commits: leaves complete / tree complete (on st.hash)
+        // staged hashes (lg_stage_hash_rows) run on st.hash behind everything issued so far on the encode stream and the encode
+        // stream does not wait for them until something reads their result (settle_hash): the hash of one row range runs beside
+        // the evaluation of the next
+        hipEvent_t stage_in = nullptr, stage_hash = nullptr;
+    } evt;
+
+    // Overlapped single-chunk commits rotate through a ring of U / leaf / node buffers: two deep, or three deep with a second hash
+    // stream when U is small (a lone small proof is a chain of dependent Blake2s compressions: two of those chains in flight).
+    // The column hash of commit i runs on st.hash BESIDE the interpolation / evaluation of commit i + 1, the tree of commit i on
+    // st.tree beside the column hash of commit i + 1.
+    struct CommitRing {
+        bool async_tree = true;                // LG_ASYNC_TREE=0 turns the tree overlap off (A/B knob)
+        bool async_hash = true;                // LG_ASYNC_HASH=0: hash on the encode stream, one U buffer (A/B knob)
+        fr* u[kRing] = {nullptr, nullptr, nullptr};          // [0] = d_u_alloc, the others allocated by the first overlapped commits
+        uint8_t* leaves[kRing] = {nullptr, nullptr, nullptr};
+        uint8_t* nodes[kRing] = {nullptr, nullptr, nullptr};
+        int slot = 0;                                        // ring slot of the current commitment
+        int depth = 2;
+        uint64_t seq = 0;                                    // overlapped commits issued: picks the hash stream
+        hipEvent_t ev_hash_free[kRing] = {nullptr, nullptr, nullptr};     // "the hash that read u[p] is done" (on its hash stream)
+        hipEvent_t ev_leaves_free[kRing] = {nullptr, nullptr, nullptr};   // "the tree that read leaves[p] / wrote nodes[p] is done" (on st.tree)
+    } ring;
+
+    // What the resident buffers hold of the CURRENT commitment.  Every entry point that reads U, the leaves, the tree or
+    // preenc_u rows checks here (need_planes / need_all_message_rows); the commits are the only writers.
+    struct Held {
+        bool committed = false;                // a complete tree exists
+        bool staging = false;                  // between lg_stage_interpolate and lg_stage_merkle
+        uint32_t planes = 0;                   // mask of the planes of d_u that belong to the current commitment
+        uint32_t row0 = 0, row1 = 0;           // message rows [row0, row1) of d_preenc that belong to it
+        bool hash_pending = false;             // staged column hashes are queued on st.hash (settle_hash)
+        bool tree_pending = false;             // the tree of the last commit is still being built on st.hash / st.tree (settle_tree)
+        // rows whose message planes (s = 0 mod 8) the interpolation of the staged commit in progress wrote itself (sorted,
+        // disjoint): the evaluation skips those planes for them
+        std::vector<std::pair<uint32_t, uint32_t>> canon_ranges;
+        // a whole commitment over all rows and planes now exists
+        void complete(uint32_t all_planes, uint32_t rows) { committed = true; staging = false; planes = all_planes; row0 = 0; row1 = rows; }
+        // a staged commit starts from nothing: what an earlier commitment left in U is void
+        void begin_staged() { staging = true; committed = false; planes = 0; canon_ranges.clear(); }
+        // re-evaluating or re-hashing over a finished commitment voids it
+        void touch_staged() { if (committed) { committed = false; planes = 0; } }
+        // a commit that failed half way, or an operation that reuses the buffers, leaves no commitment behind
+        void drop() { committed = false; staging = false; planes = 0; canon_ranges.clear(); }
+    } held;
+
+    // sharded (lg_ctx_create_sharded) single-proof context: one rank of a proof that is split over several GPUs
+    struct Shard {
+        bool on = false;
+        uint32_t plane0 = 0, planes = 0;       // planes this context can hold (all of them unless sharded)
+        uint32_t coeff_rows_alloc = 0;         // rows of LG_BUF_COEFFS (>= rows: padding for equal all-gather shards)
+        fr* d_preenc_alloc = nullptr;          // allocation behind the rows [pre_row0, pre_row0 + pre_rows) of d_preenc
+        uint32_t pre_row0 = 0, pre_rows = 0;   // rows of d_preenc that are allocated AND addressable by matrix row
+        uint32_t alloc_rows = 0;               // rows behind d_preenc_alloc, whatever their order
+        // lg_commit_sharded: the rows this rank owns are `pieces` ranges, kept compact (piece-major) in d_preenc_alloc
+        uint32_t pieces = 0, world = 0, rank = 0, compact_rows = 0;
+        uint8_t* d_digest_xchg = nullptr;      // [world][ki][planes per rank][32] staging of the digest all-gather
+        hipEvent_t ev[kShardProfRing][kShardStages + 1 + 2 * kMaxChunks] = {};   // stage marks, then (before, after) of every wait for an exchange piece
+        bool ev_valid = false;
+        uint64_t commits = 0;
+        uint32_t wait_pairs[kShardProfRing] = {};   // per profiled commit: exchange pieces it waited for (0: row relay)
+        // the resident-row note is void whenever the allocation behind it changes hands
+        void forget_layout() { pieces = 0; world = 0; rank = 0; compact_rows = 0; }
+    } shard;
+
+    // sub-proof polynomials
+    struct Subproof {
+        lg_ctx* aux2k = nullptr;               // tables of the size-2k domain (intermediate_domain, mod.rs:212), created on demand
+        fr* d_partial = nullptr; size_t partial_elems = 0;   // row-sum partials
+        fr* d_q = nullptr;                     // [batch][2k] evaluations / coefficients
+        fr* d_r = nullptr; size_t r_elems = 0;               // challenge vector
+    } sub;
+    // constraint matrix A in CSC form (lg_upload_constraint_matrix)
+    struct ConstraintMatrix {
+        uint32_t* d_colptr = nullptr; uint32_t* d_row = nullptr; fr* d_val = nullptr;
+        uint32_t* d_heavy = nullptr; uint32_t nheavy = 0;   // columns with more than lg::kHeavyColumn entries
+        uint32_t* d_seg = nullptr; uint32_t nseg = 0;       // their segments: [seg_begin | seg_end | heavy_seg_ptr] (challenge_kernels.h)
+        fr* d_seg_partial = nullptr;                        // [batch][nseg]
+        uint64_t rows = 0, nnz = 0; bool loaded = false;
+    } amat;
+    // the device-side challenge generator (ChaCha20 + F::rand)
+    struct Challenges {
+        uint32_t* d_seeds = nullptr;           // [batch][8]
+        uint32_t* d_counts = nullptr; size_t counts_cap = 0;
+        uint32_t* d_short_flag = nullptr;
+        fr* d_rlin = nullptr; size_t rlin_elems = 0;   // r_linear [batch][4mk]
+    } chal;
+    // gate map of the circuit (lg_upload_gate_map): for every position of the solution vector the sources of x and y
+    struct GateMap {
+        uint32_t* d_left = nullptr; uint32_t* d_right = nullptr; fr* d_consts = nullptr;
+        uint64_t npos = 0; uint32_t nconst = 0; bool backward = false;
+        bool loaded = false;                   // set after the LAST copy of an upload succeeded
+    } gate;
+    // domain tables: 29-bit limbs, three planes each (limbs 0-3 | 4-7 | 8)
+    struct Tables {
+        uint8_t* d_tw_fwd = nullptr;    // butterfly twiddles of the size-ki transform, pass order (lg::pass_tw_offset)
+        uint8_t* d_tw_inv = nullptr;    // same for the inverse transform
+        uint8_t* d_coset_tw = nullptr;  // [plane s < 8 O][d < k] = omega_n^(s d)
+        uint8_t* d_fold_inv = nullptr;  // O = 2: omega_k^-d, d < ki (with quotients); O = 4: [h < O][d < k] = omega_k^(-h d) / k
+        uint8_t* d_first2 = nullptr;    // log2 k = 1 (mod 3): coefficients of the dot-product radix-2 first pass (ntt_kernels.h)
+        uint32_t n_pass_tw = 0;
+        lg::f29 w8_fwd[3], w8_inv[3], w8q_fwd[3], w8q_inv[3], one29, oneq29, scale29, invk29, invkq29;
+        fr r2;                          // 2^512 mod p
+        fr r3;                          // 2^768 mod p
+    } tab;
+    // scratch for row operators / openings (grown on demand)
+    struct Scratch {
+        fr* a = nullptr; size_t a_elems = 0;  // inputs / coefficients
+        fr* b = nullptr; size_t b_elems = 0;  // planes / outputs
+        fr* c = nullptr; size_t c_elems = 0;  // natural-order output
+        uint32_t* d_idx = nullptr; size_t idx_cap = 0;
+        uint8_t* d_path = nullptr; size_t path_cap = 0;
+    } scr;
+    struct Profiler {
+        bool on = false;
+        hipEvent_t ev[kProfRing][6] = {};  // 0 start, 1 interpolate done, 2 evaluate done | hash stream: 3 first hash start, 4 last hash done, 5 tree done
+        bool ev_valid = false;
+        uint64_t commits = 0;              // commits recorded since lg_profile_enable(1)
+    } prof;
+    struct lg_batch_prover_state* bp = nullptr;   // throughput-mode prover (batch_prover.hip), created on demand
+
+    uint32_t force_chunks = 0;             // LG_FORCE_CHUNKS (testing knob): pipeline depth regardless of size
+    uint64_t quad_hash_max_columns = 32768; // single-chunk commits with at most this many columns use the four-lanes-per-column
+                                           // Blake2s (LG_HASH_QUAD_MAX_COLUMNS overrides; 0 = never)
+    gf_state* gf = nullptr;                // set for contexts over a generic field (lg_ctx_create_field): every supported
+                                           // entry point forwards to generic_path.hip, the others return LG_ERR_UNSUPPORTED
+    // resident commitment
+    fr* d_preenc = nullptr;   // [total_rows][k]  Montgomery
+    fr* d_coeffs = nullptr;   // [total_rows][k]  Montgomery
+    fr* d_u = nullptr;        // [8 O][total_rows][ki] canonical integers; planes 8c hold the message.  In a sharded
+                              // context only planes [shard.plane0, shard.plane0 + shard.planes) exist and this is the VIRTUAL
+                              // base d_u_alloc - shard.plane0 * plane, so kernels keep indexing by absolute plane id
+    fr* d_u_alloc = nullptr;  // what hipMalloc returned for d_u
+    uint8_t* d_leaves = nullptr;  // [batch][n][32]    (of the current commitment: one of ring.leaves)
+    uint8_t* d_nodes = nullptr;   // [batch][n-1][32]
+    uint4* d_hstate = nullptr;    // [batch][np][ki][lg::kColStateVec] Blake2s state between row chunks / ranks (LG_BUF_HSTATE)
+    char err[256] = {0};
+};
+
+inline int fail_hip(lg_ctx* c, hipError_t e, const char* what) {
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+    return (e == hipErrorOutOfMemory) ? LG_ERR_OOM : LG_ERR_HIP;
+}
+#define LG_HIP(c, call)                                   \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return fail_hip(c, e_, #call); \
+    } while (0)
+
+inline uint32_t all_planes_mask(const lg_ctx* c) { return c->nplanes >= 32 ? 0xffffffffu : ((1u << c->nplanes) - 1u); }
+inline uint32_t own_planes_mask(const lg_ctx* c) {
+    const uint32_t hi = c->shard.plane0 + c->shard.planes;   // <= 32
+    const uint32_t upto = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u);
+    return upto & ~((1u << c->shard.plane0) - 1u);
+}
+// A staged (coset-sharded) commit leaves only some planes of U and some message rows on this device: entry points
+// that would read the others fail with LG_ERR_STATE instead of returning stale or foreign data.
+inline int need_planes(lg_ctx* c, uint32_t mask, const char* what) {
+    if ((c->held.planes & mask) == mask) return LG_OK;
+    snprintf(c->err, sizeof(c->err), "%s needs coset planes 0x%x of the commitment, this context holds 0x%x (staged / sharded commit)", what, mask,
+             c->held.planes);
+    return LG_ERR_STATE;
+}
+inline int need_all_message_rows(lg_ctx* c, const char* what) {
+    if (c->held.row0 == 0 && c->held.row1 == c->rows) return LG_OK;
+    snprintf(c->err, sizeof(c->err), "%s needs every row of preenc_u, this context holds rows [%u, %u) of %u", what, c->held.row0, c->held.row1, c->rows);
+    return LG_ERR_STATE;
+}
+
+// every kernel launch is followed by its own error check (a failed launch must not be reported against a later one)
+#define LG_LAUNCH(c, ...)                  \
+    do {                                   \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+        LG_HIP(c, hipGetLastError());      \
+    } while (0)
+
+// Montgomery-form (2^256) host element -> 29-bit limbs of value * 2^261 mod p
+inline lg::f29 to_f29(const lg_host::Fr& a_mont) {
+    static const lg_host::Fr m32 = lg_host::to_mont(lg_host::Fr{{32, 0, 0, 0}});
+    const lg_host::Fr t = lg_host::mul(a_mont, m32);  // raw limbs now read (a * 2^5) * 2^256 = a * 2^261 mod p
+    lg::f29 r;
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t x = t.l[w] >> sh;
+        if (sh > 35 && w < 3) x |= t.l[w + 1] << (64 - sh);
+        r.v[i] = (i < 8) ? (uint32_t)(x & 0x1fffffffu) : (uint32_t)x;
+    }
+    return r;
+}
+// canonical value of a Montgomery-form host element -> 29-bit limbs (plain operand of shoup29)
+inline lg::f29 split29(const uint64_t (&t)[5]) {
+    lg::f29 r;
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t x = t[w] >> sh;
+        if (sh > 35) x |= t[w + 1] << (64 - sh);
+        r.v[i] = (uint32_t)(x & 0x1fffffffu);
+    }
+    return r;
+}
+inline lg::f29 to_f29_plain(const lg_host::Fr& a_mont) {
+    const lg_host::Fr a = lg_host::from_mont(a_mont);
+    const uint64_t t[5] = {a.l[0], a.l[1], a.l[2], a.l[3], 0};
+    return split29(t);
+}
+// Barrett quotient floor(w * 2^261 / p) of the canonical value w < p (second operand of shoup29)
+inline lg::f29 to_f29_quot(const lg_host::Fr& a_mont) {
+    lg_host::Fr rem = lg_host::from_mont(a_mont);
+    uint64_t q[5] = {0, 0, 0, 0, 0};
+    for (int bit = 260; bit >= 0; bit--) {
+        // rem < p < 2^254: the doubled value fits four words
+        rem = lg_host::Fr{{rem.l[0] << 1, (rem.l[1] << 1) | (rem.l[0] >> 63), (rem.l[2] << 1) | (rem.l[1] >> 63), (rem.l[3] << 1) | (rem.l[2] >> 63)}};
+        if (lg_host::geq(rem, lg_host::kP)) {
+            rem = lg_host::sub_raw(rem, lg_host::kP);
+            q[bit >> 6] |= 1ull << (bit & 63);
+        }
+    }
+    return split29(q);
+}
+// three-plane table image of `count` constants
+inline void fill_planes(std::vector<uint8_t>& img, size_t count, size_t e, const lg::f29& v) {
+    uint32_t* lo = reinterpret_cast<uint32_t*>(img.data());
+    uint32_t* mid = lo + 4 * count;
+    uint32_t* hi = mid + 4 * count;
+    for (int i = 0; i < 4; i++) { lo[4 * e + i] = v.v[i]; mid[4 * e + i] = v.v[4 + i]; }
+    hi[e] = v.v[8];
+}
+inline lg::Tw29 planes_of(const uint8_t* base, size_t count) {
+    lg::Tw29 t;
+    t.lo = reinterpret_cast<const uint4*>(base);
+    t.mid = reinterpret_cast<const uint4*>(base + 16 * count);
+    t.hi = reinterpret_cast<const uint32_t*>(base + 32 * count);
+    return t;
+}
+// six-plane image (constants, then their quotients) for shoup29: 72 bytes per constant
+inline void fill_planes_q(std::vector<uint8_t>& img, size_t count, size_t e, const lg_host::Fr& a_mont) {
+    fill_planes(img, count, e, to_f29_plain(a_mont));
+    const lg::f29 q = to_f29_quot(a_mont);
+    uint32_t* lo = reinterpret_cast<uint32_t*>(img.data() + 36 * count);
+    uint32_t* mid = lo + 4 * count;
+    uint32_t* hi = mid + 4 * count;
+    for (int i = 0; i < 4; i++) { lo[4 * e + i] = q.v[i]; mid[4 * e + i] = q.v[4 + i]; }
+    hi[e] = q.v[8];
+}
+inline lg::Tw29q planes_q_of(const uint8_t* base, size_t count) {
+    lg::Tw29q t;
+    t.w = planes_of(base, count);
+    t.q = planes_of(base + 36 * count, count);
+    return t;
+}
+
+// flags of the cross-stream "chunk encoded" / "tree done" events (LG_EVENT_FLAGS overrides, for experiments)
+inline unsigned lg_event_flags() {
+    if (const char* f = getenv("LG_EVENT_FLAGS")) return (unsigned)strtoul(f, nullptr, 0);
+    return hipEventDisableTiming;
+}
+
+inline fr to_dev(const lg_host::Fr& a) {
+    fr r;
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)a.l[i];
+        r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
+    }
+    return r;
+}
+inline int ilog2_exact(uint32_t x) {
+    if (x == 0 || (x & (x - 1))) return -1;
+    int l = 0;
+    while ((1u << l) < x) l++;
+    return l;
+}
+// ----------------------------------------------------------------------------- launches
+inline lg::NttArgs interp_args(const lg_ctx* c, const fr* in, fr* out, fr* canon_out, uint32_t row0, uint32_t rows) {
+    lg::NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.canon_out = canon_out;
+    a.tw = planes_q_of(c->tab.d_tw_inv, c->tab.n_pass_tw ? c->tab.n_pass_tw : 1);
+    if (c->logo == 1) {
+        a.coset_tw = planes_q_of(c->tab.d_fold_inv, c->ki);  // the odd half's factors of the radix-2 fold
+    } else {
+        a.coset_tw.w = planes_of(c->tab.d_fold_inv, (size_t)c->k << c->logo);
+        a.coset_tw.q = a.coset_tw.w;  // unused: the fold is a Montgomery dot product
+    }
+    a.first2 = a.coset_tw.w;      // unused
+    for (int i = 0; i < 3; i++) { a.w8[i] = c->tab.w8_inv[i]; a.w8q[i] = c->tab.w8q_inv[i]; }
+    a.one = c->tab.one29;
+    a.oneq = c->tab.oneq29;
+    a.invk = c->tab.invk29;
+    a.invkq = c->tab.invkq29;
+    a.chunk_rows = rows ? rows : 1;  // contiguous rows unless the caller narrows it (commit pipeline)
+    a.proof_stride = 0;
+    a.scale = c->tab.scale29;
+    a.rows = rows; a.row0 = row0; a.ncos = 0;
+    a.plane_stride = 0;
+    a.canon_mask = 0xffffffffu;
+    return a;
+}
+// with_message: also evaluate the planes that coincide with the message (needed when only
+// coefficients are given: lg_reed_solomon_evaluate); the commit path copies the message instead
+inline lg::NttArgs eval_args(const lg_ctx* c, const fr* coeffs, fr* planes, uint64_t plane_stride, uint32_t row0, uint32_t rows,
+                             bool with_message) {
+    lg::NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = coeffs; a.out = planes; a.canon_out = nullptr;
+    a.tw = planes_q_of(c->tab.d_tw_fwd, c->tab.n_pass_tw ? c->tab.n_pass_tw : 1);
+    if (c->logo == 0) {
+        a.coset_tw = planes_q_of(c->tab.d_coset_tw, (size_t)c->k * c->nplanes);
+    } else {
+        a.coset_tw.w = planes_of(c->tab.d_coset_tw, (size_t)c->k * c->nplanes);
+        a.coset_tw.q = a.coset_tw.w;  // unused: the fold is a Montgomery dot product
+    }
+    a.first2 = planes_of(c->tab.d_first2, (size_t)c->nplanes * 2 * c->k);
+    for (int i = 0; i < 3; i++) { a.w8[i] = c->tab.w8_fwd[i]; a.w8q[i] = c->tab.w8q_fwd[i]; }
+    a.one = c->tab.one29;
+    a.oneq = c->tab.oneq29;
+    a.invk = c->tab.invk29;
+    a.invkq = c->tab.invkq29;
+    a.chunk_rows = rows ? rows : 1;  // contiguous rows unless the caller narrows it (commit pipeline)
+    a.proof_stride = 0;
+    a.scale = c->tab.scale29;
+    a.rows = rows; a.row0 = row0;
+    a.ncos = 0;
+    for (uint32_t s = 0; s < c->nplanes; s++)
+        if (with_message || (s & 7) != 0) a.cosets[a.ncos++] = (uint8_t)s;
+    a.plane_stride = plane_stride;
+    return a;
+}
+
+inline int grow(lg_ctx* c, fr** p, size_t* cap, size_t need) {
+    if (*cap >= need) return LG_OK;
+    if (*p) LG_HIP(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(p), need * sizeof(fr)));
+    *cap = need;
+    return LG_OK;
+}
+
+// ---- shared between translation units (definitions in the file named) ------------------------------------------------------
+struct Chunk {
+    uint32_t proof_begin, proof_count, row_begin, row_end;
+};
+// commit_pipeline.hip
+int plan_chunks(const lg_ctx* c, Chunk* out, bool from_host = false);
+int settle_tree(lg_ctx* c);     // the encode stream waits for a tree still being built on another stream
+int settle_hash(lg_ctx* c);     // ... for staged column hashes queued on the hash stream
+int merkle_launches(lg_ctx* c, hipStream_t ms);
+// one column-hash launch on `hs`: the four-lanes-per-column kernel when `allow_quad` and the launch fits it, else one lane per column
+int colhash_launch(lg_ctx* c, hipStream_t hs, const lg::ColHashArgs& h, bool allow_quad);
+// context.hip
+int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes);
+// witness.hip
+int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs);
+// openings.hip: the gather of t columns of nproofs proofs from DEVICE indices into DEVICE buffers (queued on the encode stream)
+int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths);
+// subproof.hip: the three polynomials with their challenges already ON THE DEVICE, results left on the device
+//   interleaved: r in sub.d_r [batch][rows]      -> sub.d_q [batch][k]
+//   linear:      seeds in chal.d_seeds           -> sub.aux2k->d_coeffs [batch][2k]
+//   quadratic:   r in sub.d_r [batch][rows / 4]  -> sub.aux2k->d_coeffs [batch][2k]
+int sub_buffers(lg_ctx* c, size_t partial_elems, size_t r_elems);
+int interleaved_on_device(lg_ctx* c);
+int linear_from_device_seeds(lg_ctx* c);
+int quadratic_on_device(lg_ctx* c);
+int sub_aux2k(lg_ctx* c);
+// batch_prover.hip
+void batch_prover_release(lg_ctx* c);

@@ -157,7 +157,7 @@ __device__ __forceinline__ fr digest_element(const uint32_t (&rw)[8], uint32_t i
 
 constexpr uint32_t kSpongeMaxRounds = 96;
 template <bool TEST_MDS>
-__global__ void __launch_bounds__(64) sponge_kernel(const SpongeArgs a) {
+static __global__ void __launch_bounds__(64) sponge_kernel(const SpongeArgs a) {
     __shared__ uint32_t ark_lds[27 * kSpongeMaxRounds];
     {
         const uint32_t words = 27 * (a.P.full_rounds + a.P.partial_rounds);
@@ -285,7 +285,7 @@ struct IndexArgs {
     uint32_t* idx_out;       // [batch][t] ascending
     uint32_t batch, n, t;
 };
-__global__ void __launch_bounds__(64) distinct_indices_kernel(const IndexArgs a) {
+static __global__ void __launch_bounds__(64) distinct_indices_kernel(const IndexArgs a) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.batch) return;
     const uint32_t words = a.n >= 32 ? a.n / 32 : 1;

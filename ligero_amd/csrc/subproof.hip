@@ -1,0 +1,530 @@
+// The arithmetic of the three sub-proofs on the resident commitment (src/ligero/mod.rs:658, 723-736, 842-848), the linear
+// test's challenges and A.row_mul on the device (mod.rs:719-722), the verifier's linear-test column sums (mod.rs:748-830),
+// and the same sums as point values for coset-sharded commitments.
+#include "lg_context.h"
+#include "challenge_kernels.h"
+#include "subproof_kernels.h"
+
+// ---- sub-proof polynomials on the resident commitment -------------------------
+// Every call serves all proofs of the batch in one set of launches (proof index = blockIdx.z).
+int sub_buffers(lg_ctx* c, size_t partial_elems, size_t r_elems) {
+    int rc = grow(c, &c->sub.d_partial, &c->sub.partial_elems, partial_elems);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->sub.d_r, &c->sub.r_elems, r_elems);
+    if (rc != LG_OK) return rc;
+    if (!c->sub.d_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->sub.d_q), (size_t)c->batch * 2 * c->k * sizeof(fr)));
+    return LG_OK;
+}
+static uint32_t sub_chunks(uint32_t rows, uint32_t* per_chunk) {
+    uint32_t per = rows / 256;  // at most ~256 partial rows
+    if (per < 32) per = 32;
+    *per_chunk = per;
+    return (rows + per - 1) / per;
+}
+static int sub_finish(lg_ctx* c, uint32_t nchunks, uint32_t cols, const fr& post, fr* out, uint32_t stride, uint32_t off, uint64_t out_proof) {
+    hipLaunchKernelGGL(lg::rowsum_finish_kernel, dim3((cols + 255) / 256, 1, c->batch), dim3(256), 0, c->st.main, c->sub.d_partial, nchunks, cols, post,
+                       out, stride, off, out_proof);
+    LG_HIP(c, hipGetLastError());
+    return LG_OK;
+}
+// the context of the size-2k domain (intermediate_domain of mod.rs:212): tables + a [batch][2k] coefficient buffer
+int sub_aux2k(lg_ctx* c) {
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    if (!c->sub.aux2k) {
+        int rc = lg_ctx_create_batched(&c->sub.aux2k, c->device, 1, 2 * c->k, 16 * c->k, c->batch);
+        if (rc != LG_OK) return rc;
+        LG_HIP(c, hipSetDevice(c->device));
+    }
+    return LG_OK;
+}
+// size-2k inverse NTT of the batch rows in sub.d_q into sub.aux2k->d_coeffs, then copy out (coeffs_out == nullptr: the
+// coefficients stay on the device)
+static int sub_interpolate_2k(lg_ctx* c, uint64_t* coeffs_out) {
+    { const int rc_ = sub_aux2k(c); if (rc_ != LG_OK) return rc_; }
+    lg_ctx* x = c->sub.aux2k;
+    lg::NttArgs a = interp_args(x, c->sub.d_q, x->d_coeffs, nullptr, 0, c->batch);
+    LG_HIP(c, lg::launch_ntt(x->logki, x->logo, false, c->st.main, a));
+    if (!coeffs_out) return LG_OK;
+    return read_back(c, coeffs_out, x->d_coeffs, (size_t)c->batch * 2 * c->k * sizeof(fr));
+}
+
+// preenc_u.row_mul(r) (mod.rs:658) with r already in sub.d_r [batch][rows]: -> sub.d_q [batch][k] (buffers sized by the caller)
+int interleaved_on_device(lg_ctx* c) {
+    uint32_t per;
+    const uint32_t nch = sub_chunks(c->rows, &per);
+    lg::RowSumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = c->d_preenc; a.a_proof = (uint64_t)c->rows * c->k; a.a_row = c->k; a.a_col = 1;
+    a.b = nullptr; a.r = c->sub.d_r;
+    a.partial = c->sub.d_partial;
+    a.rows = c->rows; a.cols = c->k; a.rows_per_chunk = per; a.nchunks = nch;
+    hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->k + 255) / 256, nch, c->batch), dim3(256), 0, c->st.main, a);
+    LG_HIP(c, hipGetLastError());
+    // Montgomery x Montgomery -> Montgomery already: multiply by one (R) only to normalise
+    return sub_finish(c, nch, c->k, to_dev(lg_host::kOneMont), c->sub.d_q, 1, 0, c->k);
+}
+
+extern "C" {
+
+int lg_interleaved_row_mul(lg_ctx* c, const uint64_t* r, uint64_t* out) {
+    if (!c || !r || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_interleaved_row_mul(c->gf, r, out); }
+    { const int rc_ = need_all_message_rows(c, "lg_interleaved_row_mul"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    uint32_t per;
+    const uint32_t nch = sub_chunks(c->rows, &per);
+    int rc = sub_buffers(c, (size_t)c->batch * nch * 2 * c->k, c->total_rows);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->sub.d_r, r, (size_t)c->total_rows * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+    rc = interleaved_on_device(c);
+    if (rc != LG_OK) return rc;
+    return read_back(c, out, c->sub.d_q, (size_t)c->batch * c->k * sizeof(fr));
+}
+
+}  // extern "C"
+
+// buffers of the linear test: d_scratch_a = r_a rows | their coefficients, d_scratch_b = planes
+static int linear_buffers(lg_ctx* c, uint32_t* per_out, uint32_t* nch_out) {
+    const uint64_t R = c->total_rows;
+    const size_t mat = (size_t)R * c->k;
+    *nch_out = sub_chunks(c->rows, per_out);
+    int rc = sub_buffers(c, (size_t)c->batch * *nch_out * 2 * c->k, 1);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->scr.a, &c->scr.a_elems, 2 * mat);
+    if (rc != LG_OK) return rc;
+    // the planes s = 4 (mod 8) of the r_a rows' encodings, slot s >> 3 (an eighth of a codeword matrix, not a whole one)
+    return grow(c, &c->scr.b, &c->scr.b_elems, (size_t)((c->nplanes + 7) / 8) * R * c->ki);
+}
+// plane_mask: the planes s = 0 (mod 4) to serve (all of them, or the owned ones of a sharded context); points_out set =
+// stop before the interpolation and hand back the 2k point values (slots of planes outside the mask are zero)
+static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out);
+// the planes of the size-2k evaluation domain (s = 0 mod 4) a sub-proof call on this context serves
+static uint32_t sub_plane_mask(const lg_ctx* c) { return (c->shard.on ? own_planes_mask(c) : all_planes_mask(c)) & 0x11111111u; }
+static int sub_points_begin(lg_ctx* c) {   // unserved slots of the point array read as zero
+    if (!c->sub.d_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->sub.d_q), (size_t)c->batch * 2 * c->k * sizeof(fr)));
+    LG_HIP(c, hipMemsetAsync(c->sub.d_q, 0, (size_t)c->batch * 2 * c->k * sizeof(fr), c->st.main));
+    return LG_OK;
+}
+
+extern "C" {
+
+int lg_linear_constraint_poly(lg_ctx* c, const uint64_t* r_a, uint64_t* coeffs_out) {
+    if (!c || !r_a || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_linear_constraint_poly(c->gf, r_a, coeffs_out); }
+    if (!c->held.committed) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    uint32_t per, nch;
+    int rc = linear_buffers(c, &per, &nch);
+    if (rc != LG_OK) return rc;
+    LG_HIP(c, hipMemcpyAsync(c->scr.a, r_a, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+    return linear_core(c, per, nch, all_planes_mask(c) & 0x11111111u, coeffs_out, nullptr);
+}
+
+int lg_upload_constraint_matrix(lg_ctx* c, uint64_t num_rows, uint64_t nnz, const uint64_t* row_idx, const uint64_t* col_idx, const uint64_t* values) {
+    if (!c || (nnz && (!row_idx || !col_idx || !values))) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    const uint64_t cols = (uint64_t)c->rows * c->k;   // 4 m k
+    if (num_rows > 0xffffffffull || nnz > 0xffffffffull) return LG_ERR_UNSUPPORTED;
+    for (uint64_t e = 0; e < nnz; e++)
+        if (row_idx[e] >= num_rows || col_idx[e] >= cols) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    // COO -> CSC (counting sort by column; duplicates stay duplicates, the product adds them up like row_mul does)
+    std::vector<uint32_t> colptr(cols + 1, 0), erow(nnz);
+    std::vector<fr> eval(nnz);
+    for (uint64_t e = 0; e < nnz; e++) colptr[col_idx[e] + 1]++;
+    for (uint64_t cc = 0; cc < cols; cc++) colptr[cc + 1] += colptr[cc];
+    std::vector<uint32_t> fill(colptr.begin(), colptr.end() - 1);
+    for (uint64_t e = 0; e < nnz; e++) {
+        const uint32_t pos = fill[col_idx[e]]++;
+        erow[pos] = (uint32_t)row_idx[e];
+        memcpy(eval[pos].v, values + 4 * e, sizeof(fr));
+    }
+    std::vector<uint32_t> heavy;
+    for (uint64_t cc = 0; cc < cols; cc++)
+        if (colptr[cc + 1] - colptr[cc] > lg::kHeavyColumn) heavy.push_back((uint32_t)cc);
+    // segments of the heavy columns: [seg_begin (nseg) | seg_end (nseg) | heavy_seg_ptr (nheavy + 1)]
+    std::vector<uint32_t> seg_begin, seg_end, heavy_seg_ptr{0};
+    for (uint32_t cc : heavy) {
+        for (uint32_t e = colptr[cc]; e < colptr[cc + 1]; e += lg::kHeavySegment) {
+            seg_begin.push_back(e);
+            seg_end.push_back(std::min(colptr[cc + 1], e + lg::kHeavySegment));
+        }
+        heavy_seg_ptr.push_back((uint32_t)seg_begin.size());
+    }
+    for (void* b : {(void*)c->amat.d_colptr, (void*)c->amat.d_row, (void*)c->amat.d_val, (void*)c->amat.d_heavy, (void*)c->amat.d_seg, (void*)c->amat.d_seg_partial})
+        if (b) LG_HIP(c, hipFree(b));
+    c->amat.d_colptr = nullptr; c->amat.d_row = nullptr; c->amat.d_val = nullptr; c->amat.d_heavy = nullptr; c->amat.d_seg = nullptr; c->amat.d_seg_partial = nullptr;
+    c->amat.loaded = false;
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->amat.d_heavy), (heavy.size() ? heavy.size() : 1) * 4));
+    if (!heavy.empty()) LG_HIP(c, hipMemcpy(c->amat.d_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice));
+    c->amat.nheavy = (uint32_t)heavy.size();
+    c->amat.nseg = (uint32_t)seg_begin.size();
+    if (c->amat.nseg) {
+        std::vector<uint32_t> seg(seg_begin);
+        seg.insert(seg.end(), seg_end.begin(), seg_end.end());
+        seg.insert(seg.end(), heavy_seg_ptr.begin(), heavy_seg_ptr.end());
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->amat.d_seg), seg.size() * 4));
+        LG_HIP(c, hipMemcpy(c->amat.d_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->amat.d_seg_partial), (size_t)c->batch * c->amat.nseg * sizeof(fr)));
+    }
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->amat.d_colptr), colptr.size() * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->amat.d_row), (nnz ? nnz : 1) * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->amat.d_val), (nnz ? nnz : 1) * sizeof(fr)));
+    LG_HIP(c, hipMemcpy(c->amat.d_colptr, colptr.data(), colptr.size() * 4, hipMemcpyHostToDevice));
+    if (nnz) {
+        LG_HIP(c, hipMemcpy(c->amat.d_row, erow.data(), nnz * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->amat.d_val, eval.data(), nnz * sizeof(fr), hipMemcpyHostToDevice));
+    }
+    c->amat.rows = num_rows; c->amat.nnz = nnz; c->amat.loaded = true;
+    return LG_OK;
+}
+
+}  // extern "C"
+
+// r_linear (ChaCha20 + F::rand from the seeds) and r_a = A.row_mul(r_linear) into d_scratch_a (launches only; the caller
+// checks the candidate-stream flag with linear_seed_flag once the stream has been synchronised)
+static int linear_ra_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t* per_out, uint32_t* nch_out) {
+    uint32_t per, nch;
+    int rc = linear_buffers(c, &per, &nch);
+    if (rc != LG_OK) return rc;
+    *per_out = per; *nch_out = nch;
+    const uint64_t n = (uint64_t)c->rows * c->k;      // entries of r_a per proof = columns of A this context holds
+    // entries of r_linear = rows of A.  The reference's A is square (4mk x 4mk); a context that holds only a row shard of the proof's
+    // matrix (row relay, blocks layout) holds the matching COLUMNS of A and still needs every challenge
+    const uint64_t rlen = c->amat.rows;
+    if (n > 0x7fffffffull || rlen > 0x7fffffffull) return LG_ERR_UNSUPPORTED;
+    // 75.6 % of the 32-byte chunks are accepted; 1.5 chunks per element leaves > 50 standard deviations of margin
+    const uint32_t blocks = (uint32_t)((rlen * 3 + 3) / 4 + 64), wgs = (blocks + 255) / 256;
+    if (!c->chal.d_seeds) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_seeds), (size_t)c->batch * 32));
+    if (!c->chal.d_short_flag) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_short_flag), 4));
+    if (c->chal.counts_cap < (size_t)c->batch * wgs) {
+        if (c->chal.d_counts) LG_HIP(c, hipFree(c->chal.d_counts));
+        c->chal.d_counts = nullptr;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_counts), (size_t)c->batch * wgs * 4));
+        c->chal.counts_cap = (size_t)c->batch * wgs;
+    }
+    rc = grow(c, &c->chal.d_rlin, &c->chal.rlin_elems, (size_t)c->batch * rlen);
+    if (rc != LG_OK) return rc;
+    if (seeds) LG_HIP(c, hipMemcpyAsync(c->chal.d_seeds, seeds, (size_t)c->batch * 32, hipMemcpyHostToDevice, c->st.main));   // (null: a device transcript wrote them)
+    if (seeds) LG_HIP(c, hipMemsetAsync(c->chal.d_short_flag, 0, 4, c->st.main));   // (a device transcript checks the flag once per proof batch)
+    lg::ChaChaArgs a;
+    a.seeds = c->chal.d_seeds; a.out = c->chal.d_rlin; a.counts = c->chal.d_counts; a.short_flag = c->chal.d_short_flag;
+    a.n = (uint32_t)rlen; a.blocks = blocks; a.wgs = wgs;
+    LG_LAUNCH(c, lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
+    LG_LAUNCH(c, lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
+    lg::SparseRowMulArgs m;
+    m.col_ptr = c->amat.d_colptr; m.ent_row = c->amat.d_row; m.ent_val = c->amat.d_val;
+    m.r = c->chal.d_rlin; m.out = c->scr.a; m.heavy = c->amat.d_heavy; m.cols = (uint32_t)n; m.rows_in = (uint32_t)rlen;
+    LG_LAUNCH(c, lg::sparse_row_mul_kernel, dim3((uint32_t)((n + 255) / 256), c->batch), dim3(256), 0, c->st.main, m);
+    if (c->amat.nheavy) {
+        lg::HeavySegArgs h;
+        h.m = m;
+        h.seg_begin = c->amat.d_seg; h.seg_end = c->amat.d_seg + c->amat.nseg; h.heavy_seg_ptr = c->amat.d_seg + 2 * (size_t)c->amat.nseg;
+        h.seg_partial = c->amat.d_seg_partial; h.nseg = c->amat.nseg;
+        LG_LAUNCH(c, lg::sparse_row_mul_heavy_segments_kernel, dim3(c->amat.nseg, c->batch), dim3(256), 0, c->st.main, h);
+        LG_LAUNCH(c, lg::sparse_row_mul_heavy_finish_kernel, dim3(c->amat.nheavy, c->batch), dim3(256), 0, c->st.main, h);
+    }
+    return LG_OK;
+}
+static int linear_seed_flag(lg_ctx* c) {
+    uint32_t flag = 0;
+    LG_HIP(c, hipMemcpy(&flag, c->chal.d_short_flag, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        snprintf(c->err, sizeof(c->err), "ChaCha candidate stream too short for %llu elements", (unsigned long long)c->rows * c->k);
+        return LG_ERR_STATE;
+    }
+    return LG_OK;
+}
+static int linear_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
+    uint32_t per, nch;
+    int rc = linear_ra_from_seeds(c, seeds, &per, &nch);
+    if (rc != LG_OK) return rc;
+    rc = linear_core(c, per, nch, plane_mask, coeffs_out, points_out);   // synchronises on the stream when it reads the result back
+    if (rc != LG_OK) return rc;
+    return linear_seed_flag(c);
+}
+
+extern "C" {
+
+// The VERIFIER's side of the linear test (mod.rs:748-830) on the device: r_linear from the seed, r_a = A.row_mul(r_linear), every
+// r_a row interpolated and encoded on the large domain (mod.rs:773-781, 815-818), and for each opened column j the sum
+// sum_i r_i(eta_j) * U[i][j] with the column the proof carries.  The encodings go where a commitment's codeword matrix lives,
+// so a commitment this context held is void afterwards.
+int lg_verifier_linear_sums_from_seed(lg_ctx* c, const uint8_t* seed, const uint32_t* idx, uint32_t t, const uint64_t* cols, uint64_t* sums_out) {
+    if (!c || !seed || (t && (!idx || !cols || !sums_out))) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (c->shard.on) {
+        snprintf(c->err, sizeof(c->err), "lg_verifier_linear_sums_from_seed needs room for every coset plane; a sharded context holds [%u, %u)", c->shard.plane0,
+                 c->shard.plane0 + c->shard.planes);
+        return LG_ERR_STATE;
+    }
+    if (!c->amat.loaded) return LG_ERR_STATE;
+    for (uint32_t i = 0; i < t; i++)
+        if (idx[i] >= c->n) return LG_ERR_BAD_ARG;
+    if (t == 0) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    // nothing of an earlier commit may still be reading or writing U, the leaves or the tree
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    for (hipStream_t st : {c->st.hash, c->st.hash2, c->st.tree})
+        if (st) LG_HIP(c, hipStreamSynchronize(st));
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    c->held.committed = false; c->held.staging = false; c->held.planes = 0;
+    uint32_t per, nch;
+    int rc = linear_ra_from_seeds(c, seed, &per, &nch);
+    if (rc != LG_OK) return rc;
+    const uint64_t R = c->total_rows;
+    const size_t mat = (size_t)R * c->k;
+    const uint64_t plane = R * c->ki;
+    fr* d_ra = c->scr.a;
+    fr* d_rc = c->scr.a + mat;
+    {
+        lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, (uint32_t)R);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->st.main, a));
+        lg::NttArgs e = eval_args(c, d_rc, c->d_u, plane, 0, (uint32_t)R, true);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->st.main, e));
+    }
+    // gathered[c][i] = r_i(eta_j) for the opened j (Montgomery), next to the proof's columns
+    rc = grow(c, &c->scr.c, &c->scr.c_elems, 2 * (size_t)t * c->rows);
+    if (rc != LG_OK) return rc;
+    if (c->scr.idx_cap < t) {
+        if (c->scr.d_idx) LG_HIP(c, hipFree(c->scr.d_idx));
+        c->scr.d_idx = nullptr; c->scr.idx_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->scr.d_idx), (size_t)t * sizeof(uint32_t)));
+        c->scr.idx_cap = t;
+    }
+    fr* d_gath = c->scr.c;
+    fr* d_cols = c->scr.c + (size_t)t * c->rows;
+    LG_HIP(c, hipMemcpyAsync(c->scr.d_idx, idx, (size_t)t * sizeof(uint32_t), hipMemcpyHostToDevice, c->st.main));
+    LG_HIP(c, hipMemcpyAsync(d_cols, cols, (size_t)t * c->rows * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+    // (the gather also copies sibling digests and paths -- pieces of a stale tree here, never read: they get real memory to land in)
+    const uint32_t plen = (uint32_t)c->logn - 1;
+    const size_t path_bytes = (size_t)t * (plen + 1) * 32;
+    if (c->scr.path_cap < path_bytes) {
+        if (c->scr.d_path) LG_HIP(c, hipFree(c->scr.d_path));
+        c->scr.d_path = nullptr; c->scr.path_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->scr.d_path), path_bytes));
+        c->scr.path_cap = path_bytes;
+    }
+    rc = gather_columns_launch(c, 0, 1, c->scr.d_idx, t, d_gath, c->scr.d_path, c->scr.d_path + (size_t)t * 32);
+    if (rc != LG_OK) return rc;
+    // sums[c] = sum_i gathered[c][i] (*) cols[c][i]: "columns" of the row-sum kernel = the t openings, its rows = the 4m entries
+    const uint32_t nchs = sub_chunks(c->rows, &per);
+    rc = sub_buffers(c, std::max<size_t>((size_t)nchs * t, (size_t)nch * 2 * c->k), 1);
+    if (rc != LG_OK) return rc;
+    rc = grow(c, &c->sub.d_r, &c->sub.r_elems, t);       // the t sums
+    if (rc != LG_OK) return rc;
+    lg::RowSumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = d_gath; a.a_row = 1; a.a_col = c->rows;
+    a.b = d_cols; a.b_row = 1; a.b_col = c->rows;
+    a.partial = c->sub.d_partial;
+    a.rows = c->rows; a.cols = t; a.rows_per_chunk = per; a.nchunks = nchs;
+    LG_LAUNCH(c, lg::rowsum_mul_kernel, dim3((t + 255) / 256, nchs, 1), dim3(256), 0, c->st.main, a);
+    // Montgomery x Montgomery -> Montgomery already: multiply by one (R) only to normalise
+    LG_LAUNCH(c, lg::rowsum_finish_kernel, dim3((t + 255) / 256, 1, 1), dim3(256), 0, c->st.main, c->sub.d_partial, nchs, t, to_dev(lg_host::kOneMont), c->sub.d_r,
+              1u, 0u, (uint64_t)t);
+    rc = read_back(c, sums_out, c->sub.d_r, (size_t)t * sizeof(fr));
+    if (rc != LG_OK) return rc;
+    return linear_seed_flag(c);
+}
+
+int lg_linear_constraint_poly_from_seeds(lg_ctx* c, const uint8_t* seeds, uint64_t* coeffs_out) {
+    if (!c || !seeds || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (!c->held.committed || !c->amat.loaded) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_linear_constraint_poly_from_seeds"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    return linear_from_seeds(c, seeds, all_planes_mask(c) & 0x11111111u, coeffs_out, nullptr);
+}
+
+}  // extern "C"
+
+static int linear_core(lg_ctx* c, uint32_t per, uint32_t nch, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
+    const uint32_t rows = c->rows, O = 1u << c->logo;
+    const uint64_t R = c->total_rows;
+    const size_t mat = (size_t)R * c->k;
+    int rc = LG_OK;
+    fr* d_ra = c->scr.a;
+    fr* d_rc = c->scr.a + mat;
+    // r_polys = small_domain.ifft(row) (mod.rs:726-729), then their values on the odd points of the
+    // size-2k domain = planes s = 4 (mod 8) of their encoding
+    const uint64_t plane = R * c->ki;
+    {
+        lg::NttArgs a = interp_args(c, d_ra, d_rc, nullptr, 0, (uint32_t)R);
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->st.main, a));
+        // one launch per computed plane, each into its own slot: the kernel addresses plane s at out + s * plane_stride
+        for (uint32_t s = 4; s < c->nplanes; s += 8) {
+            if (!(plane_mask & (1u << s))) continue;
+            lg::NttArgs e = eval_args(c, d_rc, c->scr.b + (uint64_t)(s >> 3) * plane - (uint64_t)s * plane, plane, 0, (uint32_t)R, true);
+            e.ncos = 1;
+            e.cosets[0] = (uint8_t)s;
+            LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->st.main, e));
+        }
+    }
+    if (points_out) { rc = sub_points_begin(c); if (rc != LG_OK) return rc; }
+    for (uint32_t s = 0; s < c->nplanes; s += 4) {
+        if (!(plane_mask & (1u << s))) continue;
+        lg::RowSumArgs a;
+        memset(&a, 0, sizeof(a));
+        a.a = c->d_u + (uint64_t)s * plane; a.a_proof = (uint64_t)rows * c->ki; a.a_row = c->ki; a.a_col = 1;   // u_i on this plane (canonical)
+        if ((s & 7) == 0) {  // message plane 8c': r_i there = r_a[i][O j + c'] (Montgomery)
+            a.b = d_ra + (s >> 3); a.b_proof = (uint64_t)rows * c->k; a.b_row = c->k; a.b_col = O;
+        } else {             // computed plane (canonical)
+            a.b = c->scr.b + (uint64_t)(s >> 3) * plane; a.b_proof = (uint64_t)rows * c->ki; a.b_row = c->ki; a.b_col = 1;
+        }
+        a.partial = c->sub.d_partial;
+        a.rows = rows; a.cols = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
+        hipLaunchKernelGGL(lg::rowsum_mul_kernel, dim3((c->ki + 255) / 256, nch, c->batch), dim3(256), 0, c->st.main, a);
+        LG_HIP(c, hipGetLastError());
+        // canonical x Montgomery = plain -> x R^2; canonical x canonical = plain / R -> x R^3; point index j = (np/4) q + s/4
+        rc = sub_finish(c, nch, c->ki, (s & 7) == 0 ? c->tab.r2 : c->tab.r3, c->sub.d_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);
+        if (rc != LG_OK) return rc;
+    }
+    if (points_out) return read_back(c, points_out, c->sub.d_q, (size_t)c->batch * 2 * c->k * sizeof(fr));
+    return sub_interpolate_2k(c, coeffs_out);
+}
+
+static int quadratic_core(lg_ctx* c, const uint64_t* r, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out);
+extern "C" {
+
+int lg_quadratic_constraint_poly(lg_ctx* c, const uint64_t* r, uint64_t* coeffs_out) {
+    if (!c || !r || !coeffs_out) return LG_ERR_BAD_ARG;
+    if (c->gf) { LG_HIP(c, hipSetDevice(c->device)); return gf_quadratic_constraint_poly(c->gf, r, coeffs_out); }
+    if (!c->held.committed) return LG_ERR_STATE;
+    if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    { const int rc_ = need_planes(c, all_planes_mask(c) & 0x11111111u, "lg_quadratic_constraint_poly"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    return quadratic_core(c, r, all_planes_mask(c) & 0x11111111u, coeffs_out, nullptr);
+}
+
+}  // extern "C"
+
+static int quadratic_core(lg_ctx* c, const uint64_t* r, uint32_t plane_mask, uint64_t* coeffs_out, uint64_t* points_out) {
+    const uint32_t m = c->rows / 4;
+    uint32_t per;
+    const uint32_t nch = sub_chunks(m, &per);
+    int rc = sub_buffers(c, (size_t)c->batch * nch * 2 * c->k, (size_t)c->batch * m);
+    if (rc != LG_OK) return rc;
+    if (r) LG_HIP(c, hipMemcpyAsync(c->sub.d_r, r, (size_t)c->batch * m * sizeof(fr), hipMemcpyHostToDevice, c->st.main));   // (null: generated on the device)
+    const uint64_t plane = c->total_rows * c->ki;
+    if (points_out) { rc = sub_points_begin(c); if (rc != LG_OK) return rc; }
+    for (uint32_t s = 0; s < c->nplanes; s += 4) {
+        if (!(plane_mask & (1u << s))) continue;
+        lg::QuadSumArgs a;
+        memset(&a, 0, sizeof(a));
+        a.u = c->d_u + (uint64_t)s * plane;
+        a.r = c->sub.d_r;
+        a.partial = c->sub.d_partial;
+        a.r2 = c->tab.r2;
+        a.m = m; a.ki = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
+        hipLaunchKernelGGL(lg::quadsum_kernel, dim3((c->ki + 255) / 256, nch, c->batch), dim3(256), 0, c->st.main, a);
+        LG_HIP(c, hipGetLastError());
+        rc = sub_finish(c, nch, c->ki, c->tab.r2, c->sub.d_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);   // plain -> Montgomery
+        if (rc != LG_OK) return rc;
+    }
+    if (points_out) return read_back(c, points_out, c->sub.d_q, (size_t)c->batch * 2 * c->k * sizeof(fr));
+    return sub_interpolate_2k(c, coeffs_out);
+}
+
+extern "C" {
+
+// ---- the same three sums as POINT VALUES on the planes this context holds (coset-sharded commitments) --------
+// The polynomials above are interpolated from their values at the size-2k domain, codeword indices 4 j, j = (np/4) q + s/4 for
+// plane s = 0 (mod 4).  Every such value is a sum over ALL rows of data of ONE plane, so the rank owning the plane computes
+// it alone; the host layer all-gathers the 2k-slot arrays (slot j belongs to plane 4 (j mod np/4)) and any rank interpolates.
+// preenc_u.row_mul(r) is the same thing on the planes s = 0 (mod 8): message position p is codeword index 8 p, slot 2 p.
+int lg_subproof_points(lg_ctx* c, int which, const void* challenge, uint64_t* points_out, uint32_t* plane_mask_out) {
+    if (!c || !challenge || !points_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;   // generic-field contexts serve the hot path only
+    if (c->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (!c->held.committed) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    uint32_t mask = sub_plane_mask(c);
+    if (which == LG_SUB_INTERLEAVED) mask &= 0x01010101u;
+    if (plane_mask_out) *plane_mask_out = mask;
+    { const int rc_ = need_planes(c, mask, "lg_subproof_points"); if (rc_ != LG_OK) return rc_; }
+    LG_HIP(c, hipSetDevice(c->device));
+    int rc = LG_OK;
+    switch (which) {
+        case LG_SUB_INTERLEAVED: {
+            uint32_t per;
+            const uint32_t nch = sub_chunks(c->rows, &per);
+            rc = sub_buffers(c, (size_t)nch * 2 * c->k, c->total_rows);
+            if (rc != LG_OK) return rc;
+            LG_HIP(c, hipMemcpyAsync(c->sub.d_r, challenge, (size_t)c->total_rows * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+            rc = sub_points_begin(c);
+            if (rc != LG_OK) return rc;
+            const uint64_t plane = c->total_rows * c->ki;
+            for (uint32_t s = 0; s < c->nplanes; s += 8) {
+                if (!(mask & (1u << s))) continue;
+                lg::RowSumArgs a;
+                memset(&a, 0, sizeof(a));
+                a.a = c->d_u + (uint64_t)s * plane; a.a_proof = (uint64_t)c->rows * c->ki; a.a_row = c->ki; a.a_col = 1;   // canonical
+                a.b = nullptr; a.r = c->sub.d_r;                                                                        // Montgomery
+                a.partial = c->sub.d_partial;
+                a.rows = c->rows; a.cols = c->ki; a.rows_per_chunk = per; a.nchunks = nch;
+                LG_LAUNCH(c, lg::rowsum_mul_kernel, dim3((c->ki + 255) / 256, nch, 1), dim3(256), 0, c->st.main, a);
+                rc = sub_finish(c, nch, c->ki, c->tab.r2, c->sub.d_q, c->nplanes / 4, s / 4, 2 * (uint64_t)c->k);   // plain -> Montgomery
+                if (rc != LG_OK) return rc;
+            }
+            return read_back(c, points_out, c->sub.d_q, (size_t)2 * c->k * sizeof(fr));
+        }
+        case LG_SUB_LINEAR: {
+            if (mask == 0) { memset(points_out, 0, (size_t)2 * c->k * sizeof(fr)); return LG_OK; }
+            uint32_t per, nch;
+            rc = linear_buffers(c, &per, &nch);
+            if (rc != LG_OK) return rc;
+            LG_HIP(c, hipMemcpyAsync(c->scr.a, challenge, (size_t)c->total_rows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+            return linear_core(c, per, nch, mask, nullptr, points_out);
+        }
+        case LG_SUB_LINEAR_FROM_SEED:
+            if (mask == 0) { memset(points_out, 0, (size_t)2 * c->k * sizeof(fr)); return LG_OK; }   // no plane, no work (and no matrix needed)
+            if (!c->amat.loaded) return LG_ERR_STATE;
+            return linear_from_seeds(c, static_cast<const uint8_t*>(challenge), mask, nullptr, points_out);
+        case LG_SUB_QUADRATIC:
+            if ((c->rows & 3) != 0) return LG_ERR_BAD_ARG;
+            if (mask == 0) { memset(points_out, 0, (size_t)2 * c->k * sizeof(fr)); return LG_OK; }
+            return quadratic_core(c, static_cast<const uint64_t*>(challenge), mask, nullptr, points_out);
+        default: return LG_ERR_BAD_ARG;
+    }
+}
+
+int lg_subproof_finish(lg_ctx* c, int which, const uint64_t* points, uint64_t* out) {
+    if (!c || !points || !out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->batch != 1) return LG_ERR_UNSUPPORTED;
+    if (which == LG_SUB_INTERLEAVED) {   // the values at the message positions are the result
+        for (uint32_t p = 0; p < c->k; p++) memcpy(out + 4 * (size_t)p, points + 4 * (size_t)(2 * p), sizeof(fr));
+        return LG_OK;
+    }
+    if (which != LG_SUB_LINEAR && which != LG_SUB_LINEAR_FROM_SEED && which != LG_SUB_QUADRATIC) return LG_ERR_BAD_ARG;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    LG_HIP(c, hipSetDevice(c->device));
+    if (!c->sub.d_q) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->sub.d_q), (size_t)2 * c->k * sizeof(fr)));
+    LG_HIP(c, hipMemcpyAsync(c->sub.d_q, points, (size_t)2 * c->k * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+    return sub_interpolate_2k(c, out);
+}
+
+}  // extern "C"
+
+// ---- the same with challenges that never left the device (batch_prover.hip): launches only, results stay in
+// sub.aux2k->d_coeffs; the candidate-stream flag (chal.d_short_flag) is the caller's to check once it synchronises
+int linear_from_device_seeds(lg_ctx* c) {
+    if (!c->held.committed || !c->amat.loaded) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    if (!c->chal.d_seeds) return LG_ERR_STATE;
+    uint32_t per, nch;
+    int rc = linear_ra_from_seeds(c, nullptr, &per, &nch);
+    if (rc != LG_OK) return rc;
+    return linear_core(c, per, nch, all_planes_mask(c) & 0x11111111u, nullptr, nullptr);
+}
+int quadratic_on_device(lg_ctx* c) {
+    if (!c->held.committed || (c->rows & 3) != 0) return LG_ERR_STATE;
+    if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
+    return quadratic_core(c, nullptr, all_planes_mask(c) & 0x11111111u, nullptr, nullptr);
+}

@@ -27,7 +27,7 @@ struct RowSumArgs {
 };
 
 // partial[p][chunk][c] = sum_{i in chunk} A[p][i][c] (*) B[p][i][c]     ((*) = Montgomery product)
-__global__ void __launch_bounds__(256) rowsum_mul_kernel(RowSumArgs a) {
+static __global__ void __launch_bounds__(256) rowsum_mul_kernel(RowSumArgs a) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t chunk = blockIdx.y, p = blockIdx.z;
     if (c >= a.cols) return;
@@ -59,7 +59,7 @@ struct QuadSumArgs {
 };
 
 // partial[p][chunk][q] = sum_{i in chunk} r_i (x_i y_i - z_i) as a plain integer (not Montgomery)
-__global__ void __launch_bounds__(256) quadsum_kernel(QuadSumArgs a) {
+static __global__ void __launch_bounds__(256) quadsum_kernel(QuadSumArgs a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t chunk = blockIdx.y, p = blockIdx.z;
     if (q >= a.ki) return;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) quadsum_kernel(QuadSumArgs a) {
 }
 
 // out[p * out_proof + c * out_stride + out_off] = (sum_chunks partial[p][chunk][c]) (*) post, fully reduced
-__global__ void __launch_bounds__(256) rowsum_finish_kernel(const fr* partial, uint32_t nchunks, uint32_t cols, fr post, fr* out,
+static __global__ void __launch_bounds__(256) rowsum_finish_kernel(const fr* partial, uint32_t nchunks, uint32_t cols, fr post, fr* out,
                                                            uint32_t out_stride, uint32_t out_off, uint64_t out_proof) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;

@@ -1,0 +1,285 @@
+// a1 on the device (src/ligero/mod.rs:483-551): the commit from the solution vector w alone -- x, y, z are gathered from w and
+// the circuit's wiring (lg_upload_gate_map), only w crosses PCIe.
+#include "lg_context.h"
+
+namespace lg {
+
+// a1 on the device (mod.rs:483-516): x, y, z are functions of w and the circuit's wiring -- x[p] / y[p] = the values of the
+// operands of the Mul gate at position p (a position of w, or a constant that has no position), z[p] = w[p]; zero elsewhere
+struct WitnessGatherArgs {
+    fr* pre;                 // [batch][4 m][k]: blocks X, Y, Z, W; W is read, X / Y / Z are written
+    const uint32_t* left;    // [m k]: kGateNone, kGateConst | index into consts, or a position of w
+    const uint32_t* right;
+    const fr* consts;
+    uint64_t mk;             // m * k
+    uint64_t pos0, pos1;     // positions [pos0, pos1) of every proof
+    uint32_t batch;
+};
+constexpr uint32_t kGateNone = 0xffffffffu, kGateConst = 0x80000000u;
+__global__ void __launch_bounds__(256) witness_gather_kernel(const WitnessGatherArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t span = a.pos1 - a.pos0;
+    if (gid >= span * a.batch) return;
+    const uint64_t pos = a.pos0 + gid % span;
+    fr* base = a.pre + (gid / span) * 4 * a.mk;
+    const fr* w = base + 3 * a.mk;
+    const uint32_t l = a.left[pos], r = a.right[pos];
+    fr x, y, z;
+    if (l == kGateNone) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x.v[i] = 0;
+        y = x; z = x;
+    } else {
+        x = (l & kGateConst) ? fr_load(a.consts + (l & ~kGateConst)) : fr_load(w + l);
+        y = (r & kGateConst) ? fr_load(a.consts + (r & ~kGateConst)) : fr_load(w + r);
+        z = fr_load(w + pos);
+    }
+    fr_store(base + pos, x);
+    fr_store(base + a.mk + pos, y);
+    fr_store(base + 2 * a.mk + pos, z);
+}
+
+}  // namespace lg
+
+extern "C" {
+
+int lg_upload_gate_map(lg_ctx* c, uint64_t npos, const uint32_t* left, const uint32_t* right, const uint64_t* constants, uint32_t nconst) {
+    if (!c || (npos && (!left || !right)) || (nconst && !constants)) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->shard.on || (c->rows & 3)) return LG_ERR_STATE;
+    const uint64_t mk = (uint64_t)(c->rows / 4) * c->k;
+    if (npos > mk || nconst >= lg::kGateConst) return LG_ERR_BAD_ARG;
+    bool backward = true;
+    for (uint64_t p = 0; p < npos; p++) {
+        const uint32_t l = left[p], r = right[p];
+        if ((l == lg::kGateNone) != (r == lg::kGateNone)) return LG_ERR_BAD_ARG;
+        if (l == lg::kGateNone) continue;
+        for (uint32_t s : {l, r}) {
+            if (s & lg::kGateConst) { if ((s & ~lg::kGateConst) >= nconst) return LG_ERR_BAD_ARG; }
+            else { if (s >= npos) return LG_ERR_BAD_ARG; if (s >= p) backward = false; }
+        }
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    // the map counts as loaded only after the LAST copy below succeeded; a failed re-upload leaves none (and no partial buffers)
+    c->gate.loaded = false;
+    auto release = [&]() {
+        for (void* b : {(void*)c->gate.d_left, (void*)c->gate.d_right, (void*)c->gate.d_consts})
+            if (b) (void)hipFree(b);
+        c->gate.d_left = c->gate.d_right = nullptr; c->gate.d_consts = nullptr; c->gate.npos = 0;
+    };
+    release();
+    auto upload = [&]() -> int {
+    // positions past the solution vector (the zero padding up to m k, mod.rs:506-509) are no gates
+    std::vector<uint32_t> pad(mk - npos, lg::kGateNone);
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->gate.d_left), mk * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->gate.d_right), mk * 4));
+    LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->gate.d_consts), (nconst ? nconst : 1) * sizeof(fr)));
+    if (npos) {
+        LG_HIP(c, hipMemcpy(c->gate.d_left, left, npos * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->gate.d_right, right, npos * 4, hipMemcpyHostToDevice));
+    }
+    if (mk > npos) {
+        LG_HIP(c, hipMemcpy(c->gate.d_left + npos, pad.data(), (mk - npos) * 4, hipMemcpyHostToDevice));
+        LG_HIP(c, hipMemcpy(c->gate.d_right + npos, pad.data(), (mk - npos) * 4, hipMemcpyHostToDevice));
+    }
+    if (nconst) LG_HIP(c, hipMemcpy(c->gate.d_consts, constants, (size_t)nconst * sizeof(fr), hipMemcpyHostToDevice));
+        return LG_OK;
+    };
+    const int rc = upload();
+    if (rc != LG_OK) { release(); return rc; }
+    c->gate.npos = npos; c->gate.nconst = nconst; c->gate.backward = backward; c->gate.loaded = true;
+    return LG_OK;
+}
+
+}  // extern "C"
+
+// x, y, z of positions [pos0, pos1) of every proof from the W block already in d_preenc
+static int witness_gather(lg_ctx* c, uint64_t pos0, uint64_t pos1) {
+    if (pos1 <= pos0) return LG_OK;
+    lg::WitnessGatherArgs g;
+    g.pre = c->d_preenc; g.left = c->gate.d_left; g.right = c->gate.d_right; g.consts = c->gate.d_consts;
+    g.mk = (uint64_t)(c->rows / 4) * c->k; g.pos0 = pos0; g.pos1 = pos1; g.batch = c->batch;
+    const uint64_t threads = (pos1 - pos0) * c->batch;
+    LG_LAUNCH(c, lg::witness_gather_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->st.main, g);
+    return LG_OK;
+}
+
+// The commit (mod.rs:483-551) from w alone.  Only the W block crosses PCIe (a quarter of preenc_u); it travels in row steps,
+// and as soon as step j is there the X, Y, Z rows of the same positions are gathered and the X and Y rows of the step are
+// encoded (one launch for both blocks) -- with circuits whose gates refer backwards only, as compiled circuits do, a gate's
+// operands have arrived with or before its own position -- so the transfer hides behind encoding.  A column's Blake2s absorbs
+// the rows in order (X block first).  Large commits hash step by step on the hash stream, each launch held back until the NEXT
+// step's evaluation starts: a short kernel (an interpolation) that runs beside a hash launch is stretched to the hash's length
+// -- its workgroups on the CUs the hash occupies get what the older hash waves leave -- while the long evaluations absorb it
+// (measured: rocprofv3 timeline).  Small commits (one chunk in plan_chunks' terms: both kernels issue bound,
+// nothing to gain from running them side by side) hash once at the end on the encode stream.
+int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs) {
+    if (c->shard.on) return LG_ERR_STATE;
+    if (!c->gate.loaded) {
+        snprintf(c->err, sizeof(c->err), "lg_encode_commit_from_witness needs the circuit's gate map (lg_upload_gate_map)");
+        return LG_ERR_STATE;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    const uint32_t m = c->rows / 4;
+    const uint64_t mk = (uint64_t)m * c->k, plane = c->total_rows * c->ki;
+    const size_t wbytes = (size_t)c->batch * mk * sizeof(fr);
+    Chunk resident_plan[lg_ctx::kMaxChunks];
+    const bool small = plan_chunks(c, resident_plan) == 1;
+    // Steps of the W upload (row ranges of the W block = position ranges of all four blocks).  The first step's transfer has nothing
+    // to hide behind and the last rows' hash has nothing left to hide it: both ends taper (weights 1, 2, 3, 3, 3 of the upload;
+    // 4, 3, 2, 1 of the W block's rows).  LG_WITNESS_STEPS / LG_WITNESS_TAIL override the counts (experiments).
+    static const int env_steps = [] { const char* e = getenv("LG_WITNESS_STEPS"); return e ? atoi(e) : 0; }();
+    static const int env_tail = [] { const char* e = getenv("LG_WITNESS_TAIL"); return e ? atoi(e) : 0; }();
+    uint32_t J = wbytes >= (size_t{64} << 20) ? 5 : (wbytes >= (size_t{8} << 20) ? 3 : 1);
+    if (env_steps > 0) J = (uint32_t)std::min(env_steps, 5);
+    if (!c->gate.backward) J = 1;                      // forward references: the whole of w first
+    if (J > m) J = m;
+    uint32_t CW = small ? 1 : 4, CZ = small ? 1 : 2;   // rows of the Z and W blocks: chunks as large commits are cut anyway
+    if (env_tail > 0) CW = (uint32_t)std::min(env_tail, 4);
+    if (CW > m) CW = m;
+    if (CZ > m) CZ = m;
+    auto cuts = [&](uint32_t parts, const uint32_t* weight) {   // row boundaries 0 = b[0] < ... < b[parts] = m by cumulative weight
+        std::vector<uint32_t> bnd(parts + 1, 0);
+        uint64_t total = 0, acc = 0;
+        for (uint32_t i = 0; i < parts; i++) total += weight[i];
+        for (uint32_t i = 0; i < parts; i++) {
+            acc += weight[i];
+            bnd[i + 1] = (i + 1 == parts) ? m : std::max<uint32_t>(bnd[i] + 1, (uint32_t)((uint64_t)m * acc / total));
+            if (bnd[i + 1] > m) bnd[i + 1] = m;
+        }
+        return bnd;
+    };
+    static const uint32_t w_up[5][5] = {{1}, {1, 2}, {1, 2, 3}, {1, 2, 3, 3}, {1, 2, 3, 3, 3}};
+    static const uint32_t w_tail[4][4] = {{1}, {2, 1}, {3, 2, 1}, {4, 3, 2, 1}};
+    static const uint32_t w_even[2] = {1, 1};
+    const std::vector<uint32_t> ub = cuts(J, w_up[J - 1]), zb = cuts(CZ, w_even), wb = cuts(CW, w_tail[CW - 1]);
+    // encode steps: rows [r0, r1) of `blocks` consecutive blocks of every proof (blocks = 2: the X and the Y block) in one launch
+    struct Step { uint32_t r0, r1, blocks; int upload; };
+    std::vector<Step> enc;
+    // (a small commit hashes at the end anyway, so nothing is gained by finishing the X block early: every step encodes its rows of
+    // all four blocks -- the Z rows are gathered with the step, the W rows are the upload itself -- and the whole encoding overlaps
+    // the transfer)
+    for (uint32_t j = 0; j < J; j++) enc.push_back(Step{ub[j], ub[j + 1], small ? 4u : 2u, (int)j});
+    if (!small) {
+        for (uint32_t j = 0; j < CZ; j++) enc.push_back(Step{2 * m + zb[j], 2 * m + zb[j + 1], 1, -1});
+        for (uint32_t j = 0; j < CW; j++) enc.push_back(Step{3 * m + wb[j], 3 * m + wb[j + 1], 1, -1});
+    }
+    // hash launches in row order: (rows, index of the encode step that completes them)
+    struct HashStep { uint32_t r0, r1; size_t after; };
+    std::vector<HashStep> hashes;
+    if (small) {
+        hashes.push_back(HashStep{0, c->rows, enc.size() - 1});
+    } else {
+        for (uint32_t j = 0; j < J; j++) hashes.push_back(HashStep{ub[j], ub[j + 1], j});
+        hashes.push_back(HashStep{m, 2 * m, (size_t)J - 1});
+        for (size_t i = J; i < enc.size(); i++) hashes.push_back(HashStep{enc[i].r0, enc[i].r1, i});
+    }
+    hipStream_t hs = small ? c->st.main : c->st.hash;
+    // earlier work on the encode stream may still read d_preenc; the previous commit's tree may still read the leaves
+    LG_HIP(c, hipEventRecord(c->evt.done, c->st.main));
+    LG_HIP(c, hipStreamWaitEvent(c->st.up, c->evt.done, 0));
+    if (!small) LG_HIP(c, hipStreamWaitEvent(hs, c->evt.done, 0));
+    auto upload = [&](uint32_t j) -> int {
+        const uint32_t a = ub[j], b = ub[j + 1];
+        const size_t width = (size_t)(b - a) * c->k * sizeof(fr);
+        LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + ((size_t)3 * m + a) * c->k * sizeof(fr), (size_t)c->rows * c->k * sizeof(fr),
+                                   reinterpret_cast<const uint8_t*>(host_w) + (size_t)a * c->k * sizeof(fr), (size_t)mk * sizeof(fr), width, c->batch,
+                                   hipMemcpyHostToDevice, c->st.up));
+        LG_HIP(c, hipEventRecord(c->evt.up[j], c->st.up));
+        return LG_OK;
+    };
+    auto hash_launch = [&](const HashStep& hr) -> int {
+        lg::ColHashArgs h;
+        memset(&h, 0, sizeof(h));
+        h.u = reinterpret_cast<const uint4*>(c->d_u);
+        h.leaves = c->d_leaves;
+        h.state = c->d_hstate;
+        h.rows = c->rows; h.k = c->ki; h.lognp = (uint32_t)c->lognp;
+        h.proof_begin = 0; h.proof_count = c->batch;
+        h.row_begin = hr.r0; h.row_end = hr.r1;
+        h.first = hr.r0 == 0;
+        h.last = hr.r1 == c->rows;
+        h.plane_begin = 0; h.plane_count = c->nplanes;
+        h.plane_stride = plane;
+        h.col_pos = hr.r0; h.col_rows = c->rows;
+        { const int rc_ = colhash_launch(c, hs, h, h.first && h.last); if (rc_ != LG_OK) return rc_; }
+        return LG_OK;
+    };
+    { const int rc_ = upload(0); if (rc_ != LG_OK) return rc_; }
+    size_t next_hash = 0;
+    for (size_t i = 0; i < enc.size(); i++) {
+        const Step& st = enc[i];
+        if (st.upload >= 0) {
+            LG_HIP(c, hipStreamWaitEvent(c->st.main, c->evt.up[st.upload], 0));
+            const int rc_ = witness_gather(c, (uint64_t)st.r0 * c->k, (uint64_t)st.r1 * c->k);
+            if (rc_ != LG_OK) return rc_;
+        }
+        const uint32_t span = st.r1 - st.r0, nrows = c->batch * st.blocks * span;
+        lg::NttArgs ia = interp_args(c, c->d_preenc, c->d_coeffs, c->d_u, st.r0, nrows);
+        ia.chunk_rows = span;
+        ia.proof_stride = c->rows;
+        ia.blk_count = st.blocks; ia.blk_stride = m;
+        ia.plane_stride = plane;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, false, c->st.main, ia));
+        if (host_coeffs) LG_HIP(c, hipEventRecord(c->evt.coef[i % lg_ctx::kMaxChunks], c->st.main));
+        if (!small && next_hash < hashes.size() && hashes[next_hash].after < i) {
+            // the hashes of the rows complete by now start together with the evaluation below
+            LG_HIP(c, hipEventRecord(c->evt.stage_in, c->st.main));
+            LG_HIP(c, hipStreamWaitEvent(hs, c->evt.stage_in, 0));
+            while (next_hash < hashes.size() && hashes[next_hash].after < i) {
+                const int rc_ = hash_launch(hashes[next_hash++]);
+                if (rc_ != LG_OK) return rc_;
+            }
+        }
+        lg::NttArgs a = eval_args(c, c->d_coeffs, c->d_u, plane, st.r0, nrows, false);
+        a.chunk_rows = span;
+        a.proof_stride = c->rows;
+        a.blk_count = st.blocks; a.blk_stride = m;
+        LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->st.main, a));
+        // the next step's rows start travelling (issued after this step's kernels: a copy from pageable memory blocks this thread)
+        if (st.upload >= 0 && (uint32_t)st.upload + 1 < J) { const int rc_ = upload((uint32_t)st.upload + 1); if (rc_ != LG_OK) return rc_; }
+        if (host_coeffs) {
+            LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->evt.coef[i % lg_ctx::kMaxChunks], 0));
+            const size_t pitch = (size_t)c->rows * c->k * sizeof(fr), width = (size_t)span * c->k * sizeof(fr);
+            for (uint32_t blk = 0; blk < st.blocks; blk++) {
+                const size_t off = ((size_t)st.r0 + (size_t)blk * m) * c->k * sizeof(fr);
+                LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(host_coeffs) + off, pitch, reinterpret_cast<const uint8_t*>(c->d_coeffs) + off, pitch, width,
+                                           c->batch, hipMemcpyDeviceToHost, c->st.dn));
+            }
+        }
+    }
+    if (!small) {
+        LG_HIP(c, hipEventRecord(c->evt.stage_in, c->st.main));
+        LG_HIP(c, hipStreamWaitEvent(hs, c->evt.stage_in, 0));
+    }
+    while (next_hash < hashes.size()) {
+        const int rc_ = hash_launch(hashes[next_hash++]);
+        if (rc_ != LG_OK) return rc_;
+    }
+    { const int rc_ = merkle_launches(c, hs); if (rc_ != LG_OK) return rc_; }
+    if (!small) {
+        LG_HIP(c, hipEventRecord(c->evt.done, hs));
+        LG_HIP(c, hipStreamWaitEvent(c->st.main, c->evt.done, 0));
+    }
+    c->held.complete(all_planes_mask(c), c->rows);
+    if (host_coeffs) LG_HIP(c, hipStreamSynchronize(c->st.dn));
+    return LG_OK;
+}
+
+extern "C" {
+
+int lg_encode_commit_from_witness(lg_ctx* c, const uint64_t* w, uint64_t* coeffs_out, uint8_t* root_out) {
+    if (!c || !w || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    const int rc = commit_from_witness(c, w, coeffs_out);
+    if (rc != LG_OK) {
+        if (rc != LG_ERR_STATE) c->held.committed = false;
+        return rc;
+    }
+    return lg_read_root(c, root_out);
+}
+
+}  // extern "C"

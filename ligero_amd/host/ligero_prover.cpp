@@ -120,7 +120,19 @@ int lgp_batch_prover_create(lgp_batch_prover** out, const lgh_instance* inst, ui
     *out = nullptr;
     return guarded([&] { *out = new lgp_batch_prover(inst->inst, batch, device, threads); return LGP_OK; });
 }
+int lgp_batch_prover_create_ex(lgp_batch_prover** out, const lgh_instance* inst, uint32_t batch, int device, uint32_t threads, uint32_t flags) {
+    if (!out || !inst || batch == 0 || (flags & ~(uint32_t)LGP_BATCH_DEVICE_TRANSCRIPT)) return LGP_ERR_BAD_ARG;
+    *out = nullptr;
+    return guarded([&] { *out = new lgp_batch_prover(inst->inst, batch, device, threads, (flags & LGP_BATCH_DEVICE_TRANSCRIPT) != 0); return LGP_OK; });
+}
 void lgp_batch_prover_destroy(lgp_batch_prover* p) { delete p; }
+int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_proof_layout* layout_out) {
+    if (!p || !base_out || !layout_out) return LGP_ERR_BAD_ARG;
+    if (!p->hip.device_transcript()) { g_err = "this batch prover keeps its transcript on the host: no arena"; return LGP_ERR_BAD_ARG; }
+    *base_out = p->hip.arena();
+    *layout_out = p->hip.layout();
+    return LGP_OK;
+}
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p) { return p ? p->hip.threads() : 0; }
 
 int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out) {
@@ -136,7 +148,15 @@ int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_
                 std::memcpy(v.l, values + 4 * ((uint64_t)b * count + i), 32);
                 va[b].emplace_back((size_t)node_idx[i], v);
             }
+        if (p->hip.device_transcript() && !proofs_out) {
+            // the proofs stay where the device put them (lgp_batch_proof_arena); a handle copies its proof out when asked for
+            p->hip.prove_to_arena(va);
+            p->views.assign(B, lgp_proof());
+            p->view_made.assign(B, 0);
+            return LGP_OK;
+        }
         const std::vector<LigeroProof>& proofs = p->hip.prove(va);
+        p->view_made.assign(B, 1);
         if (proofs_out)
             for (uint32_t b = 0; b < B; b++) {
                 proofs_out[b] = new lgp_proof();
@@ -148,7 +168,19 @@ int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_
     });
 }
 const lgp_proof* lgp_batch_proof(const lgp_batch_prover* p, uint32_t b) {
-    return (p && b < p->views.size()) ? &p->views[b] : nullptr;
+    if (!p || b >= p->views.size()) return nullptr;
+    if (b < p->view_made.size() && !p->view_made[b]) {
+        lgp_batch_prover* q = const_cast<lgp_batch_prover*>(p);   // (a cache behind a read-only interface; one reader at a time, as for the prover itself)
+        try {
+            q->views[b].own = q->hip.materialize(b);
+            q->views[b].view = &q->views[b].own;
+            q->view_made[b] = 1;
+        } catch (const std::exception& e) {
+            g_err = e.what();
+            return nullptr;
+        }
+    }
+    return &p->views[b];
 }
 
 int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_out[32]) {

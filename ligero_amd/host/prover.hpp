@@ -1037,38 +1037,118 @@ private:
 
 class HipLigeroBatch {
 public:
-    HipLigeroBatch(const LigeroInstance& inst, uint32_t batch, int device = 0, unsigned threads = 0)
-        : inst_(inst), batch_(batch), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t) {
+    // device_transcript: the Fiat-Shamir transcript runs on the device too (include/ligero_hip.h lg_prove_batch_queue): the host
+    // builds w and nothing else, the proofs land in page-locked memory this prover owns (arena()).  Same proofs.
+    HipLigeroBatch(const LigeroInstance& inst, uint32_t batch, int device = 0, unsigned threads = 0, bool device_transcript = false)
+        : inst_(inst), batch_(batch), m_(inst.m), k_(inst.k), n_(inst.n), t_(inst.t), device_transcript_(device_transcript) {
         if (batch == 0) throw std::runtime_error("HipLigeroBatch: batch must be positive");
         const int st = lg_ctx_create_batched(&ctx_, device, (uint32_t)(4 * m_), (uint32_t)k_, (uint32_t)n_, batch);
         if (st != LG_OK) throw DeviceError(st, "lg_ctx_create_batched");
-        while ((size_t{1} << logn_) < n_) logn_++;
-        upload_constraint_matrix(ctx_, inst.a);
-        from_witness_ = upload_gate_map(ctx_, inst) && !preenc_on_host();
-        threads_ = threads ? threads : std::max(1u, std::min(usable_cpus(), batch));
-        pool_.reset(new WorkerPool(threads_));
-        mat_.resize((size_t)batch_ * (from_witness_ ? 1 : 4) * m_ * k_);
-        cols_.resize((size_t)batch_ * t_ * 4 * m_);
-        // page-lock the two big staging buffers so the PCIe copies overlap the kernels (lg_encode_commit streams)
-        // (each registration is tracked on its own: a buffer must never be freed while still page-locked)
-        pinned_mat_ = lg_host_register(ctx_, mat_.data(), mat_.size() * sizeof(Fr)) == LG_OK;
-        pinned_cols_ = lg_host_register(ctx_, cols_.data(), cols_.size() * sizeof(Fr)) == LG_OK;
+        try {
+            while ((size_t{1} << logn_) < n_) logn_++;
+            upload_constraint_matrix(ctx_, inst.a);
+            from_witness_ = upload_gate_map(ctx_, inst) && (device_transcript_ || !preenc_on_host());
+            threads_ = threads ? threads : std::max(1u, std::min(usable_cpus(), batch));
+            pool_.reset(new WorkerPool(threads_));
+            mat_.resize((size_t)batch_ * (from_witness_ ? 1 : 4) * m_ * k_);
+            // page-lock the big staging buffers so the PCIe copies overlap the kernels
+            // (each registration is tracked on its own: a buffer must never be freed while still page-locked)
+            pinned_mat_ = lg_host_register(ctx_, mat_.data(), mat_.size() * sizeof(Fr)) == LG_OK;
+            if (device_transcript_) {
+                if (!from_witness_) throw std::runtime_error("HipLigeroBatch: the device transcript needs the circuit's gate map on the device");
+                const PoseidonSponge sp = PoseidonSponge::test_sponge();
+                lg_sponge_params par;
+                par.full_rounds = (uint32_t)sp.full_rounds(); par.partial_rounds = (uint32_t)sp.partial_rounds(); par.alpha = sp.alpha();
+                par.ark = sp.ark()[0][0].l; par.mds = sp.mds()[0][0].l;
+                check(lg_prover_setup(ctx_, &par, (uint32_t)t_), "lg_prover_setup");
+                check(lg_prover_layout(ctx_, &layout_), "lg_prover_layout");
+                arena_.resize(layout_.total_bytes);
+                pinned_arena_ = lg_host_register(ctx_, arena_.data(), arena_.size()) == LG_OK;
+            } else {
+                cols_.resize((size_t)batch_ * t_ * 4 * m_);
+                pinned_cols_ = lg_host_register(ctx_, cols_.data(), cols_.size() * sizeof(Fr)) == LG_OK;
+            }
+        } catch (...) {   // a constructor that throws runs no destructor
+            release();
+            throw;
+        }
     }
-    ~HipLigeroBatch() {
-        if (pinned_mat_) lg_host_unregister(ctx_, mat_.data());
-        if (pinned_cols_) lg_host_unregister(ctx_, cols_.data());
-        lg_ctx_destroy(ctx_);
-    }
+    ~HipLigeroBatch() { release(); }
     HipLigeroBatch(const HipLigeroBatch&) = delete;
     HipLigeroBatch& operator=(const HipLigeroBatch&) = delete;
     uint32_t batch() const { return batch_; }
     unsigned threads() const { return threads_; }
+
+    bool device_transcript() const { return device_transcript_; }
+    // ---- device transcript: the batch as it lies in page-locked host memory (layout: include/ligero_hip.h lg_proof_layout),
+    // valid until the next prove_to_arena()
+    const uint8_t* arena() const { return arena_.data(); }
+    const lg_proof_layout& layout() const { return layout_; }
+    void prove_to_arena(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
+        if (!device_transcript_) throw std::runtime_error("HipLigeroBatch::prove_to_arena: created without the device transcript");
+        if (assignments.size() != batch_) throw std::runtime_error("HipLigeroBatch::prove: one assignment per proof of the batch");
+        PhaseTimer tm;
+        parallel_for(batch_, [&](size_t b) {
+            std::vector<std::pair<size_t, Fr>> bumped;
+            bumped.reserve(assignments[b].size());
+            for (const auto& v : assignments[b]) bumped.emplace_back(inst_.bump_index(v.first), v.second);
+            inst_.build_w_from_formatted(bumped, &mat_[b * m_ * k_]);
+        });
+        tm.mark("w (host)");
+        check(lg_prove_batch_queue(ctx_, mat_[0].l, arena_.data()), "lg_prove_batch_queue");
+        tm.mark("queue (host)");
+        check(lg_prove_batch_wait(ctx_, arena_.data()), "lg_prove_batch_wait");
+        tm.mark("proofs (device)");
+    }
+    // proof b of the arena as the host's proof object (a copy: tests, the verifier)
+    LigeroProof materialize(size_t b) const {
+        const lg_proof_layout& L = layout_;
+        const uint8_t* A = arena_.data();
+        const size_t rows = 4 * m_, plen = L.path_len;
+        LigeroProof p;
+        memcpy(p.u_root.data(), A + L.off_roots + 32 * b, 32);
+        auto elems = [&](uint64_t off, size_t first, size_t count) {
+            std::vector<Fr> v(count);
+            if (count) memcpy(v.data(), A + off + first * sizeof(Fr), count * sizeof(Fr));
+            return v;
+        };
+        p.interleaved_proof.preenc_u_lc = elems(L.off_lc, b * k_, k_);
+        uint32_t lens[2];
+        memcpy(&lens[0], A + L.off_poly_lens + 4 * b, 4);
+        memcpy(&lens[1], A + L.off_poly_lens + 4 * (batch_ + b), 4);
+        p.linear_constraints_proof.polynomial = elems(L.off_linear_poly, b * 2 * k_, lens[0]);
+        p.quadratic_constraints_proof.polynomial = elems(L.off_quadratic_poly, b * 2 * k_, lens[1]);
+        OpenedColumns* opens[3] = {&p.interleaved_proof.open, &p.linear_constraints_proof.open, &p.quadratic_constraints_proof.open};
+        for (int o = 0; o < 3; o++) {
+            OpenedColumns& oc = *opens[o];
+            oc.columns.resize(t_);
+            oc.paths.resize(t_);
+            for (size_t c = 0; c < t_; c++) {
+                const size_t e = b * t_ + c;
+                oc.columns[c] = elems(L.off_columns[o], e * rows, rows);
+                MerklePath& mp = oc.paths[c];
+                uint32_t li;
+                memcpy(&li, A + L.off_idx[o] + 4 * e, 4);
+                mp.leaf_index = li;
+                memcpy(mp.leaf_sibling_hash.data(), A + L.off_siblings[o] + 32 * e, 32);
+                mp.auth_path.resize(plen);
+                for (size_t l = 0; l < plen; l++) memcpy(mp.auth_path[l].data(), A + L.off_paths[o] + 32 * (e * plen + l), 32);
+            }
+        }
+        return p;
+    }
 
     // The proofs live in storage the prover owns and reuses from call to call (fresh memory for 64 proofs is 330 MB
     // of page faults, which with 32 host threads costs more than the proving): valid until the next prove().
     const std::vector<LigeroProof>& prove(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
         if (assignments.size() != batch_) throw std::runtime_error("HipLigeroBatch::prove: one assignment per proof of the batch");
         const size_t B = batch_, rows = 4 * m_, mat = rows * k_;
+        if (device_transcript_) {   // (callers that want proof objects: the arena copied out)
+            prove_to_arena(assignments);
+            proofs_.resize(B);
+            parallel_for(B, [&](size_t b) { proofs_[b] = materialize(b); });
+            return proofs_;
+        }
         PhaseTimer tm;
         std::vector<LigeroProof>& proofs = proofs_;
         proofs.resize(B);
@@ -1135,6 +1215,14 @@ public:
     }
 
 private:
+    void release() {
+        if (!ctx_) return;
+        if (pinned_mat_) lg_host_unregister(ctx_, mat_.data());
+        if (pinned_cols_) lg_host_unregister(ctx_, cols_.data());
+        if (pinned_arena_) lg_host_unregister(ctx_, arena_.data());
+        lg_ctx_destroy(ctx_);
+        ctx_ = nullptr;
+    }
     void check(int st, const char* what) const {
         if (st != LG_OK) throw DeviceError(st, std::string(what) + " (" + lg_last_error(ctx_) + ")");
     }
@@ -1202,8 +1290,11 @@ private:
     size_t m_, k_, n_, t_;
     int logn_ = 0;
     unsigned threads_ = 1;
-    bool pinned_mat_ = false, pinned_cols_ = false;
+    bool device_transcript_ = false;
+    bool pinned_mat_ = false, pinned_cols_ = false, pinned_arena_ = false;
     bool from_witness_ = false;   // gate map on the device: mat_ holds w of every proof only
+    lg_proof_layout layout_{};
+    std::vector<uint8_t> arena_;  // device transcript: the batch of proofs as the device wrote it
     lg_ctx* ctx_ = nullptr;
     std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u
     std::vector<LigeroProof> proofs_;

@@ -308,6 +308,12 @@ public:
         bytes.resize(n);
         return bytes;
     }
+    // the parameters, for a device that runs the same sponge (include/ligero_hip.h lg_prover_setup)
+    size_t full_rounds() const { return full_rounds_; }
+    size_t partial_rounds() const { return partial_rounds_; }
+    uint64_t alpha() const { return alpha_; }
+    const std::vector<std::array<Fr, 3>>& ark() const { return ark_; }
+    const std::array<std::array<Fr, 3>, 3>& mds() const { return mds_; }
     std::array<uint8_t, 32> squeeze_seed() {
         const std::vector<uint8_t> b = squeeze_bytes(kChachaSeedBytes);
         std::array<uint8_t, 32> s;

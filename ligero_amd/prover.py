@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -42,6 +42,8 @@ def lib():
         L.lgp_proof_destroy.restype = None
         L.lgp_proof_info.argtypes = [_vp, _vp, _vp]
         L.lgp_batch_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
+        L.lgp_batch_prover_create_ex.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.lgp_batch_proof_arena.argtypes = [_vp, ctypes.POINTER(_vp), _vp]
         L.lgp_batch_prover_destroy.argtypes = [_vp]
         L.lgp_batch_prover_destroy.restype = None
         L.lgp_batch_prover_threads.argtypes = [_vp]
@@ -257,12 +259,15 @@ def proofs_equal(a: Proof, b: Proof) -> bool:
 class LigeroBatchProver:
     """throughput mode: `batch` proofs of one circuit per call (include/ligero_prover.h)"""
 
-    def __init__(self, instance: LigeroInstance, batch: int, device: int = 0, threads: int = 0):
+    def __init__(self, instance: LigeroInstance, batch: int, device: int = 0, threads: int = 0, device_transcript: bool = False):
+        """device_transcript: Fiat-Shamir on the device too (one lane per proof): the host only assembles w; same proofs"""
         self._L = lib()
         self._inst = instance
         self.batch = batch
+        self.device_transcript = bool(device_transcript)
         self._h = _vp()
-        _check(self._L.lgp_batch_prover_create(ctypes.byref(self._h), instance._h, batch, device, threads), "lgp_batch_prover_create")
+        _check(self._L.lgp_batch_prover_create_ex(ctypes.byref(self._h), instance._h, batch, device, threads, 1 if device_transcript else 0),
+               "lgp_batch_prover_create_ex")
         self.threads = int(self._L.lgp_batch_prover_threads(self._h))
 
     def close(self):

@@ -53,6 +53,12 @@ int lg_host_unregister(lg_ctx*, void*) { return LG_OK; }
 int lg_sync(lg_ctx*) { return LG_OK; }
 int lg_upload_constraint_matrix(lg_ctx*, uint64_t, uint64_t, const uint64_t*, const uint64_t*, const uint64_t*) { return LG_OK; }
 int lg_upload_gate_map(lg_ctx*, uint64_t, const uint32_t*, const uint32_t*, const uint64_t*, uint32_t) { return LG_OK; }
+// the device-transcript entry points: the batch prover under this sanitizer run keeps its transcript on the host (the race
+// detector watches the HOST phases), so these only have to link
+int lg_prover_setup(lg_ctx*, const lg_sponge_params*, uint32_t) { return LG_ERR_UNSUPPORTED; }
+int lg_prover_layout(const lg_ctx*, lg_proof_layout*) { return LG_ERR_UNSUPPORTED; }
+int lg_prove_batch_queue(lg_ctx*, const uint64_t*, void*) { return LG_ERR_UNSUPPORTED; }
+int lg_prove_batch_wait(lg_ctx*, const void*) { return LG_ERR_UNSUPPORTED; }
 int lg_encode_commit(lg_ctx* c, const uint64_t* pre, uint64_t* coeffs, uint8_t* root) {
     const size_t per = (size_t)c->rows * c->k * 32;
     for (uint32_t b = 0; b < c->batch; b++) fill(root + 32 * b, 32, digest_of(reinterpret_cast<const uint8_t*>(pre) + b * per, per), false);

@@ -559,8 +559,8 @@ def test_column_hash_kernels_agree_with_oracle(lg, oracle, monkeypatch, quad, ro
 @pytest.mark.parametrize("rows,k,batch", [(9, 128, 1), (6, 64, 3)])
 def test_zero_copy_producer_fills_preenc_then_commits_resident(lg, oracle, rows, k, batch):
     """the route include/ligero_hip.h documents for zero-copy producers: write LG_BUF_PREENC through lg_device_buffer on a
-    FRESH context, lg_commit_resident, root = oracle (the message-row gate must not refuse it); and again after a
-    staged commit narrowed the held row range"""
+    FRESH context, say so (lg_preenc_mark_filled), lg_commit_resident, root = oracle; and again after a staged commit narrowed
+    the held row range"""
     import ctypes
     import torch
     from ligero_amd import _ffi
@@ -577,6 +577,17 @@ def test_zero_copy_producer_fills_preenc_then_commits_resident(lg, oracle, rows,
             t = torch.as_tensor(_CudaArray(ptr.value, size.value), device="cuda:0")
             t.copy_(torch.from_numpy(pre.view(np.uint8).reshape(-1)))
             torch.cuda.synchronize()
+            _ffi.check(L.lg_preenc_mark_filled(c._ctx), "lg_preenc_mark_filled", c._ctx)
+        # a fresh context holds no row: committing to uninitialised memory is refused, and asking for the buffer's
+        # address changes nothing about that
+        with pytest.raises(_ffi.LigeroHipError) as e0:
+            c.commit_resident()
+        assert e0.value.status == _ffi.LG_ERR_STATE
+        ptr0, size0 = ctypes.c_void_p(), ctypes.c_size_t()
+        _ffi.check(L.lg_device_buffer(c._ctx, _ffi.LG_BUF_PREENC, ctypes.cast(ctypes.byref(ptr0), ctypes.c_void_p), ctypes.cast(ctypes.byref(size0), ctypes.c_void_p)),
+                   "lg_device_buffer", c._ctx)
+        with pytest.raises(_ffi.LigeroHipError):
+            c.commit_resident()
         fill()
         c.commit_resident()
         assert c.root() == want

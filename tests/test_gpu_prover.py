@@ -123,6 +123,38 @@ def test_batch_prover_matches_single_prover(poseidon, oracle, vectors):
         assert [v.info()["u_root"].hex() for v in views2] == vectors["poseidon_batch64_roots"][:3]
 
 
+@pytest.mark.parametrize("B", [64, 3, 70])
+def test_device_transcript_batch_prover_equals_the_host_transcript_provers(poseidon, oracle, vectors, B):
+    """throughput mode with Fiat-Shamir ON THE DEVICE (lg_prove_batch_queue: sponge, challenge draws and index sampling one lane
+    per proof, no host round trip inside a proof): every proof equals the single prover's field for field -- root, preenc_u_lc,
+    both polynomials, all three openings with their paths -- and verifies; a second batch on the same prover (staging buffers
+    and the arena reused), a batch that does not fill a wave and one that needs two; an unsatisfying witness gives the same
+    (rejected) proof as the host-transcript prover"""
+    from ligero_amd.prover import LigeroBatchProver, proofs_equal
+    inst, prover, idx, vals = poseidon
+    blob = open(os.path.join(GOLDEN, "poseidon_witness_batch64.bin"), "rb").read()
+    ws = [[int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") for j in range(265)] for i in range(64)]
+    allv = np.stack([oracle.to_mont(oracle.ints_to_limbs(w[1:])) for w in ws])
+    sel = np.arange(B) % 64
+    with LigeroBatchProver(inst, B, device_transcript=True) as bp:
+        assert bp.device_transcript
+        proofs = bp.prove(idx, allv[sel])
+        assert [p.info()["u_root"].hex() for p in proofs] == [vectors["poseidon_batch64_roots"][i] for i in sel]
+        for b in sorted({0, 1, B // 2, B - 1}):
+            single = prover.prove(idx, allv[sel[b]])
+            assert proofs_equal(single, proofs[b]), b
+            assert prover.verify(proofs[b]), b
+        # second batch, other inputs, one of them unsatisfying; read through borrowed handles (copied out of the arena on first use)
+        sel2 = (sel[::-1] + 5) % 64
+        bad = allv[sel2].copy()
+        bad[1][10] = bad[1][11]
+        views = bp.prove(idx, bad, copy=False)
+        for b in sorted({0, 1, B - 1}):
+            single = prover.prove(idx, bad[b])
+            assert proofs_equal(single, views[b]), b
+            assert prover.verify(views[b]) == (b != 1)
+
+
 # ---- the reference's own prove-and-verify tests on BN254 (src/ligero/tests.rs:144-170, 195-243, 245-362), same circuits
 # (src/arithmetic_circuit/tests.rs:51-108), same assignments, same negative case (first variable + 1)
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617

@@ -372,6 +372,36 @@ def test_one_rank_commit_in_pieces_holds_every_message_row(oracle):
         be.close()
 
 
+def test_resident_rows_note_is_void_after_a_staged_reallocation(oracle):
+    """lg_commit_sharded(rows) -> lg_stage_interpolate of fewer rows OUTSIDE the held range (which frees and
+    re-allocates the rows' buffer) -> lg_commit_sharded(NULL) must refuse with LG_ERR_STATE instead of interpolating `own` rows out
+    of the smaller buffer (an out-of-bounds device read); with the rows handed over again it commits as before.  Rank 1 of a
+    two-rank layout on its own (identity callbacks: the exchanged data is irrelevant to the state machine under test)."""
+    import ctypes
+    from ligero_amd import _ffi
+    from ligero_amd.sharded import HipStageBackend, _AG, _LgComm, _P2P
+    rows, k = 24, 64
+    pre = random_mont(91, rows * k).reshape(rows, k, 4)
+    be = HipStageBackend(rows, k, device=0, world=2, rank=1)       # owns rows [12, 24) and planes [4, 8)
+    L = _ffi.lib()
+    ag = _AG(lambda user, buf, n, stream: 0)
+    comm = _LgComm(2, 1, 0, None, ag, _P2P(), _P2P(), _P2P())
+    cp = ctypes.cast(ctypes.byref(comm), ctypes.c_void_p)
+    own = np.ascontiguousarray(pre[12:24])
+    try:
+        _ffi.check(L.lg_commit_sharded(be.c._ctx, cp, own.ctypes.data_as(ctypes.c_void_p), 1), "lg_commit_sharded", be.c._ctx)
+        root1 = be.c.root()
+        _ffi.check(L.lg_commit_sharded(be.c._ctx, cp, None, 1), "lg_commit_sharded (resident)", be.c._ctx)     # same layout: trusted
+        assert be.c.root() == root1
+        be.stage_interpolate(pre[0:4], 0, 4)                       # rows [0, 4) lie outside [12, 24): a 4-row allocation replaces the 12-row one
+        assert L.lg_commit_sharded(be.c._ctx, cp, None, 1) == _ffi.LG_ERR_STATE
+        assert b"no resident rows" in L.lg_last_error(be.c._ctx)
+        _ffi.check(L.lg_commit_sharded(be.c._ctx, cp, own.ctypes.data_as(ctypes.c_void_p), 1), "lg_commit_sharded", be.c._ctx)
+        assert be.c.root() == root1
+    finally:
+        be.close()
+
+
 def ligero_amd_committer(rows, k):
     import ligero_amd
     return ligero_amd.LigeroCommitter(rows=rows, k=k)
