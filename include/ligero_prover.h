@@ -89,6 +89,12 @@ int lgp_batch_prover_create(lgp_batch_prover** out, const lgh_instance* inst, ui
 enum { LGP_BATCH_DEVICE_TRANSCRIPT = 1 };
 int lgp_batch_prover_create_ex(lgp_batch_prover** out, const lgh_instance* inst, uint32_t batch, int device, uint32_t threads, uint32_t flags);
 int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_proof_layout* layout_out);
+/* lgp_prove_batch in two halves (device-transcript provers only): submit assembles w on the host threads and queues the batch
+ * on the device, collect waits for the OLDEST batch queued; at most two may be in flight.  submit(i + 1) before collect(i)
+ * keeps the device and PCIe busy while the host works.  After collect, lgp_batch_proof_arena / lgp_batch_proof show that batch
+ * (valid until the second submit after it). */
+int lgp_prove_batch_submit(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count);
+int lgp_prove_batch_collect(lgp_batch_prover* p);
 void lgp_batch_prover_destroy(lgp_batch_prover* p);
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p);
 int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out);

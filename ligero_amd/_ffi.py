@@ -75,10 +75,11 @@ def lib():
     # reports "No HIP GPUs are available" (observed on MI355X / ROCm 7).  The multi-GPU layer
     # (sharded.py) aliases our device buffers as torch tensors, so let torch's runtime load first
     # whenever torch is installed.  Nothing else here depends on torch.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if not os.environ.get("LIGERO_NO_TORCH_PRELOAD"):      # (experiments: which HIP runtime serves the library)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     L.lg_status_string.restype = ctypes.c_char_p
     L.lg_status_string.argtypes = [_int]

@@ -18,6 +18,8 @@
 // (page-locked) memory in the flat layout lg_prover_layout describes, where a host proof object can point at them.
 // Same transcript as ligero_amd/host/transcript.hpp (PARITY UNPINNED against the Rust crates, see there): the proofs equal
 // the host-transcript provers' field for field (tests/test_gpu_prover.py).
+#include <dlfcn.h>
+
 #include "lg_context.h"
 #include "challenge_kernels.h"
 #include "sponge_kernels.h"
@@ -30,29 +32,38 @@ struct lg_batch_prover_state {
     uint32_t* d_state = nullptr;    // [batch][lg::kSpongeWords]
     uint32_t* d_seeds = nullptr;    // [2][batch][8]: what one sponge launch squeezes
     uint32_t* d_bitmap = nullptr;   // [batch][n / 32]
-    uint32_t* d_idx = nullptr;      // [3][batch][t]
-    uint32_t* d_lens = nullptr;     // [2][batch]: trimmed lengths of the linear / quadratic polynomial
-    fr* d_cols[3] = {nullptr, nullptr, nullptr};        // [batch][t][rows] opened columns of the three sub-proofs
-    uint8_t* d_paths[3] = {nullptr, nullptr, nullptr};  // [batch][t][32] sibling digests, then [batch][t][plen][32] paths
+    // Staging of what goes home.  The opened columns of sub-proof o (with their indices, sibling digests and paths) leave as soon
+    // as they are gathered, from one of three buffers; the small items (roots, preenc_u_lc, the polynomials and their lengths, the
+    // status word) leave at the end of the batch from one of TWO buffers, so that the next batch -- queued before this one is
+    // waited for -- never stands behind a copy: the buffers mirror the layout's [off_roots, small_bytes) region byte for byte.
+    uint8_t* d_open[3] = {nullptr, nullptr, nullptr};    // [idx | columns | siblings | paths] of sub-proof o, each 64-byte aligned
+    uint64_t open_idx = 0, open_cols = 0, open_sib = 0, open_paths = 0, open_bytes = 0;   // offsets inside d_open[o]
+    uint8_t* d_small[2] = {nullptr, nullptr};
+    uint64_t small_bytes = 0;
     hipEvent_t ev_gathered[3] = {nullptr, nullptr, nullptr};   // on the encode stream: staging o is complete
     hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr};     // on the copy stream: staging o has left for the host
-    hipEvent_t ev_done = nullptr;                              // everything of the batch is in host memory
-    bool copied_valid = false, queued = false;
+    bool copied_valid = false;
+    // two batches may be in flight (the second queued before the first is waited for): a slot per batch
+    struct Slot { const void* out = nullptr; hipEvent_t done = nullptr; hipEvent_t small_copied = nullptr; bool busy = false, used = false; } slot[2];
+    uint64_t batches = 0;
+    uint32_t ship_blocks = 0;           // workgroups of the ship kernel; 0 = the runtime's copy (default_ship_blocks)
     lg_proof_layout layout;
 };
 
 static void bp_free(lg_ctx* c) {
     lg_batch_prover_state* b = c->bp;
     if (!b) return;
-    for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_idx, (void*)b->d_lens})
+    for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_small[0], (void*)b->d_small[1]})
         if (p) (void)hipFree(p);
     for (int o = 0; o < 3; o++) {
-        if (b->d_cols[o]) (void)hipFree(b->d_cols[o]);
-        if (b->d_paths[o]) (void)hipFree(b->d_paths[o]);
+        if (b->d_open[o]) (void)hipFree(b->d_open[o]);
         if (b->ev_gathered[o]) (void)hipEventDestroy(b->ev_gathered[o]);
         if (b->ev_copied[o]) (void)hipEventDestroy(b->ev_copied[o]);
     }
-    if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+    for (auto& sl : b->slot) {
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.small_copied) (void)hipEventDestroy(sl.small_copied);
+    }
     delete b;
     c->bp = nullptr;
 }
@@ -60,6 +71,35 @@ static void bp_free(lg_ctx* c) {
 void batch_prover_release(lg_ctx* c) { bp_free(c); }
 
 static uint64_t align64(uint64_t x) { return (x + 63) & ~uint64_t{63}; }
+
+// A copy kernel of our own with a SMALL grid, for runtimes that would otherwise copy with a blit kernel sized for the whole chip
+// (see default_ship_blocks below): beside that one a 0.4 ms quadsum_kernel took 7.5 ms (rocprofv3 timeline).
+namespace lg {
+constexpr int kShipSegs = 8;
+struct ShipArgs {
+    const lg_u32x4* src[kShipSegs];
+    lg_u32x4* dst[kShipSegs];       // device-visible addresses of page-locked host memory
+    uint64_t n16[kShipSegs];     // 16-byte units
+    uint32_t nseg;
+};
+static __global__ void __launch_bounds__(256) ship_kernel(const ShipArgs a) {
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+    for (uint32_t s = 0; s < a.nseg; s++) {
+        const lg_u32x4* __restrict__ src = a.src[s];
+        lg_u32x4* __restrict__ dst = a.dst[s];
+        const uint64_t n = a.n16[s];
+        uint64_t i = tid;
+        for (; i + 3 * nthreads < n; i += 4 * nthreads) {   // four loads in flight per lane
+            const lg_u32x4 v0 = src[i], v1 = src[i + nthreads], v2 = src[i + 2 * nthreads], v3 = src[i + 3 * nthreads];
+            __builtin_nontemporal_store(v0, dst + i);
+            __builtin_nontemporal_store(v1, dst + i + nthreads);
+            __builtin_nontemporal_store(v2, dst + i + 2 * nthreads);
+            __builtin_nontemporal_store(v3, dst + i + 3 * nthreads);
+        }
+        for (; i < n; i += nthreads) __builtin_nontemporal_store(src[i], dst + i);
+    }
+}
+}  // namespace lg
 
 static int chacha_elements(lg_ctx* c, const uint32_t* d_seeds, fr* d_out, uint32_t n) {
     // 75.6 % of the 32-byte chunks are accepted; 1.5 chunks per element + 64 blocks leaves > 50 standard deviations of margin
@@ -87,6 +127,41 @@ static int sponge_launch(lg_ctx* c, const lg::SpongeArgs& a) {
     return LG_OK;
 }
 
+// How the proofs go home (tools/d2h_probe.hip, profiles/r04_d2h_probe.log).  A copy the runtime gives to an SDMA engine runs at
+// 55-57 GB/s and does not disturb the chain at all; a copy done by shader code does -- the runtime's own blit kernel (its choice
+// when SDMA is off: HSA_ENABLE_SDMA=0, or the ROCm 7.0 runtime a PyTorch wheel bundles, which leaves SDMA off on this GPU
+// unless HSA_ENABLE_SDMA=1) and our ship_kernel alike -- HBM-bound kernels beside it run up to 3.5 x slower, and the small-grid
+// ship_kernel (8 workgroups: 46 GB/s) is then the lesser evil: 8 200 proofs/s against 5 900 with the runtime's blit, 10 000 with
+// SDMA (Poseidon, batches of 1024).  0 = the runtime's copy; LG_SHIP_BLOCKS overrides.
+static uint32_t default_ship_blocks() {
+    const char* sdma = getenv("HSA_ENABLE_SDMA");
+    if (sdma) return atoi(sdma) == 0 ? 8u : 0u;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&hipMemcpyAsync), &info) && info.dli_fname && strstr(info.dli_fname, "/torch/lib/")) return 8u;
+    return 0u;
+}
+
+// one ship launch on the copy stream: `nseg` (device source, host destination, bytes) triples, bytes a multiple of 16
+struct ShipSeg { const void* src; void* dst; uint64_t bytes; };
+static int ship(lg_ctx* c, const ShipSeg* seg, uint32_t nseg) {
+    lg::ShipArgs a;
+    memset(&a, 0, sizeof(a));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nseg; i++) {
+        a.src[i] = static_cast<const lg::lg_u32x4*>(seg[i].src); a.dst[i] = static_cast<lg::lg_u32x4*>(seg[i].dst); a.n16[i] = seg[i].bytes / 16;
+        total += a.n16[i];
+    }
+    a.nseg = nseg;
+    if (total == 0) return LG_OK;
+    if (c->bp->ship_blocks == 0) {   // the runtime's copy (an SDMA engine, when the runtime chooses one)
+        for (uint32_t i = 0; i < nseg; i++) LG_HIP(c, hipMemcpyAsync(seg[i].dst, seg[i].src, seg[i].bytes, hipMemcpyDeviceToHost, c->st.dn));
+        return LG_OK;
+    }
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(c->bp->ship_blocks, (total + 255) / 256);
+    LG_LAUNCH(c, lg::ship_kernel, dim3(blocks), dim3(256), 0, c->st.dn, a);
+    return LG_OK;
+}
+
 extern "C" {
 
 int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
@@ -101,6 +176,7 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     LG_HIP(c, hipSetDevice(c->device));
     LG_HIP(c, hipStreamSynchronize(c->st.main));
+    LG_HIP(c, hipStreamSynchronize(c->st.dn));
     bp_free(c);
     lg_batch_prover_state* b = new (std::nothrow) lg_batch_prover_state();
     if (!b) return LG_ERR_OOM;
@@ -108,6 +184,8 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
     auto body = [&]() -> int {
         b->t = t; b->plen = (uint32_t)c->logn - 1;
         b->full_rounds = sp->full_rounds; b->partial_rounds = sp->partial_rounds;
+        b->ship_blocks = default_ship_blocks();
+        if (const char* e = getenv("LG_SHIP_BLOCKS")) { const int v = atoi(e); if (v >= 0) b->ship_blocks = (uint32_t)v; }
         const uint32_t rounds = sp->full_rounds + sp->partial_rounds;
         auto fr_at = [](const uint64_t* base, size_t i) { lg_host::Fr x; memcpy(x.l, base + 4 * i, 32); return x; };
         std::vector<uint32_t> ark(27 * (size_t)rounds);
@@ -133,30 +211,12 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_mds), mds.size() * 4));
             LG_HIP(c, hipMemcpy(b->d_mds, mds.data(), mds.size() * 4, hipMemcpyHostToDevice));
         }
-        const size_t B = c->batch;
+        const uint64_t B = c->batch;
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_state), B * lg::kSpongeWords * 4));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_seeds), 2 * B * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_bitmap), B * (c->n >= 32 ? c->n / 32 : 1) * 4));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_idx), 3 * B * t * 4));
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_lens), 2 * B * 4));
-        for (int o = 0; o < 3; o++) {
-            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_cols[o]), B * t * c->rows * sizeof(fr)));
-            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_paths[o]), B * t * (b->plen + 1) * 32));
-            LG_HIP(c, hipEventCreateWithFlags(&b->ev_gathered[o], hipEventDisableTiming));
-            LG_HIP(c, hipEventCreateWithFlags(&b->ev_copied[o], hipEventDisableTiming));
-        }
-        LG_HIP(c, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
-        // everything the sub-proof calls would otherwise grow on first use (a buffer that grows under a challenge already written
-        // into it would lose it): row-sum partials, the challenge vector, the seeds and the candidate counters
-        {
-            const uint32_t per = std::max<uint32_t>(32, c->rows / 256), nch = (c->rows + per - 1) / per;
-            const int rc_ = sub_buffers(c, B * nch * 2 * c->k, c->total_rows);
-            if (rc_ != LG_OK) return rc_;
-        }
-        if (!c->chal.d_seeds) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_seeds), B * 32));
-        if (!c->chal.d_short_flag) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_short_flag), 4));
-        { const int rc_ = sub_aux2k(c); if (rc_ != LG_OK) return rc_; }
-        // the flat layout of a batch of proofs in host memory
+        // the flat layout of a batch of proofs in host memory: the small items first (one contiguous region), then per sub-proof
+        // [idx | columns | siblings | paths], the same way its staging buffer is laid out
         lg_proof_layout& L = b->layout;
         memset(&L, 0, sizeof(L));
         L.batch = c->batch; L.k = c->k; L.rows = c->rows; L.t = t; L.path_len = b->plen;
@@ -168,13 +228,43 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
         L.off_quadratic_poly = take(B * 2 * c->k * 32);
         L.off_poly_lens = take(2 * B * 4);
         L.off_status = take(64);
+        b->small_bytes = off;
+        b->open_idx = 0;
+        b->open_cols = align64(B * t * 4);
+        b->open_sib = b->open_cols + align64(B * t * (uint64_t)c->rows * 32);
+        b->open_paths = b->open_sib + align64(B * t * 32);
+        b->open_bytes = b->open_paths + align64(B * t * (uint64_t)b->plen * 32);
         for (int o = 0; o < 3; o++) {
-            L.off_idx[o] = take(B * t * 4);
-            L.off_columns[o] = take(B * t * (uint64_t)c->rows * 32);
-            L.off_siblings[o] = take(B * t * 32);
-            L.off_paths[o] = take(B * t * (uint64_t)b->plen * 32);
+            const uint64_t base = off;
+            L.off_idx[o] = base + b->open_idx;
+            L.off_columns[o] = base + b->open_cols;
+            L.off_siblings[o] = base + b->open_sib;
+            L.off_paths[o] = base + b->open_paths;
+            off += b->open_bytes;
         }
         L.total_bytes = off;
+        for (int i = 0; i < 2; i++) {
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_small[i]), b->small_bytes));
+            LG_HIP(c, hipMemset(b->d_small[i], 0, b->small_bytes));
+            LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].done, hipEventDisableTiming | hipEventBlockingSync));
+            LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].small_copied, hipEventDisableTiming));
+        }
+        for (int o = 0; o < 3; o++) {
+            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_open[o]), b->open_bytes));
+            LG_HIP(c, hipMemset(b->d_open[o], 0, b->open_bytes));
+            LG_HIP(c, hipEventCreateWithFlags(&b->ev_gathered[o], hipEventDisableTiming));
+            LG_HIP(c, hipEventCreateWithFlags(&b->ev_copied[o], hipEventDisableTiming));
+        }
+        // everything the sub-proof calls would otherwise grow on first use (a buffer that grows under a challenge already written
+        // into it would lose it): row-sum partials, the challenge vector, the seeds and the candidate counters
+        {
+            const uint32_t per = std::max<uint32_t>(32, c->rows / 256), nch = (c->rows + per - 1) / per;
+            const int rc_ = sub_buffers(c, B * nch * 2 * c->k, c->total_rows);
+            if (rc_ != LG_OK) return rc_;
+        }
+        if (!c->chal.d_seeds) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_seeds), B * 32));
+        if (!c->chal.d_short_flag) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->chal.d_short_flag), 4));
+        { const int rc_ = sub_aux2k(c); if (rc_ != LG_OK) return rc_; }
         return LG_OK;
     };
     const int rc = body();
@@ -198,47 +288,70 @@ int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
         return LG_ERR_STATE;
     }
     LG_HIP(c, hipSetDevice(c->device));
+    // a slot for this batch: at most two in flight, never two into the same host buffer
+    int si = -1;
+    for (int i = 0; i < 2; i++)
+        if (b->slot[i].busy && b->slot[i].out == proofs_out) {
+            snprintf(c->err, sizeof(c->err), "lg_prove_batch_queue: a batch into this buffer is still in flight (lg_prove_batch_wait first)");
+            return LG_ERR_STATE;
+        }
+    for (int i = 0; i < 2 && si < 0; i++)
+        if (!b->slot[i].busy) si = i;
+    if (si < 0) {
+        snprintf(c->err, sizeof(c->err), "lg_prove_batch_queue: two batches are in flight already (lg_prove_batch_wait one of them)");
+        return LG_ERR_STATE;
+    }
+    // the proofs are written by a kernel: the buffer must be page-locked and visible to the device
+    void* dev_out = nullptr;
+    if (hipHostGetDevicePointer(&dev_out, proofs_out, 0) != hipSuccess || !dev_out) {
+        (void)hipGetLastError();
+        snprintf(c->err, sizeof(c->err), "lg_prove_batch_queue: proofs_out must be page-locked host memory (lg_host_register)");
+        return LG_ERR_BAD_ARG;
+    }
+    uint8_t* out = static_cast<uint8_t*>(dev_out);
+    lg_batch_prover_state::Slot& slot = b->slot[si];
     const lg_proof_layout& L = b->layout;
-    uint8_t* out = static_cast<uint8_t*>(proofs_out);
     const uint32_t B = c->batch, m = c->rows / 4, t = b->t;
     hipStream_t s = c->st.main;
-    b->queued = true;
+    uint8_t* small = b->d_small[si];
     int rc = LG_OK;
+    // the small staging buffer of this slot was last read by the ship of two batches ago
+    if (slot.used) LG_HIP(c, hipStreamWaitEvent(s, slot.small_copied, 0));
     // 0. the candidate-stream flag of the three challenge draws of this batch
     LG_HIP(c, hipMemsetAsync(c->chal.d_short_flag, 0, 4, s));
     // 1. the commitment (mod.rs:483-551)
     rc = commit_from_witness(c, w, nullptr);
     if (rc != LG_OK) { if (rc != LG_ERR_STATE) c->held.drop(); return rc; }
-    LG_HIP(c, hipMemcpy2DAsync(out + L.off_roots, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, B, hipMemcpyDeviceToHost, s));
+    slot.busy = true; slot.used = true; slot.out = proofs_out;
+    b->batches++;
+    LG_HIP(c, hipMemcpy2DAsync(small + L.off_roots, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, B, hipMemcpyDeviceToDevice, s));
     lg::SpongeArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.state = b->d_state; sa.P = lg::PoseidonParams{b->d_ark, b->d_mds, b->full_rounds, b->partial_rounds};
     sa.seeds = b->d_seeds; sa.batch = B;
     const uint32_t* seed0 = b->d_seeds;
     const uint32_t* seed1 = b->d_seeds + (size_t)B * 8;
+    uint32_t* d_lens = reinterpret_cast<uint32_t*>(small + L.off_poly_lens);
     // 2. absorb(u_root); squeeze the interleaved test's seed (mod.rs:560, 653)
     sa.kind = lg::kAbsorbDigest; sa.digests = c->d_nodes; sa.digest_stride = (uint64_t)(c->n - 1) * 32; sa.nsqueeze = 1; sa.reset = 1;
     if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
     // 3. r_interleaved (4m elements per proof), preenc_u.row_mul(r) (mod.rs:654-658)
     if ((rc = chacha_elements(c, seed0, c->sub.d_r, c->rows)) != LG_OK) return rc;
     if ((rc = interleaved_on_device(c)) != LG_OK) return rc;
-    LG_HIP(c, hipMemcpyAsync(out + L.off_lc, c->sub.d_q, (size_t)B * c->k * sizeof(fr), hipMemcpyDeviceToHost, s));
-    // the three openings share one routine: indices from a seed, the gather into staging, the copies home on the copy stream
+    LG_HIP(c, hipMemcpyAsync(small + L.off_lc, c->sub.d_q, (size_t)B * c->k * sizeof(fr), hipMemcpyDeviceToDevice, s));
+    // the three openings share one routine: indices from a seed, the gather into staging, the way home on the copy stream
     auto open = [&](int o, const uint32_t* d_seed) -> int {
-        uint32_t* d_idx = b->d_idx + (size_t)o * B * t;
+        uint8_t* st = b->d_open[o];
+        uint32_t* d_idx = reinterpret_cast<uint32_t*>(st + b->open_idx);
+        if (b->copied_valid) LG_HIP(c, hipStreamWaitEvent(s, b->ev_copied[o], 0));   // the previous batch's copy out of this staging
         lg::IndexArgs ia{d_seed, b->d_bitmap, d_idx, B, c->n, t};
         LG_LAUNCH(c, lg::distinct_indices_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ia);
-        if (b->copied_valid) LG_HIP(c, hipStreamWaitEvent(s, b->ev_copied[o], 0));   // the previous batch's copy out of this staging
-        uint8_t* d_sib = b->d_paths[o];
-        uint8_t* d_paths = b->d_paths[o] + (size_t)B * t * 32;
         { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
-        { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, b->d_cols[o], d_sib, d_paths); if (rc_ != LG_OK) return rc_; }
+        { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, reinterpret_cast<fr*>(st + b->open_cols), st + b->open_sib, st + b->open_paths); if (rc_ != LG_OK) return rc_; }
         LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
         LG_HIP(c, hipStreamWaitEvent(c->st.dn, b->ev_gathered[o], 0));
-        LG_HIP(c, hipMemcpyAsync(out + L.off_columns[o], b->d_cols[o], (size_t)B * t * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->st.dn));
-        LG_HIP(c, hipMemcpyAsync(out + L.off_siblings[o], d_sib, (size_t)B * t * 32, hipMemcpyDeviceToHost, c->st.dn));
-        if (b->plen) LG_HIP(c, hipMemcpyAsync(out + L.off_paths[o], d_paths, (size_t)B * t * b->plen * 32, hipMemcpyDeviceToHost, c->st.dn));
-        LG_HIP(c, hipMemcpyAsync(out + L.off_idx[o], d_idx, (size_t)B * t * 4, hipMemcpyDeviceToHost, c->st.dn));
+        const ShipSeg seg = {st, out + L.off_idx[o], b->open_bytes};   // (staging and the layout's region of sub-proof o are laid out alike)
+        { const int rc_ = ship(c, &seg, 1); if (rc_ != LG_OK) return rc_; }
         LG_HIP(c, hipEventRecord(b->ev_copied[o], c->st.dn));
         return LG_OK;
     };
@@ -250,35 +363,45 @@ int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
     LG_HIP(c, hipMemcpyAsync(c->chal.d_seeds, seed1, (size_t)B * 32, hipMemcpyDeviceToDevice, s));
     if ((rc = linear_from_device_seeds(c)) != LG_OK) return rc;
     const fr* d_poly = c->sub.aux2k->d_coeffs;
-    LG_HIP(c, hipMemcpyAsync(out + L.off_linear_poly, d_poly, (size_t)B * 2 * c->k * sizeof(fr), hipMemcpyDeviceToHost, s));
+    LG_HIP(c, hipMemcpyAsync(small + L.off_linear_poly, d_poly, (size_t)B * 2 * c->k * sizeof(fr), hipMemcpyDeviceToDevice, s));
     // 6. absorb(polynomial); squeeze the opening's seed, then the quadratic test's (mod.rs:738, 941, 839)
-    sa.src = d_poly; sa.src_proof = 2 * (uint64_t)c->k; sa.count = 2 * c->k; sa.trim = 1; sa.lens_out = b->d_lens; sa.nsqueeze = 2;
+    sa.src = d_poly; sa.src_proof = 2 * (uint64_t)c->k; sa.count = 2 * c->k; sa.trim = 1; sa.lens_out = d_lens; sa.nsqueeze = 2;
     if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
     if ((rc = open(1, seed0)) != LG_OK) return rc;
     // 7. r_quadratic (m elements per proof), p_0 (mod.rs:840-848)
     if ((rc = chacha_elements(c, seed1, c->sub.d_r, m)) != LG_OK) return rc;
     if ((rc = quadratic_on_device(c)) != LG_OK) return rc;
-    LG_HIP(c, hipMemcpyAsync(out + L.off_quadratic_poly, d_poly, (size_t)B * 2 * c->k * sizeof(fr), hipMemcpyDeviceToHost, s));
+    LG_HIP(c, hipMemcpyAsync(small + L.off_quadratic_poly, d_poly, (size_t)B * 2 * c->k * sizeof(fr), hipMemcpyDeviceToDevice, s));
     // 8. absorb(p_0); squeeze the last opening's seed (mod.rs:850, 941)
-    sa.lens_out = b->d_lens + B; sa.nsqueeze = 1;
+    sa.lens_out = d_lens + B; sa.nsqueeze = 1;
     if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
     if ((rc = open(2, seed0)) != LG_OK) return rc;
     b->copied_valid = true;
-    LG_HIP(c, hipMemcpyAsync(out + L.off_poly_lens, b->d_lens, (size_t)2 * B * 4, hipMemcpyDeviceToHost, s));
-    LG_HIP(c, hipMemcpyAsync(out + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToHost, s));
-    // "done" = the encode stream's own copies and the copy stream's
+    // 9. the small items, once everything on the encode stream is done; "done" = the copy stream has shipped them too
+    LG_HIP(c, hipMemcpyAsync(small + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToDevice, s));
     LG_HIP(c, hipEventRecord(c->evt.done, s));
     LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->evt.done, 0));
-    LG_HIP(c, hipEventRecord(b->ev_done, c->st.dn));
+    const ShipSeg seg = {small, out, b->small_bytes};
+    if ((rc = ship(c, &seg, 1)) != LG_OK) return rc;
+    LG_HIP(c, hipEventRecord(slot.small_copied, c->st.dn));
+    LG_HIP(c, hipEventRecord(slot.done, c->st.dn));
     return LG_OK;
 }
 
 int lg_prove_batch_wait(lg_ctx* c, const void* proofs_out) {
     if (!c || !proofs_out) return LG_ERR_BAD_ARG;
     lg_batch_prover_state* b = c->bp;
-    if (!b || !b->queued) return LG_ERR_STATE;
+    if (!b) return LG_ERR_STATE;
+    int si = -1;
+    for (int i = 0; i < 2; i++)
+        if (b->slot[i].busy && b->slot[i].out == proofs_out) si = i;
+    if (si < 0) {
+        snprintf(c->err, sizeof(c->err), "lg_prove_batch_wait: no batch into this buffer is in flight");
+        return LG_ERR_STATE;
+    }
     LG_HIP(c, hipSetDevice(c->device));
-    LG_HIP(c, hipEventSynchronize(b->ev_done));
+    LG_HIP(c, hipEventSynchronize(b->slot[si].done));
+    b->slot[si].busy = false;
     uint32_t flag = 0;
     memcpy(&flag, static_cast<const uint8_t*>(proofs_out) + b->layout.off_status, 4);
     if (flag) {

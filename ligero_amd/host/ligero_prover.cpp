@@ -167,6 +167,33 @@ int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_
         return LGP_OK;
     });
 }
+// device-transcript provers: the same in two halves, so that the next batch is queued before the last one is waited for
+int lgp_prove_batch_submit(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
+    if (!p || !node_idx || !values || count == 0) return LGP_ERR_BAD_ARG;
+    const uint32_t B = p->hip.batch();
+    return guarded([&] {
+        std::vector<std::vector<std::pair<size_t, Fr>>> va(B);
+        for (uint32_t b = 0; b < B; b++) {
+            va[b].reserve(count);
+            for (uint64_t i = 0; i < count; i++) {
+                Fr v;
+                std::memcpy(v.l, values + 4 * ((uint64_t)b * count + i), 32);
+                va[b].emplace_back((size_t)node_idx[i], v);
+            }
+        }
+        p->hip.submit(va);
+        return LGP_OK;
+    });
+}
+int lgp_prove_batch_collect(lgp_batch_prover* p) {
+    if (!p) return LGP_ERR_BAD_ARG;
+    return guarded([&] {
+        p->hip.collect();
+        p->views.assign(p->hip.batch(), lgp_proof());
+        p->view_made.assign(p->hip.batch(), 0);
+        return LGP_OK;
+    });
+}
 const lgp_proof* lgp_batch_proof(const lgp_batch_prover* p, uint32_t b) {
     if (!p || b >= p->views.size()) return nullptr;
     if (b < p->view_made.size() && !p->view_made[b]) {

@@ -1055,6 +1055,9 @@ public:
             // (each registration is tracked on its own: a buffer must never be freed while still page-locked)
             pinned_mat_ = lg_host_register(ctx_, mat_.data(), mat_.size() * sizeof(Fr)) == LG_OK;
             if (device_transcript_) {
+                // two batches may be in flight (submit the next before collecting the last): a second w buffer and two arenas
+                mat2_.resize(mat_.size());
+                pinned_mat2_ = lg_host_register(ctx_, mat2_.data(), mat2_.size() * sizeof(Fr)) == LG_OK;
                 if (!from_witness_) throw std::runtime_error("HipLigeroBatch: the device transcript needs the circuit's gate map on the device");
                 const PoseidonSponge sp = PoseidonSponge::test_sponge();
                 lg_sponge_params par;
@@ -1062,8 +1065,11 @@ public:
                 par.ark = sp.ark()[0][0].l; par.mds = sp.mds()[0][0].l;
                 check(lg_prover_setup(ctx_, &par, (uint32_t)t_), "lg_prover_setup");
                 check(lg_prover_layout(ctx_, &layout_), "lg_prover_layout");
-                arena_.resize(layout_.total_bytes);
-                pinned_arena_ = lg_host_register(ctx_, arena_.data(), arena_.size()) == LG_OK;
+                for (int i = 0; i < 2; i++) {
+                    arena_[i].resize(layout_.total_bytes);
+                    check(lg_host_register(ctx_, arena_[i].data(), arena_[i].size()), "lg_host_register (proof arena)");
+                    pinned_arena_[i] = true;
+                }
             } else {
                 cols_.resize((size_t)batch_ * t_ * 4 * m_);
                 pinned_cols_ = lg_host_register(ctx_, cols_.data(), cols_.size() * sizeof(Fr)) == LG_OK;
@@ -1082,28 +1088,49 @@ public:
     bool device_transcript() const { return device_transcript_; }
     // ---- device transcript: the batch as it lies in page-locked host memory (layout: include/ligero_hip.h lg_proof_layout),
     // valid until the next prove_to_arena()
-    const uint8_t* arena() const { return arena_.data(); }
+    // valid until the second submit() after the collect() that returned it
+    const uint8_t* arena() const { return arena_[last_collected_].data(); }
     const lg_proof_layout& layout() const { return layout_; }
-    void prove_to_arena(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
-        if (!device_transcript_) throw std::runtime_error("HipLigeroBatch::prove_to_arena: created without the device transcript");
+    // Two batches may be in flight: submit() builds w on the host threads and queues the whole batch on the device, collect()
+    // waits for the OLDEST batch queued.  submit(i + 1) before collect(i) keeps the device (and PCIe) busy while the host
+    // assembles the next w.
+    void submit(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
+        if (!device_transcript_) throw std::runtime_error("HipLigeroBatch::submit: created without the device transcript");
         if (assignments.size() != batch_) throw std::runtime_error("HipLigeroBatch::prove: one assignment per proof of the batch");
+        if (submitted_ - collected_ >= 2) throw std::runtime_error("HipLigeroBatch::submit: two batches are in flight already (collect() first)");
+        const int slot = (int)(submitted_ & 1);
+        std::vector<Fr>& w = slot ? mat2_ : mat_;
         PhaseTimer tm;
         parallel_for(batch_, [&](size_t b) {
             std::vector<std::pair<size_t, Fr>> bumped;
             bumped.reserve(assignments[b].size());
             for (const auto& v : assignments[b]) bumped.emplace_back(inst_.bump_index(v.first), v.second);
-            inst_.build_w_from_formatted(bumped, &mat_[b * m_ * k_]);
+            inst_.build_w_from_formatted(bumped, &w[b * m_ * k_]);
         });
         tm.mark("w (host)");
-        check(lg_prove_batch_queue(ctx_, mat_[0].l, arena_.data()), "lg_prove_batch_queue");
+        check(lg_prove_batch_queue(ctx_, w[0].l, arena_[slot].data()), "lg_prove_batch_queue");
         tm.mark("queue (host)");
-        check(lg_prove_batch_wait(ctx_, arena_.data()), "lg_prove_batch_wait");
+        submitted_++;
+    }
+    void collect() {
+        if (collected_ == submitted_) throw std::runtime_error("HipLigeroBatch::collect: nothing in flight");
+        const int slot = (int)(collected_ & 1);
+        PhaseTimer tm;
+        check(lg_prove_batch_wait(ctx_, arena_[slot].data()), "lg_prove_batch_wait");
         tm.mark("proofs (device)");
+        collected_++;
+        last_collected_ = slot;
+    }
+    size_t in_flight() const { return submitted_ - collected_; }
+    void prove_to_arena(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
+        while (in_flight()) collect();
+        submit(assignments);
+        collect();
     }
     // proof b of the arena as the host's proof object (a copy: tests, the verifier)
     LigeroProof materialize(size_t b) const {
         const lg_proof_layout& L = layout_;
-        const uint8_t* A = arena_.data();
+        const uint8_t* A = arena();
         const size_t rows = 4 * m_, plen = L.path_len;
         LigeroProof p;
         memcpy(p.u_root.data(), A + L.off_roots + 32 * b, 32);
@@ -1219,7 +1246,9 @@ private:
         if (!ctx_) return;
         if (pinned_mat_) lg_host_unregister(ctx_, mat_.data());
         if (pinned_cols_) lg_host_unregister(ctx_, cols_.data());
-        if (pinned_arena_) lg_host_unregister(ctx_, arena_.data());
+        if (pinned_mat2_) lg_host_unregister(ctx_, mat2_.data());
+        for (int i = 0; i < 2; i++)
+            if (pinned_arena_[i]) lg_host_unregister(ctx_, arena_[i].data());
         lg_ctx_destroy(ctx_);
         ctx_ = nullptr;
     }
@@ -1291,10 +1320,13 @@ private:
     int logn_ = 0;
     unsigned threads_ = 1;
     bool device_transcript_ = false;
-    bool pinned_mat_ = false, pinned_cols_ = false, pinned_arena_ = false;
+    bool pinned_mat_ = false, pinned_mat2_ = false, pinned_cols_ = false, pinned_arena_[2] = {false, false};
     bool from_witness_ = false;   // gate map on the device: mat_ holds w of every proof only
     lg_proof_layout layout_{};
-    std::vector<uint8_t> arena_;  // device transcript: the batch of proofs as the device wrote it
+    std::vector<uint8_t> arena_[2];   // device transcript: batches of proofs as the device wrote them (two in flight)
+    std::vector<Fr> mat2_;            // ... and the second w buffer
+    uint64_t submitted_ = 0, collected_ = 0;
+    int last_collected_ = 0;
     lg_ctx* ctx_ = nullptr;
     std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u
     std::vector<LigeroProof> proofs_;

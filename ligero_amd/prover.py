@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -44,6 +44,8 @@ def lib():
         L.lgp_batch_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.lgp_batch_prover_create_ex.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.lgp_batch_proof_arena.argtypes = [_vp, ctypes.POINTER(_vp), _vp]
+        L.lgp_prove_batch_submit.argtypes = [_vp, _vp, _vp, ctypes.c_uint64]
+        L.lgp_prove_batch_collect.argtypes = [_vp]
         L.lgp_batch_prover_destroy.argtypes = [_vp]
         L.lgp_batch_prover_destroy.restype = None
         L.lgp_batch_prover_threads.argtypes = [_vp]
@@ -256,6 +258,24 @@ def proofs_equal(a: Proof, b: Proof) -> bool:
     return bool(eq.value)
 
 
+class _ArenaProofs:
+    """the proofs of a device-transcript batch, read lazily (lgp_batch_proof copies one proof out of the arena per index)"""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __len__(self):
+        return self._owner.batch
+
+    def __getitem__(self, b):
+        if not 0 <= b < self._owner.batch:
+            raise IndexError(b)
+        h = self._owner._L.lgp_batch_proof(self._owner._h, b)
+        if not h:
+            raise RuntimeError(f"lgp_batch_proof: {self._owner._L.lgp_last_error().decode()}")
+        return Proof(_vp(h), owner=self._owner)
+
+
 class LigeroBatchProver:
     """throughput mode: `batch` proofs of one circuit per call (include/ligero_prover.h)"""
 
@@ -283,6 +303,17 @@ class LigeroBatchProver:
     def __exit__(self, *a):
         self.close()
 
+    def submit(self, node_idx: Sequence[int], values_mont: np.ndarray):
+        """device transcript only: assemble w and queue the batch; at most two batches in flight (collect() the oldest)"""
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(self.batch, idx.shape[0], 4)
+        _check(self._L.lgp_prove_batch_submit(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0]), "prove_batch_submit")
+
+    def collect(self):
+        """wait for the oldest batch in flight; returns its proofs, read lazily out of the prover's arena"""
+        _check(self._L.lgp_prove_batch_collect(self._h), "prove_batch_collect")
+        return _ArenaProofs(self)
+
     def prove(self, node_idx: Sequence[int], values_mont: np.ndarray, copy: bool = True):
         """values_mont: (batch, len(node_idx), 4).  Returns a list of `batch` Proof objects; with copy=False they
         borrow the prover's reused storage (valid until the next prove(), read-only)."""
@@ -290,6 +321,8 @@ class LigeroBatchProver:
         vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(self.batch, idx.shape[0], 4)
         if not copy:
             _check(self._L.lgp_prove_batch(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0], None), "prove_batch")
+            if self.device_transcript:      # the proofs stay in the prover's arena: a handle copies its proof out when first asked for
+                return _ArenaProofs(self)
             return [Proof(_vp(self._L.lgp_batch_proof(self._h, b)), owner=self) for b in range(self.batch)]
         handles = (_vp * self.batch)()
         _check(self._L.lgp_prove_batch(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0], ctypes.cast(handles, _vp)), "prove_batch")

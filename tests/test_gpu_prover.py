@@ -153,6 +153,19 @@ def test_device_transcript_batch_prover_equals_the_host_transcript_provers(posei
             single = prover.prove(idx, bad[b])
             assert proofs_equal(single, views[b]), b
             assert prover.verify(views[b]) == (b != 1)
+        # two batches in flight: the second is queued before the first is waited for (both arenas, both small-item staging slots,
+        # the three column staging buffers handed from batch to batch); a third submit is refused until one is collected
+        bp.submit(idx, allv[sel])
+        bp.submit(idx, allv[sel2])
+        with pytest.raises(RuntimeError):
+            bp.submit(idx, allv[sel])
+        first = bp.collect()
+        assert proofs_equal(proofs[0], first[0]) and proofs_equal(proofs[B - 1], first[B - 1])
+        bp.submit(idx, allv[sel])                    # (into the arena `first` was read from: its handles are stale from here on)
+        second = bp.collect()
+        assert proofs_equal(prover.prove(idx, allv[sel2[B - 1]]), second[B - 1])
+        third = bp.collect()
+        assert proofs_equal(proofs[B // 2], third[B // 2])
 
 
 # ---- the reference's own prove-and-verify tests on BN254 (src/ligero/tests.rs:144-170, 195-243, 245-362), same circuits

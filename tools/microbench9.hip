@@ -9,6 +9,7 @@
 //   3. prints the projection the kill criterion asks for: proofs/s with <= 1024 proofs in flight.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I ligero_amd/csrc tools/microbench9.hip -o tools/microbench9
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -254,6 +255,51 @@ int main(int argc, char** argv) {
             printf("  %5u  %6u  %9.3f  %14.2f  %.3e\n", waves, B, ms, us, (double)B * PERMS / (ms * 1e-3));
             if (waves == 16) (loaded ? us_loaded_16 : us_alone_16) = us;
             hipFree(d_state); hipFree(d_el);
+        }
+    }
+    // ---- 2b. TWO sponge kernels at once (two provers in flight), 4 waves each: on plain streams the dispatcher puts the first
+    // workgroups of every kernel on the same CUs -- the waves share SIMDs and each chain runs at half speed; streams created
+    // with disjoint CU masks (hipExtStreamCreateWithCUMask) keep them apart
+    {
+        const uint32_t waves = 4, B = 64 * waves, NK = 4;
+        uint32_t* d_state[NK]; fr* d_el[NK];
+        for (uint32_t i = 0; i < NK; i++) {
+            CK(hipMalloc(&d_state[i], (size_t)B * kSpongeWords * 4)); CK(hipMalloc(&d_el[i], (size_t)B * K * 32));
+            CK(hipMemset(d_el[i], 1, (size_t)B * K * 32));
+        }
+        for (int masked = 0; masked < 3; masked++) {
+            hipStream_t st[NK];
+            for (uint32_t i = 0; i < NK; i++) {
+                if (masked) {
+                    // 256 CUs = 8 words; slot i takes 8 CUs: masked == 1: bits [8 i, 8 i + 8) of word 0..; masked == 2: one bit per word
+                    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (masked == 1) mask[(8 * i) / 32] = 0xffu << ((8 * i) % 32);
+                    else for (int w = 0; w < 8; w++) mask[w] = 1u << (4 + i);
+                    hipError_t e = hipExtStreamCreateWithCUMask(&st[i], 8, mask);
+                    if (e != hipSuccess) { printf("hipExtStreamCreateWithCUMask: %s\n", hipGetErrorString(e)); return 3; }
+                } else {
+                    CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+                }
+            }
+            for (uint32_t nk = 1; nk <= NK; nk *= 2) {
+                hipEvent_t b0[NK], b1[NK];
+                for (uint32_t i = 0; i < nk; i++) { CK(hipEventCreate(&b0[i])); CK(hipEventCreate(&b1[i])); }
+                for (int rep = 0; rep < 2; rep++) {
+                    for (uint32_t i = 0; i < nk; i++) {
+                        SpongeArgs a{};
+                        a.state = d_state[i]; a.P = P; a.batch = B; a.kind = kAbsorbElems; a.src = d_el[i]; a.src_proof = K; a.count = K; a.reset = 1;
+                        CK(hipEventRecord(b0[i], st[i]));
+                        hipLaunchKernelGGL(sponge_kernel<true>, dim3(waves), dim3(64), 0, st[i], a);
+                        CK(hipEventRecord(b1[i], st[i]));
+                    }
+                    for (uint32_t i = 0; i < nk; i++) CK(hipStreamSynchronize(st[i]));
+                }
+                float worst = 0;
+                for (uint32_t i = 0; i < nk; i++) { float ms = 0; CK(hipEventElapsedTime(&ms, b0[i], b1[i])); worst = std::max(worst, ms); }
+                printf("  %u sponge kernels of %u waves at once on %s streams: %.2f ms each (%.1f us per permutation)\n", nk, waves,
+                       masked == 0 ? "plain" : (masked == 1 ? "CU-masked (8 adjacent bits)" : "CU-masked (one bit per mask word)"), worst, 1e3 * worst / PERMS);
+            }
+            for (uint32_t i = 0; i < NK; i++) CK(hipStreamDestroy(st[i]));
         }
     }
     // ---- 3. the projection: a Poseidon-shape proof is 326 permutations; the device's other work for a batch
