@@ -162,41 +162,110 @@ def commit_leg(workload, e, st, launches, root, steps, tfile):
     return leg
 
 
-def full_prover_rate(device: int, steps: int = 8):
-    """proofs/s of the complete prove() (ligero_amd/host/prover.hpp: commit + three sub-proofs + openings + transcript)
-    on the 64 committed Poseidon witnesses, batch-wide device calls + host threads.  The transcript is the restated
-    test_sponge() -- unpinned against the Rust crates -- so this is the cost of the same work, not a
-    claim of byte-identical proofs."""
+PROVER_BATCH = 1024      # proofs per batch of the throughput-mode prover (device transcript); two batches in flight
+
+
+def prover_child(argv):
+    """`python bench.py --prover-child <device> <mode> <batch> <steps> <cpus>`: the proofs/s leg in a process of its own that never
+    loads torch -- a PyTorch wheel bundles a ROCm 7.0 runtime that leaves the SDMA engines off on this GPU, and a device-to-host
+    copy done by shader code instead slows every HBM-bound kernel beside it (tools/d2h_probe.hip); a Rust or C++ host links the
+    system runtime, which is what this child measures.  Prints one JSON object."""
+    device, mode, batch, steps, cpus = int(argv[0]), argv[1], int(argv[2]), int(argv[3]), int(argv[4])
+    os.environ["LIGERO_NO_TORCH_PRELOAD"] = "1"
+    if cpus > 0:      # what one rank of an 8-GPU node gets of the box's CPU quota
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:cpus]))
+    ncpu = cpus if cpus > 0 else usable_cpus()
     from ligero_amd.prover import LigeroBatchProver
     inst, idx, vals = poseidon_batch_inputs()
-    # four batch provers in flight: the host phases of one (transcript on host threads) overlap the device phases of the
-    # others; measured on the GPU box (16 usable CPUs): 1 prover 2 600 proofs/s, 4 provers 4 500 proofs/s
-    import threading
-    nprov, threads = 4, max(1, usable_cpus() // 2)
-    if os.environ.get("LIGERO_BENCH_PROVERS"):      # "provers x threads", e.g. 8x4 (tools: finding the best split of the host cores)
-        nprov, threads = (int(x) for x in os.environ["LIGERO_BENCH_PROVERS"].split("x"))
-    provers = [LigeroBatchProver(inst, 64, device=device, threads=threads) for _ in range(nprov)]
-    try:
-        for bp in provers:
-            bp.prove(idx, vals, copy=False)
-
-        def work(bp):
-            for _ in range(steps):
-                bp.prove(idx, vals, copy=False)
-        ts = [threading.Thread(target=work, args=(bp,)) for bp in provers]
-        t0 = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        dt = time.perf_counter() - t0
-    finally:
-        for bp in provers:
+    out = {"mode": mode, "batch": batch, "host_cpus": ncpu}
+    if mode == "device":
+        allv = np.ascontiguousarray(vals[np.arange(batch) % 64])
+        bp = LigeroBatchProver(inst, batch, device=device, threads=ncpu, device_transcript=True)
+        try:
+            bp.prove(idx, allv, copy=False)                      # warm-up: buffers, page-locking, the first launches
+            h0 = bp.host_stats()
+            c0, t0 = time.process_time(), time.perf_counter()
+            bp.submit(idx, allv)
+            for _ in range(steps - 1):
+                bp.submit(idx, allv)
+                bp.collect()
+            bp.collect()
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            h1 = bp.host_stats()
+        finally:
             bp.close()
-    n = nprov * 64 * steps
-    return {"value": n / dt, "unit": "proofs/s", "proofs": n, "seconds": dt, "ms_per_64_proofs": dt / (nprov * steps) * 1e3, "concurrent_batch_provers": nprov,
-            "host_threads_each": threads, "host_cpus_usable": usable_cpus(),
-            "note": "full prove() incl. transcript on host threads; host bound; transcript unpinned vs the Rust crates"}
+        n = batch * steps
+        w_core, queue, wait = (h1[k_] - h0[k_] for k_ in ("w_core_ms", "queue_ms", "wait_ms"))
+        out.update({"value": n / dt, "unit": "proofs/s", "proofs": n, "seconds": dt, "ms_per_batch": dt / steps * 1e3, "batches_in_flight": 2,
+                    "host_core_ms_per_proof": {
+                        "total": cpu / n * 1e3, "trace_and_w": w_core / n, "queue_hip_calls": queue / n,
+                        "python_ffi_and_copies_in": max(0.0, (cpu * 1e3 - w_core - queue) / n),
+                        "sponge": 0.0, "a_row_mul": 0.0, "openings_repack": 0.0,
+                        "note": "core-milliseconds per proof (process CPU time); the transcript, A.row_mul and the openings never touch the host: "
+                                "the proofs land in page-locked memory in their final layout (lg_proof_layout)"},
+                    "host_idle_waiting_ms_per_batch": wait / steps})
+    else:       # the host-transcript batch provers of rounds 2-3, for comparison: 4 in flight, batches of 64
+        import threading
+        nprov, threads = 4, max(1, ncpu // 2)
+        provers = [LigeroBatchProver(inst, 64, device=device, threads=threads) for _ in range(nprov)]
+        try:
+            for bp in provers:
+                bp.prove(idx, vals, copy=False)
+
+            def work(bp):
+                for _ in range(steps):
+                    bp.prove(idx, vals, copy=False)
+            ts = [threading.Thread(target=work, args=(bp,)) for bp in provers]
+            c0, t0 = time.process_time(), time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+        finally:
+            for bp in provers:
+                bp.close()
+        n = nprov * 64 * steps
+        out.update({"value": n / dt, "unit": "proofs/s", "proofs": n, "seconds": dt, "concurrent_batch_provers": nprov, "host_threads_each": threads,
+                    "host_core_ms_per_proof": {"total": cpu / n * 1e3}})
+    print(json.dumps(out), flush=True)
+
+
+def _run_prover_child(device: int, mode: str, batch: int, steps: int, cpus: int = 0, timeout: float = 240.0):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_SDMA", None)      # the system runtime's default (SDMA on)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--prover-child", str(device), mode, str(batch), str(steps), str(cpus)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"prover child ({mode}) failed with status {r.returncode}: {r.stderr[-400:]}")
+    return json.loads(lines[-1])
+
+
+def full_prover_rate(device: int, steps: int = 6, extras: bool = True):
+    """proofs/s of the complete prove() on the committed Poseidon witnesses in throughput mode: batches of PROVER_BATCH proofs, two
+    in flight, commit + three sub-proofs + openings AND the Fiat-Shamir transcript on the device (lg_prove_batch_queue), the host
+    assembling w only.  The transcript is the restated test_sponge() -- unpinned against the Rust crates -- so this
+    is the cost of the same work, not a claim of byte-identical proofs.  extras: also the same with the process confined to TWO
+    cores (one rank's share of this box's quota on an 8-GPU node) and the host-transcript provers of earlier rounds."""
+    res = _run_prover_child(device, "device", PROVER_BATCH, steps)
+    res["note"] = ("full prove() per proof, transcript on the device (one lane per proof), proofs delivered to page-locked host memory; "
+                   "PCIe bound (5.4 MB of opened columns per proof); transcript unpinned vs the Rust crates; measured in a child process "
+                   "on the system HIP runtime (see prover_child)")
+    res["pcie_GBs"] = res["value"] * 5.44e6 / 1e9
+    if extras:
+        try:
+            two = _run_prover_child(device, "device", PROVER_BATCH, steps, cpus=2)
+            res["two_core_cap"] = {k_: two[k_] for k_ in ("value", "unit", "host_cpus", "ms_per_batch", "host_core_ms_per_proof")}
+        except Exception as e:
+            res["two_core_cap"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            host = _run_prover_child(device, "host", 64, 8)
+            res["host_transcript"] = {k_: host[k_] for k_ in ("value", "unit", "concurrent_batch_provers", "host_threads_each", "host_cpus", "host_core_ms_per_proof")}
+        except Exception as e:
+            res["host_transcript"] = {"error": f"{type(e).__name__}: {e}"}
+    return res
 
 
 def repeated_squaring_instance(log_n: int):
@@ -597,7 +666,8 @@ def roofline_of(workload, stage, launches, traffic_file):
     overlapped = {"colhash": True, "merkle": launches == 1, "interpolate": launches == 1}
     eligible = [s for s in names if not overlapped.get(s, False)] or ["evaluate"]
     dom = max(eligible, key=lambda s: stage[s])
-    tall = json.load(open(traffic_file)).get(workload, {}) if os.path.exists(traffic_file) else {}
+    tall_src = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+    tall = tall_src.get(workload, {})
     rl, dom_rl = {}, None
     for sname in names:
         nl = launches if sname in ("evaluate", "colhash") else 1
@@ -607,11 +677,15 @@ def roofline_of(workload, stage, launches, traffic_file):
                      "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname),
                      "overlapped_span": bool(overlapped.get(sname, False))}
         if sname == dom:
-            dom_rl = {"bound": "hbm", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
+            src = tall_src.get("_source", {})
+            dom_rl = {"bound": "valu-issue (hbm fraction reported per contract)", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
                                                  "colhash": "blake2s_columns_kernel", "merkle": "merkle_subtree_kernel"}[dom],
                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname),
                       "algorithmic_bytes_per_launch": per_stage_bytes[sname] / nl, "ms_per_launch": ms, "launches_per_step": nl,
-                      "samples": stage["samples"] * nl}
+                      "samples": stage["samples"] * nl,
+                      "traffic_source": (f"{src.get('file', 'profiles/pmc_traffic.json')} @ {src.get('commit', '?')} (round {src.get('round', '?')}): a committed rocprofv3 PMC "
+                                         "measurement of this kernel on this shape, replayed -- not measured in this process") if tall.get(sname) is not None else None,
+                      "bound_note": "the kernel is limited by vector-ALU issue, not by HBM (valu_roofline, DESIGN.md 4.2); frac is the algorithmic-bytes rate over the 8 TB/s HBM peak as the bench contract defines it"}
     return dom_rl, rl
 
 
@@ -628,6 +702,8 @@ def valu_roofline_of(workload, stage):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--prover-child":
+        return prover_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -740,7 +816,7 @@ def main():
     if dist is not None and args.workload == "poseidon" and not args.no_cpu_baseline:
         dist.barrier()
         try:                                        # (local work only inside the try: every rank must reach the reductions below)
-            fp = full_prover_rate(local_rank, steps=4)
+            fp = full_prover_rate(local_rank, steps=4, extras=(rank == 0))
         except Exception as e:
             fp = {"error": f"{type(e).__name__}: {e}", "proofs": 0, "seconds": 0.0}
         dev_ = "cuda" if backend == "nccl" else "cpu"
@@ -754,7 +830,7 @@ def main():
         else:
             multi_prover = {"value": float(tot[0].item()) / float(slow.item()), "unit": "proofs/s", "n_gpus": world, "scaling": "weak",
                             "proofs": int(tot[0].item()), "seconds_slowest_rank": float(slow.item()), "rank0": fp,
-                            "note": "complete prove() per proof, independent batches per rank; host bound; transcript unpinned vs the Rust crates"}
+                            "note": "complete prove() per proof (transcript on the device), independent batches per rank, no collective; PCIe bound per GPU; transcript unpinned vs the Rust crates"}
         partial["full_prover"] = multi_prover
     if dist is not None and args.sharded_leg != "none" and not args.no_cpu_baseline:
         import threading

@@ -95,6 +95,9 @@ int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_p
  * (valid until the second submit after it). */
 int lgp_prove_batch_submit(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count);
 int lgp_prove_batch_collect(lgp_batch_prover* p);
+/* host time of the device-transcript batches since the prover was created: { batches, core-ms of assembling w (summed over the
+ * worker threads), its wall ms, wall ms of queueing the device work, wall ms asleep waiting for the device } */
+int lgp_batch_prover_host_stats(const lgp_batch_prover* p, double out[5]);
 void lgp_batch_prover_destroy(lgp_batch_prover* p);
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p);
 int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out);

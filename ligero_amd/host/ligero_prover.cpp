@@ -167,6 +167,12 @@ int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_
         return LGP_OK;
     });
 }
+int lgp_batch_prover_host_stats(const lgp_batch_prover* p, double out[5]) {
+    if (!p || !out) return LGP_ERR_BAD_ARG;
+    const auto& st = p->hip.host_stats();
+    out[0] = (double)st.batches; out[1] = st.w_core_ms; out[2] = st.w_wall_ms; out[3] = st.queue_ms; out[4] = st.wait_ms;
+    return LGP_OK;
+}
 // device-transcript provers: the same in two halves, so that the next batch is queued before the last one is waited for
 int lgp_prove_batch_submit(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
     if (!p || !node_idx || !values || count == 0) return LGP_ERR_BAD_ARG;

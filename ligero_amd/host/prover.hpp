@@ -1101,27 +1101,44 @@ public:
         const int slot = (int)(submitted_ & 1);
         std::vector<Fr>& w = slot ? mat2_ : mat_;
         PhaseTimer tm;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::atomic<uint64_t> busy_ns{0};   // core time of the w phase: the sum over the worker threads' tasks
         parallel_for(batch_, [&](size_t b) {
+            const auto a0 = std::chrono::steady_clock::now();
             std::vector<std::pair<size_t, Fr>> bumped;
             bumped.reserve(assignments[b].size());
             for (const auto& v : assignments[b]) bumped.emplace_back(inst_.bump_index(v.first), v.second);
             inst_.build_w_from_formatted(bumped, &w[b * m_ * k_]);
+            busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a0).count();
         });
+        const auto t1 = std::chrono::steady_clock::now();
         tm.mark("w (host)");
         check(lg_prove_batch_queue(ctx_, w[0].l, arena_[slot].data()), "lg_prove_batch_queue");
+        const auto t2 = std::chrono::steady_clock::now();
         tm.mark("queue (host)");
         submitted_++;
+        stats_.batches++;
+        stats_.w_core_ms += busy_ns.load() * 1e-6;
+        stats_.w_wall_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        stats_.queue_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
     }
     void collect() {
         if (collected_ == submitted_) throw std::runtime_error("HipLigeroBatch::collect: nothing in flight");
         const int slot = (int)(collected_ & 1);
         PhaseTimer tm;
+        const auto t0 = std::chrono::steady_clock::now();
         check(lg_prove_batch_wait(ctx_, arena_[slot].data()), "lg_prove_batch_wait");
+        stats_.wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         tm.mark("proofs (device)");
         collected_++;
         last_collected_ = slot;
     }
     size_t in_flight() const { return submitted_ - collected_; }
+    // where the HOST's time of the device-transcript batches went since the prover was made: core time of the w phase (evaluation
+    // trace + assembly, summed over the worker threads), its wall time, wall time of queueing the device work (HIP calls), wall
+    // time asleep waiting for the device (blocking event: no core burnt)
+    struct HostStats { uint64_t batches = 0; double w_core_ms = 0, w_wall_ms = 0, queue_ms = 0, wait_ms = 0; };
+    const HostStats& host_stats() const { return stats_; }
     void prove_to_arena(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
         while (in_flight()) collect();
         submit(assignments);
@@ -1326,6 +1343,7 @@ private:
     std::vector<uint8_t> arena_[2];   // device transcript: batches of proofs as the device wrote them (two in flight)
     std::vector<Fr> mat2_;            // ... and the second w buffer
     uint64_t submitted_ = 0, collected_ = 0;
+    HostStats stats_;
     int last_collected_ = 0;
     lg_ctx* ctx_ = nullptr;
     std::vector<Fr> mat_;   // [batch][4m][k]: preenc_u

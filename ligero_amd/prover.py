@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -46,6 +46,7 @@ def lib():
         L.lgp_batch_proof_arena.argtypes = [_vp, ctypes.POINTER(_vp), _vp]
         L.lgp_prove_batch_submit.argtypes = [_vp, _vp, _vp, ctypes.c_uint64]
         L.lgp_prove_batch_collect.argtypes = [_vp]
+        L.lgp_batch_prover_host_stats.argtypes = [_vp, _vp]
         L.lgp_batch_prover_destroy.argtypes = [_vp]
         L.lgp_batch_prover_destroy.restype = None
         L.lgp_batch_prover_threads.argtypes = [_vp]
@@ -308,6 +309,12 @@ class LigeroBatchProver:
         idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
         vals = np.ascontiguousarray(values_mont, dtype=np.uint64).reshape(self.batch, idx.shape[0], 4)
         _check(self._L.lgp_prove_batch_submit(self._h, idx.ctypes.data_as(_vp), vals.ctypes.data_as(_vp), idx.shape[0]), "prove_batch_submit")
+
+    def host_stats(self):
+        """host time of the device-transcript batches so far (lgp_batch_prover_host_stats)"""
+        out = (ctypes.c_double * 5)()
+        _check(self._L.lgp_batch_prover_host_stats(self._h, ctypes.cast(out, _vp)), "lgp_batch_prover_host_stats")
+        return {"batches": int(out[0]), "w_core_ms": out[1], "w_wall_ms": out[2], "queue_ms": out[3], "wait_ms": out[4]}
 
     def collect(self):
         """wait for the oldest batch in flight; returns its proofs, read lazily out of the prover's arena"""
