@@ -95,6 +95,16 @@ uint32_t lg_ctx_element_words(const lg_ctx* ctx);
 /* number of coset planes of this shape, and the run of them this context holds (all of them unless sharded) */
 int lg_ctx_planes(const lg_ctx* ctx, uint32_t* nplanes, uint32_t* plane_begin, uint32_t* plane_count);
 void lg_ctx_destroy(lg_ctx* ctx);
+/* The same with a verdict.  The context's streams are drained under a deadline (LG_TEARDOWN_TIMEOUT_MS, default 120 000) instead
+ * of waited for without end.  LG_OK: everything released.  LG_ERR_HIP: a stream still held unfinished work, or could not be
+ * queried, when the deadline passed -- lg_last_teardown_error() (thread local) names it.  The context is then LEAKED on purpose:
+ * nothing it owns is freed under a device that may still write to it.  After that status the handle is gone as after a
+ * successful call (do not use it), other contexts and devices are unaffected, and the device this one lived on should be
+ * considered suspect: finish or abandon the work on it and let the process end (a process that has touched the GPU exits -- it
+ * never re-executes itself).  LG_TRACE_TEARDOWN=1 prints one line to stderr before every step of a teardown.
+ * lg_ctx_destroy is this call with the status dropped (a failure is still reported on stderr). */
+int lg_ctx_destroy_checked(lg_ctx* ctx);
+const char* lg_last_teardown_error(void);
 
 /*
  * The hot path, mod.rs:521-551, for every proof of the batch:

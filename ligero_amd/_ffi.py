@@ -26,7 +26,7 @@ SYMBOLS = [
     "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
     "lg_shard_row_ranges", "lg_commit_sharded", "lg_relay_row_ranges", "lg_commit_row_relay", "lg_shard_profile_read",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
-    "lg_preenc_mark_filled", "lg_prover_setup", "lg_prover_layout", "lg_prove_batch_queue", "lg_prove_batch_wait",
+    "lg_ctx_destroy_checked", "lg_last_teardown_error", "lg_preenc_mark_filled", "lg_prover_setup", "lg_prover_layout", "lg_prove_batch_queue", "lg_prove_batch_wait",
 ]
 
 LG_OK = 0
@@ -95,6 +95,9 @@ def lib():
     L.lg_ctx_planes.argtypes = [_vp, _vp, _vp, _vp]
     L.lg_ctx_destroy.argtypes = [_vp]
     L.lg_ctx_destroy.restype = None
+    L.lg_ctx_destroy_checked.argtypes = [_vp]
+    L.lg_last_teardown_error.restype = ctypes.c_char_p
+    L.lg_last_teardown_error.argtypes = []
     L.lg_encode_commit.argtypes = [_vp, _vp, _vp, _vp]
     L.lg_upload_gate_map.argtypes = [_vp, ctypes.c_uint64, _vp, _vp, _vp, _u32]
     L.lg_encode_commit_from_witness.argtypes = [_vp, _vp, _vp, _vp]
@@ -147,7 +150,7 @@ def lib():
     L.lg_prove_batch_wait.argtypes = [_vp, _vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is ctypes.c_int and name not in ("lg_abi_version", "lg_ctx_element_words"):
+        if fn.restype is ctypes.c_int and name not in ("lg_abi_version", "lg_ctx_element_words", "lg_last_teardown_error"):
             fn.restype = _int
     _lib = L
     return L

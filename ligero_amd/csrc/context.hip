@@ -1,6 +1,11 @@
 // Context of the MI355X Ligero encode-and-commit library (include/ligero_hip.h): creation with the domain tables
 // (small_domain / large_domain of src/ligero/mod.rs:204-211), destruction, dimension queries, synchronisation, read-backs,
 // stage profiling.  gfx950 only; there is no CPU fallback anywhere in this library.
+#include <unistd.h>
+
+#include <chrono>
+#include <thread>
+
 #include "lg_context.h"
 
 // ----------------------------------------------------------------------------- ABI
@@ -23,16 +28,67 @@ const char* lg_status_string(int s) {
 const char* lg_last_error(const lg_ctx* c) { return c ? c->err : ""; }
 uint32_t lg_abi_version(void) { return LG_ABI_VERSION; }
 
-void lg_ctx_destroy(lg_ctx* c) {
-    if (!c) return;
+// ---- teardown.  A context owns seven streams; destroying it while one of them holds work that never completes must not
+// become a wait without end inside hipStreamSynchronize (a fuzz run of round 3 stopped at or after this point twice in ~100 runs and
+// never again under observation: DESIGN.md section 8).  So: every stream is drained with hipStreamQuery under a deadline, each step
+// can be traced (LG_TRACE_TEARDOWN=1: one line on stderr BEFORE every HIP call, unbuffered, so that a wedged call names itself),
+// and when the deadline passes the context is LEAKED -- nothing it owns is freed under a device that may still write to it -- and
+// the caller is told which stream it was.
+static thread_local char g_teardown_err[192] = {0};
+static bool teardown_trace_on() {
+    static const bool on = [] { const char* e = getenv("LG_TRACE_TEARDOWN"); return e && atoi(e) != 0; }();
+    return on;
+}
+static void teardown_mark(const lg_ctx* c, const char* what) {
+    if (!teardown_trace_on()) return;
+    char line[160];
+    const int n = snprintf(line, sizeof(line), "[lg teardown %p] %s\n", static_cast<const void*>(c), what);
+    if (n > 0) (void)!write(2, line, (size_t)std::min<int>(n, (int)sizeof(line) - 1));
+}
+static long teardown_deadline_ms() {
+    static const long ms = [] { const char* e = getenv("LG_TEARDOWN_TIMEOUT_MS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 120000L; }();
+    return ms;
+}
+// waits for `s` to drain, at most until `deadline`; false = still busy (or the query itself failed)
+static bool drain_stream(const lg_ctx* c, hipStream_t s, const char* name, std::chrono::steady_clock::time_point deadline) {
+    if (!s) return true;
+    char what[64];
+    snprintf(what, sizeof(what), "hipStreamQuery(%s)", name);
+    teardown_mark(c, what);
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            snprintf(g_teardown_err, sizeof(g_teardown_err), "stream %s: %s", name, hipGetErrorString(e));
+            return false;
+        }
+        if (std::chrono::steady_clock::now() > deadline) {
+            snprintf(g_teardown_err, sizeof(g_teardown_err), "stream %s still holds unfinished work after %ld ms", name, teardown_deadline_ms());
+            return false;
+        }
+        if (++spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 1000 : 50));
+    }
+}
+
+const char* lg_last_teardown_error(void) { return g_teardown_err; }
+
+int lg_ctx_destroy_checked(lg_ctx* c) {
+    g_teardown_err[0] = 0;
+    if (!c) return LG_OK;
+    teardown_mark(c, "hipSetDevice");
     hipSetDevice(c->device);
-    if (c->st.main) hipStreamSynchronize(c->st.main);
-    if (c->st.hash) hipStreamSynchronize(c->st.hash);
-    if (c->st.up) hipStreamSynchronize(c->st.up);
-    if (c->st.dn) hipStreamSynchronize(c->st.dn);
-    if (c->st.tree) hipStreamSynchronize(c->st.tree);
-    if (c->st.hash2) hipStreamSynchronize(c->st.hash2);
-    if (c->st.xchg) hipStreamSynchronize(c->st.xchg);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(teardown_deadline_ms());
+    const struct { hipStream_t s; const char* name; } all[] = {{c->st.main, "main"}, {c->st.hash, "hash"}, {c->st.up, "up"}, {c->st.dn, "dn"},
+                                                               {c->st.tree, "tree"}, {c->st.hash2, "hash2"}, {c->st.xchg, "xchg"}};
+    for (const auto& st : all)
+        if (!drain_stream(c, st.s, st.name, deadline)) {
+            teardown_mark(c, "a stream did not drain: the context is leaked, nothing is freed");
+            fprintf(stderr, "libligero_hip: context %p not destroyed: %s\n", static_cast<void*>(c), g_teardown_err);
+            return LG_ERR_HIP;
+        }
+    teardown_mark(c, "streams drained; releasing");
     batch_prover_release(c);
     if (c->sub.aux2k) lg_ctx_destroy(c->sub.aux2k);
     hipSetDevice(c->device);
@@ -76,8 +132,12 @@ void lg_ctx_destroy(lg_ctx* c) {
     if (c->st.dn) hipStreamDestroy(c->st.dn);
     if (c->st.hash) hipStreamDestroy(c->st.hash);
     if (c->st.main) hipStreamDestroy(c->st.main);
+    teardown_mark(c, "done");
     delete c;
+    return LG_OK;
 }
+
+void lg_ctx_destroy(lg_ctx* c) { (void)lg_ctx_destroy_checked(c); }
 
 }  // extern "C"
 struct ShardSpec {

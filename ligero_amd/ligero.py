@@ -13,6 +13,7 @@ Montgomery form -- the in-memory layout of ``ark_bn254::Fr``.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Optional, Sequence, Tuple
 
@@ -104,9 +105,15 @@ class LigeroCommitter:
 
     # -- lifetime
     def close(self):
+        """lg_ctx_destroy_checked: the streams are drained under a deadline; a context whose device work never finishes is
+        leaked and reported (RuntimeError) instead of blocking this thread for ever"""
         if getattr(self, "_ctx", None):
-            self._L.lg_ctx_destroy(self._ctx)
-            self._ctx = None
+            ctx, self._ctx = self._ctx, None
+            if os.environ.get("LG_TRACE_TEARDOWN"):
+                os.write(2, f"[LigeroCommitter.close {ctx.value:#x}] lg_ctx_destroy_checked\n".encode())
+            st = self._L.lg_ctx_destroy_checked(ctx)
+            if st != _ffi.LG_OK:
+                raise RuntimeError(f"lg_ctx_destroy_checked: status {st} ({self._L.lg_last_teardown_error().decode()}); the context was leaked")
 
     def __del__(self):
         try:

@@ -7,7 +7,7 @@ row product).  Every answer is compared with what a FRESH context gives for the 
 after: state carried from one entry-point family into the next -- which rows and planes the context believes it holds, parked hash
 states, pending asynchronous hash / tree work, the canonical message copy.
 
-    python tools/fuzz_api_sequences.py <seconds> [rows=24] [k=64] [seed=1] [batch=1]        (rows = 4 m)
+    python tools/fuzz_api_sequences.py <seconds> [rows=24] [k=64] [seed=1] [batch=1] [cycles=1]        (rows = 4 m)
 
 batch > 1: the three entry points that take a batch (resident, host buffers, from `w`), the reads per proof and for the whole batch.
 """
@@ -33,6 +33,12 @@ def main():
     k = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    cycles = int(sys.argv[6]) if len(sys.argv) > 6 else 1      # > 1: that many runs of `seconds` each, every one on contexts of its own
+    for cyc in range(cycles):                                  # (many TEARDOWNS after varied activity per process: tools/hang_hunt.sh)
+        run_once(seconds, rows, k, seed + 1000 * cyc, batch)
+
+
+def run_once(seconds, rows, k, seed, batch):
     assert rows % 4 == 0
     rng = np.random.default_rng(seed)
     n, m = 8 * k, rows // 4
