@@ -132,6 +132,13 @@ int lg_encode_commit(lg_ctx* ctx, const uint64_t* preenc, uint64_t* coeffs_out, 
 #define LG_GATE_CONST 0x80000000u
 int lg_upload_gate_map(lg_ctx* ctx, uint64_t npos, const uint32_t* left, const uint32_t* right, const uint64_t* constants, uint32_t nconst);
 int lg_encode_commit_from_witness(lg_ctx* ctx, const uint64_t* w, uint64_t* coeffs_out, uint8_t* root_out);
+/* The same while w is still being PRODUCED: *w_positions_ready (written by another host thread with release semantics, read
+ * here with acquire) is the number of leading positions of every proof's w that are final; the call hands each step of rows to
+ * the copy engine as soon as they are, so the transfer and the encoding of the early rows run beside the evaluation of the
+ * circuit that produces the late ones (the producer ends by storing m k).  Positions at or beyond the gate map's length (the
+ * zero padding of mod.rs:506-509) are never waited for: they must be zero before the call.  NULL = all of w is final. */
+int lg_encode_commit_from_witness_progress(lg_ctx* ctx, const uint64_t* w, const volatile uint64_t* w_positions_ready, uint64_t* coeffs_out,
+                                           uint8_t* root_out);
 /*
  * lg_encode_commit streams its host buffers: the rows travel over PCIe in chunks while earlier
  * chunks are being encoded, and the coefficient rows travel back the same way.  The overlap needs page-locked host memory -- copies from/to pageable memory
@@ -173,6 +180,9 @@ int lg_open_columns(lg_ctx* ctx, uint32_t proof, const uint32_t* idx, uint32_t t
  * each proof has its own Fiat-Shamir indices), outputs are the per-proof outputs concatenated. */
 int lg_open_columns_batch(lg_ctx* ctx, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out,
                           uint8_t* paths_out);
+/* lg_open_columns without the wait: the gather and the copies are queued on the context's stream and the call returns; the
+ * outputs (page-locked memory, or the copies block) are complete after lg_sync or any later call that waits for the stream. */
+int lg_open_columns_async(lg_ctx* ctx, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out);
 
 /* Row-level operators, independent of the resident commitment (own scratch):
  *   reed_solomon_interpolate  mod.rs:998-1002   nrows * k -> nrows * k

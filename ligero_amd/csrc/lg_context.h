@@ -418,7 +418,7 @@ int colhash_launch(lg_ctx* c, hipStream_t hs, const lg::ColHashArgs& h, bool all
 // context.hip
 int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes);
 // witness.hip
-int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs);
+int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready = nullptr);
 // openings.hip: the gather of t columns of nproofs proofs from DEVICE indices into DEVICE buffers (queued on the encode stream)
 int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths);
 // subproof.hip: the three polynomials with their challenges already ON THE DEVICE, results left on the device

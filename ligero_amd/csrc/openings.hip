@@ -135,7 +135,7 @@ int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const ui
 
 // opens t columns of each of `nproofs` consecutive proofs starting at `proof0` (one launch)
 static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out,
-                             uint8_t* paths_out) {
+                             uint8_t* paths_out, bool wait = true) {
     if (!c || !idx || !cols_out || !sib_out || (!paths_out && c->logn > 1)) return LG_ERR_BAD_ARG;
     if (c->gf) {
         if (!gf_committed(c->gf)) return LG_ERR_STATE;
@@ -182,7 +182,7 @@ static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const
     LG_HIP(c, hipMemcpyAsync(cols_out, c->scr.c, nidx * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->st.main));
     LG_HIP(c, hipMemcpyAsync(sib_out, d_sib, nidx * 32, hipMemcpyDeviceToHost, c->st.main));
     if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, d_paths, nidx * plen * 32, hipMemcpyDeviceToHost, c->st.main));
-    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    if (wait) LG_HIP(c, hipStreamSynchronize(c->st.main));
     return LG_OK;
 }
 
@@ -190,6 +190,10 @@ extern "C" {
 
 int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
     return open_columns_impl(c, proof, 1, idx, t, cols_out, sib_out, paths_out);
+}
+
+int lg_open_columns_async(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
+    return open_columns_impl(c, proof, 1, idx, t, cols_out, sib_out, paths_out, false);
 }
 
 int lg_open_columns_batch(lg_ctx* c, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {

@@ -1,5 +1,8 @@
 // a1 on the device (src/ligero/mod.rs:483-551): the commit from the solution vector w alone -- x, y, z are gathered from w and
 // the circuit's wiring (lg_upload_gate_map), only w crosses PCIe.
+#include <chrono>
+#include <thread>
+
 #include "lg_context.h"
 
 namespace lg {
@@ -114,7 +117,7 @@ static int witness_gather(lg_ctx* c, uint64_t pos0, uint64_t pos1) {
 // -- its workgroups on the CUs the hash occupies get what the older hash waves leave -- while the long evaluations absorb it
 // (measured: rocprofv3 timeline).  Small commits (one chunk in plan_chunks' terms: both kernels issue bound,
 // nothing to gain from running them side by side) hash once at the end on the encode stream.
-int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs) {
+int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready) {
     if (c->shard.on) return LG_ERR_STATE;
     if (!c->gate.loaded) {
         snprintf(c->err, sizeof(c->err), "lg_encode_commit_from_witness needs the circuit's gate map (lg_upload_gate_map)");
@@ -141,29 +144,44 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
     if (env_tail > 0) CW = (uint32_t)std::min(env_tail, 4);
     if (CW > m) CW = m;
     if (CZ > m) CZ = m;
-    auto cuts = [&](uint32_t parts, const uint32_t* weight) {   // row boundaries 0 = b[0] < ... < b[parts] = m by cumulative weight
+    auto cuts = [&](uint32_t parts, const uint32_t* weight, uint32_t upto) {   // row boundaries 0 = b[0] < ... < b[parts] = upto by cumulative weight
         std::vector<uint32_t> bnd(parts + 1, 0);
         uint64_t total = 0, acc = 0;
         for (uint32_t i = 0; i < parts; i++) total += weight[i];
         for (uint32_t i = 0; i < parts; i++) {
             acc += weight[i];
-            bnd[i + 1] = (i + 1 == parts) ? m : std::max<uint32_t>(bnd[i] + 1, (uint32_t)((uint64_t)m * acc / total));
-            if (bnd[i + 1] > m) bnd[i + 1] = m;
+            bnd[i + 1] = (i + 1 == parts) ? upto : std::max<uint32_t>(bnd[i] + 1, (uint32_t)((uint64_t)upto * acc / total));
+            if (bnd[i + 1] > upto) bnd[i + 1] = upto;
         }
         return bnd;
     };
+    // A producer that is still evaluating the circuit (`ready`) turns the plan round: the device waits for rows, not the other way,
+    // so every step encodes its rows of ALL FOUR blocks as soon as they exist (the Z rows are gathered with the step, the W rows are
+    // the upload itself) and the steps SHRINK towards the end -- what is left to do once the last position is final is one small
+    // step and the part of the column hash that has to come after the X block (the rows of Y, Z, W: three quarters of it).  The
+    // steps are cut over the rows the SOLUTION VECTOR reaches (the gate map's length); the zero padding behind it (mod.rs:506-509;
+    // half of the matrix at 2^20 constraints) is final from the start and goes first.
+    const bool producer = ready != nullptr && !small && c->gate.backward;
+    const uint32_t live_rows = producer ? (uint32_t)std::min<uint64_t>(m, (c->gate.npos + c->k - 1) / c->k) : m;
+    if (producer && J > live_rows) J = std::max<uint32_t>(1, live_rows);
+    static const uint32_t w_prod[5][5] = {{1}, {2, 1}, {3, 2, 1}, {3, 3, 2, 1}, {3, 3, 3, 2, 1}};
     static const uint32_t w_up[5][5] = {{1}, {1, 2}, {1, 2, 3}, {1, 2, 3, 3}, {1, 2, 3, 3, 3}};
     static const uint32_t w_tail[4][4] = {{1}, {2, 1}, {3, 2, 1}, {4, 3, 2, 1}};
     static const uint32_t w_even[2] = {1, 1};
-    const std::vector<uint32_t> ub = cuts(J, w_up[J - 1]), zb = cuts(CZ, w_even), wb = cuts(CW, w_tail[CW - 1]);
+    const std::vector<uint32_t> ub = cuts(J, producer ? w_prod[J - 1] : w_up[J - 1], live_rows), zb = cuts(CZ, w_even, m), wb = cuts(CW, w_tail[CW - 1], m);
+    // the uploads, in the order they are issued: rows [a, b) of the W block, released once `need` leading positions are final
+    struct Up { uint32_t a, b; uint64_t need; };
+    std::vector<Up> ups;
+    if (producer && live_rows < m) ups.push_back(Up{live_rows, m, 0});
+    for (uint32_t j = 0; j < J; j++) ups.push_back(Up{ub[j], ub[j + 1], producer ? std::min<uint64_t>((uint64_t)ub[j + 1] * c->k, c->gate.npos) : (ready ? mk : 0)});
     // encode steps: rows [r0, r1) of `blocks` consecutive blocks of every proof (blocks = 2: the X and the Y block) in one launch
     struct Step { uint32_t r0, r1, blocks; int upload; };
     std::vector<Step> enc;
     // (a small commit hashes at the end anyway, so nothing is gained by finishing the X block early: every step encodes its rows of
     // all four blocks -- the Z rows are gathered with the step, the W rows are the upload itself -- and the whole encoding overlaps
     // the transfer)
-    for (uint32_t j = 0; j < J; j++) enc.push_back(Step{ub[j], ub[j + 1], small ? 4u : 2u, (int)j});
-    if (!small) {
+    for (size_t j = 0; j < ups.size(); j++) enc.push_back(Step{ups[j].a, ups[j].b, (small || producer) ? 4u : 2u, (int)j});
+    if (!small && !producer) {
         for (uint32_t j = 0; j < CZ; j++) enc.push_back(Step{2 * m + zb[j], 2 * m + zb[j + 1], 1, -1});
         for (uint32_t j = 0; j < CW; j++) enc.push_back(Step{3 * m + wb[j], 3 * m + wb[j + 1], 1, -1});
     }
@@ -172,6 +190,11 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
     std::vector<HashStep> hashes;
     if (small) {
         hashes.push_back(HashStep{0, c->rows, enc.size() - 1});
+    } else if (producer) {
+        const size_t pad = ups.size() - J;                                                                   // 1 if the padding rows went first
+        for (uint32_t j = 0; j < J; j++) hashes.push_back(HashStep{ub[j], ub[j + 1], pad + j});              // the X rows, step by step
+        if (pad) hashes.push_back(HashStep{live_rows, m, enc.size() - 1});                                   // ... and the X block's padding rows
+        for (uint32_t blk = 1; blk < 4; blk++) hashes.push_back(HashStep{blk * m, (blk + 1) * m, enc.size() - 1});   // Y, Z, W once every row exists
     } else {
         for (uint32_t j = 0; j < J; j++) hashes.push_back(HashStep{ub[j], ub[j + 1], j});
         hashes.push_back(HashStep{m, 2 * m, (size_t)J - 1});
@@ -182,8 +205,21 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
     LG_HIP(c, hipEventRecord(c->evt.done, c->st.main));
     LG_HIP(c, hipStreamWaitEvent(c->st.up, c->evt.done, 0));
     if (!small) LG_HIP(c, hipStreamWaitEvent(hs, c->evt.done, 0));
+    static const bool trace_steps = getenv("LG_PROVER_TIMING") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
     auto upload = [&](uint32_t j) -> int {
-        const uint32_t a = ub[j], b = ub[j + 1];
+        const uint32_t a = ups[j].a, b = ups[j].b;
+        if (ready && ups[j].need) {
+            // the producer of w (a host thread still evaluating the circuit) publishes how many leading positions are final: the
+            // rows of this step are handed to the copy engine once they are (positions past the solution vector count as ready
+            // when the producer says m k)
+            const uint64_t need = ups[j].need;
+            unsigned spins = 0;
+            while (__atomic_load_n(const_cast<const uint64_t*>(ready), __ATOMIC_ACQUIRE) < need)
+                if (++spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if (trace_steps) fprintf(stderr, "    [commit_from_witness] step %u of %zu (rows [%u, %u) of each block) released %.3f ms after the call\n", j, ups.size(), a, b,
+                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
+        }
         const size_t width = (size_t)(b - a) * c->k * sizeof(fr);
         LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + ((size_t)3 * m + a) * c->k * sizeof(fr), (size_t)c->rows * c->k * sizeof(fr),
                                    reinterpret_cast<const uint8_t*>(host_w) + (size_t)a * c->k * sizeof(fr), (size_t)mk * sizeof(fr), width, c->batch,
@@ -240,7 +276,7 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
         a.blk_count = st.blocks; a.blk_stride = m;
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->st.main, a));
         // the next step's rows start travelling (issued after this step's kernels: a copy from pageable memory blocks this thread)
-        if (st.upload >= 0 && (uint32_t)st.upload + 1 < J) { const int rc_ = upload((uint32_t)st.upload + 1); if (rc_ != LG_OK) return rc_; }
+        if (st.upload >= 0 && (size_t)st.upload + 1 < ups.size()) { const int rc_ = upload((uint32_t)st.upload + 1); if (rc_ != LG_OK) return rc_; }
         if (host_coeffs) {
             LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->evt.coef[i % lg_ctx::kMaxChunks], 0));
             const size_t pitch = (size_t)c->rows * c->k * sizeof(fr), width = (size_t)span * c->k * sizeof(fr);
@@ -272,9 +308,13 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
 extern "C" {
 
 int lg_encode_commit_from_witness(lg_ctx* c, const uint64_t* w, uint64_t* coeffs_out, uint8_t* root_out) {
+    return lg_encode_commit_from_witness_progress(c, w, nullptr, coeffs_out, root_out);
+}
+
+int lg_encode_commit_from_witness_progress(lg_ctx* c, const uint64_t* w, const volatile uint64_t* w_positions_ready, uint64_t* coeffs_out, uint8_t* root_out) {
     if (!c || !w || !root_out) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;
-    const int rc = commit_from_witness(c, w, coeffs_out);
+    const int rc = commit_from_witness(c, w, coeffs_out, w_positions_ready);
     if (rc != LG_OK) {
         if (rc != LG_ERR_STATE) c->held.committed = false;
         return rc;

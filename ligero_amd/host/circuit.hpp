@@ -18,6 +18,7 @@
 // this layer throws std::runtime_error with the reference's message.  Product code: independent
 // of oracle/.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -676,13 +677,20 @@ public:
     // the same, but only elements [elem_begin, elem_end) of the flat row-major 4m x k matrix, written to out[0 ..): the row
     // shard one rank of a coset-sharded proof uploads (elem = row * k; the trace is still evaluated in full)
     void build_preenc_range_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, size_t elem_begin, size_t elem_end, E* out,
-                                           bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
-        build_preenc_ranges_from_formatted(bumped, {{elem_begin, elem_end}}, out, all_outputs_one, scratch);
+                                           bool* all_outputs_one = nullptr, Scratch* scratch = nullptr, std::atomic<uint64_t>* positions_done = nullptr) const {
+        build_preenc_ranges_from_formatted(bumped, {{elem_begin, elem_end}}, out, all_outputs_one, scratch, positions_done);
     }
     // ... or several element ranges at once (one evaluation of the trace), written back to back into out[0 ..): the rows one rank
     // of a row-relay proof keeps in the blocks layout -- its share of each of the X, Y, Z, W blocks
+    // positions_done (optional): advanced, with release semantics, to the number of leading positions of the solution vector whose
+    // entries in `out` are final -- a consumer on another thread may ship those rows while the rest is still being evaluated
+    // (lg_encode_commit_from_witness_progress); m k once everything, the zero padding included, is final
     void build_preenc_ranges_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, const std::vector<std::pair<size_t, size_t>>& ranges, E* out,
-                                            bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
+                                            bool* all_outputs_one = nullptr, Scratch* scratch = nullptr, std::atomic<uint64_t>* positions_done = nullptr) const {
+        struct Finish {     // whatever way the function is left -- an exception included -- the consumer must not wait for ever
+            std::atomic<uint64_t>* p; uint64_t all;
+            ~Finish() { if (p) p->store(all, std::memory_order_release); }
+        } finish{positions_done, (uint64_t)(m * k)};
         const size_t mk = m * k;
         size_t total = 0;
         std::vector<size_t> out_off;
@@ -729,6 +737,7 @@ public:
             };
             size_t pos = 0, ci = 0;
             for (size_t i = 0; i < nn; i++) {
+                if (positions_done && (i & 0xffff) == 0) positions_done->store(pos, std::memory_order_release);
                 const uint8_t kd = prog_.kind[i];
                 if (kd == Node::Constant) {
                     val[i] = prog_.constants[ci++];
@@ -818,8 +827,9 @@ public:
         return g;
     }
     // w alone: the W block of preenc_u, m k elements (zero padded)
-    void build_w_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr, Scratch* scratch = nullptr) const {
-        build_preenc_range_from_formatted(bumped, 3 * m * k, 4 * m * k, out, all_outputs_one, scratch);
+    void build_w_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr, Scratch* scratch = nullptr,
+                                std::atomic<uint64_t>* positions_done = nullptr) const {
+        build_preenc_range_from_formatted(bumped, 3 * m * k, 4 * m * k, out, all_outputs_one, scratch, positions_done);
     }
     std::vector<std::vector<E>> build_preenc_u(const std::vector<std::pair<size_t, E>>& var_assignment, bool* all_outputs_one = nullptr) const {
         std::vector<E> flat(4 * m * k);

@@ -62,20 +62,16 @@ int lgp_prove(lgp_prover* p, const uint64_t* node_idx, const uint64_t* values, u
     if (!p || !proof_out || (count && (!node_idx || !values))) return LGP_ERR_BAD_ARG;
     *proof_out = nullptr;
     return guarded([&] {
-        std::vector<std::pair<size_t, Fr>> va;
-        for (uint64_t i = 0; i < count; i++) {
-            Fr v;
-            std::memcpy(v.l, values + 4 * i, 32);
-            va.emplace_back((size_t)node_idx[i], v);
-        }
+        ligero::PhaseTimer tm;
         PoseidonSponge sponge = PoseidonSponge::test_sponge();
         auto* pr = new lgp_proof();
         try {
-            pr->own = p->hip.prove(va, sponge);
+            pr->own = p->hip.prove_arrays(node_idx, values, count, sponge);
         } catch (...) {
             delete pr;
             throw;
         }
+        tm.mark("lgp_prove: prove() returned");
         *proof_out = pr;
         return LGP_OK;
     });

@@ -296,6 +296,10 @@ public:
         }
     }
     ~HipLigeroT() {
+        for (auto& po : pending_) {
+            if (po.worker.joinable()) po.worker.join();
+            if (po.pinned) lg_host_unregister(ctx_, po.cols.data());
+        }
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
         if (cols_pinned_) lg_host_unregister(ctx_, cols_stage_.data());
         release_exchange();
@@ -306,10 +310,34 @@ public:
 
     // ---------------------------------------------------------------- prove (mod.rs:435-578)
     LigeroProof prove(const std::vector<std::pair<size_t, E>>& var_assignment, PoseidonSponge& sponge) {   // mod.rs:435-455
+        PhaseTimer tm;
         std::vector<std::pair<size_t, E>> bumped;
         bumped.reserve(var_assignment.size());
         for (const auto& v : var_assignment) bumped.emplace_back(inst_.bump_index(v.first), v.second);
+        tm.mark("prove: indices bumped");
         return prove_inner(bumped, sponge);
+    }
+    // prove() from the C ABI's arrays (node index, 32-byte value): the bumped assignment is written once, by a few threads, into a
+    // vector this prover keeps -- at 2^20 constraints two passes of a million (index, value) pairs through fresh vectors cost 17 ms
+    LigeroProof prove_arrays(const uint64_t* node_idx, const uint64_t* values, uint64_t count, PoseidonSponge& sponge) {
+        static_assert(sizeof(E) % 8 == 0, "elements are whole 64-bit limbs");
+        constexpr size_t limbs = sizeof(E) / 8;
+        assign_buf_.resize(count);
+        auto fill = [&](uint64_t a, uint64_t b) {
+            for (uint64_t i = a; i < b; i++) {
+                assign_buf_[i].first = inst_.bump_index((size_t)node_idx[i]);
+                std::memcpy(assign_buf_[i].second.l, values + limbs * i, sizeof(E));
+            }
+        };
+        const unsigned nt = count >= (1u << 16) ? std::min(4u, usable_cpus()) : 1u;
+        if (nt <= 1) {
+            fill(0, count);
+        } else {
+            std::vector<std::thread> ts;
+            for (unsigned t = 0; t < nt; t++) ts.emplace_back(fill, count * t / nt, count * (t + 1) / nt);
+            for (auto& t : ts) t.join();
+        }
+        return prove_inner(assign_buf_, sponge);
     }
     // mod.rs:580-611: labels resolve in the formatted circuit's variable map; "Variable not found: <label>" otherwise
     LigeroProof prove_with_labels(const std::vector<std::pair<std::string, E>>& var_assignment, PoseidonSponge& sponge) {
@@ -333,13 +361,38 @@ private:
             scratch_.buffer_replaced();
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
+        PhaseTimer tm0;
+        tm0.mark("prove_inner: buffers ready");
         PhaseTimer tm;
         LigeroProof proof;
+        struct Joiner {     // the helper threads of the openings write into `proof`: none may outlive it, whichever way this function is left
+            HipLigeroT* self;
+            ~Joiner() { self->open_columns_join(); }
+        } joiner{this};
         if (witness_only) {
-            inst_.build_w_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_);
-            tm.mark("evaluation trace + w (host)");
-            check(lg_encode_commit_from_witness(ctx_, flat_[0].l, nullptr, proof.u_root.data()), "lg_encode_commit_from_witness");   // mod.rs:483-551
-            tm.mark("lg_encode_commit_from_witness (H2D of w + gather + commit)");
+            // The evaluation of the circuit runs on a thread of its own and publishes how far the solution vector is final; this
+            // thread hands every step of rows to the device as soon as it is (lg_encode_commit_from_witness_progress): the
+            // transfer and the encoding of the early rows run beside the evaluation of the late ones.  (What stays serial after
+            // the trace: the last step's rows, the Z and W blocks' encoding and the tail of the column hash.)
+            // (the evaluation stays on THIS thread, next to the memory it has always touched -- moved to a fresh thread it ran a
+            // third slower on the two-socket GPU box -- and the helper only issues the device calls)
+            std::atomic<uint64_t> done{0};
+            static_assert(sizeof(std::atomic<uint64_t>) == sizeof(uint64_t), "the progress word is read as a plain 64-bit integer");
+            int st = LG_OK;
+            std::thread consumer([&] {
+                st = lg_encode_commit_from_witness_progress(ctx_, flat_[0].l, reinterpret_cast<const volatile uint64_t*>(&done), nullptr, proof.u_root.data());   // mod.rs:483-551
+            });
+            std::exception_ptr trace_err;
+            try {
+                inst_.build_w_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_, &done);
+            } catch (...) {
+                trace_err = std::current_exception();   // (the builder has released the consumer: positions_done = m k)
+            }
+            tm.mark("evaluation trace + w (beside the H2D of w, the gathers and the encoding of the rows already final)");
+            consumer.join();
+            if (trace_err) std::rethrow_exception(trace_err);
+            check(st, "lg_encode_commit_from_witness_progress");
+            tm.mark("rest of the commit (last rows, the column hash after the X block, tree, root)");
         } else {
             inst_.build_preenc_from_formatted(formatted_assignment, flat_.data(), nullptr, &scratch_);
             tm.mark("evaluation trace + preenc_u (host)");
@@ -355,8 +408,8 @@ private:
             tm.mark("interleaved: challenges + row_mul");
             sponge.absorb_elements(proof.interleaved_proof.preenc_u_lc);
             tm.mark("interleaved: sponge absorbs k elements");
-            proof.interleaved_proof.open = open_columns(sponge);
-            tm.mark("interleaved: open_columns");
+            open_columns_begin(sponge, 0, proof.interleaved_proof.open);
+            tm.mark("interleaved: open_columns queued");
         }
         {   // prove_linear_constraints, mod.rs:712-747
             // r_linear (ChaCha20 + F::rand) and r_a = A.row_mul(r_linear) are produced on the device from the seed
@@ -369,25 +422,31 @@ private:
                 check(lg_linear_constraint_poly(ctx_, r_a[0].l, poly[0].l), "lg_linear_constraint_poly");
             }
             tm.mark("linear: challenges + polynomial");
+            open_columns_unpack(0);      // (the call above waited for the stream: the first opening is in host memory; a thread unpacks it)
             trim_zeros(poly);
             proof.linear_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
             tm.mark("linear: sponge absorbs 2k elements");
-            proof.linear_constraints_proof.open = open_columns(sponge);
-            tm.mark("linear: open_columns");
+            open_columns_begin(sponge, 1, proof.linear_constraints_proof.open);
+            tm.mark("linear: open_columns queued");
         }
         {   // prove_quadratic_constraints, mod.rs:832-859
             const std::vector<Fr> r = get_field_elements_from_prng<E>(m_, sponge.squeeze_seed());
             std::vector<Fr> poly(2 * k_);
             check(lg_quadratic_constraint_poly(ctx_, r[0].l, poly[0].l), "lg_quadratic_constraint_poly");
             tm.mark("quadratic: challenges + polynomial");
+            open_columns_unpack(1);
             trim_zeros(poly);
             proof.quadratic_constraints_proof.polynomial = poly;
             sponge.absorb_elements(poly);
             tm.mark("quadratic: sponge absorbs 2k elements");
-            proof.quadratic_constraints_proof.open = open_columns(sponge);
+            open_columns_begin(sponge, 2, proof.quadratic_constraints_proof.open);
+            check(lg_sync(ctx_), "lg_sync");
+            open_columns_unpack(2);
             tm.mark("quadratic: open_columns");
         }
+        open_columns_join();
+        tm.mark("openings unpacked (helper threads joined)");
         return proof;
     }
 
@@ -749,6 +808,57 @@ private:
         if (st != LG_OK) throw DeviceError(st, std::string(what) + " (" + lg_last_error(ctx_) + ")");
     }
 
+    // open_columns (mod.rs:935-955) in three steps, so that an opening costs the proof's critical path only its index sampling:
+    //   begin   squeeze the indices, queue the gather and the copies into this opening's page-locked staging (no wait)
+    //   unpack  once a later synchronous call has drained the stream: a helper thread moves the columns into the proof object
+    //           (50 MB of freshly faulted vectors per opening at 2^20 constraints) while this thread absorbs the next polynomial
+    //   join    before the proof is returned
+    struct PendingOpen {
+        std::vector<Fr> cols; bool pinned = false;
+        std::vector<uint8_t> sib, paths;
+        std::vector<uint64_t> indices;
+        OpenedColumns* dst = nullptr;
+        std::thread worker;
+    };
+    void open_columns_begin(PoseidonSponge& sponge, int slot, OpenedColumns& dst) {
+        PendingOpen& po = pending_[slot];
+        if (po.worker.joinable()) po.worker.join();
+        po.indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
+        const size_t t = po.indices.size(), rows = 4 * m_, plen = (size_t)logn_ - 1;
+        std::vector<uint32_t> idx(po.indices.begin(), po.indices.end());
+        if (po.cols.size() != t * rows) {
+            if (po.pinned) lg_host_unregister(ctx_, po.cols.data());
+            po.cols.resize(t * rows);
+            po.pinned = lg_host_register(ctx_, po.cols.data(), po.cols.size() * sizeof(Fr)) == LG_OK;
+        }
+        po.sib.resize(t * 32);
+        po.paths.resize(t * plen * 32 + 1);
+        po.dst = &dst;
+        check(lg_open_columns_async(ctx_, 0, idx.data(), (uint32_t)t, po.cols[0].l, po.sib.data(), po.paths.data()), "lg_open_columns_async");
+    }
+    void open_columns_unpack(int slot) {
+        PendingOpen& po = pending_[slot];
+        const size_t rows = 4 * m_, plen = (size_t)logn_ - 1;
+        po.worker = std::thread([&po, rows, plen] {
+            OpenedColumns& out = *po.dst;
+            const size_t t = po.indices.size();
+            out.columns.resize(t);
+            out.paths.resize(t);
+            for (size_t c = 0; c < t; c++) {
+                out.columns[c].assign(po.cols.begin() + c * rows, po.cols.begin() + (c + 1) * rows);
+                MerklePath& p = out.paths[c];
+                p.leaf_index = po.indices[c];
+                memcpy(p.leaf_sibling_hash.data(), &po.sib[32 * c], 32);
+                p.auth_path.resize(plen);
+                for (size_t l = 0; l < plen; l++) memcpy(p.auth_path[l].data(), &po.paths[32 * (c * plen + l)], 32);
+            }
+        });
+    }
+    void open_columns_join() {
+        for (auto& po : pending_)
+            if (po.worker.joinable()) po.worker.join();
+    }
+
     // mod.rs:935-955
     OpenedColumns open_columns(PoseidonSponge& sponge) {
         const std::vector<uint64_t> indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
@@ -940,6 +1050,8 @@ private:
     std::vector<Fr> flat_;      // preenc_u (or only its W block, from_witness_) of the proof being made, reused between proofs; a sharded prover: its row shard
     bool pinned_ = false;
     bool from_witness_ = false; // the circuit's gate map is on the device: commits upload w alone
+    PendingOpen pending_[3];       // the three openings of an unsharded proof in flight (open_columns_begin)
+    std::vector<std::pair<size_t, E>> assign_buf_;   // prove_arrays' bumped assignment, kept between proofs
     std::vector<Fr> cols_stage_;   // opened columns as they come off the device (reused, page-locked)
     bool cols_pinned_ = false;
     typename LigeroInstance::Scratch scratch_;   // trace storage and the "flat_ already holds a preenc_u" note, kept between proofs

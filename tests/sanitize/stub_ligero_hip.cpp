@@ -55,6 +55,14 @@ int lg_upload_constraint_matrix(lg_ctx*, uint64_t, uint64_t, const uint64_t*, co
 int lg_upload_gate_map(lg_ctx*, uint64_t, const uint32_t*, const uint32_t*, const uint64_t*, uint32_t) { return LG_OK; }
 // the device-transcript entry points: the batch prover under this sanitizer run keeps its transcript on the host (the race
 // detector watches the HOST phases), so these only have to link
+int lg_encode_commit_from_witness_progress(lg_ctx* c, const uint64_t* w, const volatile uint64_t* ready, uint64_t* coeffs, uint8_t* root) {
+    if (ready)      // (the real library ships rows as they become final; the stand-in waits for all of them)
+        while (__atomic_load_n(const_cast<const uint64_t*>(ready), __ATOMIC_ACQUIRE) < (uint64_t)(c->rows / 4) * c->k) {}
+    return lg_encode_commit_from_witness(c, w, coeffs, root);
+}
+int lg_open_columns_async(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths) {
+    return lg_open_columns(c, proof, idx, t, cols, sib, paths);
+}
 int lg_prover_setup(lg_ctx*, const lg_sponge_params*, uint32_t) { return LG_ERR_UNSUPPORTED; }
 int lg_prover_layout(const lg_ctx*, lg_proof_layout*) { return LG_ERR_UNSUPPORTED; }
 int lg_prove_batch_queue(lg_ctx*, const uint64_t*, void*) { return LG_ERR_UNSUPPORTED; }

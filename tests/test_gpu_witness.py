@@ -89,6 +89,59 @@ def test_synthetic_gate_maps_match_oracle(oracle, m, k, batch, forward):
         assert np.array_equal(c.leaves(), np.stack([x["leaves"] for x in want]))
 
 
+@pytest.mark.parametrize("m,k,pad_rows,chunks", [(40, 1024, 13, 3), (24, 512, 0, 4), (9, 256, 8, 2), (12, 128, 3, 0)])
+def test_commit_while_w_is_still_being_produced(oracle, monkeypatch, m, k, pad_rows, chunks):
+    """lg_encode_commit_from_witness_progress: another thread writes w front to back and publishes how many leading positions are
+    final; the commit ships rows as they become final (the padding rows behind the solution vector first, then steps over the rows
+    it reaches, all four blocks per step) and must equal the commit from a finished w.  Until a position is published the buffer
+    holds GARBAGE there: a row shipped too early changes the root.  Pipelined plan forced at a small size (LG_FORCE_CHUNKS); the
+    last case is a single-chunk commit, which waits for all of w."""
+    import ctypes
+    import threading
+    import time
+    import ligero_amd
+    from ligero_amd import _ffi
+    if chunks:
+        monkeypatch.setenv("LG_FORCE_CHUNKS", str(chunks))
+    rng = np.random.default_rng(m + k)
+    mk = m * k
+    npos = mk - pad_rows * k - 5
+    left = np.full(npos, 0xffffffff, dtype=np.uint32)
+    right = left.copy()
+    gates = np.sort(rng.choice(np.arange(1, npos), size=npos // 4, replace=False))
+    left[gates] = np.array([rng.integers(0, p) for p in gates], dtype=np.uint32)
+    right[gates] = np.array([rng.integers(0, p) for p in gates], dtype=np.uint32)
+    consts = np.zeros((0, 4), dtype=np.uint64)
+    final = np.zeros((mk, 4), dtype=np.uint64)
+    final[:npos] = random_mont(5, npos).reshape(npos, 4)
+    pre = rebuild_preenc_from_w(final, left, right, consts, m, k)
+    want = oracle.encode_commit(pre, k, 8 * k, want_u=False)["root"]
+    L = _ffi.lib()
+    with ligero_amd.LigeroCommitter(rows=4 * m, k=k) as c:
+        c.upload_gate_map(left, right, consts)
+        for rep in range(3):
+            buf = np.ascontiguousarray(final.copy())
+            buf[:npos] = np.uint64(0x1111111111111111)          # not yet produced
+            ready = np.zeros(1, dtype=np.uint64)
+            root = (ctypes.c_uint8 * 32)()
+
+            def producer():
+                step = max(1, npos // 23)
+                for a in range(0, npos, step):
+                    b = min(npos, a + step)
+                    buf[a:b] = final[a:b]
+                    ready[0] = b                                 # (CPython: the store above is complete before this one)
+                    time.sleep(0.002)
+                ready[0] = mk
+            t = threading.Thread(target=producer)
+            t.start()
+            st = L.lg_encode_commit_from_witness_progress(c._ctx, buf.ctypes.data_as(ctypes.c_void_p), ready.ctypes.data_as(ctypes.c_void_p), None,
+                                                          ctypes.cast(root, ctypes.c_void_p))
+            t.join()
+            _ffi.check(st, "lg_encode_commit_from_witness_progress", c._ctx)
+            assert bytes(root) == want, rep
+
+
 def test_refusals(oracle):
     import ligero_amd
     from ligero_amd import _ffi
