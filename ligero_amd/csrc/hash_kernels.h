@@ -107,7 +107,14 @@ static __global__ void __launch_bounds__(256, 8) blake2s_columns_kernel(const Co
     const uint32_t b = a.proof_begin + (uint32_t)((gid / a.k) / a.plane_count);
     // element (row i) = p[i * 2k], p[i * 2k + 1]
     const uint4* p = a.u + 2 * ((uint64_t)s * a.plane_stride + ((uint64_t)b * a.rows + a.row_begin) * a.k + q);
+#ifdef LG_AB_HASH_ALIASED_ROWS
+    // ABLATION (tools/ab_hash_reads.sh, EXPERIMENTS.md section I): every row read of a column hits the column's FIRST row -- the same
+    // instruction stream with the hash's pass over U served from cache instead of HBM (digests are wrong): the upper bound of what an
+    // evaluate + hash fusion could save, without any of its costs.  (col_rows < 2^58: a zero the compiler cannot see.)
+    const uint64_t step = 2 * (uint64_t)a.k * (a.col_rows >> 62);
+#else
     const uint64_t step = 2 * (uint64_t)a.k;
+#endif
     uint4* st = a.state + kColStateVec * ((((uint64_t)b << a.lognp) + s) * a.k + q);
 
     uint32_t h[8];
