@@ -409,12 +409,17 @@ int lg_commit_sharded(lg_ctx* ctx, const lg_comm* comm, const uint64_t* preenc_r
  * rank takes an odd last row).  LG_RELAY_BLOCKS: the rank's
  * share of each of the four row blocks X, Y, Z, W of preenc_u (mod.rs:516) -- its rows then form a small [X; Y; Z; W]
  * matrix of their own (the quadratic test's row triples stay on one rank); the relay then has 4 * world hops.
- * lg_relay_row_ranges: (first row in the column, rows) x up to 4.
+ * LG_RELAY_ROUND_ROBIN(C), C = 2 .. 8: the rows are cut into C * world balanced ranges (even boundaries) dealt to the ranks in turn
+ * -- rank g keeps ranges g, g + world, ... -- so that a rank evaluates its next range while the column states of its current
+ * one travel round the ring: the relay's serial chain and the encoding overlap instead of adding up (C * world hops of n * 80
+ * bytes; one plane group).
+ * lg_relay_row_ranges: (first row in the column, rows) x up to 8.
  * plane_groups P (0 = chosen by the library; contiguous layout only): every hop is cut into P runs of planes, rank g works on
  * group c while rank g + 1 works on group c - 1 -- G + P - 1 steps instead of G, each over n / P columns, which pays once a
  * group is small enough for the four-lanes-per-column hash kernel (<= 32 768 columns).
  */
-enum { LG_RELAY_CONTIGUOUS = 0, LG_RELAY_BLOCKS = 1 };
+enum { LG_RELAY_CONTIGUOUS = 0, LG_RELAY_BLOCKS = 1, LG_RELAY_ROUND_ROBIN_BASE = 0x100 };
+#define LG_RELAY_ROUND_ROBIN(chunks_per_rank) (LG_RELAY_ROUND_ROBIN_BASE + (chunks_per_rank))
 int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int layout, uint64_t* ranges_out, uint32_t* nranges_out);
 int lg_commit_row_relay(lg_ctx* ctx, const lg_comm* comm, uint64_t col_rows, int layout, uint32_t plane_groups, const uint64_t* preenc_rows);
 /* Mean milliseconds per stage (HIP events on the library's stream, no host laps) of the sharded commits issued since

@@ -39,7 +39,7 @@ LG_ERR_STATE = -6
 LG_ERR_UNSUPPORTED = -7
 LG_ERR_COMM = -8
 LG_COMM_EXCHANGE_AT_WORLD_1 = 1
-LG_RELAY_CONTIGUOUS, LG_RELAY_BLOCKS = 0, 1
+LG_RELAY_CONTIGUOUS, LG_RELAY_BLOCKS, LG_RELAY_ROUND_ROBIN_BASE = 0, 1, 0x100
 LG_SHARD_STAGE_NAMES = ("interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle")
 LG_RELAY_STAGE_NAMES = ("encode", "unused", "relay", "digests", "merkle")
 LG_STAGE_NAMES = ("interpolate", "evaluate", "colhash", "merkle")

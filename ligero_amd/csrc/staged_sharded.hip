@@ -557,6 +557,16 @@ int lg_relay_row_ranges(uint64_t col_rows, uint32_t world, uint32_t rank, int la
         const uint64_t m = col_rows / 4, a = m * rank / world, b = m * (rank + 1) / world;
         if (b > a)
             for (uint32_t blk = 0; blk < 4; blk++) { ranges_out[2 * n] = blk * m + a; ranges_out[2 * n + 1] = b - a; n++; }
+    } else if (layout > LG_RELAY_ROUND_ROBIN_BASE && layout <= LG_RELAY_ROUND_ROBIN_BASE + 8) {
+        // the rows are cut into C * world balanced ranges (even boundaries, the last range takes the odd row) dealt to the ranks in
+        // turn: rank g keeps ranges g, g + world, g + 2 world, ... -- it can encode its next range while the column states of the
+        // current one are somewhere else on the ring
+        const uint64_t C = (uint64_t)(layout - LG_RELAY_ROUND_ROBIN_BASE), R = C * world, half = col_rows / 2;
+        for (uint64_t cidx = 0; cidx < C; cidx++) {
+            const uint64_t i = cidx * world + rank;
+            const uint64_t a = 2 * (half * i / R), b = i + 1 == R ? col_rows : 2 * (half * (i + 1) / R);
+            if (b > a) { ranges_out[2 * n] = a; ranges_out[2 * n + 1] = b - a; n++; }
+        }
     } else {
         return LG_ERR_BAD_ARG;
     }
@@ -577,7 +587,7 @@ static int commit_row_relay_body(lg_ctx* c, const lg_comm* comm, uint64_t col_ro
     std::vector<Link> chain;
     uint32_t local_rows = 0;
     for (uint32_t r = 0; r < world; r++) {
-        uint64_t rg[8]; uint32_t nr = 0;
+        uint64_t rg[16]; uint32_t nr = 0;
         { const int rc_ = lg_relay_row_ranges(col_rows, world, r, layout, rg, &nr); if (rc_ != LG_OK) return rc_; }
         uint32_t local = 0;
         for (uint32_t i = 0; i < nr; i++) {
@@ -599,7 +609,46 @@ static int commit_row_relay_body(lg_ctx* c, const lg_comm* comm, uint64_t col_ro
     if (ev) LG_HIP(c, hipEventRecord(ev[0], c->st.main));
     const uint32_t all = all_planes_mask(c);
     bool head_done = false;
-    if (local_rows) {
+    const bool round_robin = layout > LG_RELAY_ROUND_ROBIN_BASE;
+    if (round_robin) {
+        // Round robin: this rank keeps several ranges that are far apart in the column.  Encode stream: interpolate everything,
+        // then evaluate range after range, an event behind each.  Hash stream: for every range in column order -- wait for ITS
+        // evaluation, receive the column states from the rank before, absorb the rows, hand the states on.  The evaluation of the
+        // next range runs while the states of this one are still on their way round the ring: the relay's serial chain (G hops of
+        // one rank's hash each) and the encoding overlap instead of adding up.  One plane group: a wrap-around ring with rendezvous
+        // sends cannot have a rank send and receive in the same step.
+        { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+        { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
+        if (local_rows) { const int rc_ = lg_stage_interpolate(c, preenc_rows, 0, local_rows); if (rc_ != LG_OK) return rc_; }
+        else c->held.touch_staged();
+        uint32_t ci = 0;
+        for (const Link& l : chain) {
+            if (l.owner != rank) continue;
+            { const int rc_ = lg_stage_evaluate_rows(c, all, l.local, (uint32_t)l.n); if (rc_ != LG_OK) return rc_; }
+            LG_HIP(c, hipEventRecord(c->evt.chunk[ci++ % lg_ctx::kMaxChunks], c->st.main));
+        }
+        if (ev) LG_HIP(c, hipEventRecord(ev[1], c->st.main));
+        if (ev) LG_HIP(c, hipEventRecord(ev[2], c->st.main));
+        const size_t state_bytes = (size_t)c->n * LG_HSTATE_BYTES;
+        ci = 0;
+        for (size_t i = 0; i < chain.size(); i++) {
+            const Link& l = chain[i];
+            if (l.owner != rank) continue;
+            LG_HIP(c, hipStreamWaitEvent(c->st.hash, c->evt.chunk[ci++ % lg_ctx::kMaxChunks], 0));
+            if (exchange && i > 0 && chain[i - 1].owner != rank) {
+                const int rc_ = comm->recv(comm->user, c->d_hstate, state_bytes, chain[i - 1].owner, static_cast<void*>(c->st.hash));
+                if (rc_ != 0) return comm_fail(c, "receive of the column states", rc_);
+            }
+            { const int rc_ = stage_hash_launch(c, c->st.hash, all, l.local, (uint32_t)l.n, l.pos, col_rows); if (rc_ != LG_OK) return rc_; }
+            if (exchange && i + 1 < chain.size() && chain[i + 1].owner != rank) {
+                const int rc_ = comm->send(comm->user, c->d_hstate, state_bytes, chain[i + 1].owner, static_cast<void*>(c->st.hash));
+                if (rc_ != 0) return comm_fail(c, "send of the column states", rc_);
+            }
+        }
+        LG_HIP(c, hipEventRecord(c->evt.stage_hash, c->st.hash));
+        c->held.hash_pending = true;
+        c->held.planes |= all;
+    } else if (local_rows) {
         { const int rc_ = lg_stage_interpolate(c, preenc_rows, 0, local_rows); if (rc_ != LG_OK) return rc_; }
         // evaluate in row chunks; the rank that holds the first rows of the columns hashes each chunk as soon as it is evaluated
         // (on the hash stream, beside the evaluation of the next chunk)
@@ -623,8 +672,8 @@ static int commit_row_relay_body(lg_ctx* c, const lg_comm* comm, uint64_t col_ro
     } else {
         c->held.touch_staged();
     }
-    if (ev) LG_HIP(c, hipEventRecord(ev[1], c->st.main));
-    if (ev) LG_HIP(c, hipEventRecord(ev[2], c->st.main));
+    if (ev && !round_robin) LG_HIP(c, hipEventRecord(ev[1], c->st.main));
+    if (ev && !round_robin) LG_HIP(c, hipEventRecord(ev[2], c->st.main));
     // Plane groups: every hop is cut into P runs of planes and rank g works on group c while rank g + 1 works on group c - 1.  With
     // n / P <= 32 768 columns per launch the four-lanes-per-column kernel takes the hash (a shorter chain per block), which is what
     // makes the (G + P - 1) steps cheaper than G steps over all columns -- measured per rank at S22: 2.26 ms for all 65 536
@@ -640,7 +689,7 @@ static int commit_row_relay_body(lg_ctx* c, const lg_comm* comm, uint64_t col_ro
     if (P < 1) P = 1;
     const uint32_t per = c->nplanes / P;
     const size_t group_bytes = (size_t)per * c->ki * LG_HSTATE_BYTES;
-    for (size_t i = 0; i < chain.size(); i++) {
+    for (size_t i = 0; i < chain.size() && !round_robin; i++) {
         const Link& l = chain[i];
         if (l.owner != rank) continue;
         for (uint32_t g = 0; g < P; g++) {

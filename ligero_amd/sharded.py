@@ -485,6 +485,17 @@ def relay_row_ranges(rows: int, world: int, rank: int, layout: str = "contiguous
         a = 2 * (half * rank // world)
         b = rows if rank + 1 == world else 2 * (half * (rank + 1) // world)
         return [(a, b - a)] if b > a else []
+    if layout.startswith("round_robin:"):
+        # C * world balanced ranges (even boundaries, the last one takes the odd row) dealt in turn: rank g keeps g, g + world, ...
+        chunks = relay_layout_code(layout) - _ffi.LG_RELAY_ROUND_ROBIN_BASE
+        total, half, out = chunks * world, rows // 2, []
+        for c in range(chunks):
+            i = c * world + rank
+            a = 2 * (half * i // total)
+            b = rows if i + 1 == total else 2 * (half * (i + 1) // total)
+            if b > a:
+                out.append((a, b - a))
+        return out
     if layout != "blocks":
         raise ValueError(f"unknown relay layout {layout!r}")
     if rows % 4:
@@ -492,6 +503,20 @@ def relay_row_ranges(rows: int, world: int, rank: int, layout: str = "contiguous
     m = rows // 4
     a, b = shard_range(m, world, rank)
     return [(blk * m + a, b - a) for blk in range(4)] if b > a else []
+
+
+def relay_layout_code(layout: str) -> int:
+    """the `layout` argument of lg_relay_row_ranges / lg_commit_row_relay: "contiguous", "blocks" or "round_robin:C" (C = 2 .. 8 ranges per rank)"""
+    if layout == "contiguous":
+        return _ffi.LG_RELAY_CONTIGUOUS
+    if layout == "blocks":
+        return _ffi.LG_RELAY_BLOCKS
+    if layout.startswith("round_robin:"):
+        chunks = int(layout.split(":")[1])
+        if not 2 <= chunks <= 8:
+            raise ValueError("round_robin:C needs 2 <= C <= 8")
+        return _ffi.LG_RELAY_ROUND_ROBIN_BASE + chunks
+    raise ValueError(f"unknown relay layout {layout!r}")
 
 
 def relay_chain(rows: int, world: int, layout: str = "contiguous") -> List[Tuple[int, int, int, int]]:
@@ -561,7 +586,7 @@ class HipRelayBackend:
             preenc_rows = np.ascontiguousarray(preenc_rows, dtype=np.uint64)
             p = preenc_rows.ctypes.data_as(_vp)
         comm.error = None
-        st = self._L.lg_commit_row_relay(self.c._ctx, comm.ptr(), col_rows, {"contiguous": _ffi.LG_RELAY_CONTIGUOUS, "blocks": _ffi.LG_RELAY_BLOCKS}[layout],
+        st = self._L.lg_commit_row_relay(self.c._ctx, comm.ptr(), col_rows, relay_layout_code(layout),
                                          plane_groups, p)
         if st == _ffi.LG_ERR_COMM and comm.error:
             raise RuntimeError(f"lg_commit_row_relay: {comm.error}")

@@ -109,12 +109,15 @@ def test_row_ownership_rules_of_the_library_equal_the_host_layer():
                 out, n = np.zeros(16, dtype=np.uint32), ctypes.c_uint32(0)
                 assert L.lg_shard_row_ranges(rows, world, rank, pieces, out.ctypes.data_as(vp), ctypes.cast(ctypes.byref(n), vp)) == 0
                 assert [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)] == shard_row_ranges(rows, world, rank, pieces)
-        for layout, code in (("contiguous", _ffi.LG_RELAY_CONTIGUOUS), ("blocks", _ffi.LG_RELAY_BLOCKS)):
+        for layout, code in (("contiguous", _ffi.LG_RELAY_CONTIGUOUS), ("blocks", _ffi.LG_RELAY_BLOCKS), ("round_robin:2", _ffi.LG_RELAY_ROUND_ROBIN_BASE + 2),
+                             ("round_robin:4", _ffi.LG_RELAY_ROUND_ROBIN_BASE + 4), ("round_robin:8", _ffi.LG_RELAY_ROUND_ROBIN_BASE + 8)):
             if layout == "blocks" and rows % 4:
                 continue
             for rank in range(world):
-                out, n = np.zeros(8, dtype=np.uint64), ctypes.c_uint32(0)
+                out, n = np.zeros(16, dtype=np.uint64), ctypes.c_uint32(0)
                 assert L.lg_relay_row_ranges(rows, world, rank, code, out.ctypes.data_as(vp), ctypes.cast(ctypes.byref(n), vp)) == 0
                 assert [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)] == relay_row_ranges(rows, world, rank, layout)
     bad = np.zeros(8, dtype=np.uint64)
     assert L.lg_relay_row_ranges(10, 2, 0, _ffi.LG_RELAY_BLOCKS, bad.ctypes.data_as(vp), ctypes.cast(ctypes.byref(ctypes.c_uint32(0)), vp)) == _ffi.LG_ERR_BAD_ARG
+    for code in (_ffi.LG_RELAY_ROUND_ROBIN_BASE, _ffi.LG_RELAY_ROUND_ROBIN_BASE + 9, 7):      # no such layout
+        assert L.lg_relay_row_ranges(10, 2, 0, code, bad.ctypes.data_as(vp), ctypes.cast(ctypes.byref(ctypes.c_uint32(0)), vp)) == _ffi.LG_ERR_BAD_ARG

@@ -112,7 +112,8 @@ def _check(oracle, out, world, rows, k, layout):
 
 # even / odd boundaries, a rank without rows, one row per workgroup at k = 4096, folded k = 8192, the four-block layout, plane groups
 @pytest.mark.parametrize("rows,k,layout,groups", [(20, 128, "contiguous", 1), (21, 128, "contiguous", 2), (1, 128, "contiguous", 1), (7, 4096, "contiguous", 1),
-                                                  (5, 8192, "contiguous", 4), (20, 128, "blocks", 1), (12, 8192, "blocks", 1)])
+                                                  (5, 8192, "contiguous", 4), (20, 128, "blocks", 1), (12, 8192, "blocks", 1),
+                                                  (43, 128, "round_robin:4", 1), (21, 8192, "round_robin:2", 1)])
 def test_world2_on_one_gpu_matches_oracle(oracle, rows, k, layout, groups):
     import torch.multiprocessing as mp
     world = 2
@@ -123,7 +124,8 @@ def test_world2_on_one_gpu_matches_oracle(oracle, rows, k, layout, groups):
 
 
 @pytest.mark.parametrize("world,rows,k,layout,groups", [(4, 21, 128, "contiguous", 1), (8, 12, 128, "contiguous", 2), (8, 7, 8192, "contiguous", 1),
-                                                        (4, 44, 128, "blocks", 1), (8, 36, 128, "blocks", 1)])
+                                                        (4, 44, 128, "blocks", 1), (8, 36, 128, "blocks", 1),
+                                                        (4, 45, 128, "round_robin:3", 1), (8, 70, 128, "round_robin:4", 1), (8, 37, 8192, "round_robin:2", 1)])
 def test_world4_and_world8_on_one_gpu(oracle, world, rows, k, layout, groups):
     if world <= 4:
         import torch.multiprocessing as mp
