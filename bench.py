@@ -454,11 +454,12 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
     """ONE proof of the `workload` shape over `world` ranks (BASELINE configs[3]); returns the result dict on every rank.
     Timed region: barrier + sync, `steps` commits QUEUED back to back with the message rows resident (each commit is one
     library call -- lg_commit_sharded / lg_commit_row_relay -- whose exchanges come back through TorchComm on the library's own
-    streams; no host synchronisation inside), barrier + sync, max over ranks.  Three modes are timed one after the other and
+    streams; no host synchronisation inside), barrier + sync, max over ranks.  Four modes are timed one after the other and
     `value` is the fastest whose root equals the first mode's:
       coset-sharded, ONE coefficient all-gather          (row shard -> all-gather -> each rank evaluates + hashes its planes)
       coset-sharded, LIGERO_BENCH_EXCHANGE_PIECES pieces (default 4: piece p + 1 on the wire while piece p is evaluated and hashed)
       row relay                                          (rows end to end, the columns' Blake2s states handed from rank to rank)
+      row relay, round robin                             (LIGERO_BENCH_RELAY_CHUNKS ranges per rank, default 4: hops beside the next range's evaluation)
     `partial` (rank 0's watchdog reads it) receives the first mode's result before the others start."""
     from ligero_amd.sharded import CosetShardedCommitter, HipRelayBackend, HipStageBackend, RowRelayCommitter
     rows, k, _ = WORKLOADS[workload]
@@ -558,6 +559,30 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
         finally:
             if rc is not None:
                 rc.be.close()
+        # fourth mode: the relay with every rank's rows dealt ROUND ROBIN in C ranges -- a rank evaluates its next range while the
+        # column states of its current one are on their way round the ring (needs more than one rank to show anything)
+        chunks = int(os.environ.get("LIGERO_BENCH_RELAY_CHUNKS", "4"))
+        rr = None
+        try:
+            rr = RowRelayCommitter(lambda local: HipRelayBackend(local, k, device=local_rank), rows, dist, collectives_at_world_1=True,
+                                   layout=f"round_robin:{chunks}")
+            qroot, qelapsed, qstage = timed(rr, local_rows(rr.row_ranges()), ("encode", "relay", "digests", "merkle"))
+            out["row_relay_round_robin"] = {
+                "chunks_per_rank": chunks, "hops": len(rr.chain), "ms_per_commit": 1e3 * qelapsed / steps, "value": steps * rows * n / qelapsed,
+                "stage_ms_max_over_ranks": qstage, "rows_per_rank": rr.local_rows, "hop_bytes": n * 80,
+                "note": "rows dealt round robin: the hops of range c run on the hash stream beside the evaluation of range c + 1; `encode` ends when the last "
+                        "range is evaluated, `relay` when the last hop of this rank is done",
+                "root_matches_golden": (qroot.hex() == gold["root"]) if gold else None, "root_equals_coset_sharded": qroot == root,
+            }
+            if qelapsed < best and qroot == root:
+                best = qelapsed
+                out["value"], out["ms_per_commit"] = steps * rows * n / qelapsed, 1e3 * qelapsed / steps
+                out["mode"] = f"row relay, {chunks} ranges per rank dealt round robin"
+        except Exception as e:
+            out["row_relay_round_robin"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if rr is not None:
+                rr.be.close()
     return out
 
 

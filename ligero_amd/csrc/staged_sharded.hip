@@ -615,8 +615,10 @@ static int commit_row_relay_body(lg_ctx* c, const lg_comm* comm, uint64_t col_ro
         // then evaluate range after range, an event behind each.  Hash stream: for every range in column order -- wait for ITS
         // evaluation, receive the column states from the rank before, absorb the rows, hand the states on.  The evaluation of the
         // next range runs while the states of this one are still on their way round the ring: the relay's serial chain (G hops of
-        // one rank's hash each) and the encoding overlap instead of adding up.  One plane group: a wrap-around ring with rendezvous
-        // sends cannot have a rank send and receive in the same step.
+        // one rank's hash each) and the encoding overlap instead of adding up.  Plane groups as in the contiguous layout (P runs of
+        // planes per hop: G C + P - 1 steps of one group each, small enough for the four-lanes-per-column kernel), but the ring
+        // wraps round -- rank G - 1 hands range c to rank 0's range c + 1 -- and its transfers are rendezvous: with every rank
+        // posting its operations in order, P groups in flight stay free of a cycle only while P <= G - 1.
         { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
         { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
         if (local_rows) { const int rc_ = lg_stage_interpolate(c, preenc_rows, 0, local_rows); if (rc_ != LG_OK) return rc_; }
@@ -629,20 +631,29 @@ static int commit_row_relay_body(lg_ctx* c, const lg_comm* comm, uint64_t col_ro
         }
         if (ev) LG_HIP(c, hipEventRecord(ev[1], c->st.main));
         if (ev) LG_HIP(c, hipEventRecord(ev[2], c->st.main));
-        const size_t state_bytes = (size_t)c->n * LG_HSTATE_BYTES;
+        uint32_t P = plane_groups ? plane_groups : (world <= 2 ? 1 : (world <= 4 ? 2 : 4));
+        while (P & (P - 1)) P &= P - 1;                                       // a power of two (the planes are)
+        while (P > 1 && (P > c->nplanes || P > world - 1 || (!plane_groups && (c->n / P) < 8192))) P >>= 1;
+        if (P < 1) P = 1;
+        const uint32_t per = c->nplanes / P;
+        const size_t group_bytes = (size_t)per * c->ki * LG_HSTATE_BYTES;
         ci = 0;
         for (size_t i = 0; i < chain.size(); i++) {
             const Link& l = chain[i];
             if (l.owner != rank) continue;
             LG_HIP(c, hipStreamWaitEvent(c->st.hash, c->evt.chunk[ci++ % lg_ctx::kMaxChunks], 0));
-            if (exchange && i > 0 && chain[i - 1].owner != rank) {
-                const int rc_ = comm->recv(comm->user, c->d_hstate, state_bytes, chain[i - 1].owner, static_cast<void*>(c->st.hash));
-                if (rc_ != 0) return comm_fail(c, "receive of the column states", rc_);
-            }
-            { const int rc_ = stage_hash_launch(c, c->st.hash, all, l.local, (uint32_t)l.n, l.pos, col_rows); if (rc_ != LG_OK) return rc_; }
-            if (exchange && i + 1 < chain.size() && chain[i + 1].owner != rank) {
-                const int rc_ = comm->send(comm->user, c->d_hstate, state_bytes, chain[i + 1].owner, static_cast<void*>(c->st.hash));
-                if (rc_ != 0) return comm_fail(c, "send of the column states", rc_);
+            for (uint32_t g = 0; g < P; g++) {
+                uint8_t* gstate = reinterpret_cast<uint8_t*>(c->d_hstate) + (size_t)g * group_bytes;
+                const uint32_t gmask = (per >= 32 ? 0xffffffffu : ((1u << per) - 1u)) << (g * per);
+                if (exchange && i > 0 && chain[i - 1].owner != rank) {
+                    const int rc_ = comm->recv(comm->user, gstate, group_bytes, chain[i - 1].owner, static_cast<void*>(c->st.hash));
+                    if (rc_ != 0) return comm_fail(c, "receive of the column states", rc_);
+                }
+                { const int rc_ = stage_hash_launch(c, c->st.hash, gmask, l.local, (uint32_t)l.n, l.pos, col_rows); if (rc_ != LG_OK) return rc_; }
+                if (exchange && i + 1 < chain.size() && chain[i + 1].owner != rank) {
+                    const int rc_ = comm->send(comm->user, gstate, group_bytes, chain[i + 1].owner, static_cast<void*>(c->st.hash));
+                    if (rc_ != 0) return comm_fail(c, "send of the column states", rc_);
+                }
             }
         }
         LG_HIP(c, hipEventRecord(c->evt.stage_hash, c->st.hash));

@@ -670,11 +670,16 @@ class RowRelayCommitter:
         self.groups = max(1, min(self.asked_groups, self.be.nplanes))
         while self.be.nplanes % self.groups:
             self.groups -= 1
-        if layout != "contiguous":
+        if layout == "blocks":
             # the block layout's chain wraps around (rank G - 1 hands back to rank 0): with several groups in flight a rank
             # would have to send and receive in the same step, which plain blocking sends cannot express; one group = a strictly
             # sequential chain, which is also the faster choice (see the class comment)
             self.groups = 1
+        elif layout != "contiguous":
+            # round robin wraps around too, but is built for groups in flight: with every rank posting its (rendezvous) transfers in
+            # order the ring stays free of a cycle while P <= G - 1 (lg_commit_row_relay clamps the same way)
+            while self.groups > 1 and self.groups > self.world - 1:
+                self.groups //= 2
         self.force = bool(collectives_at_world_1) and dist is not None
         self.stage_ms: Dict[str, float] = {}
         self._stream = self.be.stream() if hasattr(self.be, "stream") else None

@@ -125,7 +125,7 @@ def test_world2_on_one_gpu_matches_oracle(oracle, rows, k, layout, groups):
 
 @pytest.mark.parametrize("world,rows,k,layout,groups", [(4, 21, 128, "contiguous", 1), (8, 12, 128, "contiguous", 2), (8, 7, 8192, "contiguous", 1),
                                                         (4, 44, 128, "blocks", 1), (8, 36, 128, "blocks", 1),
-                                                        (4, 45, 128, "round_robin:3", 1), (8, 70, 128, "round_robin:4", 1), (8, 37, 8192, "round_robin:2", 1)])
+                                                        (4, 45, 128, "round_robin:3", 2), (8, 70, 128, "round_robin:4", 4), (8, 37, 8192, "round_robin:2", 0)])
 def test_world4_and_world8_on_one_gpu(oracle, world, rows, k, layout, groups):
     if world <= 4:
         import torch.multiprocessing as mp

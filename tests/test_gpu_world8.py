@@ -68,11 +68,11 @@ def test_full_size_s22_coset_sharded_over_eight_rank_contexts(oracle, model, s22
     assert roots == [gold["root"]] * WORLD
 
 
-@pytest.mark.parametrize("layout,groups", [("contiguous", 4), ("blocks", 1), ("round_robin:4", 1)])
+@pytest.mark.parametrize("layout,groups", [("contiguous", 4), ("blocks", 1), ("round_robin:4", 4)])
 def test_full_size_s22_row_relay_over_eight_rank_contexts(oracle, model, s22_matrix, layout, groups):
     """lg_commit_row_relay: rank g keeps its rows END TO END (all 16 planes of 2508 / 2510 rows, or of its share of each of the
-    X, Y, Z, W blocks, or four ranges dealt round robin: 32 hops, the evaluation of a rank's next range beside the hops of its
-    current one), the columns' Blake2s states travel from rank to rank (four plane groups in flight on the contiguous layout),
+    X, Y, Z, W blocks, or four ranges dealt round robin: 32 hops of four plane groups each, the evaluation of a rank's next
+    range beside the hops of its current one), the columns' Blake2s states travel from rank to rank (four plane groups in flight on the contiguous layout),
     the last rank broadcasts the digests.  Root = golden on every rank; an opened column is the ranks' row pieces put
     together in row order: Blake2s of it = its leaf, the path leads to the root."""
     from ligero_amd.sharded import HipRelayBackend, RowRelayCommitter

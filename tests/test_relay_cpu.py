@@ -181,7 +181,7 @@ def test_world2_gloo_matches_single_process(oracle, rows, k, layout, groups):
 
 @pytest.mark.parametrize("world,rows,k,layout,groups", [(4, 10, 4, "contiguous", 1), (8, 12, 4, "contiguous", 2), (8, 5, 2, "contiguous", 1),
                                                         (4, 20, 4, "blocks", 1), (8, 36, 4, "blocks", 8), (8, 12, 2, "blocks", 1),
-                                                        (4, 37, 4, "round_robin:2", 1), (8, 70, 4, "round_robin:4", 1), (8, 19, 2, "round_robin:8", 1)])
+                                                        (4, 37, 4, "round_robin:2", 2), (8, 70, 4, "round_robin:4", 4), (8, 19, 2, "round_robin:8", 1)])
 def test_world4_and_world8_on_thread_ranks(oracle, world, rows, k, layout, groups):
     """the world sizes of the scaling run; ragged and empty shards, the four-block layout (4 G hops), one hop per plane"""
     from thread_dist import run_ranks
