@@ -105,7 +105,8 @@ class TorchComm:
     """include/ligero_hip.h `lg_comm` served by torch.distributed (backend "nccl" = RCCL over xGMI): the library calls back with
     a device pointer and one of ITS streams; the collective is issued with that stream current, so it is ordered with the
     library's kernels on both sides and nothing waits on the host.  Backends that cannot move device memory point to point
-    (gloo in the tests) get host copies, made on the same stream."""
+    (gloo in the tests) get host copies, made on the same stream -- with a wait for the device on the host, which the library's
+    contract for callbacks excludes: the gloo path is for functional tests, its stage times are not comparable with RCCL's."""
 
     def __init__(self, dist, group=None, device: int = 0, exchange_at_world_1: bool = False):
         if dist is not None:
@@ -380,9 +381,8 @@ class CosetShardedCommitter:
         """preenc_rows_local: this rank's rows (row_ranges(), concatenated; None: they are resident from an earlier
         commit).  Returns u_root."""
         if self.native:
-            if not self._profiling:
-                self.be.profile(True)
-                self._profiling = True
+            self.be.profile(True)                       # restarts the event ring: stage_ms below is THIS commit's, not a running mean
+            self._profiling = True
             self.be.commit_native(self._comm, preenc_rows_local, self._asked_pieces)
             root = self.be.root()                       # waits for the tree: the only host wait of the commit
             self.stage_ms = self.be.shard_stage_ms()
@@ -721,6 +721,8 @@ class RowRelayCommitter:
         """preenc_rows_local: this rank's rows (its ranges, concatenated in column order), or None when they are resident from
         an earlier commit.  Returns u_root."""
         if self.native:
+            self.be.profile(True)                       # restarts the event ring: stage_ms below is THIS commit's, not a running mean
+            self._profiling = True
             self.commit_queued(preenc_rows_local)
             root = self.be.root()                       # waits for the tree: the only host wait of the commit
             self.stage_ms = self.be.shard_stage_ms()
