@@ -1,40 +1,63 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun) and regenerates everything under profiles/ that the bench
-# line's roofline refers to.  Usage: tools/collect_profiles.sh <round tag, e.g. r01>
-# Trace pass and the two PMC passes are separate rocprofv3 runs (MI355X guide, HBM section).
+# Runs ON THE GPU BOX (through gpurun): regenerates what profiles/<tag>_* and profiles/pmc_traffic.json hold for the tree as shipped.
+#   1. the three commit shapes (Poseidon x64, S20, S22): the bench line of the timed workload alone, rocprofv3 kernel stats of the
+#      same command, and the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the MI355X guide prescribes)
+#   2. the proofs/s leg (device-transcript prover, two batches of 1024 in flight) on the system HIP runtime: kernel stats + memory
+#      copies of the same child command bench.py runs, and tools/device_transcript_probe.py's table
+#   3. one proof over the "ranks" of this box: RCCL itself at world 1 (all four modes), two gloo ranks sharing the GPU
+#   4. the default bench line (what the driver runs)
+# Usage: tools/collect_profiles.sh <round tag, e.g. r04>      (copy gpurun_out/profiles/* into profiles/ afterwards;
+#        profiles/pmc_traffic.json is rewritten in place by tools/pmc_traffic.py -- set its _source.commit when committing)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for WL in poseidon s20; do
-  STEPS=20; [ "$WL" = s20 ] && STEPS=5
-  python3 bench.py --workload $WL --steps $STEPS --warmup 3 > "$OUT/${TAG}_${WL}_bench.json" 2> "$OUT/${TAG}_${WL}_bench.err"
+for WL in poseidon s20 s22; do
+  STEPS=20; [ "$WL" = s20 ] && STEPS=5; [ "$WL" = s22 ] && STEPS=3
+  python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_${WL}_bench.json" 2> "$OUT/${TAG}_${WL}_bench.err"
+  echo "bench $WL done"
   D=/tmp/prof_${WL}_trace; rm -rf $D
   rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline \
       > "$OUT/${TAG}_${WL}_bench_under_rocprof.json" 2> "$OUT/${TAG}_${WL}_rocprof.err"
   cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_${WL}_kernel_stats.csv"
+  echo "trace $WL done"
   for C in FETCH_SIZE WRITE_SIZE; do
     D=/tmp/prof_${WL}_$C; rm -rf $D
-    rocprofv3 --pmc $C --output-format csv -d $D -- python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline \
+    rocprofv3 --pmc $C --output-format csv -d $D -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline \
         > /dev/null 2> "$OUT/${TAG}_${WL}_pmc_${C}.err"
     lc=$(echo $C | tr A-Z a-z)
-    # keep the per-dispatch rows of our kernels only (file is otherwise MBs of torch fill kernels)
     f=$(find $D -name '*counter_collection.csv' | head -1)
     (head -1 "$f"; grep -E 'ntt_rows_kernel|blake2s_columns_kernel|merkle_subtree_kernel' "$f") > "$OUT/${TAG}_${WL}_pmc_${lc}.csv"
+    cp "$f" /tmp/pq_${WL}_$C.csv
+    echo "pmc $C $WL done"
   done
+  python3 tools/pmc_traffic.py $WL /tmp/pq_${WL}_FETCH_SIZE.csv /tmp/pq_${WL}_WRITE_SIZE.csv > /dev/null
 done
-# constant-operand product microbenchmark (Montgomery vs Barrett with precomputed quotient) + its correctness leg
-hipcc -O3 --offload-arch=gfx950 -I ligero_amd/csrc tools/microbench4.hip -o /tmp/microbench4 2>/dev/null \
-  && python3 tools/mb4.py gen && /tmp/microbench4 > "$OUT/${TAG}_microbench4_shoup.log" 2>&1 && python3 tools/mb4.py check >> "$OUT/${TAG}_microbench4_shoup.log" 2>&1
-# instruction-issue microbenchmark of the non-multiplier instructions, small-commit latency with both column-hash kernels
-hipcc -O2 --offload-arch=gfx950 -o /tmp/microbench5 tools/microbench5.hip 2>/dev/null && /tmp/microbench5 > "$OUT/${TAG}_microbench5_instruction_issue.log" 2>&1
-python3 tools/hash_latency_probe.py > "$OUT/${TAG}_hash_latency_quad_vs_single.log" 2>&1
-# BASELINE configs[3] shape on one GPU, and the coset-sharded commit as a 2-rank dry run over gloo (both ranks on this box's one GPU)
-python3 bench.py --workload s22 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_s22_bench.json" 2> "$OUT/${TAG}_s22_bench.err"
-LIGERO_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --workload s22 --steps 3 --warmup 1 \
-    2> "$OUT/${TAG}_s22_sharded_gloo2.err" | grep '^{' > "$OUT/${TAG}_s22_sharded_gloo2_bench.json"
-# PCIe-inclusive host-buffer entry point
-for m in pageable registered; do for w in root coeffs; do python3 tools/pcie_probe.py poseidon $m $w; python3 tools/pcie_probe.py s20 $m $w; done; done > "$OUT/${TAG}_pcie_inclusive.log" 2>/dev/null
+cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
+# the proofs/s leg: the child bench.py runs, under the profiler (the program itself after `--`, no torch in it)
+D=/tmp/prof_prover; rm -rf $D
+LIGERO_NO_TORCH_PRELOAD=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $D -- python3 bench.py --prover-child 0 device 1024 6 0 \
+    > "$OUT/${TAG}_prover_child_under_rocprof.json" 2> "$OUT/${TAG}_prover_rocprof.err"
+cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_prover_kernel_stats.csv"
+cp $(find $D -name '*memory_copy_stats.csv' | head -1) "$OUT/${TAG}_prover_memory_copy_stats.csv"
+python3 tools/timeline_summary.py $(find $D -name '*kernel_trace.csv' | head -1) > "$OUT/${TAG}_prover_timeline_summary.log" 2>&1
+LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py host:4x64 1x64 1x256 1x1024 pipe:1x256 pipe:1x512 pipe:1x1024 pipe:1x2048 2x256 2x512 --steps=8 \
+    2>&1 | grep -v amdgpu > "$OUT/${TAG}_device_transcript_probe.log"
+LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 --cpus=2 2>&1 | grep proofs/s >> "$OUT/${TAG}_device_transcript_probe.log"
+echo "(torch preloaded: its bundled runtime copies with shader kernels)" >> "$OUT/${TAG}_device_transcript_probe.log"
+LG_SHIP_BLOCKS=0 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [runtime blit copies]/' >> "$OUT/${TAG}_device_transcript_probe.log"
+python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [ship_kernel, 8 workgroups]/' >> "$OUT/${TAG}_device_transcript_probe.log"
+echo "prover done"
+python3 tools/s20_prove_timing.py 20 6 2>&1 | grep -v amdgpu > "$OUT/${TAG}_s20_prove_timing.log"
+# one proof over the "ranks" of this box
+LIGERO_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload s22 --steps 5 --warmup 2 --no-cpu-baseline \
+    2> "$OUT/${TAG}_s22_rccl_world1.err" | grep '^{' > "$OUT/${TAG}_s22_rccl_world1_four_modes.json"
+echo "rccl world 1 done"
+LIGERO_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 50 --warmup 5 --sharded-leg s20 \
+    2> "$OUT/${TAG}_poseidon_gloo2.err" | grep '^{' > "$OUT/${TAG}_poseidon_gloo2_default_with_sharded_legs.json"
+echo "gloo 2 done"
+python3 bench.py > "$OUT/${TAG}_poseidon_bench_default_run.json" 2> "$OUT/${TAG}_poseidon_bench_default_run.err"
+rm -f "$OUT"/*.err.empty; find "$OUT" -name '*.err' -size 0 -delete
 ls -la "$OUT"
