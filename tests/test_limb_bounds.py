@@ -355,3 +355,73 @@ def test_w8shift_table_and_wshift29_model():
             acc >>= 29
         r = sum(l << (29 * i) for i, l in enumerate(out))
         assert r % P == (sum(x << (29 * i) for i, x in enumerate(a)) * w) % P and r < P + (P >> 9)
+
+
+# ---- the device sponge (ligero_amd/csrc/sponge_kernels.h): conversion constants, and one permutation replayed limb for limb
+def test_sponge_constants_and_permutation_model():
+    """sponge_kernels.h keeps the Poseidon state as x * 2^261 in 29-bit limbs and never reduces fully between rounds: replay its
+    round function with the exact models of mul29 / reduce29 (64-bit column sums asserted inside them) on random and on worst-case
+    states -- limbs below 2^32 everywhere, values below 2p after every round, S-box inputs below the 8p its comment allows -- and
+    compare with the big-int permutation; the 2^266 / 2^256 / 2^522 constants against pow()."""
+    src = open(os.path.join(ROOT, "ligero_amd", "csrc", "sponge_kernels.h")).read()
+    for name, e in (("kC266", 266), ("kC256", 256), ("kC522", 522)):
+        t = re.search(name + r"\(int i\) \{\s*constexpr uint32_t T\[9\] = \{([^}]*)\}", src).group(1)
+        assert [int(x, 16) for x in t.replace("u", "").split(",")] == limbs29(pow(2, e, P)), name
+    # the round function as the kernel spells it (the test breaks if its order of operations changes)
+    body = src[src.index("__device__ __forceinline__ void poseidon_permute"):src.index("// ---- per-proof sponge state")]
+    assert re.findall(r"(norm29_strict\(s\[j\]\)|sbox17\(s\[\d\]\)|add29\(n\[\d\], s\[\d\], s\[\d\]\)|reduce29\(s\[j\], n\[j\]\))", body) == [
+        "norm29_strict(s[j])", "sbox17(s[0])", "sbox17(s[1])", "sbox17(s[2])", "add29(n[0], s[0], s[2])", "add29(n[1], s[0], s[1])", "add29(n[2], s[1], s[2])",
+        "reduce29(s[j], n[j])"]
+    rng = random.Random(17)
+    R = pow(2, 261, P)
+    full, partial = 8, 31
+    ark = [[rng.randrange(P) for _ in range(3)] for _ in range(full + partial)]
+
+    def norm_strict(a):
+        out, c = [], 0
+        for i in range(8):
+            t = a[i] + c
+            assert t < 2**32
+            out.append(t & M)
+            c = t >> 29
+        assert a[8] + c < 2**32
+        return out + [a[8] + c]
+
+    def sbox(x):
+        assert all(v < B for v in x[:8]) and value(x) < 8 * P
+        y = mul29_model(x, x)
+        for _ in range(3):
+            y = mul29_model(y, y)
+        return mul29_model(y, x)
+
+    def permute(s):
+        for r in range(full + partial):
+            s = [norm_strict([s[j][i] + limbs29(ark[r][j] * R % P)[i] for i in range(9)]) for j in range(3)]
+            is_full = r < full // 2 or r >= full // 2 + partial
+            s[0] = sbox(s[0])
+            if is_full:
+                s[1], s[2] = sbox(s[1]), sbox(s[2])
+            n = [[s[a][i] + s[b][i] for i in range(9)] for a, b in ((0, 2), (0, 1), (1, 2))]
+            assert all(v < 2**32 for row in n for v in row)
+            s = [reduce29_model(row) for row in n]
+            assert all(value(x) < 2 * P and all(v < B for v in x[:8]) for x in s)
+        return s
+
+    def reference(x):
+        for r in range(full + partial):
+            x = [(x[j] + ark[r][j]) % P for j in range(3)]
+            is_full = r < full // 2 or r >= full // 2 + partial
+            x[0] = pow(x[0], 17, P)
+            if is_full:
+                x[1], x[2] = pow(x[1], 17, P), pow(x[2], 17, P)
+            x = [(x[0] + x[2]) % P, (x[0] + x[1]) % P, (x[1] + x[2]) % P]
+        return x
+
+    rinv = pow(R, -1, P)
+    states = [[rng.randrange(P) for _ in range(3)] for _ in range(3)] + [[0, 0, 0], [P - 1, P - 1, P - 1]]
+    for x in states:
+        # as the kernel holds them after an absorb into both rate slots: (a value below 2p) + (an element below 1.1p), limbs dirty
+        s = [limbs29(x[0] * R % P)] + [[a + b for a, b in zip(limbs29(x[j] * R % P + P), limbs29(P // 10))] for j in (1, 2)]
+        want = reference([x[0], (x[1] + (P // 10) * rinv) % P, (x[2] + (P // 10) * rinv) % P])
+        got = permute(s)
+        assert [value(g) * rinv % P for g in got] == want
