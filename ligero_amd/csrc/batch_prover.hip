@@ -279,7 +279,21 @@ int lg_prover_layout(const lg_ctx* c, lg_proof_layout* out) {
     return LG_OK;
 }
 
+static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out, int* slot_taken);
+
 int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
+    int slot_taken = -1;
+    const int rc = prove_batch_queue_body(c, w, proofs_out, &slot_taken);
+    if (rc != LG_OK && slot_taken >= 0) {
+        // a batch that failed half way is not in flight: its slot is free again (whatever was queued drains on its own; the
+        // commitment it made, if any, is void) and a wait on this buffer is refused instead of returning garbage
+        c->bp->slot[slot_taken].busy = false;
+        c->held.drop();
+    }
+    return rc;
+}
+
+static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out, int* slot_taken) {
     if (!c || !w || !proofs_out) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;
     lg_batch_prover_state* b = c->bp;
@@ -323,6 +337,7 @@ int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
     rc = commit_from_witness(c, w, nullptr);
     if (rc != LG_OK) { if (rc != LG_ERR_STATE) c->held.drop(); return rc; }
     slot.busy = true; slot.used = true; slot.out = proofs_out;
+    *slot_taken = si;
     b->batches++;
     LG_HIP(c, hipMemcpy2DAsync(small + L.off_roots, 32, c->d_nodes, (size_t)(c->n - 1) * 32, 32, B, hipMemcpyDeviceToDevice, s));
     lg::SpongeArgs sa;
