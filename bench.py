@@ -167,9 +167,8 @@ PROVER_BATCH = 1024      # proofs per batch of the throughput-mode prover (devic
 
 def prover_child(argv):
     """`python bench.py --prover-child <device> <mode> <batch> <steps> <cpus>`: the proofs/s leg in a process of its own that never
-    loads torch -- a PyTorch wheel bundles a ROCm 7.0 runtime that leaves the SDMA engines off on this GPU, and a device-to-host
-    copy done by shader code instead slows every HBM-bound kernel beside it (tools/d2h_probe.hip); a Rust or C++ host links the
-    system runtime, which is what this child measures.  Prints one JSON object."""
+    loads torch: the runtime a Rust or C++ host links (the system ROCm), no thread pools of torch's beside the prover's, and the
+    page-locked arenas of 2 x 5.6 GB gone with the process.  Prints one JSON object."""
     device, mode, batch, steps, cpus = int(argv[0]), argv[1], int(argv[2]), int(argv[3]), int(argv[4])
     os.environ["LIGERO_NO_TORCH_PRELOAD"] = "1"
     if cpus > 0:      # what one rank of an 8-GPU node gets of the box's CPU quota

@@ -18,7 +18,7 @@
 // (page-locked) memory in the flat layout lg_prover_layout describes, where a host proof object can point at them.
 // Same transcript as ligero_amd/host/transcript.hpp (PARITY UNPINNED against the Rust crates, see there): the proofs equal
 // the host-transcript provers' field for field (tests/test_gpu_prover.py).
-#include <dlfcn.h>
+#include <string>
 
 #include "lg_context.h"
 #include "challenge_kernels.h"
@@ -47,6 +47,11 @@ struct lg_batch_prover_state {
     struct Slot { const void* out = nullptr; hipEvent_t done = nullptr; hipEvent_t small_copied = nullptr; bool busy = false, used = false; } slot[2];
     uint64_t batches = 0;
     uint32_t ship_blocks = 0;           // workgroups of the ship kernel; 0 = the runtime's copy (default_ship_blocks)
+    // The copy stream is the prover's own, created at ANOTHER PRIORITY than the encode stream: the runtime maps streams onto a
+    // handful of hardware queues per priority level, and a context that is not the first of its process was seen with its copy
+    // stream on its encode stream's queue -- the copies then wait for the chain, 6 000 proofs/s instead of 9 800.  Different
+    // priority levels never share a queue.  (It carries copies, not kernels -- unless the small-grid ship kernel is in use.)
+    hipStream_t copy = nullptr;
     lg_proof_layout layout;
 };
 
@@ -60,6 +65,7 @@ static void bp_free(lg_ctx* c) {
         if (b->ev_gathered[o]) (void)hipEventDestroy(b->ev_gathered[o]);
         if (b->ev_copied[o]) (void)hipEventDestroy(b->ev_copied[o]);
     }
+    if (b->copy) { (void)hipStreamSynchronize(b->copy); (void)hipStreamDestroy(b->copy); }
     for (auto& sl : b->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.small_copied) (void)hipEventDestroy(sl.small_copied);
@@ -129,16 +135,13 @@ static int sponge_launch(lg_ctx* c, const lg::SpongeArgs& a) {
 
 // How the proofs go home (tools/d2h_probe.hip, profiles/r04_d2h_probe.log).  A copy the runtime gives to an SDMA engine runs at
 // 55-57 GB/s and does not disturb the chain at all; a copy done by shader code does -- the runtime's own blit kernel (its choice
-// when SDMA is off: HSA_ENABLE_SDMA=0, or the ROCm 7.0 runtime a PyTorch wheel bundles, which leaves SDMA off on this GPU
-// unless HSA_ENABLE_SDMA=1) and our ship_kernel alike -- HBM-bound kernels beside it run up to 3.5 x slower, and the small-grid
-// ship_kernel (8 workgroups: 46 GB/s) is then the lesser evil: 8 200 proofs/s against 5 900 with the runtime's blit, 10 000 with
-// SDMA (Poseidon, batches of 1024).  0 = the runtime's copy; LG_SHIP_BLOCKS overrides.
+// when SDMA is off: HSA_ENABLE_SDMA=0; also what a ROCm 7.0 runtime does under rocprofv3's memory-copy tracing) and our
+// ship_kernel alike: HBM-bound kernels beside it run up to 3.5 x slower, and the small-grid ship_kernel (8 workgroups: 46 GB/s)
+// is then the lesser evil: 8 200 proofs/s against 5 900 with the runtime's blit, 9 800 - 10 000 with SDMA (Poseidon, batches of
+// 1024).  0 = the runtime's copy (the default unless SDMA is switched off); LG_SHIP_BLOCKS overrides.
 static uint32_t default_ship_blocks() {
     const char* sdma = getenv("HSA_ENABLE_SDMA");
-    if (sdma) return atoi(sdma) == 0 ? 8u : 0u;
-    Dl_info info;
-    if (dladdr(reinterpret_cast<const void*>(&hipMemcpyAsync), &info) && info.dli_fname && strstr(info.dli_fname, "/torch/lib/")) return 8u;
-    return 0u;
+    return (sdma && atoi(sdma) == 0) ? 8u : 0u;
 }
 
 // one ship launch on the copy stream: `nseg` (device source, host destination, bytes) triples, bytes a multiple of 16
@@ -154,11 +157,11 @@ static int ship(lg_ctx* c, const ShipSeg* seg, uint32_t nseg) {
     a.nseg = nseg;
     if (total == 0) return LG_OK;
     if (c->bp->ship_blocks == 0) {   // the runtime's copy (an SDMA engine, when the runtime chooses one)
-        for (uint32_t i = 0; i < nseg; i++) LG_HIP(c, hipMemcpyAsync(seg[i].dst, seg[i].src, seg[i].bytes, hipMemcpyDeviceToHost, c->st.dn));
+        for (uint32_t i = 0; i < nseg; i++) LG_HIP(c, hipMemcpyAsync(seg[i].dst, seg[i].src, seg[i].bytes, hipMemcpyDeviceToHost, c->bp->copy));
         return LG_OK;
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(c->bp->ship_blocks, (total + 255) / 256);
-    LG_LAUNCH(c, lg::ship_kernel, dim3(blocks), dim3(256), 0, c->st.dn, a);
+    LG_LAUNCH(c, lg::ship_kernel, dim3(blocks), dim3(256), 0, c->bp->copy, a);
     return LG_OK;
 }
 
@@ -176,7 +179,6 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     LG_HIP(c, hipSetDevice(c->device));
     LG_HIP(c, hipStreamSynchronize(c->st.main));
-    LG_HIP(c, hipStreamSynchronize(c->st.dn));
     bp_free(c);
     lg_batch_prover_state* b = new (std::nothrow) lg_batch_prover_state();
     if (!b) return LG_ERR_OOM;
@@ -184,6 +186,14 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
     auto body = [&]() -> int {
         b->t = t; b->plen = (uint32_t)c->logn - 1;
         b->full_rounds = sp->full_rounds; b->partial_rounds = sp->partial_rounds;
+        {
+            int least = 0, greatest = 0;
+            LG_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const char* e = getenv("LG_COPY_STREAM_PRIORITY");       // low (default) | high | none: A/B knob
+            const std::string want = e ? e : "low";                  // (low: should a shader copy ever run there, it yields to the chain)
+            if (want == "none" || least == greatest) LG_HIP(c, hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+            else LG_HIP(c, hipStreamCreateWithPriority(&b->copy, hipStreamNonBlocking, want == "high" ? greatest : least));
+        }
         b->ship_blocks = default_ship_blocks();
         if (const char* e = getenv("LG_SHIP_BLOCKS")) { const int v = atoi(e); if (v >= 0) b->ship_blocks = (uint32_t)v; }
         const uint32_t rounds = sp->full_rounds + sp->partial_rounds;
@@ -364,10 +374,10 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out
         { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
         { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, reinterpret_cast<fr*>(st + b->open_cols), st + b->open_sib, st + b->open_paths); if (rc_ != LG_OK) return rc_; }
         LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
-        LG_HIP(c, hipStreamWaitEvent(c->st.dn, b->ev_gathered[o], 0));
+        LG_HIP(c, hipStreamWaitEvent(b->copy, b->ev_gathered[o], 0));
         const ShipSeg seg = {st, out + L.off_idx[o], b->open_bytes};   // (staging and the layout's region of sub-proof o are laid out alike)
         { const int rc_ = ship(c, &seg, 1); if (rc_ != LG_OK) return rc_; }
-        LG_HIP(c, hipEventRecord(b->ev_copied[o], c->st.dn));
+        LG_HIP(c, hipEventRecord(b->ev_copied[o], b->copy));
         return LG_OK;
     };
     // 4. absorb(preenc_u_lc); squeeze the opening's seed, then the linear test's (mod.rs:660, 941, 719)
@@ -395,11 +405,11 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out
     // 9. the small items, once everything on the encode stream is done; "done" = the copy stream has shipped them too
     LG_HIP(c, hipMemcpyAsync(small + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToDevice, s));
     LG_HIP(c, hipEventRecord(c->evt.done, s));
-    LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->evt.done, 0));
+    LG_HIP(c, hipStreamWaitEvent(b->copy, c->evt.done, 0));
     const ShipSeg seg = {small, out, b->small_bytes};
     if ((rc = ship(c, &seg, 1)) != LG_OK) return rc;
-    LG_HIP(c, hipEventRecord(slot.small_copied, c->st.dn));
-    LG_HIP(c, hipEventRecord(slot.done, c->st.dn));
+    LG_HIP(c, hipEventRecord(slot.small_copied, b->copy));
+    LG_HIP(c, hipEventRecord(slot.done, b->copy));
     return LG_OK;
 }
 
