@@ -140,6 +140,85 @@ int lg_ctx_destroy_checked(lg_ctx* c) {
 void lg_ctx_destroy(lg_ctx* c) { (void)lg_ctx_destroy_checked(c); }
 
 }  // extern "C"
+// ---- the pipeline's streams on hardware queues of their own ------------------------------------------------------------------
+// The runtime places the streams of a process on a few hardware queues (four per priority on this stack).  Kernels of two streams
+// that share a queue still run side by side, but a cross-stream wait (hipStreamWaitEvent) is a barrier packet, and a barrier packet
+// holds back EVERY later packet of its hardware queue, whichever stream it came from.  The overlapped single-chunk commit keeps four
+// streams in flight that wait on one another's events (encode, two hash streams, the tree), and which queue a new stream gets
+// depends on every stream the process has made before (the runtime hands out the least-used queue): a stream of Poseidon
+// commitments ran at 0.10 ms each or at 0.16-0.34, by the luck of the creation order (EXPERIMENTS N; rocprofv3's Queue_Id column
+// shows the placement).  So the four are CHOSEN: out of a small pool of fresh streams, keep a candidate only if a wait parked on it
+// does not hold back the streams kept so far -- a bounded 250 us spin on a low-priority helper stream (its own set of queues), the
+// candidate waits for the event behind the spin, an empty kernel on every kept stream: if those all finish while the event is
+// still pending, the candidate has a queue of its own.  ~2 ms per context.  When fewer than four independent queues exist
+// (GPU_MAX_HW_QUEUES, a busy neighbour) the remaining roles take pool streams as they come, i.e. the former behaviour.
+static __global__ void queue_probe_spin(uint64_t ticks) {       // wall_clock64: 100 MHz whatever the shader clock does
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static __global__ void queue_probe_noop() {}
+
+static int pick_pipeline_streams(lg_ctx* c) {
+    constexpr int kPool = 8, kWant = 4;
+    constexpr uint64_t kSpinTicks = 25000;                      // 250 us
+    hipStream_t pool[kPool] = {};
+    hipStream_t helper = nullptr;
+    hipEvent_t ev = nullptr;
+    bool used[kPool] = {};
+    int kept[kWant], nkept = 0;
+    auto release = [&]() {
+        for (int i = 0; i < kPool; i++)
+            if (pool[i] && !used[i]) hipStreamDestroy(pool[i]);
+        if (helper) hipStreamDestroy(helper);
+        if (ev) hipEventDestroy(ev);
+    };
+    auto hip = [&](hipError_t e, const char* what) -> int { if (e == hipSuccess) return LG_OK; release(); return fail_hip(c, e, what); };
+#define LG_PICK(call) do { if (int r_ = hip((call), #call); r_ != LG_OK) return r_; } while (0)
+    const char* off = getenv("LG_PICK_STREAMS");                // LG_PICK_STREAMS=0: streams as the runtime places them (A/B)
+    int least = 0, greatest = 0;
+    LG_PICK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const bool probe = !(off && atoi(off) == 0) && least != greatest;
+    const int npool = probe ? kPool : kWant;
+    for (int i = 0; i < npool; i++) LG_PICK(hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
+    if (probe) {
+        LG_PICK(hipStreamCreateWithPriority(&helper, hipStreamNonBlocking, least));
+        LG_PICK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(1), 0, helper, (uint64_t)1);       // code object loaded before anything is timed
+        hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[0]);
+        LG_PICK(hipGetLastError());
+        LG_PICK(hipStreamSynchronize(helper));
+        LG_PICK(hipStreamSynchronize(pool[0]));
+        kept[nkept++] = 0;
+        for (int cand = 1; cand < npool && nkept < kWant; cand++) {
+            bool alone = false;
+            for (int attempt = 0; attempt < 2 && !alone; attempt++) {        // a host hiccup reads as "shared": ask twice
+                hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(1), 0, helper, kSpinTicks);
+                LG_PICK(hipEventRecord(ev, helper));
+                LG_PICK(hipStreamWaitEvent(pool[cand], ev, 0));
+                hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[cand]);
+                for (int j = 0; j < nkept; j++) hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[kept[j]]);
+                LG_PICK(hipGetLastError());
+                for (int j = 0; j < nkept; j++) LG_PICK(hipStreamSynchronize(pool[kept[j]]));
+                alone = hipEventQuery(ev) == hipErrorNotReady;
+                (void)hipGetLastError();                         // "not ready" is an answer, not an error
+                LG_PICK(hipStreamSynchronize(helper));
+                LG_PICK(hipStreamSynchronize(pool[cand]));
+            }
+            if (alone) kept[nkept++] = cand;
+        }
+    }
+#undef LG_PICK
+    c->st.independent_queues = nkept;
+    hipStream_t* roles[kWant] = {&c->st.main, &c->st.hash, &c->st.tree, &c->st.hash2};
+    int r = 0;
+    for (int j = 0; j < nkept; j++, r++) { *roles[r] = pool[kept[j]]; used[kept[j]] = true; }
+    for (int i = 0; i < npool && r < kWant; i++)
+        if (!used[i]) { *roles[r++] = pool[i]; used[i] = true; }
+    release();
+    if (getenv("LG_TRACE_STREAMS")) fprintf(stderr, "[ligero_hip] pipeline streams with a hardware queue of their own: %d of %d\n", nkept, kWant);
+    return LG_OK;
+}
+
 struct ShardSpec {
     uint32_t plane_begin, plane_count, coeff_rows_alloc;
 };
@@ -179,12 +258,9 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
     int rc = LG_OK;
     auto body = [&]() -> int {
         LG_HIP(c, hipSetDevice(device));
-        LG_HIP(c, hipStreamCreateWithFlags(&c->st.main, hipStreamNonBlocking));
-        LG_HIP(c, hipStreamCreateWithFlags(&c->st.hash, hipStreamNonBlocking));
+        if (int r = pick_pipeline_streams(c); r != LG_OK) return r;
         LG_HIP(c, hipStreamCreateWithFlags(&c->st.up, hipStreamNonBlocking));
         LG_HIP(c, hipStreamCreateWithFlags(&c->st.dn, hipStreamNonBlocking));
-        LG_HIP(c, hipStreamCreateWithFlags(&c->st.tree, hipStreamNonBlocking));
-        LG_HIP(c, hipStreamCreateWithFlags(&c->st.hash2, hipStreamNonBlocking));
         for (auto& e : c->ring.ev_leaves_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->evt.chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->evt.up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));

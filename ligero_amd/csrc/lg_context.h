@@ -59,6 +59,7 @@ struct lg_ctx {
         hipStream_t up = nullptr;     // host -> device copies of lg_encode_commit's row chunks
         hipStream_t dn = nullptr;     // device -> host copies of the coefficient rows
         hipStream_t xchg = nullptr;   // exchange stream of lg_commit_sharded: the all-gather of piece c + 1 beside the evaluation of piece c
+        int independent_queues = 0;   // how many of main / hash / tree / hash2 were shown to run beside one another (pick_pipeline_streams)
     } st;
 
     struct Events {

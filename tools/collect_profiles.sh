@@ -15,11 +15,12 @@ OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 for WL in poseidon s20 s22; do
-  STEPS=20; [ "$WL" = s20 ] && STEPS=5; [ "$WL" = s22 ] && STEPS=3
-  python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_${WL}_bench.json" 2> "$OUT/${TAG}_${WL}_bench.err"
+  STEPS=200; WARM=10                        # Poseidon: bench.py's defaults, so the profiler's average is of the driver's command
+  [ "$WL" = s20 ] && STEPS=5 && WARM=3; [ "$WL" = s22 ] && STEPS=3 && WARM=3
+  python3 bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline > "$OUT/${TAG}_${WL}_bench.json" 2> "$OUT/${TAG}_${WL}_bench.err"
   echo "bench $WL done"
   D=/tmp/prof_${WL}_trace; rm -rf $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline \
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline \
       > "$OUT/${TAG}_${WL}_bench_under_rocprof.json" 2> "$OUT/${TAG}_${WL}_rocprof.err"
   cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_${WL}_kernel_stats.csv"
   echo "trace $WL done"
@@ -46,9 +47,9 @@ python3 tools/timeline_summary.py $(find $D -name '*kernel_trace.csv' | head -1)
 LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py host:4x64 1x64 1x256 1x1024 pipe:1x256 pipe:1x512 pipe:1x1024 pipe:1x2048 2x256 2x512 --steps=8 \
     2>&1 | grep -v amdgpu > "$OUT/${TAG}_device_transcript_probe.log"
 LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 --cpus=2 2>&1 | grep proofs/s >> "$OUT/${TAG}_device_transcript_probe.log"
-echo "(torch preloaded: its bundled runtime copies with shader kernels)" >> "$OUT/${TAG}_device_transcript_probe.log"
-LG_SHIP_BLOCKS=0 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [runtime blit copies]/' >> "$OUT/${TAG}_device_transcript_probe.log"
-python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [ship_kernel, 8 workgroups]/' >> "$OUT/${TAG}_device_transcript_probe.log"
+echo "(copies by shader kernels instead of the SDMA engines: they stretch the HBM-bound kernels beside them, EXPERIMENTS K)" >> "$OUT/${TAG}_device_transcript_probe.log"
+LIGERO_NO_TORCH_PRELOAD=1 LG_SHIP_BLOCKS=8 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [ship_kernel, 8 workgroups]/' >> "$OUT/${TAG}_device_transcript_probe.log"
+LIGERO_NO_TORCH_PRELOAD=1 LG_COPY_STREAM_PRIORITY=none python3 tools/device_transcript_probe.py pipe:1x1024 pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [copy stream at the encode stream'"'"'s priority: the second prover of a process may share its hardware queue, EXPERIMENTS L]/' >> "$OUT/${TAG}_device_transcript_probe.log"
 echo "prover done"
 python3 tools/s20_prove_timing.py 20 6 2>&1 | grep -v amdgpu > "$OUT/${TAG}_s20_prove_timing.log"
 # one proof over the "ranks" of this box
