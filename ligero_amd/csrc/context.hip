@@ -159,15 +159,17 @@ static __global__ void queue_probe_spin(uint64_t ticks) {       // wall_clock64:
 static __global__ void queue_probe_noop() {}
 
 static int pick_pipeline_streams(lg_ctx* c) {
-    constexpr int kPool = 8, kWant = 4;
+    constexpr int kPool = 8, kExtra = 8, kWant = 4;             // kExtra: further streams made one by one while looking for a queue
     constexpr uint64_t kSpinTicks = 25000;                      // 250 us
-    hipStream_t pool[kPool] = {};
+    hipStream_t pool[kPool + kExtra] = {};
     hipStream_t helper = nullptr;
     hipEvent_t ev = nullptr;
-    bool used[kPool] = {};
+    bool used[kPool + kExtra] = {};
     int kept[kWant], nkept = 0;
+    int shares[kPool + kExtra];                                        // pool stream i was shown to share the queue of kept[shares[i]] (-1: unknown)
+    for (int& x : shares) x = -1;
     auto release = [&]() {
-        for (int i = 0; i < kPool; i++)
+        for (int i = 0; i < kPool + kExtra; i++)
             if (pool[i] && !used[i]) hipStreamDestroy(pool[i]);
         if (helper) hipStreamDestroy(helper);
         if (ev) hipEventDestroy(ev);
@@ -178,7 +180,7 @@ static int pick_pipeline_streams(lg_ctx* c) {
     int least = 0, greatest = 0;
     LG_PICK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     const bool probe = !(off && atoi(off) == 0) && least != greatest;
-    const int npool = probe ? kPool : kWant;
+    int npool = probe ? kPool : kWant;
     for (int i = 0; i < npool; i++) LG_PICK(hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
     if (probe) {
         LG_PICK(hipStreamCreateWithPriority(&helper, hipStreamNonBlocking, least));
@@ -189,22 +191,63 @@ static int pick_pipeline_streams(lg_ctx* c) {
         LG_PICK(hipStreamSynchronize(helper));
         LG_PICK(hipStreamSynchronize(pool[0]));
         kept[nkept++] = 0;
-        for (int cand = 1; cand < npool && nkept < kWant; cand++) {
-            bool alone = false;
-            for (int attempt = 0; attempt < 2 && !alone; attempt++) {        // a host hiccup reads as "shared": ask twice
-                hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(1), 0, helper, kSpinTicks);
-                LG_PICK(hipEventRecord(ev, helper));
-                LG_PICK(hipStreamWaitEvent(pool[cand], ev, 0));
-                hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[cand]);
-                for (int j = 0; j < nkept; j++) hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[kept[j]]);
-                LG_PICK(hipGetLastError());
-                for (int j = 0; j < nkept; j++) LG_PICK(hipStreamSynchronize(pool[kept[j]]));
-                alone = hipEventQuery(ev) == hipErrorNotReady;
-                (void)hipGetLastError();                         // "not ready" is an answer, not an error
-                LG_PICK(hipStreamSynchronize(helper));
-                LG_PICK(hipStreamSynchronize(pool[cand]));
+        // one question: does a wait parked on `cand` hold back a kept stream, and which?  -1 = none of them (a queue of its own)
+        auto blocked_by = [&](int cand, int* who) -> int {
+            hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(1), 0, helper, kSpinTicks);
+            LG_PICK(hipEventRecord(ev, helper));
+            LG_PICK(hipStreamWaitEvent(pool[cand], ev, 0));
+            hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[cand]);
+            for (int j = 0; j < nkept; j++) hipLaunchKernelGGL(queue_probe_noop, dim3(1), dim3(1), 0, pool[kept[j]]);
+            LG_PICK(hipGetLastError());
+            *who = -1;
+            for (int j = 0; j < nkept; j++) {                   // the first kept stream whose empty kernel outlasted the spin
+                LG_PICK(hipStreamSynchronize(pool[kept[j]]));
+                if (*who < 0 && hipEventQuery(ev) != hipErrorNotReady) *who = j;
             }
-            if (alone) kept[nkept++] = cand;
+            (void)hipGetLastError();                             // "not ready" is an answer, not an error
+            LG_PICK(hipStreamSynchronize(helper));
+            LG_PICK(hipStreamSynchronize(pool[cand]));
+            return LG_OK;
+        };
+        auto classify = [&](int cand, int* who) -> int {         // -1 alone, j >= 0 the queue of kept[j], -2 no clear answer
+            int again = 0;
+            if (int r = blocked_by(cand, who); r != LG_OK) return r;
+            if (*who >= 0) {                                     // a host hiccup reads as "shared": ask twice
+                if (int r = blocked_by(cand, &again); r != LG_OK) return r;
+                *who = again < 0 ? -1 : (again == *who ? *who : -2);
+            }
+            return LG_OK;
+        };
+        for (int cand = 1; cand < npool; cand++) {
+            int who = 0;
+            if (int r = classify(cand, &who); r != LG_OK) return r;
+            if (who == -1 && nkept < kWant) kept[nkept++] = cand;
+            else if (who >= 0) shares[cand] = who;
+        }
+        // The copy streams of lg_encode_commit wait on the encode stream's events too and cannot have queues of their own (four
+        // queues, six streams): the coefficient rows' stream goes on the TREE's queue (the tree runs when the copies are over), the
+        // upload stream on the second hash stream's (used by small overlapped commits only) or else the encode stream's -- S20 from
+        // page-locked host buffers: 28.0 ms root only / 30.3 with the coefficient rows coming home; with the download stream on the
+        // hash stream's or the second hash stream's queue 33.5, with the upload stream on the hash stream's 30.4 / 32.5 (EXPERIMENTS N)
+        if (nkept == kWant) {
+            auto take = [&](int want, hipStream_t* out) -> int {
+                for (int i = 0; i < npool; i++)
+                    if (!used[i] && shares[i] == want) { *out = pool[i]; used[i] = true; return LG_OK; }
+                while (npool < kPool + kExtra) {                 // none in the pool: make streams until one lands there
+                    const int i = npool;
+                    LG_PICK(hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
+                    npool++;
+                    int who = 0;
+                    if (int r = classify(i, &who); r != LG_OK) return r;
+                    shares[i] = who;
+                    if (who == want) { *out = pool[i]; used[i] = true; return LG_OK; }
+                }
+                return LG_OK;                                    // *out stays null: the caller creates one as the runtime places it
+            };
+            if (int r = take(2, &c->st.dn); r != LG_OK) return r;
+            if (int r = take(3, &c->st.up); r != LG_OK) return r;
+            if (!c->st.up)
+                if (int r = take(0, &c->st.up); r != LG_OK) return r;
         }
     }
 #undef LG_PICK
@@ -215,7 +258,7 @@ static int pick_pipeline_streams(lg_ctx* c) {
     for (int i = 0; i < npool && r < kWant; i++)
         if (!used[i]) { *roles[r++] = pool[i]; used[i] = true; }
     release();
-    if (getenv("LG_TRACE_STREAMS")) fprintf(stderr, "[ligero_hip] pipeline streams with a hardware queue of their own: %d of %d\n", nkept, kWant);
+    if (getenv("LG_TRACE_STREAMS")) fprintf(stderr, "[ligero_hip] pipeline streams with a hardware queue of their own: %d of %d; up %s dn %s\n", nkept, kWant, c->st.up ? "placed" : "-", c->st.dn ? "placed" : "-");
     return LG_OK;
 }
 
@@ -259,8 +302,8 @@ static int ctx_create_impl(lg_ctx** out, int device, uint32_t rows, uint32_t k, 
     auto body = [&]() -> int {
         LG_HIP(c, hipSetDevice(device));
         if (int r = pick_pipeline_streams(c); r != LG_OK) return r;
-        LG_HIP(c, hipStreamCreateWithFlags(&c->st.up, hipStreamNonBlocking));
-        LG_HIP(c, hipStreamCreateWithFlags(&c->st.dn, hipStreamNonBlocking));
+        if (!c->st.up) LG_HIP(c, hipStreamCreateWithFlags(&c->st.up, hipStreamNonBlocking));
+        if (!c->st.dn) LG_HIP(c, hipStreamCreateWithFlags(&c->st.dn, hipStreamNonBlocking));
         for (auto& e : c->ring.ev_leaves_free) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->evt.chunk) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
         for (auto& e : c->evt.up) LG_HIP(c, hipEventCreateWithFlags(&e, lg_event_flags()));
