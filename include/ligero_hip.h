@@ -140,6 +140,33 @@ int lg_encode_commit_from_witness(lg_ctx* ctx, const uint64_t* w, uint64_t* coef
 int lg_encode_commit_from_witness_progress(lg_ctx* ctx, const uint64_t* w, const volatile uint64_t* w_positions_ready, uint64_t* coeffs_out,
                                            uint8_t* root_out);
 /*
+ * f3 ON THE DEVICE: w itself is the evaluation trace of the circuit on the prover's inputs
+ * (src/arithmetic_circuit/mod.rs:325-358 evaluation_trace_multioutput, called at src/ligero/mod.rs:476-478) -- one field operation per
+ * gate, data parallel over the gates whose operands are known.  Scheduled by dependency level, a circuit compiled from R1CS is a
+ * handful of launches whatever its size (every wire is an assigned variable), and only the assignment crosses PCIe:
+ *   lg_upload_trace_program       once per circuit, after lg_upload_gate_map (whose constants it shares): op[p] of every position
+ *                                 (LG_TRACE_INPUT an assigned variable, LG_TRACE_ADD / LG_TRACE_MUL a gate with operands left[p] /
+ *                                 right[p] in the gate map's encoding, LG_TRACE_ONE the leading constant at position 0),
+ *                                 order[ngates] = the gates' positions level by level, level_off[nlevels + 1] into it, outputs[nout] =
+ *                                 positions that must evaluate to one (mod.rs:519).  Checked here, once: every gate listed exactly
+ *                                 once and every operand in an earlier level than its gate -- LG_ERR_BAD_ARG otherwise.
+ *   lg_encode_commit_from_inputs  in_pos[nin] = positions of the assigned variables (the same for every proof of the batch),
+ *                                 in_vals = batch * nin elements.  Every variable exactly once, nothing else ("Uninitialised
+ *                                 variable" / "Value supplied for non-variable node" there: LG_ERR_BAD_ARG with the text in
+ *                                 lg_last_error here).  Evaluates w of every proof on the device, gathers X, Y, Z, commits: outputs
+ *                                 and residency as lg_encode_commit_from_witness -- the same bytes in LG_BUF_PREENC, the same
+ *                                 root.  outputs_all_one (may be NULL): batch words, 1 = every output of that proof is one.
+ *   lg_prove_batch_queue_inputs   (further down) the throughput-mode prover fed the same way.
+ */
+#define LG_TRACE_INPUT 0
+#define LG_TRACE_ADD 1
+#define LG_TRACE_MUL 2
+#define LG_TRACE_ONE 3
+int lg_upload_trace_program(lg_ctx* ctx, uint64_t npos, const uint8_t* op, const uint32_t* left, const uint32_t* right, const uint32_t* order,
+                            uint64_t ngates, const uint64_t* level_off, uint32_t nlevels, const uint32_t* outputs, uint32_t nout);
+int lg_encode_commit_from_inputs(lg_ctx* ctx, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, uint64_t* coeffs_out, uint8_t* root_out,
+                                 uint32_t* outputs_all_one);
+/*
  * lg_encode_commit streams its host buffers: the rows travel over PCIe in chunks while earlier
  * chunks are being encoded, and the coefficient rows travel back the same way.  The overlap needs page-locked host memory -- copies from/to pageable memory
  * block the calling thread, so only the upload overlaps there.  These two pin / unpin a buffer
@@ -277,10 +304,15 @@ typedef struct lg_proof_layout {
     uint64_t off_roots, off_lc, off_linear_poly, off_quadratic_poly, off_poly_lens, off_status;
     uint64_t off_idx[3], off_columns[3], off_siblings[3], off_paths[3];
     uint32_t batch, k, rows, t, path_len;
+    uint64_t off_outputs_ok;   /* [batch] words: 1 = every output of the proof's circuit evaluated to one (lg_prove_batch_queue_inputs;
+                                  all 1 for lg_prove_batch_queue, whose caller evaluated the circuit) */
 } lg_proof_layout;
 int lg_prover_setup(lg_ctx* ctx, const lg_sponge_params* sponge, uint32_t t);
 int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
 int lg_prove_batch_queue(lg_ctx* ctx, const uint64_t* w, void* proofs_out);
+/* the same with w evaluated on the device from every proof's inputs (lg_upload_trace_program; in_vals = batch * nin elements,
+ * page-locked or the copy blocks the calling thread); status word of a proof whose outputs are not all one: see lg_proof_layout */
+int lg_prove_batch_queue_inputs(lg_ctx* ctx, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, void* proofs_out);
 int lg_prove_batch_wait(lg_ctx* ctx, const void* proofs_out);
 
 /*

@@ -106,6 +106,19 @@ int lgh_build_preenc_with_labels(const lgh_instance* inst, const char* const* la
 int lgh_gate_map(const lgh_instance* inst, uint64_t* npos_out, uint64_t* nconst_out, uint32_t* left, uint32_t* right, uint64_t* constants);
 int lgh_build_w(const lgh_instance* inst, const uint64_t* node_idx, const uint64_t* values, uint64_t count, uint64_t* w_out, int* all_outputs_one);
 
+/* f3 on the device (include/ligero_hip.h lg_upload_trace_program / lg_encode_commit_from_inputs): the evaluation trace
+ * (src/arithmetic_circuit/mod.rs:325-358) as a program over the positions of w, scheduled by dependency level.
+ *   lgh_trace_program   sizes first (every array NULL): sizes[0] = npos, [1] = constants, [2] = gates (= length of order),
+ *                       [3] = levels, [4] = outputs, [5] = variables (inputs), [6] = formatted nodes (= length of pos_of_node);
+ *                       then the arrays: op[npos] (0 input, 1 add, 2 mul, 3 the leading one), left / right [npos] (gates: a position or
+ *                       0x80000000 | constant index; otherwise 0xffffffff), constants (4 words each, Montgomery form), order[gates]
+ *                       (positions level by level), level_off[levels + 1], outputs[], pos_of_node[nodes] (0xffffffff: no position)
+ *   lgh_input_positions the assignment convention of lgh_build_preenc (ORIGINAL node indices) -> positions of w, for
+ *                       lg_encode_commit_from_inputs; LGH_ERR_PANIC with the reference's wording for a non-variable node */
+int lgh_trace_program(const lgh_instance* inst, uint64_t sizes[7], uint8_t* op, uint32_t* left, uint32_t* right, uint64_t* constants, uint32_t* order,
+                      uint64_t* level_off, uint32_t* outputs, uint32_t* pos_of_node);
+int lgh_input_positions(const lgh_instance* inst, const uint64_t* node_idx, uint64_t count, uint32_t* positions_out);
+
 /* r_a = A.row_mul(r): r and out have 4 * m * k elements */
 int lgh_a_row_mul(const lgh_instance* inst, const uint64_t* r, uint64_t* out);
 /* COO dump of A (nnz entries each), row-major order */

@@ -238,6 +238,7 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
         L.off_quadratic_poly = take(B * 2 * c->k * 32);
         L.off_poly_lens = take(2 * B * 4);
         L.off_status = take(64);
+        L.off_outputs_ok = take(B * 4);
         b->small_bytes = off;
         b->open_idx = 0;
         b->open_cols = align64(B * t * 4);
@@ -289,11 +290,12 @@ int lg_prover_layout(const lg_ctx* c, lg_proof_layout* out) {
     return LG_OK;
 }
 
-static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out, int* slot_taken);
+struct BatchInputs { const uint32_t* pos; const uint64_t* vals; uint64_t n; };
+static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInputs* in, void* proofs_out, int* slot_taken);
 
-int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
+static int prove_batch_queue(lg_ctx* c, const uint64_t* w, const BatchInputs* in, void* proofs_out) {
     int slot_taken = -1;
-    const int rc = prove_batch_queue_body(c, w, proofs_out, &slot_taken);
+    const int rc = prove_batch_queue_body(c, w, in, proofs_out, &slot_taken);
     if (rc != LG_OK && slot_taken >= 0) {
         // a batch that failed half way is not in flight: its slot is free again (whatever was queued drains on its own; the
         // commitment it made, if any, is void) and a wait on this buffer is refused instead of returning garbage
@@ -303,8 +305,18 @@ int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
     return rc;
 }
 
-static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out, int* slot_taken) {
-    if (!c || !w || !proofs_out) return LG_ERR_BAD_ARG;
+int lg_prove_batch_queue(lg_ctx* c, const uint64_t* w, void* proofs_out) {
+    if (!w) return LG_ERR_BAD_ARG;
+    return prove_batch_queue(c, w, nullptr, proofs_out);
+}
+
+int lg_prove_batch_queue_inputs(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, void* proofs_out) {
+    const BatchInputs in{in_pos, in_vals, nin};
+    return prove_batch_queue(c, nullptr, &in, proofs_out);
+}
+
+static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInputs* in, void* proofs_out, int* slot_taken) {
+    if (!c || (!w && !in) || !proofs_out) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;
     lg_batch_prover_state* b = c->bp;
     if (!b || !c->amat.loaded || !c->gate.loaded) {
@@ -344,7 +356,12 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out
     // 0. the candidate-stream flag of the three challenge draws of this batch
     LG_HIP(c, hipMemsetAsync(c->chal.d_short_flag, 0, 4, s));
     // 1. the commitment (mod.rs:483-551)
-    rc = commit_from_witness(c, w, nullptr);
+    if (in) {       // w itself is made on the device: the evaluation trace of every proof from its inputs (witness.hip)
+        if ((rc = trace_on_device(c, in->pos, in->vals, in->n)) != LG_OK) return rc;
+        rc = commit_from_witness(c, nullptr, nullptr, nullptr, true);
+    } else {
+        rc = commit_from_witness(c, w, nullptr);
+    }
     if (rc != LG_OK) { if (rc != LG_ERR_STATE) c->held.drop(); return rc; }
     slot.busy = true; slot.used = true; slot.out = proofs_out;
     *slot_taken = si;
@@ -404,6 +421,8 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, void* proofs_out
     b->copied_valid = true;
     // 9. the small items, once everything on the encode stream is done; "done" = the copy stream has shipped them too
     LG_HIP(c, hipMemcpyAsync(small + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToDevice, s));
+    if (in) LG_HIP(c, hipMemcpyAsync(small + L.off_outputs_ok, c->trace.d_ok, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    else LG_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(small + L.off_outputs_ok), 1, B, s));     // the caller evaluated the circuit itself
     LG_HIP(c, hipEventRecord(c->evt.done, s));
     LG_HIP(c, hipStreamWaitEvent(b->copy, c->evt.done, 0));
     const ShipSeg seg = {small, out, b->small_bytes};

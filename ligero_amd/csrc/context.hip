@@ -93,6 +93,10 @@ int lg_ctx_destroy_checked(lg_ctx* c) {
     if (c->sub.aux2k) lg_ctx_destroy(c->sub.aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
+    for (void* b : {(void*)c->trace.d_op, (void*)c->trace.d_left, (void*)c->trace.d_right, (void*)c->trace.d_order, (void*)c->trace.d_outputs, (void*)c->trace.d_in_pos, (void*)c->trace.d_in_vals, (void*)c->trace.d_ok})
+        if (b) hipFree(b);
+    if (c->trace.ev_in) hipEventDestroy(c->trace.ev_in);
+    if (c->trace.ev_scattered) hipEventDestroy(c->trace.ev_scattered);
     for (void* b : {(void*)c->gate.d_left, (void*)c->gate.d_right, (void*)c->gate.d_consts})
         if (b) hipFree(b);
     void* bufs2[] = {c->shard.d_digest_xchg, c->sub.d_partial, c->sub.d_q, c->sub.d_r, c->amat.d_colptr, c->amat.d_row, c->amat.d_val, c->amat.d_heavy, c->amat.d_seg, c->amat.d_seg_partial, c->chal.d_seeds, c->chal.d_counts, c->chal.d_short_flag, c->chal.d_rlin};

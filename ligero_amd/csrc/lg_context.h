@@ -160,6 +160,21 @@ struct lg_ctx {
         uint64_t npos = 0; uint32_t nconst = 0; bool backward = false;
         bool loaded = false;                   // set after the LAST copy of an upload succeeded
     } gate;
+    // the circuit as a level-scheduled program over the positions of w (lg_upload_trace_program): the evaluation trace on the device
+    struct TraceProgram {
+        uint8_t* d_op = nullptr; uint32_t* d_left = nullptr; uint32_t* d_right = nullptr; uint32_t* d_order = nullptr; uint32_t* d_outputs = nullptr;
+        std::vector<uint64_t> level_off;       // [levels + 1] into d_order
+        std::vector<uint8_t> h_op;             // host copy: which positions are inputs (checked against every assignment)
+        uint64_t npos = 0; uint32_t nout = 0; uint64_t ninputs = 0;
+        bool has_one = false;                  // position 0 is the leading constant one
+        bool loaded = false;                   // set after the LAST copy of an upload succeeded
+        // the assignment of the commit being queued: positions (kept while the caller passes the same ones) and values [batch][nin]
+        std::vector<uint32_t> h_in_pos;
+        uint32_t* d_in_pos = nullptr; fr* d_in_vals = nullptr; size_t in_pos_cap = 0, in_vals_cap = 0;
+        uint32_t* d_ok = nullptr;              // [batch]: 1 = every output of the proof evaluated to one
+        hipEvent_t ev_in = nullptr, ev_scattered = nullptr;   // values have arrived (on st.up) / have been read (on st.main)
+        bool scattered_valid = false;
+    } trace;
     // domain tables: 29-bit limbs, three planes each (limbs 0-3 | 4-7 | 8)
     struct Tables {
         uint8_t* d_tw_fwd = nullptr;    // butterfly twiddles of the size-ki transform, pass order (lg::pass_tw_offset)
@@ -419,7 +434,8 @@ int colhash_launch(lg_ctx* c, hipStream_t hs, const lg::ColHashArgs& h, bool all
 // context.hip
 int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes);
 // witness.hip
-int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready = nullptr);
+int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready = nullptr, bool w_on_device = false);
+int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin);   // witness.hip: w of every proof from its inputs
 // openings.hip: the gather of t columns of nproofs proofs from DEVICE indices into DEVICE buffers (queued on the encode stream)
 int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths);
 // subproof.hip: the three polynomials with their challenges already ON THE DEVICE, results left on the device

@@ -42,6 +42,79 @@ __global__ void __launch_bounds__(256) witness_gather_kernel(const WitnessGather
     fr_store(base + 2 * a.mk + pos, z);
 }
 
+
+// f3 on the device (arithmetic_circuit/mod.rs:325-358): the evaluation trace, one launch per dependency level.  w of every proof
+// sits in the W block of d_preenc; a gate reads its operands (positions of w written by earlier levels or by the scatter of the
+// assignment, or constants that have no position) and writes its own position.  Values stay fully reduced Montgomery words, as the
+// host's evaluation leaves them, so the W block is the same bytes.
+constexpr uint8_t kTraceInput = 0, kTraceAdd = 1, kTraceMul = 2, kTraceOne = 3;
+struct TraceLevelArgs {
+    fr* pre;                 // [batch][4 m][k]
+    const uint8_t* op;       // [npos]
+    const uint32_t* left;    // [npos]
+    const uint32_t* right;
+    const fr* consts;
+    const uint32_t* order;   // positions of the gates, level by level
+    uint64_t begin, end;     // this level = order[begin, end)
+    uint64_t mk;
+    uint32_t batch;
+};
+__global__ void __launch_bounds__(256) trace_level_kernel(const TraceLevelArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t span = a.end - a.begin;
+    if (gid >= span * a.batch) return;
+    const uint32_t pos = a.order[a.begin + gid % span];
+    fr* w = a.pre + (gid / span) * 4 * a.mk + 3 * a.mk;
+    const uint32_t l = a.left[pos], r = a.right[pos];
+    const fr x = (l & kGateConst) ? fr_load(a.consts + (l & ~kGateConst)) : fr_load(w + l);
+    const fr y = (r & kGateConst) ? fr_load(a.consts + (r & ~kGateConst)) : fr_load(w + r);
+    fr t, z;
+    if (a.op[pos] == kTraceMul) fr_mul_lazy(t, x, y);
+    else fr_add_raw(t, x, y);                    // both < p: the sum < 2p
+    fr_reduce(z, t);
+    fr_store(w + pos, z);
+}
+
+struct TraceScatterArgs {
+    fr* pre;
+    const uint32_t* in_pos;  // [nin] positions of the assigned variables (the same for every proof)
+    const fr* in_vals;       // [batch][nin]
+    uint64_t nin, mk;
+    uint32_t batch;
+    uint32_t has_one;        // position 0 is the leading constant one
+    fr one;
+};
+__global__ void __launch_bounds__(256) trace_scatter_kernel(const TraceScatterArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per = a.nin + 1;              // slot nin of every proof writes the one
+    if (gid >= per * a.batch) return;
+    const uint64_t b = gid / per, i = gid % per;
+    fr* w = a.pre + b * 4 * a.mk + 3 * a.mk;
+    if (i == a.nin) { if (a.has_one) fr_store(w, a.one); return; }
+    fr_store(w + a.in_pos[i], fr_load(a.in_vals + b * a.nin + i));
+}
+
+struct TraceOutputsArgs {
+    const fr* pre;
+    const uint32_t* outputs; // [nout] positions
+    uint32_t* ok;            // [batch]
+    uint64_t mk;
+    uint32_t nout, batch;
+    fr one;
+};
+__global__ void __launch_bounds__(64) trace_outputs_kernel(const TraceOutputsArgs a) {
+    const uint32_t b = blockIdx.x;
+    const fr* w = a.pre + (uint64_t)b * 4 * a.mk + 3 * a.mk;
+    uint32_t bad = 0;
+    for (uint32_t i = threadIdx.x; i < a.nout; i += 64) {
+        const fr v = fr_load(w + a.outputs[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) bad |= v.v[j] ^ a.one.v[j];
+    }
+    const uint64_t any = __ballot(bad != 0);
+    if (threadIdx.x == 0) a.ok[b] = any ? 0u : 1u;
+}
+
 }  // namespace lg
 
 extern "C" {
@@ -117,7 +190,8 @@ static int witness_gather(lg_ctx* c, uint64_t pos0, uint64_t pos1) {
 // -- its workgroups on the CUs the hash occupies get what the older hash waves leave -- while the long evaluations absorb it
 // (measured: rocprofv3 timeline).  Small commits (one chunk in plan_chunks' terms: both kernels issue bound,
 // nothing to gain from running them side by side) hash once at the end on the encode stream.
-int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready) {
+int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready, bool w_on_device) {
+    if (w_on_device) ready = nullptr;          // the W block is in d_preenc already (trace_on_device): the same steps without the transfers
     if (c->shard.on) return LG_ERR_STATE;
     if (!c->gate.loaded) {
         snprintf(c->err, sizeof(c->err), "lg_encode_commit_from_witness needs the circuit's gate map (lg_upload_gate_map)");
@@ -221,6 +295,7 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
                                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
         }
         const size_t width = (size_t)(b - a) * c->k * sizeof(fr);
+        if (!w_on_device)
         LG_HIP(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_preenc) + ((size_t)3 * m + a) * c->k * sizeof(fr), (size_t)c->rows * c->k * sizeof(fr),
                                    reinterpret_cast<const uint8_t*>(host_w) + (size_t)a * c->k * sizeof(fr), (size_t)mk * sizeof(fr), width, c->batch,
                                    hipMemcpyHostToDevice, c->st.up));
@@ -305,7 +380,189 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
     return LG_OK;
 }
 
+static lg::fr mont_one() {
+    const lg_host::Fr o = lg_host::to_mont(lg_host::Fr{{1, 0, 0, 0}});
+    lg::fr r;
+    memcpy(r.v, o.l, 32);
+    return r;
+}
+
+extern "C" int lg_upload_trace_program(lg_ctx* c, uint64_t npos, const uint8_t* op, const uint32_t* left, const uint32_t* right, const uint32_t* order,
+                                       uint64_t ngates, const uint64_t* level_off, uint32_t nlevels, const uint32_t* outputs, uint32_t nout) {
+    if (!c || (npos && (!op || !left || !right)) || (ngates && !order) || !level_off || (nout && !outputs)) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->shard.on || (c->rows & 3)) return LG_ERR_STATE;
+    if (!c->gate.loaded || c->gate.npos != npos) {
+        snprintf(c->err, sizeof(c->err), "lg_upload_trace_program: load the gate map of the same circuit first (lg_upload_gate_map; it holds the constants)");
+        return LG_ERR_STATE;
+    }
+    // The device trusts nothing of the program it has not seen checked: every gate exactly once in `order`, operands in range, and every
+    // operand in an EARLIER level than its gate (inputs and the one are level 0) -- which is also what makes the launches race free.
+    if (level_off[0] != 0 || level_off[nlevels] != ngates) return LG_ERR_BAD_ARG;
+    for (uint32_t l = 0; l < nlevels; l++)
+        if (level_off[l + 1] < level_off[l]) return LG_ERR_BAD_ARG;
+    std::vector<uint32_t> lev(npos, 0);
+    uint64_t gates = 0, inputs = 0;
+    for (uint64_t p = 0; p < npos; p++) {
+        if (op[p] == lg::kTraceAdd || op[p] == lg::kTraceMul) { gates++; lev[p] = 0xffffffffu; }
+        else if (op[p] == lg::kTraceInput) inputs++;
+        else if (op[p] != lg::kTraceOne || p != 0) return LG_ERR_BAD_ARG;
+    }
+    if (gates != ngates) return LG_ERR_BAD_ARG;
+    for (uint32_t l = 0; l < nlevels; l++)
+        for (uint64_t i = level_off[l]; i < level_off[l + 1]; i++) {
+            const uint32_t p = order[i];
+            if (p >= npos || lev[p] != 0xffffffffu) return LG_ERR_BAD_ARG;      // not a gate, or listed twice
+            lev[p] = l + 1;
+        }
+    for (uint64_t p = 0; p < npos; p++) {
+        if (op[p] != lg::kTraceAdd && op[p] != lg::kTraceMul) continue;
+        for (uint32_t s : {left[p], right[p]}) {
+            if (s & lg::kGateConst) { if ((s & ~lg::kGateConst) >= c->gate.nconst) return LG_ERR_BAD_ARG; }
+            else if (s >= npos || lev[s] >= lev[p]) return LG_ERR_BAD_ARG;
+        }
+    }
+    for (uint32_t i = 0; i < nout; i++)
+        if (outputs[i] >= npos) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipStreamSynchronize(c->st.main));
+    lg_ctx::TraceProgram& t = c->trace;
+    t.loaded = false;
+    auto release = [&]() {
+        for (void* b : {(void*)t.d_op, (void*)t.d_left, (void*)t.d_right, (void*)t.d_order, (void*)t.d_outputs, (void*)t.d_ok})
+            if (b) (void)hipFree(b);
+        t.d_op = nullptr; t.d_left = t.d_right = t.d_order = t.d_outputs = t.d_ok = nullptr;
+    };
+    release();
+    auto upload = [&]() -> int {
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_op), npos ? npos : 1));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_left), (npos ? npos : 1) * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_right), (npos ? npos : 1) * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_order), (ngates ? ngates : 1) * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_outputs), (nout ? nout : 1) * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_ok), (size_t)c->batch * 4));
+        if (npos) {
+            LG_HIP(c, hipMemcpy(t.d_op, op, npos, hipMemcpyHostToDevice));
+            LG_HIP(c, hipMemcpy(t.d_left, left, npos * 4, hipMemcpyHostToDevice));
+            LG_HIP(c, hipMemcpy(t.d_right, right, npos * 4, hipMemcpyHostToDevice));
+        }
+        if (ngates) LG_HIP(c, hipMemcpy(t.d_order, order, ngates * 4, hipMemcpyHostToDevice));
+        if (nout) LG_HIP(c, hipMemcpy(t.d_outputs, outputs, (size_t)nout * 4, hipMemcpyHostToDevice));
+        if (!t.ev_in) LG_HIP(c, hipEventCreateWithFlags(&t.ev_in, lg_event_flags()));
+        if (!t.ev_scattered) LG_HIP(c, hipEventCreateWithFlags(&t.ev_scattered, lg_event_flags()));
+        return LG_OK;
+    };
+    const int rc = upload();
+    if (rc != LG_OK) { release(); return rc; }
+    t.level_off.assign(level_off, level_off + nlevels + 1);
+    t.h_op.assign(op, op + npos);
+    t.h_in_pos.clear();
+    t.npos = npos; t.nout = nout; t.ninputs = inputs; t.has_one = npos && op[0] == lg::kTraceOne;
+    t.scattered_valid = false;
+    t.loaded = true;
+    return LG_OK;
+}
+
+// w of every proof of the batch from its inputs, into the W block of d_preenc (queued on the encode stream)
+int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin) {
+    lg_ctx::TraceProgram& t = c->trace;
+    if (!t.loaded || !c->gate.loaded) {
+        snprintf(c->err, sizeof(c->err), "the evaluation trace on the device needs the circuit's program (lg_upload_gate_map, lg_upload_trace_program)");
+        return LG_ERR_STATE;
+    }
+    if ((nin && (!in_pos || !in_vals)) || nin > 0xffffffffull) return LG_ERR_BAD_ARG;
+    LG_HIP(c, hipSetDevice(c->device));
+    const uint32_t m = c->rows / 4;
+    const uint64_t mk = (uint64_t)m * c->k;
+    // the assignment must name every variable once and nothing else (mod.rs:476-478; "Value supplied for non-variable node",
+    // arithmetic_circuit/mod.rs:341).  The same positions as last time (the usual case) are not looked at again.
+    const bool same = t.h_in_pos.size() == nin && (nin == 0 || memcmp(t.h_in_pos.data(), in_pos, nin * 4) == 0);
+    if (!same) {
+        std::vector<uint8_t> seen(t.npos, 0);
+        for (uint64_t i = 0; i < nin; i++) {
+            const uint32_t p = in_pos[i];
+            if (p >= t.npos || t.h_op[p] != lg::kTraceInput) {
+                snprintf(c->err, sizeof(c->err), "Value supplied for non-variable node (position %u of the solution vector)", p);
+                return LG_ERR_BAD_ARG;
+            }
+            if (seen[p]) { snprintf(c->err, sizeof(c->err), "variable at position %u assigned twice", p); return LG_ERR_BAD_ARG; }
+            seen[p] = 1;
+        }
+        if (nin != t.ninputs) {
+            snprintf(c->err, sizeof(c->err), "Uninitialised variable: %llu of the circuit's %llu variables are assigned", (unsigned long long)nin, (unsigned long long)t.ninputs);
+            return LG_ERR_BAD_ARG;
+        }
+    }
+    const size_t vbytes = (size_t)c->batch * nin * sizeof(fr);
+    if (t.in_pos_cap < nin) {
+        if (t.d_in_pos) LG_HIP(c, hipFree(t.d_in_pos));
+        t.d_in_pos = nullptr; t.in_pos_cap = 0; t.h_in_pos.clear();
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_in_pos), (nin ? nin : 1) * 4));
+        t.in_pos_cap = nin ? nin : 1;
+    }
+    if (t.in_vals_cap < vbytes) {
+        LG_HIP(c, hipStreamSynchronize(c->st.main));       // the scatter of an earlier commit may still read the old block
+        if (t.d_in_vals) LG_HIP(c, hipFree(t.d_in_vals));
+        t.d_in_vals = nullptr; t.in_vals_cap = 0;
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_in_vals), vbytes ? vbytes : 1));
+        t.in_vals_cap = vbytes ? vbytes : 1;
+        t.scattered_valid = false;
+    }
+    // the values travel on the upload stream, behind the scatter that read the previous assignment out of the same staging block
+    if (t.scattered_valid) LG_HIP(c, hipStreamWaitEvent(c->st.up, t.ev_scattered, 0));
+    if (!same || t.h_in_pos.empty()) {
+        if (nin) LG_HIP(c, hipMemcpyAsync(t.d_in_pos, in_pos, nin * 4, hipMemcpyHostToDevice, c->st.up));
+        t.h_in_pos.assign(in_pos, in_pos + nin);
+    }
+    if (vbytes) LG_HIP(c, hipMemcpyAsync(t.d_in_vals, in_vals, vbytes, hipMemcpyHostToDevice, c->st.up));
+    LG_HIP(c, hipEventRecord(t.ev_in, c->st.up));
+    // everything else on the encode stream, behind whatever still reads d_preenc there
+    hipStream_t s = c->st.main;
+    if (mk > t.npos)      // the zero padding behind the solution vector (mod.rs:506-509)
+        LG_HIP(c, hipMemset2DAsync(c->d_preenc + 3 * mk + t.npos, (size_t)4 * mk * sizeof(fr), 0, (size_t)(mk - t.npos) * sizeof(fr), c->batch, s));
+    LG_HIP(c, hipStreamWaitEvent(s, t.ev_in, 0));
+    const lg::fr one = mont_one();
+    {
+        lg::TraceScatterArgs a;
+        a.pre = c->d_preenc; a.in_pos = t.d_in_pos; a.in_vals = t.d_in_vals; a.nin = nin; a.mk = mk; a.batch = c->batch; a.has_one = t.has_one ? 1u : 0u; a.one = one;
+        const uint64_t threads = (nin + 1) * c->batch;
+        LG_LAUNCH(c, lg::trace_scatter_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, a);
+    }
+    LG_HIP(c, hipEventRecord(t.ev_scattered, s));
+    t.scattered_valid = true;
+    lg::TraceLevelArgs la;
+    la.pre = c->d_preenc; la.op = t.d_op; la.left = t.d_left; la.right = t.d_right; la.consts = c->gate.d_consts; la.order = t.d_order; la.mk = mk; la.batch = c->batch;
+    for (size_t l = 0; l + 1 < t.level_off.size(); l++) {
+        la.begin = t.level_off[l]; la.end = t.level_off[l + 1];
+        const uint64_t threads = (la.end - la.begin) * c->batch;
+        if (!threads) continue;
+        LG_LAUNCH(c, lg::trace_level_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, la);
+    }
+    lg::TraceOutputsArgs oa;
+    oa.pre = c->d_preenc; oa.outputs = t.d_outputs; oa.ok = t.d_ok; oa.mk = mk; oa.nout = t.nout; oa.batch = c->batch; oa.one = one;
+    LG_LAUNCH(c, lg::trace_outputs_kernel, dim3(c->batch), dim3(64), 0, s, oa);
+    return LG_OK;
+}
+
 extern "C" {
+
+int lg_encode_commit_from_inputs(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, uint64_t* coeffs_out, uint8_t* root_out,
+                                 uint32_t* outputs_all_one) {
+    if (!c || !root_out) return LG_ERR_BAD_ARG;
+    if (c->gf) return LG_ERR_UNSUPPORTED;
+    if (c->shard.on) return LG_ERR_STATE;
+    // (the trace rewrites d_preenc: the hashes and the tree of the previous commitment are settled by commit_from_witness below before
+    // anything of it is overwritten -- they read U and the leaves, not d_preenc)
+    int rc = trace_on_device(c, in_pos, in_vals, nin);
+    if (rc != LG_OK) return rc;
+    rc = commit_from_witness(c, nullptr, coeffs_out, nullptr, true);
+    if (rc != LG_OK) {
+        if (rc != LG_ERR_STATE) c->held.committed = false;
+        return rc;
+    }
+    if (outputs_all_one) LG_HIP(c, hipMemcpyAsync(outputs_all_one, c->trace.d_ok, (size_t)c->batch * 4, hipMemcpyDeviceToHost, c->st.main));
+    return lg_read_root(c, root_out);
+}
 
 int lg_encode_commit_from_witness(lg_ctx* c, const uint64_t* w, uint64_t* coeffs_out, uint8_t* root_out) {
     return lg_encode_commit_from_witness_progress(c, w, nullptr, coeffs_out, root_out);

@@ -826,6 +826,99 @@ public:
             }
         return g;
     }
+    // f3 on the device (include/ligero_hip.h lg_upload_trace_program): evaluation_trace_multioutput (arithmetic_circuit/mod.rs:325-358)
+    // as a program over the POSITIONS of the solution vector, scheduled by dependency level -- every gate of a level has its operands
+    // in earlier levels, so a level is one data-parallel launch and the order inside it is free.  Circuits compiled from R1CS are a
+    // few levels deep whatever their size (every wire is an assigned variable: a constraint's nodes hang off variables directly);
+    // expression-made circuits as deep as their longest chain.  Forward references are fine (levels, not node order, schedule).
+    struct TraceProgram {
+        static constexpr uint8_t kInput = 0, kAdd = 1, kMul = 2, kOne = 3;    // kOne: the leading constant (position 0, mod.rs:491)
+        std::vector<uint8_t> op;             // [npos]
+        std::vector<uint32_t> left, right;   // [npos]: gates only -- a position, or GateMap::kConst | index into `constants`
+        std::vector<E> constants;            // the same list, in the same order, as gate_map().constants
+        std::vector<uint32_t> order;         // the gates' positions, level by level
+        std::vector<uint64_t> level_off;     // [levels + 1] into order
+        std::vector<uint32_t> outputs;       // positions of the output nodes (each must evaluate to one, mod.rs:519)
+        std::vector<uint32_t> pos_of_node;   // formatted node index -> position (GateMap::kNone: a constant without one)
+        size_t num_inputs = 0;               // variables: every one of them must be assigned (mod.rs:476-478)
+    };
+    TraceProgram trace_program() const {
+        const auto& nodes = circuit.nodes;
+        const size_t nn = nodes.size();
+        if (nn >= GateMap::kConst) throw std::runtime_error("trace program: circuit too large for 31-bit positions");
+        TraceProgram t;
+        t.pos_of_node.assign(nn, GateMap::kNone);
+        std::vector<uint32_t> src(nn);
+        uint32_t pos = 0;
+        for (size_t i = 0; i < nn; i++) {
+            if (nodes[i].kind == Node::Constant && i != 0) {
+                src[i] = GateMap::kConst | (uint32_t)t.constants.size();
+                t.constants.push_back(nodes[i].value);
+            } else {
+                src[i] = t.pos_of_node[i] = pos++;
+            }
+        }
+        if (pos > m * k) throw std::runtime_error("solution vector longer than m * k");
+        // level of every node: 0 for constants and variables, 1 + max over the operands for gates
+        std::vector<uint32_t> level(nn, 0);
+        if (plan_.backward_only) {
+            for (size_t i = 0; i < nn; i++)
+                if (nodes[i].kind == Node::Add || nodes[i].kind == Node::Mul) level[i] = 1 + std::max(level[nodes[i].l], level[nodes[i].r]);
+        } else {
+            std::vector<uint8_t> state(nn, 0);               // 0 untouched, 1 open (operands being visited), 2 done
+            std::vector<size_t> stack;
+            for (size_t root = 0; root < nn; root++) {
+                if (state[root]) continue;
+                stack.push_back(root);
+                while (!stack.empty()) {
+                    const size_t i = stack.back();
+                    const Node& nd = nodes[i];
+                    if (state[i] == 2) { stack.pop_back(); continue; }
+                    if (nd.kind != Node::Add && nd.kind != Node::Mul) { state[i] = 2; stack.pop_back(); continue; }
+                    if (nd.l >= nn || nd.r >= nn) throw std::runtime_error("index out of bounds: gate operand not in the circuit");
+                    if (state[nd.l] == 2 && state[nd.r] == 2) {
+                        level[i] = 1 + std::max(level[nd.l], level[nd.r]);
+                        state[i] = 2;
+                        stack.pop_back();
+                        continue;
+                    }
+                    state[i] = 1;
+                    for (size_t c : {nd.r, nd.l}) {
+                        if (state[c] == 2) continue;
+                        if (state[c] == 1) throw std::runtime_error("circuit has a cycle");
+                        stack.push_back(c);
+                    }
+                }
+            }
+        }
+        t.op.assign(pos, TraceProgram::kInput);
+        t.left.assign(pos, GateMap::kNone);
+        t.right.assign(pos, GateMap::kNone);
+        uint32_t levels = 0;
+        for (size_t i = 0; i < nn; i++) {
+            const Node& nd = nodes[i];
+            if (nd.kind == Node::Constant) { if (i == 0) t.op[0] = TraceProgram::kOne; continue; }
+            if (nd.kind == Node::Variable) { t.num_inputs++; continue; }
+            const uint32_t p = src[i];
+            t.op[p] = nd.kind == Node::Add ? TraceProgram::kAdd : TraceProgram::kMul;
+            t.left[p] = src[nd.l];
+            t.right[p] = src[nd.r];
+            levels = std::max(levels, level[i]);
+        }
+        t.level_off.assign((size_t)levels + 1, 0);
+        for (size_t i = 0; i < nn; i++)
+            if (level[i]) t.level_off[level[i]]++;               // level L counted into slot L; slot 0 stays 0
+        for (size_t l = 1; l <= levels; l++) t.level_off[l] += t.level_off[l - 1];    // level_off[L] = end of level L = begin of level L + 1
+        t.order.resize(levels ? t.level_off[levels] : 0);
+        std::vector<uint64_t> cursor(t.level_off.begin(), t.level_off.end());          // cursor[L - 1] = begin of level L
+        for (size_t i = 0; i < nn; i++)
+            if (level[i]) t.order[cursor[level[i] - 1]++] = src[i];
+        for (size_t o : outputs) {
+            if (src[o] & GateMap::kConst) throw std::runtime_error("trace program: an output is a constant without a position");
+            t.outputs.push_back(src[o]);
+        }
+        return t;
+    }
     // w alone: the W block of preenc_u, m k elements (zero padded)
     void build_w_from_formatted(const std::vector<std::pair<size_t, E>>& bumped, E* out, bool* all_outputs_one = nullptr, Scratch* scratch = nullptr,
                                 std::atomic<uint64_t>* positions_done = nullptr) const {

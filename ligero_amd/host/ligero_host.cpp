@@ -267,6 +267,42 @@ int lgh_gate_map(const lgh_instance* i, uint64_t* npos_out, uint64_t* nconst_out
     });
 }
 
+int lgh_trace_program(const lgh_instance* i, uint64_t sizes[7], uint8_t* op, uint32_t* left, uint32_t* right, uint64_t* constants, uint32_t* order,
+                      uint64_t* level_off, uint32_t* outputs, uint32_t* pos_of_node) {
+    if (!i || !sizes) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const auto t = i->inst.trace_program();
+        sizes[0] = t.op.size(); sizes[1] = t.constants.size(); sizes[2] = t.order.size(); sizes[3] = t.level_off.size() - 1;
+        sizes[4] = t.outputs.size(); sizes[5] = t.num_inputs; sizes[6] = t.pos_of_node.size();
+        if (op) std::memcpy(op, t.op.data(), t.op.size());
+        if (left) std::memcpy(left, t.left.data(), t.left.size() * sizeof(uint32_t));
+        if (right) std::memcpy(right, t.right.data(), t.right.size() * sizeof(uint32_t));
+        if (constants && !t.constants.empty()) std::memcpy(constants, t.constants[0].l, t.constants.size() * sizeof(Fr));
+        if (order && !t.order.empty()) std::memcpy(order, t.order.data(), t.order.size() * sizeof(uint32_t));
+        if (level_off) std::memcpy(level_off, t.level_off.data(), t.level_off.size() * sizeof(uint64_t));
+        if (outputs && !t.outputs.empty()) std::memcpy(outputs, t.outputs.data(), t.outputs.size() * sizeof(uint32_t));
+        if (pos_of_node) std::memcpy(pos_of_node, t.pos_of_node.data(), t.pos_of_node.size() * sizeof(uint32_t));
+        return LGH_OK;
+    });
+}
+
+int lgh_input_positions(const lgh_instance* i, const uint64_t* node_idx, uint64_t count, uint32_t* positions_out) {
+    if (!i || (count && (!node_idx || !positions_out))) return LGH_ERR_BAD_ARG;
+    return guarded([&] {
+        const auto& nodes = i->inst.circuit.nodes;
+        // position = formatted index minus the constants in front of it (index 0, the one, keeps its position)
+        std::vector<uint32_t> consts_before(nodes.size() + 1, 0);
+        for (size_t j = 0; j < nodes.size(); j++) consts_before[j + 1] = consts_before[j] + ((nodes[j].kind == Node::Constant && j != 0) ? 1u : 0u);
+        for (uint64_t j = 0; j < count; j++) {
+            const size_t f = i->inst.bump_index((size_t)node_idx[j]);
+            if (f >= nodes.size()) throw std::runtime_error("index out of bounds: assigned node not in the circuit");
+            if (nodes[f].kind != Node::Variable) throw std::runtime_error("Value supplied for non-variable node");
+            positions_out[j] = (uint32_t)(f - consts_before[f]);
+        }
+        return LGH_OK;
+    });
+}
+
 int lgh_build_w(const lgh_instance* i, const uint64_t* node_idx, const uint64_t* values, uint64_t count, uint64_t* w_out, int* all_outputs_one) {
     if (!i || (count && (!node_idx || !values)) || !w_out) return LGH_ERR_BAD_ARG;
     return guarded([&] {

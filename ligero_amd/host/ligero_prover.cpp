@@ -137,6 +137,13 @@ int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_
     if (proofs_out)
         for (uint32_t b = 0; b < B; b++) proofs_out[b] = nullptr;
     return guarded([&] {
+        if (p->hip.device_transcript() && !proofs_out) {
+            // the proofs stay where the device put them (lgp_batch_proof_arena); a handle copies its proof out when asked for
+            p->hip.prove_arrays_to_arena(node_idx, values, count);
+            p->views.assign(B, lgp_proof());
+            p->view_made.assign(B, 0);
+            return LGP_OK;
+        }
         std::vector<std::vector<std::pair<size_t, Fr>>> va(B);
         for (uint32_t b = 0; b < B; b++)
             for (uint64_t i = 0; i < count; i++) {
@@ -144,13 +151,6 @@ int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_
                 std::memcpy(v.l, values + 4 * ((uint64_t)b * count + i), 32);
                 va[b].emplace_back((size_t)node_idx[i], v);
             }
-        if (p->hip.device_transcript() && !proofs_out) {
-            // the proofs stay where the device put them (lgp_batch_proof_arena); a handle copies its proof out when asked for
-            p->hip.prove_to_arena(va);
-            p->views.assign(B, lgp_proof());
-            p->view_made.assign(B, 0);
-            return LGP_OK;
-        }
         const std::vector<LigeroProof>& proofs = p->hip.prove(va);
         p->view_made.assign(B, 1);
         if (proofs_out)
@@ -172,18 +172,8 @@ int lgp_batch_prover_host_stats(const lgp_batch_prover* p, double out[5]) {
 // device-transcript provers: the same in two halves, so that the next batch is queued before the last one is waited for
 int lgp_prove_batch_submit(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
     if (!p || !node_idx || !values || count == 0) return LGP_ERR_BAD_ARG;
-    const uint32_t B = p->hip.batch();
     return guarded([&] {
-        std::vector<std::vector<std::pair<size_t, Fr>>> va(B);
-        for (uint32_t b = 0; b < B; b++) {
-            va[b].reserve(count);
-            for (uint64_t i = 0; i < count; i++) {
-                Fr v;
-                std::memcpy(v.l, values + 4 * ((uint64_t)b * count + i), 32);
-                va[b].emplace_back((size_t)node_idx[i], v);
-            }
-        }
-        p->hip.submit(va);
+        p->hip.submit_arrays(node_idx, values, count);
         return LGP_OK;
     });
 }

@@ -167,6 +167,59 @@ inline bool preenc_on_host() {
     return e && std::atoi(e) != 0;
 }
 
+// f3 on the device (include/ligero_hip.h lg_upload_trace_program): the circuit's evaluation trace as a level-scheduled program on
+// the device, so that a commit needs the prover's INPUTS only.  Taken when it pays: a launch per level against one host
+// multiplication per gate and proof (a lone Poseidon proof, 64 levels of a hundred gates, is quicker on one core; a batch of them, or
+// any large compiled circuit -- three levels at 2^20 constraints -- is not).  LG_DEVICE_TRACE=0 / 1 overrides the estimate.
+struct DeviceTrace {
+    bool on = false;
+    std::vector<uint32_t> pos_of_node;   // formatted node index -> position of w (0xffffffff: a constant without one)
+    std::vector<uint8_t> is_input;       // [npos]: the position holds a variable
+    size_t num_inputs = 0, levels = 0;
+};
+template <class Inst>
+inline DeviceTrace upload_trace_program(lg_ctx* ctx, const Inst& inst, size_t batch, unsigned host_threads) {
+    DeviceTrace d;
+    const char* e = std::getenv("LG_DEVICE_TRACE");
+    if (e && std::atoi(e) == 0) return d;
+    try {
+        const auto t = inst.trace_program();
+        const double gates = (double)t.order.size() * (double)batch, levels = (double)(t.level_off.size() - 1);
+        const double device_s = levels * 8e-6 + gates * 2e-10, host_s = gates * 12e-9 / std::max(1u, host_threads);
+        if (!(e && std::atoi(e) != 0) && device_s >= host_s) return d;
+        const int st = lg_upload_trace_program(ctx, t.op.size(), t.op.data(), t.left.data(), t.right.data(), t.order.data(), t.order.size(),
+                                               t.level_off.data(), (uint32_t)(t.level_off.size() - 1), t.outputs.data(), (uint32_t)t.outputs.size());
+        if (st == LG_ERR_UNSUPPORTED) return DeviceTrace();     // (a library without it: the host evaluates)
+        if (st != LG_OK) throw DeviceError(st, std::string("lg_upload_trace_program (") + lg_last_error(ctx) + ")");
+        d.pos_of_node = t.pos_of_node;
+        d.is_input.resize(t.op.size());
+        for (size_t p = 0; p < t.op.size(); p++) d.is_input[p] = t.op[p] == 0;
+        d.num_inputs = t.num_inputs;
+        d.levels = t.level_off.size() - 1;
+        d.on = true;
+    } catch (const DeviceError&) {
+        throw;
+    } catch (const std::exception&) {
+        d = DeviceTrace();   // (a circuit too large for 31-bit positions, a cycle: the host path words the panic)
+    }
+    return d;
+}
+// positions of an assignment given by FORMATTED node indices; false if it is anything but "every variable, nothing else" -- the
+// caller then takes the host path, which words the reference's panics (or accepts a variable assigned twice: the last value wins)
+template <class GetIndex>
+inline bool device_trace_positions(const DeviceTrace& d, size_t count, GetIndex formatted_index, std::vector<uint32_t>& pos_out) {
+    if (!d.on || count != d.num_inputs) return false;
+    pos_out.resize(count);
+    for (size_t i = 0; i < count; i++) {
+        const size_t f = formatted_index(i);
+        if (f >= d.pos_of_node.size()) return false;
+        const uint32_t p = d.pos_of_node[f];
+        if (p == 0xffffffffu || !d.is_input[p]) return false;
+        pos_out[i] = p;
+    }
+    return true;
+}
+
 // CPUs this process may actually use: hardware threads, capped by a cgroup v2 CPU quota (cpu.max "quota period") and shared with
 // the other ranks a launcher started on this box (LOCAL_WORLD_SIZE, as torch.distributed.run exports it)
 inline unsigned usable_cpus() {
@@ -246,6 +299,7 @@ public:
             try {
                 upload_constraint_matrix(ctx_, inst.a);
                 from_witness_ = upload_gate_map(ctx_, inst);
+                if (from_witness_) dtrace_ = upload_trace_program(ctx_, inst, 1, 1);
             } catch (...) {     // a constructor that throws runs no destructor
                 lg_ctx_destroy(ctx_);
                 throw;
@@ -301,6 +355,7 @@ public:
             if (po.pinned) lg_host_unregister(ctx_, po.cols.data());
         }
         if (pinned_) lg_host_unregister(ctx_, flat_.data());
+        if (in_vals_pinned_) lg_host_unregister(ctx_, in_vals_.data());
         if (cols_pinned_) lg_host_unregister(ctx_, cols_stage_.data());
         release_exchange();
         lg_ctx_destroy(ctx_);
@@ -354,7 +409,11 @@ private:
         // With the circuit's gate map on the device only w -- the W block, a quarter of preenc_u -- is built and uploaded; x, y, z
         // are gathered there (lg_encode_commit_from_witness).  LG_PREENC_ON_HOST=1 keeps the whole matrix on the host (A/B, tests).
         const bool witness_only = from_witness_ && !preenc_on_host();
-        const size_t want = witness_only ? m_ * k_ : 4 * m_ * k_;
+        // ... and with the circuit's trace program there too, only the ASSIGNMENT is: w is evaluated on the device
+        // (lg_encode_commit_from_inputs).  Anything but "every variable once" goes the host's way, which words the reference's panics.
+        bool inputs_only = false;
+        if constexpr (kDeviceChallenges) inputs_only = witness_only && stage_inputs(formatted_assignment);
+        const size_t want = inputs_only ? flat_.size() : (witness_only ? m_ * k_ : 4 * m_ * k_);
         if (flat_.size() != want) {
             if (pinned_) lg_host_unregister(ctx_, flat_.data());
             flat_.assign(want, F::zero());
@@ -369,7 +428,16 @@ private:
             HipLigeroT* self;
             ~Joiner() { self->open_columns_join(); }
         } joiner{this};
-        if (witness_only) {
+        if (inputs_only) {
+            const int st = lg_encode_commit_from_inputs(ctx_, in_pos_.data(), in_vals_.empty() ? nullptr : in_vals_[0].l, in_pos_.size(), nullptr, proof.u_root.data(), nullptr);
+            if (st == LG_ERR_BAD_ARG) {     // (a variable named twice: legal for the reference -- the last value wins -- so the host evaluates)
+                dtrace_skip_ = true;
+                struct Reset { bool& f; ~Reset() { f = false; } } reset{dtrace_skip_};
+                return prove_inner(formatted_assignment, sponge);
+            }
+            check(st, "lg_encode_commit_from_inputs");
+            tm.mark("assignment H2D, evaluation trace + gathers on the device, commit");
+        } else if (witness_only) {
             // The evaluation of the circuit runs on a thread of its own and publishes how far the solution vector is final; this
             // thread hands every step of rows to the device as soon as it is (lg_encode_commit_from_witness_progress): the
             // transfer and the encoding of the early rows run beside the evaluation of the late ones.  (What stays serial after
@@ -1052,6 +1120,28 @@ private:
     bool from_witness_ = false; // the circuit's gate map is on the device: commits upload w alone
     PendingOpen pending_[3];       // the three openings of an unsharded proof in flight (open_columns_begin)
     std::vector<std::pair<size_t, E>> assign_buf_;   // prove_arrays' bumped assignment, kept between proofs
+    DeviceTrace dtrace_;        // the circuit's trace program is on the device: commits upload the assignment alone
+    bool dtrace_skip_ = false;  // (set for the one host-path retry of an assignment the device call refused)
+    std::vector<uint32_t> in_pos_;
+    std::vector<Fr> in_vals_;   // the assignment's values in the order of in_pos_, page-locked
+    bool in_vals_pinned_ = false;
+    // the assignment as the device wants it; false = not "every variable, nothing else" (or no trace program): the host's way
+    bool stage_inputs(const std::vector<std::pair<size_t, E>>& fa) {
+        if (dtrace_skip_ || !dtrace_.on) return false;
+        if (!device_trace_positions(dtrace_, fa.size(), [&](size_t i) { return fa[i].first; }, in_pos_)) return false;
+        if (in_vals_.size() != fa.size()) {
+            if (in_vals_pinned_) lg_host_unregister(ctx_, in_vals_.data());
+            in_vals_.assign(fa.size(), F::zero());
+            in_vals_pinned_ = !in_vals_.empty() && lg_host_register(ctx_, in_vals_.data(), in_vals_.size() * sizeof(Fr)) == LG_OK;
+        }
+        auto fill = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) in_vals_[i] = fa[i].second; };
+        const unsigned nt = fa.size() >= (1u << 16) ? std::min(4u, usable_cpus()) : 1u;
+        if (nt <= 1) { fill(0, fa.size()); return true; }
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < nt; t++) ts.emplace_back(fill, fa.size() * t / nt, fa.size() * (t + 1) / nt);
+        for (auto& t : ts) t.join();
+        return true;
+    }
     std::vector<Fr> cols_stage_;   // opened columns as they come off the device (reused, page-locked)
     bool cols_pinned_ = false;
     typename LigeroInstance::Scratch scratch_;   // trace storage and the "flat_ already holds a preenc_u" note, kept between proofs
@@ -1162,6 +1252,8 @@ public:
             from_witness_ = upload_gate_map(ctx_, inst) && (device_transcript_ || !preenc_on_host());
             threads_ = threads ? threads : std::max(1u, std::min(usable_cpus(), batch));
             pool_.reset(new WorkerPool(threads_));
+            // throughput mode with the circuit's trace program on the device too: the host hands over assignments and nothing else
+            if (from_witness_ && device_transcript_) dtrace_ = upload_trace_program(ctx_, inst, batch_, threads_);
             mat_.resize((size_t)batch_ * (from_witness_ ? 1 : 4) * m_ * k_);
             // page-lock the big staging buffers so the PCIe copies overlap the kernels
             // (each registration is tracked on its own: a buffer must never be freed while still page-locked)
@@ -1234,6 +1326,48 @@ public:
         stats_.w_wall_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats_.queue_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
     }
+    // the C ABI's arrays: one list of (original) node indices for the whole batch, values [batch][count].  With the trace program on
+    // the device the assignment goes there as it is (lg_prove_batch_queue_inputs) -- no w on the host; anything but "every variable
+    // once" takes submit()'s way, which words the reference's panics.
+    bool device_trace() const { return dtrace_.on; }
+    void submit_arrays(const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
+        if (!device_transcript_) throw std::runtime_error("HipLigeroBatch::submit: created without the device transcript");
+        if (submitted_ - collected_ >= 2) throw std::runtime_error("HipLigeroBatch::submit: two batches are in flight already (collect() first)");
+        const int slot = (int)(submitted_ & 1);
+        if (dtrace_.on && device_trace_positions(dtrace_, count, [&](size_t i) { return inst_.bump_index((size_t)node_idx[i]); }, in_pos_)) {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<Fr>& v = in_vals_[slot];
+            if (v.size() != (size_t)batch_ * count) {
+                if (pinned_in_vals_[slot]) lg_host_unregister(ctx_, v.data());
+                v.assign((size_t)batch_ * count, Fr{});
+                pinned_in_vals_[slot] = lg_host_register(ctx_, v.data(), v.size() * sizeof(Fr)) == LG_OK;
+            }
+            parallel_for(batch_, [&](size_t b) { std::memcpy(static_cast<void*>(&v[b * count]), values + 4 * b * count, count * sizeof(Fr)); });
+            const auto t1 = std::chrono::steady_clock::now();
+            const int st = lg_prove_batch_queue_inputs(ctx_, in_pos_.data(), v[0].l, count, arena_[slot].data());
+            if (st != LG_ERR_BAD_ARG) {
+                check(st, "lg_prove_batch_queue_inputs");
+                const auto t2 = std::chrono::steady_clock::now();
+                submitted_++;
+                stats_.batches++;
+                stats_.w_wall_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                stats_.w_core_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();    // (the copy of the values: an upper bound)
+                stats_.queue_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+                return;
+            }
+            // (a variable named twice: legal for the reference, the last value wins -- the host evaluates)
+        }
+        std::vector<std::vector<std::pair<size_t, Fr>>> va(batch_);
+        for (uint32_t b = 0; b < batch_; b++) {
+            va[b].reserve(count);
+            for (uint64_t i = 0; i < count; i++) {
+                Fr x;
+                std::memcpy(x.l, values + 4 * ((uint64_t)b * count + i), 32);
+                va[b].emplace_back((size_t)node_idx[i], x);
+            }
+        }
+        submit(va);
+    }
     void collect() {
         if (collected_ == submitted_) throw std::runtime_error("HipLigeroBatch::collect: nothing in flight");
         const int slot = (int)(collected_ & 1);
@@ -1254,6 +1388,11 @@ public:
     void prove_to_arena(const std::vector<std::vector<std::pair<size_t, Fr>>>& assignments) {
         while (in_flight()) collect();
         submit(assignments);
+        collect();
+    }
+    void prove_arrays_to_arena(const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
+        while (in_flight()) collect();
+        submit_arrays(node_idx, values, count);
         collect();
     }
     // proof b of the arena as the host's proof object (a copy: tests, the verifier)
@@ -1376,8 +1515,10 @@ private:
         if (pinned_mat_) lg_host_unregister(ctx_, mat_.data());
         if (pinned_cols_) lg_host_unregister(ctx_, cols_.data());
         if (pinned_mat2_) lg_host_unregister(ctx_, mat2_.data());
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) {
             if (pinned_arena_[i]) lg_host_unregister(ctx_, arena_[i].data());
+            if (pinned_in_vals_[i]) lg_host_unregister(ctx_, in_vals_[i].data());
+        }
         lg_ctx_destroy(ctx_);
         ctx_ = nullptr;
     }
@@ -1450,6 +1591,10 @@ private:
     unsigned threads_ = 1;
     bool device_transcript_ = false;
     bool pinned_mat_ = false, pinned_mat2_ = false, pinned_cols_ = false, pinned_arena_[2] = {false, false};
+    DeviceTrace dtrace_;                // the trace program is on the device: submit_arrays ships assignments only
+    std::vector<uint32_t> in_pos_;
+    std::vector<Fr> in_vals_[2];        // [batch][count] values of the two batches in flight, page-locked
+    bool pinned_in_vals_[2] = {false, false};
     bool from_witness_ = false;   // gate map on the device: mat_ holds w of every proof only
     lg_proof_layout layout_{};
     std::vector<uint8_t> arena_[2];   // device transcript: batches of proofs as the device wrote them (two in flight)

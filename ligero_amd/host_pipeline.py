@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libligero_host.so")
 SYMBOLS = [
     "lgh_last_error", "lgh_circuit_new", "lgh_circuit_destroy", "lgh_circuit_num_nodes", "lgh_constant", "lgh_new_variable",
     "lgh_add", "lgh_mul", "lgh_pow", "lgh_minus", "lgh_circuit_from_r1cs", "lgh_circuit_num_outputs", "lgh_circuit_outputs",
-    "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_gate_map", "lgh_build_w", "lgh_a_row_mul", "lgh_a_entries",
+    "lgh_instance_new", "lgh_instance_destroy", "lgh_instance_info", "lgh_build_preenc", "lgh_gate_map", "lgh_trace_program", "lgh_input_positions", "lgh_build_w", "lgh_a_row_mul", "lgh_a_entries",
     "lgh_read_witness", "lgh_chacha_block", "lgh_field_elements_from_seed", "lgh_distinct_indices_from_seed", "lgh_sponge_new", "lgh_sponge_destroy",
     "lgh_sponge_absorb_bytes", "lgh_sponge_absorb_elements", "lgh_sponge_squeeze_bytes", "lgh_sponge_squeeze_elements",
     "lgh_new_variable_with_label", "lgh_get_variable", "lgh_circuit_num_gates", "lgh_pow_bigint", "lgh_indicator", "lgh_scalar_product",
@@ -71,6 +71,8 @@ def lib():
         L.lgh_instance_info.argtypes = [_vp, _vp]
         L.lgh_build_preenc.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_gate_map.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+        L.lgh_trace_program.argtypes = [_vp] * 10
+        L.lgh_input_positions.argtypes = [_vp, _vp, ctypes.c_uint64, _vp]
         L.lgh_build_w.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_build_preenc_with_labels.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp]
         L.lgh_evaluate_multioutput.argtypes = [_vp, _vp, _vp, _u64, _vp, _u64, _vp, _vp]
@@ -330,6 +332,27 @@ class LigeroInstance:
         ok = _int(0)
         _check(self._L.lgh_build_preenc(self._h, _p(idx), _p(vals), idx.shape[0], _p(out), ctypes.cast(ctypes.byref(ok), _vp)), "prove_inner")
         return out, bool(ok.value)
+
+    def trace_program(self):
+        """the evaluation trace as a level-scheduled program over the positions of w (lgh_trace_program), for
+        lg_upload_trace_program: dict of op, left, right, constants, order, level_off, outputs, pos_of_node, num_inputs"""
+        sizes = np.zeros(7, dtype=np.uint64)
+        _check(self._L.lgh_trace_program(self._h, _p(sizes), None, None, None, None, None, None, None, None), "trace_program")
+        npos, nconst, ngates, nlev, nout, nin, nnodes = (int(x) for x in sizes)
+        t = {"op": np.zeros(npos, dtype=np.uint8), "left": np.zeros(npos, dtype=np.uint32), "right": np.zeros(npos, dtype=np.uint32),
+             "constants": np.zeros((nconst, 4), dtype=np.uint64), "order": np.zeros(ngates, dtype=np.uint32),
+             "level_off": np.zeros(nlev + 1, dtype=np.uint64), "outputs": np.zeros(nout, dtype=np.uint32),
+             "pos_of_node": np.zeros(nnodes, dtype=np.uint32), "num_inputs": nin}
+        _check(self._L.lgh_trace_program(self._h, _p(sizes), _p(t["op"]), _p(t["left"]), _p(t["right"]), _p(t["constants"]), _p(t["order"]),
+                                         _p(t["level_off"]), _p(t["outputs"]), _p(t["pos_of_node"])), "trace_program")
+        return t
+
+    def input_positions(self, node_idx):
+        """positions of w for an assignment given by ORIGINAL node indices (the convention of build_preenc_u)"""
+        idx = np.ascontiguousarray(node_idx, dtype=np.uint64)
+        out = np.zeros(idx.shape[0], dtype=np.uint32)
+        _check(self._L.lgh_input_positions(self._h, _p(idx), idx.shape[0], _p(out)), "input_positions")
+        return out
 
     def gate_map(self):
         """the circuit's wiring for lg_upload_gate_map: (left, right) uint32 arrays over the positions of the solution vector

@@ -173,6 +173,33 @@ class LigeroCommitter:
         self._chk(self._L.lg_encode_commit_from_witness(self._ctx, _ptr(wm), _ptr(coeffs), _ptr(root)), "lg_encode_commit_from_witness")
         return coeffs, root.tobytes()
 
+    def upload_trace_program(self, program):
+        """lg_upload_trace_program: the circuit's evaluation trace as a level-scheduled program
+        (host_pipeline.LigeroInstance.trace_program()), once per context, after upload_gate_map"""
+        t = program
+        op = np.ascontiguousarray(t["op"], dtype=np.uint8)
+        l = np.ascontiguousarray(t["left"], dtype=np.uint32)
+        r = np.ascontiguousarray(t["right"], dtype=np.uint32)
+        order = np.ascontiguousarray(t["order"], dtype=np.uint32)
+        lo = np.ascontiguousarray(t["level_off"], dtype=np.uint64)
+        outs = np.ascontiguousarray(t["outputs"], dtype=np.uint32)
+        self._chk(self._L.lg_upload_trace_program(self._ctx, op.shape[0], _ptr(op), _ptr(l), _ptr(r), _ptr(order) if order.shape[0] else None, order.shape[0],
+                                                  _ptr(lo), lo.shape[0] - 1, _ptr(outs) if outs.shape[0] else None, outs.shape[0]), "lg_upload_trace_program")
+
+    def encode_commit_from_inputs(self, in_pos, in_vals, want_coeffs: bool = False):
+        """f3 on the device: in_pos = positions of the assigned variables (LigeroInstance.input_positions), in_vals = (batch, nin, 4)
+        Montgomery words.  The trace, the X / Y / Z gathers and the commit all run on the GPU.
+        Returns (coefficients or None, u_root bytes, outputs_all_one per proof)."""
+        pos = np.ascontiguousarray(in_pos, dtype=np.uint32)
+        vals = np.ascontiguousarray(in_vals, dtype=np.uint64).reshape(self.batch, -1, 4)
+        if vals.shape[1] != pos.shape[0]:
+            raise ValueError(f"{vals.shape[1]} values per proof for {pos.shape[0]} positions")
+        coeffs = np.empty((self.batch * self.rows, self.k, 4), dtype=np.uint64) if want_coeffs else None
+        root = np.empty(32 * self.batch, dtype=np.uint8)
+        ok = np.zeros(self.batch, dtype=np.uint32)
+        self._chk(self._L.lg_encode_commit_from_inputs(self._ctx, _ptr(pos), _ptr(vals), pos.shape[0], _ptr(coeffs), _ptr(root), _ptr(ok)), "lg_encode_commit_from_inputs")
+        return coeffs, root.tobytes(), ok.astype(bool)
+
     def host_register(self, array: np.ndarray):
         """page-lock a host array so that encode_commit can overlap its PCIe copies with the kernels"""
         self._chk(self._L.lg_host_register(self._ctx, _ptr(array), array.nbytes), "lg_host_register")

@@ -66,6 +66,10 @@ int lg_open_columns_async(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32
 int lg_prover_setup(lg_ctx*, const lg_sponge_params*, uint32_t) { return LG_ERR_UNSUPPORTED; }
 int lg_prover_layout(const lg_ctx*, lg_proof_layout*) { return LG_ERR_UNSUPPORTED; }
 int lg_prove_batch_queue(lg_ctx*, const uint64_t*, void*) { return LG_ERR_UNSUPPORTED; }
+int lg_prove_batch_queue_inputs(lg_ctx*, const uint32_t*, const uint64_t*, uint64_t, void*) { return LG_ERR_UNSUPPORTED; }
+// (the stub evaluates nothing: the provers under the sanitizers keep the trace on the host, LG_DEVICE_TRACE=0 in their recipe or this status)
+int lg_upload_trace_program(lg_ctx*, uint64_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t, const uint64_t*, uint32_t, const uint32_t*, uint32_t) { return LG_ERR_UNSUPPORTED; }
+int lg_encode_commit_from_inputs(lg_ctx*, const uint32_t*, const uint64_t*, uint64_t, uint64_t*, uint8_t*, uint32_t*) { return LG_ERR_UNSUPPORTED; }
 int lg_prove_batch_wait(lg_ctx*, const void*) { return LG_ERR_UNSUPPORTED; }
 int lg_encode_commit(lg_ctx* c, const uint64_t* pre, uint64_t* coeffs, uint8_t* root) {
     const size_t per = (size_t)c->rows * c->k * 32;

@@ -1,0 +1,197 @@
+"""GPU tests of f3 on the device (include/ligero_hip.h lg_upload_trace_program / lg_encode_commit_from_inputs): the evaluation
+trace (src/arithmetic_circuit/mod.rs:325-358, called at src/ligero/mod.rs:476-478) run on the GPU level by level from the
+prover's inputs alone must leave the bytes the host's evaluation leaves -- checked through everything that depends on them:
+coefficient rows of all 4m rows (the interpolation is a bijection of the rows), leaves, root; the goldens pin the root."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, random_mont
+from test_gpu_witness import _batch_witnesses
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def poseidon_inst():
+    from ligero_amd import host_pipeline as hp
+    return hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs")))
+
+
+def _committers(inst, batch):
+    import ligero_amd
+    left, right, consts = inst.gate_map()
+    ref = ligero_amd.LigeroCommitter(rows=inst.rows, k=inst.k, batch=batch)
+    dev = ligero_amd.LigeroCommitter(rows=inst.rows, k=inst.k, batch=batch)
+    for c in (ref, dev):
+        c.upload_gate_map(left, right, consts)
+    dev.upload_trace_program(inst.trace_program())
+    return ref, dev
+
+
+@pytest.mark.parametrize("batch", [1, 3, 64])
+def test_poseidon_trace_on_the_device_equals_the_host_trace(oracle, vectors, poseidon_inst, batch):
+    """the Poseidon fixture (batch 1: the golden root) and the committed 64-witness batch: 64 levels, 6 748 gates per proof"""
+    inst = poseidon_inst
+    idx = list(range(1, 265))
+    wit = _batch_witnesses(oracle, batch)
+    w = np.concatenate([inst.build_w(idx, v)[0] for v in wit])
+    pos = inst.input_positions(idx)
+    vals = np.stack(wit)
+    ref, dev = _committers(inst, batch)
+    with ref, dev:
+        coeffs_ref, root_ref = ref.encode_commit_from_witness(w, want_coeffs=True)
+        for _ in range(2):                                                  # twice: the second overwrites a resident commitment
+            coeffs, root, ok = dev.encode_commit_from_inputs(pos, vals, want_coeffs=True)
+            assert root == root_ref
+            assert np.array_equal(coeffs, coeffs_ref)
+            assert ok.all()
+        if batch == 1:
+            assert root.hex() == vectors["poseidon"]["root"]
+        assert np.array_equal(dev.leaves(), ref.leaves())
+        r = random_mont(5, batch * inst.rows).reshape(batch * inst.rows, 4)
+        assert np.array_equal(dev.interleaved_row_mul(r), ref.interleaved_row_mul(r))      # LG_BUF_PREENC holds the same preenc_u
+        # the same assignment in another order names the same variables
+        perm = np.random.default_rng(1).permutation(len(idx))
+        assert dev.encode_commit_from_inputs(pos[perm], vals[:, perm])[1] == root_ref
+        # a wrong witness is a commitment to a trace whose outputs are not one -- for that proof only
+        bad = vals.copy()
+        bad[batch - 1, 7, 0] ^= 1
+        _, root_bad, ok = dev.encode_commit_from_inputs(pos, bad)
+        wb, ok_host = inst.build_w(idx, bad[batch - 1])
+        assert not ok_host and not ok[batch - 1] and ok[:batch - 1].all()
+        assert root_bad[:32 * (batch - 1)] == root_ref[:32 * (batch - 1)]
+        w2 = w.copy().reshape(batch, -1, inst.k, 4)
+        w2[batch - 1] = wb
+        assert root_bad == ref.encode_commit_from_witness(w2.reshape(-1, inst.k, 4))[1]
+
+
+def _random_circuit(seed, nvars, ngates, deep):
+    from ligero_amd import host_pipeline as hp
+    rng = np.random.default_rng(seed)
+    c = hp.ArithmeticCircuit()
+    consts = [c.constant(hp.fr_mont(int(v))) for v in (2, 5, 12345678901234567890123)]
+    var = c.new_variables(nvars)
+    live = list(var)                                       # nodes with a position
+    used = set()
+    gates = []
+    for g in range(ngates):
+        a = live[-1] if (deep and g % 3) else live[rng.integers(len(live))]      # deep: long dependency chains, narrow levels
+        b = consts[rng.integers(len(consts))] if rng.random() < 0.2 else live[rng.integers(len(live))]
+        if rng.random() < 0.5:
+            a, b = b, a
+        node = c.mul(a, b) if rng.random() < 0.5 else c.add(a, b)
+        used.update((a, b))
+        live.append(node)
+        gates.append(node)
+    loose = [n for n in gates + list(var) if n not in used]
+    out = c.add_nodes(loose) if len(loose) > 1 else loose[0]
+    return c, list(var), out
+
+
+@pytest.mark.parametrize("seed,nvars,ngates,deep,batch", [(1, 5, 40, False, 1), (2, 12, 700, False, 3), (3, 3, 300, True, 2), (4, 40, 5000, False, 1)])
+def test_builder_made_circuits(seed, nvars, ngates, deep, batch):
+    """random add / mul circuits with constants through the builder API: wide and shallow, and deep chains (hundreds of levels of
+    a few gates); the device trace against the host's on random assignments"""
+    from ligero_amd import host_pipeline as hp
+    circ, var, out = _random_circuit(seed, nvars, ngates, deep)
+    inst = hp.LigeroInstance(circ, outputs=[out])
+    prog = inst.trace_program()
+    assert len(prog["level_off"]) - 1 >= (40 if deep else 2)
+    vals = random_mont(seed + 10, batch * nvars).reshape(batch, nvars, 4)
+    built = [inst.build_w(var, vals[b]) for b in range(batch)]
+    w = np.concatenate([x[0] for x in built])
+    ref, dev = _committers(inst, batch)
+    with ref, dev:
+        coeffs_ref, root_ref = ref.encode_commit_from_witness(w, want_coeffs=True)
+        coeffs, root, ok = dev.encode_commit_from_inputs(inst.input_positions(var), vals, want_coeffs=True)
+        assert np.array_equal(coeffs, coeffs_ref) and root == root_ref
+        assert list(ok) == [x[1] for x in built]
+
+
+def test_expression_made_circuit_and_refusals(poseidon_inst):
+    import ligero_amd
+    from ligero_amd import host_pipeline as hp
+    x, y = hp.Expression.variable("x"), hp.Expression.variable("y")
+    e = (x * x + 3) * (x + y) - y.pow(5) * 7 + x
+    circ = e.to_arithmetic_circuit()
+    inst = hp.LigeroInstance(circ, outputs=[circ.last()])
+    labels = ["x", "y"]
+    nodes = [circ.get_variable(l) for l in labels]
+    vals = random_mont(3, 2).reshape(1, 2, 4)
+    w, ok_host = inst.build_w(nodes, vals[0])
+    ref, dev = _committers(inst, 1)
+    with ref, dev:
+        _, root, ok = dev.encode_commit_from_inputs(inst.input_positions(nodes), vals)
+        assert root == ref.encode_commit_from_witness(w)[1] and bool(ok[0]) == ok_host
+        pos = inst.input_positions(nodes)
+        # every variable, once, and nothing else
+        with pytest.raises(ligero_amd.LigeroHipError, match="Uninitialised variable"):
+            dev.encode_commit_from_inputs(pos[:1], vals[:, :1])
+        with pytest.raises(ligero_amd.LigeroHipError, match="assigned twice"):
+            dev.encode_commit_from_inputs(np.array([pos[0], pos[0]], dtype=np.uint32), vals)
+        with pytest.raises(ligero_amd.LigeroHipError, match="non-variable"):
+            dev.encode_commit_from_inputs(np.array([pos[0], 0], dtype=np.uint32), vals)
+        # the context still works
+        assert dev.encode_commit_from_inputs(pos, vals)[1] == root
+        # a program that is not a schedule is refused at upload: an operand in the same level as its gate
+        prog = inst.trace_program()
+        lo = prog["level_off"].copy()
+        if len(lo) > 2:
+            merged = dict(prog)
+            merged["level_off"] = np.concatenate([lo[:1], lo[2:]])             # levels 1 and 2 fused
+            with pytest.raises(ligero_amd.LigeroHipError):
+                dev.upload_trace_program(merged)
+        twice = dict(prog)
+        twice["order"] = prog["order"].copy()
+        twice["order"][0] = twice["order"][-1]                                  # a gate listed twice, another never
+        with pytest.raises(ligero_amd.LigeroHipError):
+            dev.upload_trace_program(twice)
+        # a refused program leaves the loaded one in place
+        assert dev.encode_commit_from_inputs(pos, vals)[1] == root
+    # without the gate map there are no constants to share
+    with ligero_amd.LigeroCommitter(rows=inst.rows, k=inst.k) as c:
+        with pytest.raises(ligero_amd.LigeroHipError):
+            c.upload_trace_program(prog)
+
+
+def test_provers_make_the_same_proofs_with_the_trace_on_the_device(oracle, model, poseidon_inst, monkeypatch):
+    """the single prover and the throughput-mode prover with the evaluation trace forced onto the device (LG_DEVICE_TRACE=1; a lone
+    Poseidon proof would keep it on the host by the cost estimate) and forced off: the same proofs field for field, accepted; an
+    assignment that names a variable twice (legal for the reference: the last value wins) and one that leaves a variable out (the
+    reference's panic) behave as on the host"""
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroBatchProver, LigeroProver, proofs_equal
+    inst = poseidon_inst
+    idx = list(range(1, 265))
+    wit = np.stack(_batch_witnesses(oracle, 5))
+    monkeypatch.setenv("LG_DEVICE_TRACE", "0")
+    with LigeroProver(inst) as host:
+        ref = [host.prove(idx, wit[b]) for b in range(5)]
+        monkeypatch.setenv("LG_DEVICE_TRACE", "1")
+        with LigeroProver(inst) as dev:
+            for b in range(5):
+                p = dev.prove(idx, wit[b])
+                assert proofs_equal(ref[b], p) and host.verify(p)
+            # a variable named twice: the last value wins (the host evaluates this one)
+            twice_idx = idx + [idx[3]]
+            twice_val = np.concatenate([wit[0], wit[1][3:4]])
+            fixed = wit[0].copy()
+            fixed[3] = wit[1][3]
+            assert proofs_equal(dev.prove(twice_idx, twice_val), host.prove(idx, fixed))
+            # a variable left out: the reference's panic, in the reference's words
+            with pytest.raises(Exception, match="Uninitialised variable"):
+                dev.prove(idx[:-1], wit[0][:-1])
+            assert proofs_equal(dev.prove(idx, wit[2]), ref[2])                   # ... and the prover still works
+        with LigeroBatchProver(inst, 5, device_transcript=True) as bp:
+            got = bp.prove(idx, wit)
+            for b in range(5):
+                assert proofs_equal(ref[b], got[b]), b
+            bad = wit.copy()
+            bad[4][10] = bad[4][11]
+            views = bp.prove(idx, bad, copy=False)
+            assert proofs_equal(views[0], ref[0]) and not host.verify(views[4]) and proofs_equal(views[4], host.prove(idx, bad[4]))
+        monkeypatch.setenv("LG_DEVICE_TRACE", "0")
+        with LigeroBatchProver(inst, 5, device_transcript=True) as bp:
+            assert all(proofs_equal(ref[b], p) for b, p in enumerate(bp.prove(idx, wit)))

@@ -308,3 +308,64 @@ def test_gate_map_and_w_rebuild_preenc_u(hp, oracle, model):
     pre2, _ = inst2.build_preenc_u_with_labels(labels, v)
     l2, r2, c2 = inst2.gate_map()
     assert np.array_equal(rebuild_preenc_from_w(pre2[3 * inst2.m:], l2, r2, c2, inst2.m, inst2.k), pre2)
+
+
+def run_trace_program(oracle, model, prog, in_pos, in_vals_mont, mk):
+    """what the device does with lgh_trace_program's output (include/ligero_hip.h lg_encode_commit_from_inputs), in Python ints:
+    scatter the assignment, then level by level every gate from operands that earlier levels (or the scatter) wrote"""
+    p = model.P
+    w = [None] * mk
+    consts = oracle.limbs_to_ints(oracle.from_mont(prog["constants"])) if len(prog["constants"]) else []
+    for pos, v in zip(in_pos, oracle.limbs_to_ints(oracle.from_mont(np.ascontiguousarray(in_vals_mont)))):
+        w[int(pos)] = v
+    if prog["op"][0] == 3:
+        w[0] = 1
+    lo = prog["level_off"]
+    for lev in range(len(lo) - 1):
+        vals = {}
+        for g in prog["order"][int(lo[lev]):int(lo[lev + 1])]:
+            g = int(g)
+            a, b = int(prog["left"][g]), int(prog["right"][g])
+            x = consts[a & 0x7fffffff] if a & 0x80000000 else w[a]
+            y = consts[b & 0x7fffffff] if b & 0x80000000 else w[b]
+            assert x is not None and y is not None, "operand not ready: not a level schedule"
+            vals[g] = (x * y if prog["op"][g] == 2 else x + y) % p
+        for g, v in vals.items():                                   # a level's gates do not see one another
+            assert w[g] is None
+            w[g] = v
+    npos = len(prog["op"])
+    assert all(v is not None for v in w[:npos])
+    return oracle.to_mont(oracle.ints_to_limbs([v if v is not None else 0 for v in w]))
+
+
+def test_trace_program_reproduces_build_w(hp, oracle, model):
+    """f3 on the device: the level-scheduled program (lgh_trace_program) executed the way the device executes it gives the W block
+    build_w gives -- Poseidon (64 levels) and an expression-made circuit; input_positions follows the assignment convention"""
+    c = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+    inst = hp.LigeroInstance(c)
+    wit = model.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))
+    vals = oracle.to_mont(oracle.ints_to_limbs(wit[1:]))
+    idx = list(range(1, len(wit)))
+    wblk, ok = inst.build_w(idx, vals)
+    prog = inst.trace_program()
+    left, right, consts = inst.gate_map()
+    assert np.array_equal(prog["constants"], consts)                              # one list of constants for both maps
+    muls = prog["op"] == 2
+    assert np.array_equal(prog["left"][muls], left[muls]) and np.array_equal(muls, left != 0xffffffff)
+    assert prog["num_inputs"] == 264 and len(prog["level_off"]) - 1 == 64 and len(prog["order"]) == int((prog["op"] == 1).sum() + muls.sum())
+    pos = inst.input_positions(idx)
+    assert (prog["op"][pos] == 0).all() and len(set(pos.tolist())) == 264
+    got = run_trace_program(oracle, model, prog, pos, vals, inst.m * inst.k)
+    assert np.array_equal(got.reshape(wblk.shape), wblk)
+    one = oracle.to_mont(oracle.ints_to_limbs([1]))[0]
+    assert ok and all(np.array_equal(got[int(o)], one) for o in prog["outputs"])
+    with pytest.raises(hp.HostPanic, match="non-variable"):
+        inst.input_positions([0])
+    x, y = hp.Expression.variable("x"), hp.Expression.variable("y")
+    circ = ((x * (x + 3)) * y - y.pow(3) + x).to_arithmetic_circuit()
+    inst2 = hp.LigeroInstance(circ, [circ.num_nodes() - 1])
+    nodes = [circ.get_variable("x"), circ.get_variable("y")]
+    v = np.stack([_mont(oracle, 5), _mont(oracle, 7)])
+    w2, _ = inst2.build_w(nodes, v)
+    got2 = run_trace_program(oracle, model, inst2.trace_program(), inst2.input_positions(nodes), v, inst2.m * inst2.k)
+    assert np.array_equal(got2.reshape(w2.shape), w2)
