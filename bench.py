@@ -181,26 +181,32 @@ def prover_child(argv):
         allv = np.ascontiguousarray(vals[np.arange(batch) % 64])
         bp = LigeroBatchProver(inst, batch, device=device, threads=ncpu, device_transcript=True)
         try:
+            bp_device_trace = bp.device_trace
             bp.prove(idx, allv, copy=False)                      # warm-up: buffers, page-locking, the first launches
             h0 = bp.host_stats()
-            c0, t0 = time.process_time(), time.perf_counter()
+            c0, t0, m0 = time.process_time(), time.perf_counter(), time.thread_time()
             bp.submit(idx, allv)
             for _ in range(steps - 1):
                 bp.submit(idx, allv)
                 bp.collect()
             bp.collect()
-            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            dt, cpu, cpu_main = time.perf_counter() - t0, time.process_time() - c0, time.thread_time() - m0
             h1 = bp.host_stats()
         finally:
             bp.close()
         n = batch * steps
         w_core, queue, wait = (h1[k_] - h0[k_] for k_ in ("w_core_ms", "queue_ms", "wait_ms"))
         out.update({"value": n / dt, "unit": "proofs/s", "proofs": n, "seconds": dt, "ms_per_batch": dt / steps * 1e3, "batches_in_flight": 2,
+                    "evaluation_trace": "device (lg_prove_batch_queue_inputs: the host ships the assignment, 8.4 KB per proof)" if bp_device_trace
+                                        else "host (w built by the worker threads, 352 KB per proof shipped)",
                     "host_core_ms_per_proof": {
-                        "total": cpu / n * 1e3, "trace_and_w": w_core / n, "queue_hip_calls": queue / n,
-                        "python_ffi_and_copies_in": max(0.0, (cpu * 1e3 - w_core - queue) / n),
+                        "total": cpu / n * 1e3, "calling_thread": cpu_main / n * 1e3, "trace_and_w": w_core / n, "queue_hip_calls": queue / n,
+                        "other_threads": max(0.0, (cpu - cpu_main) * 1e3 / n),
+                        "other_threads_note": "one thread of the HIP runtime polls while device work is in flight (a core per process whatever the prover "
+                                              "does; tools/prover_cpu_threads.py) -- the prover's own threads sleep: lg_prove_batch_wait naps between event queries",
                         "sponge": 0.0, "a_row_mul": 0.0, "openings_repack": 0.0,
-                        "note": "core-milliseconds per proof (process CPU time); the transcript, A.row_mul and the openings never touch the host: "
+                        "note": "core-milliseconds per proof (process CPU time); trace_and_w = the copy of the assignment into page-locked memory when the "
+                                "trace runs on the device; the transcript, A.row_mul and the openings never touch the host: "
                                 "the proofs land in page-locked memory in their final layout (lg_proof_layout)"},
                     "host_idle_waiting_ms_per_batch": wait / steps})
     else:       # the host-transcript batch provers of rounds 2-3, for comparison: 4 in flight, batches of 64

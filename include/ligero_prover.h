@@ -100,6 +100,10 @@ int lgp_prove_batch_collect(lgp_batch_prover* p);
 int lgp_batch_prover_host_stats(const lgp_batch_prover* p, double out[5]);
 void lgp_batch_prover_destroy(lgp_batch_prover* p);
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p);
+/* 1 if the circuit's evaluation trace runs on the device for this prover (include/ligero_hip.h lg_upload_trace_program): the host hands
+ * over the assignment and builds no w.  Decided per prover by a cost estimate; LG_DEVICE_TRACE=0 / 1 overrides it. */
+int lgp_batch_prover_device_trace(const lgp_batch_prover* p);
+int lgp_prover_device_trace(const lgp_prover* p);
 int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out);
 /* proofs_out may be NULL: the proofs then stay in storage the prover reuses from call to call (copies of 64 proofs are
  * 330 MB of fresh memory) and are read through borrowed handles, valid until the next lgp_prove_batch; they can be

@@ -20,6 +20,9 @@
 // the host-transcript provers' field for field (tests/test_gpu_prover.py).
 #include <string>
 
+#include <chrono>
+#include <thread>
+
 #include "lg_context.h"
 #include "challenge_kernels.h"
 #include "sponge_kernels.h"
@@ -444,7 +447,22 @@ int lg_prove_batch_wait(lg_ctx* c, const void* proofs_out) {
         return LG_ERR_STATE;
     }
     LG_HIP(c, hipSetDevice(c->device));
-    LG_HIP(c, hipEventSynchronize(b->slot[si].done));
+    {   // A batch takes ~100 ms and this thread has nothing to do meanwhile.  hipEventSynchronize spins on this stack even for a
+        // hipEventBlockingSync event (a whole core per waiting prover, measured: tools/prover_cpu_threads.py), so the wait is a
+        // query every 200 us with the thread asleep in between -- LG_WAIT_POLL_US=0 restores the runtime's wait.
+        static const long poll_us = [] { const char* e = getenv("LG_WAIT_POLL_US"); return e ? atol(e) : 200L; }();
+        if (poll_us <= 0) {
+            LG_HIP(c, hipEventSynchronize(b->slot[si].done));
+        } else {
+            for (;;) {
+                const hipError_t q = hipEventQuery(b->slot[si].done);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return fail_hip(c, q, "hipEventQuery(batch done)");
+                (void)hipGetLastError();
+                std::this_thread::sleep_for(std::chrono::microseconds(poll_us));
+            }
+        }
+    }
     b->slot[si].busy = false;
     uint32_t flag = 0;
     memcpy(&flag, static_cast<const uint8_t*>(proofs_out) + b->layout.off_status, 4);

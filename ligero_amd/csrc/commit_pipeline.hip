@@ -299,6 +299,8 @@ static int commit_checked(lg_ctx* c, const uint64_t* host_pre, uint64_t* host_co
     if (rc != LG_OK && rc != LG_ERR_STATE) c->held.drop();
     return rc;
 }
+int commit_resident_matrix(lg_ctx* c) { return commit_checked(c, nullptr, nullptr); }   // (witness.hip: preenc_u made on the device)
+
 extern "C" {
 
 int lg_commit_resident(lg_ctx* c) {

@@ -435,6 +435,7 @@ int colhash_launch(lg_ctx* c, hipStream_t hs, const lg::ColHashArgs& h, bool all
 int read_back(lg_ctx* c, void* dst, const void* src, size_t bytes);
 // witness.hip
 int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs, const volatile uint64_t* ready = nullptr, bool w_on_device = false);
+int commit_resident_matrix(lg_ctx* c);   // commit_pipeline.hip: lg_commit_resident's body
 int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin);   // witness.hip: w of every proof from its inputs
 // openings.hip: the gather of t columns of nproofs proofs from DEVICE indices into DEVICE buffers (queued on the encode stream)
 int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths);

@@ -102,17 +102,16 @@ struct TraceOutputsArgs {
     uint32_t nout, batch;
     fr one;
 };
-__global__ void __launch_bounds__(64) trace_outputs_kernel(const TraceOutputsArgs a) {
-    const uint32_t b = blockIdx.x;
+__global__ void __launch_bounds__(256) trace_outputs_kernel(const TraceOutputsArgs a) {      // ok[] preset to 1; grid (slices, batch)
+    const uint32_t b = blockIdx.y;
     const fr* w = a.pre + (uint64_t)b * 4 * a.mk + 3 * a.mk;
     uint32_t bad = 0;
-    for (uint32_t i = threadIdx.x; i < a.nout; i += 64) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nout; i += (uint64_t)gridDim.x * blockDim.x) {
         const fr v = fr_load(w + a.outputs[i]);
 #pragma unroll
         for (int j = 0; j < 8; j++) bad |= v.v[j] ^ a.one.v[j];
     }
-    const uint64_t any = __ballot(bad != 0);
-    if (threadIdx.x == 0) a.ok[b] = any ? 0u : 1u;
+    if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicExch(a.ok + b, 0u);
 }
 
 }  // namespace lg
@@ -540,7 +539,11 @@ int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, 
     }
     lg::TraceOutputsArgs oa;
     oa.pre = c->d_preenc; oa.outputs = t.d_outputs; oa.ok = t.d_ok; oa.mk = mk; oa.nout = t.nout; oa.batch = c->batch; oa.one = one;
-    LG_LAUNCH(c, lg::trace_outputs_kernel, dim3(c->batch), dim3(64), 0, s, oa);
+    LG_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(t.d_ok), 1, c->batch, s));
+    if (t.nout) {
+        const uint32_t slices = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)t.nout + 255) / 256);
+        LG_LAUNCH(c, lg::trace_outputs_kernel, dim3(slices, c->batch), dim3(256), 0, s, oa);
+    }
     return LG_OK;
 }
 
@@ -555,10 +558,29 @@ int lg_encode_commit_from_inputs(lg_ctx* c, const uint32_t* in_pos, const uint64
     // anything of it is overwritten -- they read U and the leaves, not d_preenc)
     int rc = trace_on_device(c, in_pos, in_vals, nin);
     if (rc != LG_OK) return rc;
-    rc = commit_from_witness(c, nullptr, coeffs_out, nullptr, true);
-    if (rc != LG_OK) {
-        if (rc != LG_ERR_STATE) c->held.committed = false;
-        return rc;
+    Chunk plan[lg_ctx::kMaxChunks];
+    if (plan_chunks(c, plan) > 1) {
+        // a large matrix that is wholly on the device is committed the way lg_commit_resident commits it (every row interpolated in
+        // one launch, the evaluation in tapered chunks with the column hash beside it: 21 ms at 2^20 constraints) -- the row steps of
+        // the commit from w exist to hide a transfer that does not happen here (23 ms)
+        if (!c->gate.loaded) return LG_ERR_STATE;
+        const uint64_t mk = (uint64_t)(c->rows / 4) * c->k;
+        rc = witness_gather(c, 0, mk);
+        if (rc != LG_OK) return rc;
+        if (c->held.staging) return LG_ERR_STATE;
+        c->held.row0 = 0; c->held.row1 = c->rows;
+        rc = commit_resident_matrix(c);
+        if (rc != LG_OK) return rc;
+        if (coeffs_out) {
+            rc = read_back(c, coeffs_out, c->d_coeffs, (size_t)c->total_rows * c->k * sizeof(fr));
+            if (rc != LG_OK) return rc;
+        }
+    } else {
+        rc = commit_from_witness(c, nullptr, coeffs_out, nullptr, true);
+        if (rc != LG_OK) {
+            if (rc != LG_ERR_STATE) c->held.committed = false;
+            return rc;
+        }
     }
     if (outputs_all_one) LG_HIP(c, hipMemcpyAsync(outputs_all_one, c->trace.d_ok, (size_t)c->batch * 4, hipMemcpyDeviceToHost, c->st.main));
     return lg_read_root(c, root_out);

@@ -130,6 +130,8 @@ int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_p
     return LGP_OK;
 }
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p) { return p ? p->hip.threads() : 0; }
+int lgp_batch_prover_device_trace(const lgp_batch_prover* p) { return p && p->hip.device_trace() ? 1 : 0; }
+int lgp_prover_device_trace(const lgp_prover* p) { return p && p->hip.device_trace() ? 1 : 0; }
 
 int lgp_prove_batch(lgp_batch_prover* p, const uint64_t* node_idx, const uint64_t* values, uint64_t count, lgp_proof** proofs_out) {
     if (!p || !node_idx || !values || count == 0) return LGP_ERR_BAD_ARG;

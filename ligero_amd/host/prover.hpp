@@ -363,6 +363,7 @@ public:
     HipLigeroT(const HipLigeroT&) = delete;
     HipLigeroT& operator=(const HipLigeroT&) = delete;
 
+    bool device_trace() const { return dtrace_.on; }   // the evaluation trace of this prover's circuit runs on the device
     // ---------------------------------------------------------------- prove (mod.rs:435-578)
     LigeroProof prove(const std::vector<std::pair<size_t, E>>& var_assignment, PoseidonSponge& sponge) {   // mod.rs:435-455
         PhaseTimer tm;
@@ -377,6 +378,19 @@ public:
     LigeroProof prove_arrays(const uint64_t* node_idx, const uint64_t* values, uint64_t count, PoseidonSponge& sponge) {
         static_assert(sizeof(E) % 8 == 0, "elements are whole 64-bit limbs");
         constexpr size_t limbs = sizeof(E) / 8;
+        if constexpr (kDeviceChallenges) {
+            // with the circuit's trace program on the device the arrays go there almost as they are: positions instead of node
+            // indices (kept while the caller passes the same indices), the values into page-locked memory
+            if (dtrace_.on && !sharded_ && !preenc_on_host() && stage_input_arrays(node_idx, values, count)) {
+                staged_ = true;
+                struct Reset { bool& f; ~Reset() { f = false; } } reset{staged_};
+                try {
+                    return prove_inner(assign_buf_, sponge);           // (the assignment itself is not looked at)
+                } catch (const NeedHostTrace&) {
+                    // a variable named twice: the host evaluates (below)
+                }
+            }
+        }
         assign_buf_.resize(count);
         auto fill = [&](uint64_t a, uint64_t b) {
             for (uint64_t i = a; i < b; i++) {
@@ -392,6 +406,8 @@ public:
             for (unsigned t = 0; t < nt; t++) ts.emplace_back(fill, count * t / nt, count * (t + 1) / nt);
             for (auto& t : ts) t.join();
         }
+        dtrace_skip_ = staged_failed_;
+        struct Reset { bool& a; bool& b; ~Reset() { a = false; b = false; } } reset{dtrace_skip_, staged_failed_};
         return prove_inner(assign_buf_, sponge);
     }
     // mod.rs:580-611: labels resolve in the formatted circuit's variable map; "Variable not found: <label>" otherwise
@@ -412,7 +428,7 @@ private:
         // ... and with the circuit's trace program there too, only the ASSIGNMENT is: w is evaluated on the device
         // (lg_encode_commit_from_inputs).  Anything but "every variable once" goes the host's way, which words the reference's panics.
         bool inputs_only = false;
-        if constexpr (kDeviceChallenges) inputs_only = witness_only && stage_inputs(formatted_assignment);
+        if constexpr (kDeviceChallenges) inputs_only = witness_only && (staged_ || stage_inputs(formatted_assignment));
         const size_t want = inputs_only ? flat_.size() : (witness_only ? m_ * k_ : 4 * m_ * k_);
         if (flat_.size() != want) {
             if (pinned_) lg_host_unregister(ctx_, flat_.data());
@@ -431,6 +447,7 @@ private:
         if (inputs_only) {
             const int st = lg_encode_commit_from_inputs(ctx_, in_pos_.data(), in_vals_.empty() ? nullptr : in_vals_[0].l, in_pos_.size(), nullptr, proof.u_root.data(), nullptr);
             if (st == LG_ERR_BAD_ARG) {     // (a variable named twice: legal for the reference -- the last value wins -- so the host evaluates)
+                if (staged_) { staged_failed_ = true; throw NeedHostTrace(); }
                 dtrace_skip_ = true;
                 struct Reset { bool& f; ~Reset() { f = false; } } reset{dtrace_skip_};
                 return prove_inner(formatted_assignment, sponge);
@@ -1122,12 +1139,36 @@ private:
     std::vector<std::pair<size_t, E>> assign_buf_;   // prove_arrays' bumped assignment, kept between proofs
     DeviceTrace dtrace_;        // the circuit's trace program is on the device: commits upload the assignment alone
     bool dtrace_skip_ = false;  // (set for the one host-path retry of an assignment the device call refused)
+    bool staged_ = false, staged_failed_ = false;   // prove_arrays staged in_pos_ / in_vals_ itself; ... and the device call refused them
+    struct NeedHostTrace {};
+    std::vector<uint64_t> last_node_idx_;           // the indices in_pos_ was made from
+    bool stage_input_arrays(const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
+        const bool same = last_node_idx_.size() == count && in_pos_.size() == count && (count == 0 || std::memcmp(last_node_idx_.data(), node_idx, count * 8) == 0);
+        if (!same) {
+            last_node_idx_.clear();
+            if (!device_trace_positions(dtrace_, count, [&](size_t i) { return inst_.bump_index((size_t)node_idx[i]); }, in_pos_)) return false;
+            last_node_idx_.assign(node_idx, node_idx + count);
+        }
+        if (in_vals_.size() != count) {
+            if (in_vals_pinned_) lg_host_unregister(ctx_, in_vals_.data());
+            in_vals_.assign(count, F::zero());
+            in_vals_pinned_ = !in_vals_.empty() && lg_host_register(ctx_, in_vals_.data(), in_vals_.size() * sizeof(Fr)) == LG_OK;
+        }
+        auto fill = [&](size_t a, size_t b) { std::memcpy(static_cast<void*>(&in_vals_[a]), values + 4 * a, (b - a) * sizeof(Fr)); };
+        const unsigned nt = count >= (1u << 16) ? std::min(4u, usable_cpus()) : 1u;
+        if (nt <= 1) { fill(0, count); return true; }
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < nt; t++) ts.emplace_back(fill, count * t / nt, count * (t + 1) / nt);
+        for (auto& t : ts) t.join();
+        return true;
+    }
     std::vector<uint32_t> in_pos_;
     std::vector<Fr> in_vals_;   // the assignment's values in the order of in_pos_, page-locked
     bool in_vals_pinned_ = false;
     // the assignment as the device wants it; false = not "every variable, nothing else" (or no trace program): the host's way
     bool stage_inputs(const std::vector<std::pair<size_t, E>>& fa) {
         if (dtrace_skip_ || !dtrace_.on) return false;
+        last_node_idx_.clear();      // (in_pos_ is rewritten)
         if (!device_trace_positions(dtrace_, fa.size(), [&](size_t i) { return fa[i].first; }, in_pos_)) return false;
         if (in_vals_.size() != fa.size()) {
             if (in_vals_pinned_) lg_host_unregister(ctx_, in_vals_.data());

@@ -16,7 +16,7 @@ from .host_pipeline import LigeroInstance
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
-           "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads",
+           "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads", "lgp_batch_prover_device_trace", "lgp_prover_device_trace",
            "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
 _vp = ctypes.c_void_p
 _lib = None
@@ -51,6 +51,8 @@ def lib():
         L.lgp_batch_prover_destroy.restype = None
         L.lgp_batch_prover_threads.argtypes = [_vp]
         L.lgp_batch_prover_threads.restype = ctypes.c_uint32
+        L.lgp_batch_prover_device_trace.argtypes = [_vp]
+        L.lgp_prover_device_trace.argtypes = [_vp]
         L.lgp_prove_batch.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, _vp]
         L.lgp_batch_proof.argtypes = [_vp, ctypes.c_uint32]
         L.lgp_batch_proof.restype = _vp
@@ -290,6 +292,7 @@ class LigeroBatchProver:
         _check(self._L.lgp_batch_prover_create_ex(ctypes.byref(self._h), instance._h, batch, device, threads, 1 if device_transcript else 0),
                "lgp_batch_prover_create_ex")
         self.threads = int(self._L.lgp_batch_prover_threads(self._h))
+        self.device_trace = bool(self._L.lgp_batch_prover_device_trace(self._h))     # w itself is made on the device: the host ships assignments
 
     def close(self):
         if getattr(self, "_h", None):
