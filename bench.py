@@ -391,7 +391,8 @@ def s20_prover_rate(device: int, proofs: int = 2, log_n: int = 20):
     return {"value": 1.0 / dt, "unit": "proofs/s", "s_per_proof": dt, "proofs_timed": proofs, "dims_m_k_n_t": dims,
             "dims_match_survey": dims == {20: (2509, 4096, 32768, 156), 22: (5017, 8192, 65536, 156)}.get(log_n, dims), "nodes": inst.num_nodes, "a_nnz": inst.a_nnz, "u_root": root,
             "setup_s": {"generate_r1cs_and_witness": t_gen, "compile_and_ligero_new": t_inst, "prover_create_upload_A": t_upload},
-            "note": "one proof at a time (single HipLigero prover): host evaluation trace + preenc_u assembly, then device; transcript unpinned"}
+            "note": "one proof at a time (single HipLigero prover): the assignment goes to the device, which evaluates the trace, gathers x / y / z and commits; "
+                    "the Fiat-Shamir chain (10 240 Poseidon permutations) stays on one host core; transcript unpinned"}
 
 
 def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0, min_s: float = 2.0):
