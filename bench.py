@@ -329,8 +329,8 @@ def sharded_prove_leg(torch, dist, world: int, rank: int, device: int, log_n: in
     out = {"unit": "proofs/s", "proofs_timed": proofs, "n_gpus": world,
            "workload": f"one proof of the 2^{log_n}-constraint repeated-squaring R1CS over {world} GPU(s)",
            "dims_m_k_n_t": (inst.m, inst.k, inst.n, inst.t), "setup_s": setup,
-           "note": "the host side (evaluation trace, transcript) is replicated on every rank and is most of a proof's time; the device "
-                   "side is sharded.  coset: row shard + coset planes per rank, two device all-gathers, sub-proof points from the plane "
+           "note": "the transcript is replicated on every rank's host and is most of a proof's time; the evaluation trace is replicated too, on every "
+                   "rank's device (lg_tracer_rows; LG_DEVICE_TRACE=0: on its host); the rest of the device side is sharded.  coset: row shard + coset planes per rank, two device all-gathers, sub-proof points from the plane "
                    "owners.  relay: rows end to end, column hash states handed from rank to rank, sub-proof points = sums of per-rank partial sums"}
     roots = {}
     for mode in ("coset", "relay"):
@@ -392,7 +392,7 @@ def s20_prover_rate(device: int, proofs: int = 2, log_n: int = 20):
             "dims_match_survey": dims == {20: (2509, 4096, 32768, 156), 22: (5017, 8192, 65536, 156)}.get(log_n, dims), "nodes": inst.num_nodes, "a_nnz": inst.a_nnz, "u_root": root,
             "setup_s": {"generate_r1cs_and_witness": t_gen, "compile_and_ligero_new": t_inst, "prover_create_upload_A": t_upload},
             "note": "one proof at a time (single HipLigero prover): the assignment goes to the device, which evaluates the trace, gathers x / y / z and commits; "
-                    "the Fiat-Shamir chain (10 240 Poseidon permutations) stays on one host core; transcript unpinned"}
+                    f"the Fiat-Shamir chain ({5 * inst.k // 2} Poseidon permutations) stays on one host core; transcript unpinned"}
 
 
 def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0, min_s: float = 2.0):

@@ -316,6 +316,41 @@ int lg_prove_batch_queue_inputs(lg_ctx* ctx, const uint32_t* in_pos, const uint6
 int lg_prove_batch_wait(lg_ctx* ctx, const void* proofs_out);
 
 /*
+ * The evaluation trace for a rank of a SHARDED proof.  A sharded or relay context holds a share of the rows of preenc_u and refuses
+ * the circuit's maps (it has no room for the matrix they describe), but a rank needs the whole of w to know its rows.  A tracer keeps
+ * the program and one scratch w (m k elements) on the device and writes any row ranges of the 4m x k matrix [X; Y; Z; W]
+ * (mod.rs:483-516) -- concatenated in the order given -- into a device buffer of its own:
+ *   lg_tracer_create   the gate map's constants and the trace program of lg_upload_trace_program in one descriptor (same checks)
+ *   lg_tracer_rows     in_pos / in_vals as for lg_encode_commit_from_inputs (one proof); row_ranges = nranges <= 64 pairs
+ *                      (first row, rows).  *device_rows_out is valid until the next call on this tracer and complete when the call
+ *                      returns: hand it to lg_commit_sharded / lg_commit_row_relay / lg_stage_interpolate as preenc_rows (they take
+ *                      host or device memory).  outputs_all_one as there (one word).
+ * Every rank repeats the same fraction of a millisecond of device work instead of the same host evaluation of the whole circuit.
+ */
+typedef struct lg_tracer lg_tracer;
+typedef struct lg_trace_program_desc {
+    uint64_t m;                /* rows of each of the X, Y, Z, W blocks */
+    uint32_t k;
+    uint64_t npos;             /* positions of the solution vector, <= m k */
+    const uint8_t* op;         /* [npos] LG_TRACE_* */
+    const uint32_t* left;      /* [npos] */
+    const uint32_t* right;     /* [npos] */
+    const uint64_t* constants; /* [nconst] elements */
+    uint32_t nconst;
+    const uint32_t* order;     /* [ngates] */
+    uint64_t ngates;
+    const uint64_t* level_off; /* [nlevels + 1] */
+    uint32_t nlevels;
+    const uint32_t* outputs;   /* [nout] */
+    uint32_t nout;
+} lg_trace_program_desc;
+int lg_tracer_create(lg_tracer** out, int device, const lg_trace_program_desc* program);
+int lg_tracer_rows(lg_tracer* tracer, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, const uint64_t* row_ranges, uint32_t nranges,
+                   const uint64_t** device_rows_out, uint32_t* outputs_all_one);
+void lg_tracer_destroy(lg_tracer* tracer);
+const char* lg_tracer_last_error(const lg_tracer* tracer);   /* NULL: the last failed lg_tracer_create of this thread */
+
+/*
  * Staged commit for ONE proof (batch = 1) sharded over several GPUs, one context per GPU
  * (DESIGN.md section 7).  With these stage calls the exchanges between the stages are the caller's (RCCL all-gather on the
  * device buffers below); lg_commit_sharded / lg_commit_row_relay further down queue the same stages as ONE call and ask for the

@@ -49,7 +49,7 @@ int lg_stage_interpolate(lg_ctx* c, const uint64_t* preenc_rows, uint32_t row0, 
         }
     }
     if (preenc_rows)
-        LG_HIP(c, hipMemcpyAsync(c->d_preenc + (size_t)row0 * c->k, preenc_rows, (size_t)nrows * c->k * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+        LG_HIP(c, hipMemcpyAsync(c->d_preenc + (size_t)row0 * c->k, preenc_rows, (size_t)nrows * c->k * sizeof(fr), hipMemcpyDefault, c->st.main));   // (host or device rows: lg_tracer_rows)
     // The code is systematic: the message planes (s = 0 mod 8) of these rows ARE the message, so the interpolation writes their
     // canonical copy into the ones this context holds and the evaluation skips them for these rows (a rank of a coset-sharded
     // proof still has to evaluate them for the rows it only receives coefficients of)
@@ -447,7 +447,7 @@ static int commit_sharded_body(lg_ctx* c, const lg_comm* comm, const uint64_t* p
         compact = c->d_preenc;
     }
     c->shard.pieces = np; c->shard.world = world; c->shard.rank = rank; c->shard.compact_rows = own;
-    if (preenc_rows && own) LG_HIP(c, hipMemcpyAsync(compact, preenc_rows, (size_t)own * c->k * sizeof(fr), hipMemcpyHostToDevice, c->st.main));
+    if (preenc_rows && own) LG_HIP(c, hipMemcpyAsync(compact, preenc_rows, (size_t)own * c->k * sizeof(fr), hipMemcpyDefault, c->st.main));   // (host or device rows)
     hipEvent_t* ev = nullptr;
     { const int rc_ = shard_events(c, &ev); if (rc_ != LG_OK) return rc_; }
     if (ev) LG_HIP(c, hipEventRecord(ev[0], c->st.main));

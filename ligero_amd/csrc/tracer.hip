@@ -1,0 +1,266 @@
+// The evaluation trace without a commitment context (src/arithmetic_circuit/mod.rs:325-358; src/ligero/mod.rs:476-516): a rank of
+// a SHARDED proof holds a share of the rows of preenc_u only -- its context has no room for the whole matrix and refuses the
+// circuit's maps -- but every rank needs the whole of w to know its rows (a gate's operands sit anywhere).  A tracer keeps the
+// program and one scratch w (m k elements) on the device, evaluates the trace from the assignment level by level with the kernels
+// of trace_kernels.h, and writes the rows a rank asks for -- any row ranges of the 4m x k matrix [X; Y; Z; W], concatenated -- into
+// a device buffer that lg_commit_sharded / lg_commit_row_relay / lg_stage_interpolate take as their preenc_rows.  Every rank repeats
+// the same 0.2 ms of device work instead of the same 61 ms (2^20 constraints) of host evaluation.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ligero_hip.h"
+#include "host_fr.h"
+#include "trace_kernels.h"
+
+using lg::fr;
+
+struct lg_tracer {
+    int device = 0;
+    uint64_t m = 0, mk = 0, npos = 0, ninputs = 0;
+    uint32_t k = 0, nout = 0, nconst = 0;
+    bool has_one = false;
+    hipStream_t stream = nullptr;
+    uint8_t* d_op = nullptr; uint32_t* d_left = nullptr; uint32_t* d_right = nullptr; uint32_t* d_order = nullptr; uint32_t* d_outputs = nullptr;
+    fr* d_consts = nullptr; fr* d_w = nullptr; uint32_t* d_ok = nullptr;
+    std::vector<uint64_t> level_off;
+    std::vector<uint8_t> h_op;
+    std::vector<uint32_t> h_in_pos;
+    uint32_t* d_in_pos = nullptr; fr* d_in_vals = nullptr; size_t in_pos_cap = 0, in_vals_cap = 0;
+    fr* d_rows = nullptr; size_t rows_cap = 0;      // elements
+    uint64_t* d_ranges = nullptr;
+    char err[256] = {0};
+};
+
+namespace {
+
+thread_local char g_create_err[256] = {0};
+
+// rows [first, first + count) of the 4m x k matrix, range after range, from w and the wiring (mod.rs:495-516)
+struct TraceRowsArgs {
+    const fr* w;             // [m k]
+    const uint8_t* op;
+    const uint32_t* left;
+    const uint32_t* right;
+    const fr* consts;
+    const uint64_t* ranges;  // [nranges][3]: first element of the range in the flat matrix, its length, its offset in out
+    fr* out;
+    uint64_t mk, npos, total;
+    uint32_t nranges;
+};
+__global__ void __launch_bounds__(256) trace_rows_kernel(const TraceRowsArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.total) return;
+    uint32_t r = 0;
+    while (r + 1 < a.nranges && gid >= a.ranges[3 * (r + 1) + 2]) r++;
+    const uint64_t flat = a.ranges[3 * r] + (gid - a.ranges[3 * r + 2]);
+    const uint32_t blk = (uint32_t)(flat / a.mk);
+    const uint64_t pos = flat % a.mk;
+    fr v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.v[i] = 0;
+    if (pos < a.npos) {
+        if (blk == 3) {
+            v = lg::fr_load(a.w + pos);
+        } else if (a.op[pos] == lg::kTraceMul) {             // x, y = the operands of the Mul gate at this position, z = its value
+            if (blk == 2) v = lg::fr_load(a.w + pos);
+            else {
+                const uint32_t s = blk == 0 ? a.left[pos] : a.right[pos];
+                v = (s & lg::kGateConst) ? lg::fr_load(a.consts + (s & ~lg::kGateConst)) : lg::fr_load(a.w + s);
+            }
+        }
+    }
+    lg::fr_store(a.out + gid, v);
+}
+
+int fail(lg_tracer* t, hipError_t e, const char* what) {
+    snprintf(t->err, sizeof(t->err), "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? LG_ERR_OOM : LG_ERR_HIP;
+}
+#define TR_HIP(t, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(t, e_, #call); } while (0)
+
+fr mont_one() {
+    const lg_host::Fr o = lg_host::to_mont(lg_host::Fr{{1, 0, 0, 0}});
+    fr r;
+    memcpy(r.v, o.l, 32);
+    return r;
+}
+
+void release(lg_tracer* t) {
+    (void)hipSetDevice(t->device);
+    if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
+    for (void* b : {(void*)t->d_op, (void*)t->d_left, (void*)t->d_right, (void*)t->d_order, (void*)t->d_outputs, (void*)t->d_consts, (void*)t->d_w, (void*)t->d_ok,
+                    (void*)t->d_in_pos, (void*)t->d_in_vals, (void*)t->d_rows, (void*)t->d_ranges})
+        if (b) (void)hipFree(b);
+    delete t;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int lg_tracer_create(lg_tracer** out, int device, const lg_trace_program_desc* p) {
+    if (!out || !p) return LG_ERR_BAD_ARG;
+    *out = nullptr;
+    if (p->m == 0 || p->k == 0 || (p->npos && (!p->op || !p->left || !p->right)) || (p->ngates && !p->order) || !p->level_off || (p->nout && !p->outputs) ||
+        (p->nconst && !p->constants))
+        return LG_ERR_BAD_ARG;
+    const uint64_t mk = p->m * p->k;
+    if (p->npos > mk || p->nconst >= lg::kGateConst) return LG_ERR_BAD_ARG;
+    uint64_t inputs = 0;
+    if (!lg::trace_program_ok(p->npos, p->op, p->left, p->right, p->nconst, p->order, p->ngates, p->level_off, p->nlevels, p->outputs, p->nout, &inputs)) return LG_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return LG_ERR_NO_DEVICE;
+    lg_tracer* t = new (std::nothrow) lg_tracer();
+    if (!t) return LG_ERR_OOM;
+    t->device = device; t->m = p->m; t->k = p->k; t->mk = mk; t->npos = p->npos; t->ninputs = inputs; t->nout = p->nout; t->nconst = p->nconst;
+    t->has_one = p->npos && p->op[0] == lg::kTraceOne;
+    auto body = [&]() -> int {
+        TR_HIP(t, hipSetDevice(device));
+        TR_HIP(t, hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+        const uint64_t np = p->npos ? p->npos : 1;
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_op), np));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_left), np * 4));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_right), np * 4));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_order), (p->ngates ? p->ngates : 1) * 4));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_outputs), (size_t)(p->nout ? p->nout : 1) * 4));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_consts), (size_t)(p->nconst ? p->nconst : 1) * sizeof(fr)));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_w), mk * sizeof(fr)));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_ok), 4));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_ranges), 3 * 64 * sizeof(uint64_t)));
+        if (p->npos) {
+            TR_HIP(t, hipMemcpy(t->d_op, p->op, p->npos, hipMemcpyHostToDevice));
+            TR_HIP(t, hipMemcpy(t->d_left, p->left, p->npos * 4, hipMemcpyHostToDevice));
+            TR_HIP(t, hipMemcpy(t->d_right, p->right, p->npos * 4, hipMemcpyHostToDevice));
+        }
+        if (p->ngates) TR_HIP(t, hipMemcpy(t->d_order, p->order, p->ngates * 4, hipMemcpyHostToDevice));
+        if (p->nout) TR_HIP(t, hipMemcpy(t->d_outputs, p->outputs, (size_t)p->nout * 4, hipMemcpyHostToDevice));
+        if (p->nconst) TR_HIP(t, hipMemcpy(t->d_consts, p->constants, (size_t)p->nconst * sizeof(fr), hipMemcpyHostToDevice));
+        TR_HIP(t, hipMemset(t->d_w, 0, mk * sizeof(fr)));        // the zero padding behind the solution vector (mod.rs:506-509): never written again
+        return LG_OK;
+    };
+    const int rc = body();
+    if (rc != LG_OK) {
+        snprintf(g_create_err, sizeof(g_create_err), "%s", t->err);
+        release(t);
+        return rc;
+    }
+    t->level_off.assign(p->level_off, p->level_off + p->nlevels + 1);
+    t->h_op.assign(p->op, p->op + p->npos);
+    *out = t;
+    return LG_OK;
+}
+
+void lg_tracer_destroy(lg_tracer* t) {
+    if (t) release(t);
+}
+
+const char* lg_tracer_last_error(const lg_tracer* t) { return t ? t->err : g_create_err; }
+
+int lg_tracer_rows(lg_tracer* t, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, const uint64_t* row_ranges, uint32_t nranges,
+                   const uint64_t** device_rows_out, uint32_t* outputs_all_one) {
+    if (!t || !device_rows_out || (nin && (!in_pos || !in_vals)) || (nranges && !row_ranges) || nranges > 64 || nin > 0xffffffffull) return LG_ERR_BAD_ARG;
+    *device_rows_out = nullptr;
+    // every variable exactly once and nothing else, in the reference's words (mod.rs:476-478; arithmetic_circuit/mod.rs:341)
+    const bool same = t->h_in_pos.size() == nin && (nin == 0 || memcmp(t->h_in_pos.data(), in_pos, nin * 4) == 0);
+    if (!same) {
+        std::vector<uint8_t> seen(t->npos, 0);
+        for (uint64_t i = 0; i < nin; i++) {
+            const uint32_t p = in_pos[i];
+            if (p >= t->npos || t->h_op[p] != lg::kTraceInput) {
+                snprintf(t->err, sizeof(t->err), "Value supplied for non-variable node (position %u of the solution vector)", p);
+                return LG_ERR_BAD_ARG;
+            }
+            if (seen[p]) { snprintf(t->err, sizeof(t->err), "variable at position %u assigned twice", p); return LG_ERR_BAD_ARG; }
+            seen[p] = 1;
+        }
+        if (nin != t->ninputs) {
+            snprintf(t->err, sizeof(t->err), "Uninitialised variable: %llu of the circuit's %llu variables are assigned", (unsigned long long)nin, (unsigned long long)t->ninputs);
+            return LG_ERR_BAD_ARG;
+        }
+    }
+    // the ranges: rows of the 4m x k matrix, as flat element ranges with their offsets in the output
+    std::vector<uint64_t> rg(3 * (size_t)(nranges ? nranges : 1), 0);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nranges; i++) {
+        const uint64_t first = row_ranges[2 * i], count = row_ranges[2 * i + 1];
+        if (first > 4 * t->m || count > 4 * t->m - first) { snprintf(t->err, sizeof(t->err), "row range %u lies outside the %llu rows of preenc_u", i, (unsigned long long)(4 * t->m)); return LG_ERR_BAD_ARG; }
+        rg[3 * i] = first * t->k; rg[3 * i + 1] = count * t->k; rg[3 * i + 2] = total;
+        total += count * t->k;
+    }
+    TR_HIP(t, hipSetDevice(t->device));
+    hipStream_t s = t->stream;
+    if (t->in_pos_cap < nin) {
+        TR_HIP(t, hipStreamSynchronize(s));
+        if (t->d_in_pos) TR_HIP(t, hipFree(t->d_in_pos));
+        t->d_in_pos = nullptr; t->in_pos_cap = 0; t->h_in_pos.clear();
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_in_pos), (nin ? nin : 1) * 4));
+        t->in_pos_cap = nin ? nin : 1;
+    }
+    const size_t vbytes = nin * sizeof(fr);
+    if (t->in_vals_cap < vbytes) {
+        TR_HIP(t, hipStreamSynchronize(s));
+        if (t->d_in_vals) TR_HIP(t, hipFree(t->d_in_vals));
+        t->d_in_vals = nullptr; t->in_vals_cap = 0;
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_in_vals), vbytes ? vbytes : 1));
+        t->in_vals_cap = vbytes ? vbytes : 1;
+    }
+    if (t->rows_cap < total) {
+        TR_HIP(t, hipStreamSynchronize(s));
+        if (t->d_rows) TR_HIP(t, hipFree(t->d_rows));
+        t->d_rows = nullptr; t->rows_cap = 0;
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_rows), (total ? total : 1) * sizeof(fr)));
+        t->rows_cap = total ? total : 1;
+    }
+    if (!same || t->h_in_pos.empty()) {
+        if (nin) TR_HIP(t, hipMemcpyAsync(t->d_in_pos, in_pos, nin * 4, hipMemcpyHostToDevice, s));
+        t->h_in_pos.assign(in_pos, in_pos + nin);
+    }
+    if (vbytes) TR_HIP(t, hipMemcpyAsync(t->d_in_vals, in_vals, vbytes, hipMemcpyHostToDevice, s));
+    if (nranges) TR_HIP(t, hipMemcpyAsync(t->d_ranges, rg.data(), 3 * (size_t)nranges * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    // the kernels address w of proof b as pre + b * 4 mk + 3 mk: one proof, and a base that is never dereferenced below its W block
+    fr* pre = t->d_w - 3 * t->mk;
+    const fr one = mont_one();
+    {
+        lg::TraceScatterArgs a;
+        a.pre = pre; a.in_pos = t->d_in_pos; a.in_vals = t->d_in_vals; a.nin = nin; a.mk = t->mk; a.batch = 1; a.has_one = t->has_one ? 1u : 0u; a.one = one;
+        hipLaunchKernelGGL(lg::trace_scatter_kernel, dim3((uint32_t)((nin + 1 + 255) / 256)), dim3(256), 0, s, a);
+        TR_HIP(t, hipGetLastError());
+    }
+    lg::TraceLevelArgs la;
+    la.pre = pre; la.op = t->d_op; la.left = t->d_left; la.right = t->d_right; la.consts = t->d_consts; la.order = t->d_order; la.mk = t->mk; la.batch = 1;
+    for (size_t l = 0; l + 1 < t->level_off.size(); l++) {
+        la.begin = t->level_off[l]; la.end = t->level_off[l + 1];
+        if (la.end == la.begin) continue;
+        hipLaunchKernelGGL(lg::trace_level_kernel, dim3((uint32_t)((la.end - la.begin + 255) / 256)), dim3(256), 0, s, la);
+        TR_HIP(t, hipGetLastError());
+    }
+    TR_HIP(t, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(t->d_ok), 1, 1, s));
+    if (t->nout) {
+        lg::TraceOutputsArgs oa;
+        oa.pre = pre; oa.outputs = t->d_outputs; oa.ok = t->d_ok; oa.mk = t->mk; oa.nout = t->nout; oa.batch = 1; oa.one = one;
+        hipLaunchKernelGGL(lg::trace_outputs_kernel, dim3((uint32_t)std::min<uint64_t>(1024, ((uint64_t)t->nout + 255) / 256), 1), dim3(256), 0, s, oa);
+        TR_HIP(t, hipGetLastError());
+    }
+    if (total) {
+        TraceRowsArgs ra;
+        ra.w = t->d_w; ra.op = t->d_op; ra.left = t->d_left; ra.right = t->d_right; ra.consts = t->d_consts; ra.ranges = t->d_ranges; ra.out = t->d_rows;
+        ra.mk = t->mk; ra.npos = t->npos; ra.total = total; ra.nranges = nranges;
+        hipLaunchKernelGGL(trace_rows_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, ra);
+        TR_HIP(t, hipGetLastError());
+    }
+    uint32_t ok = 1;
+    TR_HIP(t, hipMemcpyAsync(&ok, t->d_ok, 4, hipMemcpyDeviceToHost, s));
+    TR_HIP(t, hipStreamSynchronize(s));          // the rows are there when this returns: any stream of any context may read them
+    if (outputs_all_one) *outputs_all_one = ok;
+    *device_rows_out = reinterpret_cast<const uint64_t*>(t->d_rows);
+    return LG_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

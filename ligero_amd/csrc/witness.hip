@@ -4,6 +4,7 @@
 #include <thread>
 
 #include "lg_context.h"
+#include "trace_kernels.h"
 
 namespace lg {
 
@@ -18,7 +19,6 @@ struct WitnessGatherArgs {
     uint64_t pos0, pos1;     // positions [pos0, pos1) of every proof
     uint32_t batch;
 };
-constexpr uint32_t kGateNone = 0xffffffffu, kGateConst = 0x80000000u;
 __global__ void __launch_bounds__(256) witness_gather_kernel(const WitnessGatherArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t span = a.pos1 - a.pos0;
@@ -42,77 +42,6 @@ __global__ void __launch_bounds__(256) witness_gather_kernel(const WitnessGather
     fr_store(base + 2 * a.mk + pos, z);
 }
 
-
-// f3 on the device (arithmetic_circuit/mod.rs:325-358): the evaluation trace, one launch per dependency level.  w of every proof
-// sits in the W block of d_preenc; a gate reads its operands (positions of w written by earlier levels or by the scatter of the
-// assignment, or constants that have no position) and writes its own position.  Values stay fully reduced Montgomery words, as the
-// host's evaluation leaves them, so the W block is the same bytes.
-constexpr uint8_t kTraceInput = 0, kTraceAdd = 1, kTraceMul = 2, kTraceOne = 3;
-struct TraceLevelArgs {
-    fr* pre;                 // [batch][4 m][k]
-    const uint8_t* op;       // [npos]
-    const uint32_t* left;    // [npos]
-    const uint32_t* right;
-    const fr* consts;
-    const uint32_t* order;   // positions of the gates, level by level
-    uint64_t begin, end;     // this level = order[begin, end)
-    uint64_t mk;
-    uint32_t batch;
-};
-__global__ void __launch_bounds__(256) trace_level_kernel(const TraceLevelArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t span = a.end - a.begin;
-    if (gid >= span * a.batch) return;
-    const uint32_t pos = a.order[a.begin + gid % span];
-    fr* w = a.pre + (gid / span) * 4 * a.mk + 3 * a.mk;
-    const uint32_t l = a.left[pos], r = a.right[pos];
-    const fr x = (l & kGateConst) ? fr_load(a.consts + (l & ~kGateConst)) : fr_load(w + l);
-    const fr y = (r & kGateConst) ? fr_load(a.consts + (r & ~kGateConst)) : fr_load(w + r);
-    fr t, z;
-    if (a.op[pos] == kTraceMul) fr_mul_lazy(t, x, y);
-    else fr_add_raw(t, x, y);                    // both < p: the sum < 2p
-    fr_reduce(z, t);
-    fr_store(w + pos, z);
-}
-
-struct TraceScatterArgs {
-    fr* pre;
-    const uint32_t* in_pos;  // [nin] positions of the assigned variables (the same for every proof)
-    const fr* in_vals;       // [batch][nin]
-    uint64_t nin, mk;
-    uint32_t batch;
-    uint32_t has_one;        // position 0 is the leading constant one
-    fr one;
-};
-__global__ void __launch_bounds__(256) trace_scatter_kernel(const TraceScatterArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t per = a.nin + 1;              // slot nin of every proof writes the one
-    if (gid >= per * a.batch) return;
-    const uint64_t b = gid / per, i = gid % per;
-    fr* w = a.pre + b * 4 * a.mk + 3 * a.mk;
-    if (i == a.nin) { if (a.has_one) fr_store(w, a.one); return; }
-    fr_store(w + a.in_pos[i], fr_load(a.in_vals + b * a.nin + i));
-}
-
-struct TraceOutputsArgs {
-    const fr* pre;
-    const uint32_t* outputs; // [nout] positions
-    uint32_t* ok;            // [batch]
-    uint64_t mk;
-    uint32_t nout, batch;
-    fr one;
-};
-__global__ void __launch_bounds__(256) trace_outputs_kernel(const TraceOutputsArgs a) {      // ok[] preset to 1; grid (slices, batch)
-    const uint32_t b = blockIdx.y;
-    const fr* w = a.pre + (uint64_t)b * 4 * a.mk + 3 * a.mk;
-    uint32_t bad = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nout; i += (uint64_t)gridDim.x * blockDim.x) {
-        const fr v = fr_load(w + a.outputs[i]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) bad |= v.v[j] ^ a.one.v[j];
-    }
-    if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicExch(a.ok + b, 0u);
-}
 
 }  // namespace lg
 
@@ -395,34 +324,8 @@ extern "C" int lg_upload_trace_program(lg_ctx* c, uint64_t npos, const uint8_t* 
         snprintf(c->err, sizeof(c->err), "lg_upload_trace_program: load the gate map of the same circuit first (lg_upload_gate_map; it holds the constants)");
         return LG_ERR_STATE;
     }
-    // The device trusts nothing of the program it has not seen checked: every gate exactly once in `order`, operands in range, and every
-    // operand in an EARLIER level than its gate (inputs and the one are level 0) -- which is also what makes the launches race free.
-    if (level_off[0] != 0 || level_off[nlevels] != ngates) return LG_ERR_BAD_ARG;
-    for (uint32_t l = 0; l < nlevels; l++)
-        if (level_off[l + 1] < level_off[l]) return LG_ERR_BAD_ARG;
-    std::vector<uint32_t> lev(npos, 0);
-    uint64_t gates = 0, inputs = 0;
-    for (uint64_t p = 0; p < npos; p++) {
-        if (op[p] == lg::kTraceAdd || op[p] == lg::kTraceMul) { gates++; lev[p] = 0xffffffffu; }
-        else if (op[p] == lg::kTraceInput) inputs++;
-        else if (op[p] != lg::kTraceOne || p != 0) return LG_ERR_BAD_ARG;
-    }
-    if (gates != ngates) return LG_ERR_BAD_ARG;
-    for (uint32_t l = 0; l < nlevels; l++)
-        for (uint64_t i = level_off[l]; i < level_off[l + 1]; i++) {
-            const uint32_t p = order[i];
-            if (p >= npos || lev[p] != 0xffffffffu) return LG_ERR_BAD_ARG;      // not a gate, or listed twice
-            lev[p] = l + 1;
-        }
-    for (uint64_t p = 0; p < npos; p++) {
-        if (op[p] != lg::kTraceAdd && op[p] != lg::kTraceMul) continue;
-        for (uint32_t s : {left[p], right[p]}) {
-            if (s & lg::kGateConst) { if ((s & ~lg::kGateConst) >= c->gate.nconst) return LG_ERR_BAD_ARG; }
-            else if (s >= npos || lev[s] >= lev[p]) return LG_ERR_BAD_ARG;
-        }
-    }
-    for (uint32_t i = 0; i < nout; i++)
-        if (outputs[i] >= npos) return LG_ERR_BAD_ARG;
+    uint64_t inputs = 0;
+    if (!lg::trace_program_ok(npos, op, left, right, c->gate.nconst, order, ngates, level_off, nlevels, outputs, nout, &inputs)) return LG_ERR_BAD_ARG;
     LG_HIP(c, hipSetDevice(c->device));
     LG_HIP(c, hipStreamSynchronize(c->st.main));
     lg_ctx::TraceProgram& t = c->trace;

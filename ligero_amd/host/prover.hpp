@@ -204,6 +204,42 @@ inline DeviceTrace upload_trace_program(lg_ctx* ctx, const Inst& inst, size_t ba
     }
     return d;
 }
+// the same program in a tracer of its own (include/ligero_hip.h lg_tracer_create): for the ranks of a sharded proof, whose contexts hold
+// row shares only.  nullptr (and d.on false) when the estimate keeps the trace on the host or the library has no tracer.
+template <class Inst>
+inline lg_tracer* make_tracer(const Inst& inst, int device, DeviceTrace& d) {
+    d = DeviceTrace();
+    const char* e = std::getenv("LG_DEVICE_TRACE");
+    if (e && std::atoi(e) == 0) return nullptr;
+    try {
+        const auto t = inst.trace_program();
+        const double gates = (double)t.order.size(), levels = (double)(t.level_off.size() - 1);
+        if (!(e && std::atoi(e) != 0) && levels * 8e-6 + gates * 2e-10 >= gates * 12e-9) return nullptr;
+        lg_trace_program_desc desc;
+        std::memset(&desc, 0, sizeof(desc));
+        desc.m = inst.m; desc.k = (uint32_t)inst.k; desc.npos = t.op.size();
+        desc.op = t.op.data(); desc.left = t.left.data(); desc.right = t.right.data();
+        desc.constants = t.constants.empty() ? nullptr : t.constants[0].l; desc.nconst = (uint32_t)t.constants.size();
+        desc.order = t.order.data(); desc.ngates = t.order.size(); desc.level_off = t.level_off.data(); desc.nlevels = (uint32_t)(t.level_off.size() - 1);
+        desc.outputs = t.outputs.data(); desc.nout = (uint32_t)t.outputs.size();
+        lg_tracer* tr = nullptr;
+        const int st = lg_tracer_create(&tr, device, &desc);
+        if (st == LG_ERR_UNSUPPORTED) return nullptr;
+        if (st != LG_OK) throw DeviceError(st, std::string("lg_tracer_create (") + lg_tracer_last_error(nullptr) + ")");
+        d.pos_of_node = t.pos_of_node;
+        d.is_input.resize(t.op.size());
+        for (size_t p = 0; p < t.op.size(); p++) d.is_input[p] = t.op[p] == 0;
+        d.num_inputs = t.num_inputs;
+        d.levels = t.level_off.size() - 1;
+        d.on = true;
+        return tr;
+    } catch (const DeviceError&) {
+        throw;
+    } catch (const std::exception&) {
+        d = DeviceTrace();
+        return nullptr;
+    }
+}
 // positions of an assignment given by FORMATTED node indices; false if it is anything but "every variable, nothing else" -- the
 // caller then takes the host path, which words the reference's panics (or accepts a variable assigned twice: the last value wins)
 template <class GetIndex>
@@ -340,13 +376,12 @@ public:
         own_mask_ = 0;
         for (uint32_t s = p0; s < p0 + pc; s++) own_mask_ |= 1u << s;
         // the linear test's challenges and A.row_mul run where a plane of the size-2k domain (s = 0 mod 4) lives: only those ranks hold A
-        if (own_mask_ & 0x11111111u) {
-            try {
-                upload_constraint_matrix(ctx_, inst.a);
-            } catch (...) {
-                lg_ctx_destroy(ctx_);
-                throw;
-            }
+        try {
+            if (own_mask_ & 0x11111111u) upload_constraint_matrix(ctx_, inst.a);
+            tracer_ = make_tracer(inst, device, dtrace_);      // the evaluation trace of every rank on its own device (the same rows, replicated work)
+        } catch (...) {
+            lg_ctx_destroy(ctx_);
+            throw;
         }
     }
     ~HipLigeroT() {
@@ -358,6 +393,7 @@ public:
         if (in_vals_pinned_) lg_host_unregister(ctx_, in_vals_.data());
         if (cols_pinned_) lg_host_unregister(ctx_, cols_stage_.data());
         release_exchange();
+        if (tracer_) lg_tracer_destroy(tracer_);
         lg_ctx_destroy(ctx_);
     }
     HipLigeroT(const HipLigeroT&) = delete;
@@ -563,7 +599,20 @@ private:
     // mod.rs:521-551 as the five stages of DESIGN.md section 7
     void sharded_commit(const std::vector<std::pair<size_t, E>>& formatted_assignment, Digest& root) {
         const size_t own = (size_t)(row1_ - row0_) * k_;
-        if (flat_.size() != std::max<size_t>(own, 1)) {
+        // this rank's rows from the assignment, on its device (lg_tracer_rows) -- or, for an assignment that is not "every variable
+        // once" (every rank decides alike: the same assignment), from the host's evaluation, which words the reference's panics
+        const uint64_t* dev_rows = nullptr;
+        if (tracer_ && stage_inputs(formatted_assignment)) {
+            together("the evaluation trace of a row shard (device)", [&] {
+                const uint64_t rg[2] = {row0_, (uint64_t)(row1_ - row0_)};
+                const int st = lg_tracer_rows(tracer_, in_pos_.data(), in_vals_.empty() ? nullptr : in_vals_[0].l, in_pos_.size(), rg, own ? 1 : 0, &dev_rows, nullptr);
+                if (st == LG_ERR_BAD_ARG) { dev_rows = nullptr; return; }
+                if (st != LG_OK) throw DeviceError(st, std::string("lg_tracer_rows (") + lg_tracer_last_error(tracer_) + ")");
+                if (!own) dev_rows = reinterpret_cast<const uint64_t*>(this);      // (no rows to hand over; only "the device path was taken")
+            });
+        }
+        const bool on_device = dev_rows != nullptr;
+        if (!on_device && flat_.size() != std::max<size_t>(own, 1)) {
             if (pinned_) lg_host_unregister(ctx_, flat_.data());
             flat_.assign(std::max<size_t>(own, 1), F::zero());
             scratch_.buffer_replaced();
@@ -574,6 +623,7 @@ private:
         // drained before each exchange (its callback ends with a device synchronisation of its own).
         // (the evaluation trace is where a bad assignment fails: its own step, so that every rank learns of it BEFORE any rank enters
         // the commit's collectives)
+        if (!on_device)
         together("the evaluation trace of a row shard", [&] {
             inst_.build_preenc_range_from_formatted(formatted_assignment, (size_t)row0_ * k_, (size_t)row1_ * k_, flat_.data(), nullptr, &scratch_);
         });
@@ -589,7 +639,7 @@ private:
                 if (lg_sync(me->ctx_) != LG_OK) return -1;
                 return me->comm_.all_gather_device(me->comm_.user, buf, bytes_per_rank);
             };
-            const int st = lg_commit_sharded(ctx_, &lc, own ? flat_[0].l : nullptr, 1);
+            const int st = lg_commit_sharded(ctx_, &lc, own ? (on_device ? dev_rows : flat_[0].l) : nullptr, 1);
             if (st == LG_ERR_COMM) throw std::runtime_error(std::string("the host layer's collective failed (") + lg_last_error(ctx_) + ")");
             check(st, "lg_commit_sharded");
         });
@@ -702,6 +752,12 @@ private:
         if (st != LG_OK) throw DeviceError(st, "lg_ctx_create (row relay)");
         logn_ = 0;
         while ((size_t{1} << logn_) < n_) logn_++;
+        try {
+            tracer_ = make_tracer(inst, device, dtrace_);
+        } catch (...) {
+            lg_ctx_destroy(ctx_);
+            throw;
+        }
         if (mg_ == 0) return;
         try {
             // the columns of A that belong to this rank's rows: column c = (block b, row i of the block, position j in the row)
@@ -725,12 +781,25 @@ private:
     }
     void relay_commit(const std::vector<std::pair<size_t, E>>& formatted_assignment, Digest& root) {
         const size_t own = (size_t)4 * mg_ * k_;
-        if (flat_.size() != std::max<size_t>(own, 1)) {
+        const uint64_t* dev_rows = nullptr;
+        if (tracer_ && stage_inputs(formatted_assignment)) {
+            together("the evaluation trace of a rank's rows (device)", [&] {
+                uint64_t rg[8];
+                for (size_t b = 0; b < 4; b++) { rg[2 * b] = b * m_ + relay_lo_[comm_.rank]; rg[2 * b + 1] = mg_; }
+                const int st = lg_tracer_rows(tracer_, in_pos_.data(), in_vals_.empty() ? nullptr : in_vals_[0].l, in_pos_.size(), rg, mg_ ? 4 : 0, &dev_rows, nullptr);
+                if (st == LG_ERR_BAD_ARG) { dev_rows = nullptr; return; }
+                if (st != LG_OK) throw DeviceError(st, std::string("lg_tracer_rows (") + lg_tracer_last_error(tracer_) + ")");
+                if (!mg_) dev_rows = reinterpret_cast<const uint64_t*>(this);
+            });
+        }
+        const bool on_device = dev_rows != nullptr;
+        if (!on_device && flat_.size() != std::max<size_t>(own, 1)) {
             if (pinned_) lg_host_unregister(ctx_, flat_.data());
             flat_.assign(std::max<size_t>(own, 1), F::zero());
             scratch_.buffer_replaced();
             pinned_ = lg_host_register(ctx_, flat_.data(), flat_.size() * sizeof(Fr)) == LG_OK;
         }
+        if (!on_device)
         together("the evaluation trace of a rank's rows", [&] {
             std::vector<std::pair<size_t, size_t>> ranges;
             if (mg_)
@@ -757,7 +826,7 @@ private:
                 return me->comm_.broadcast_stream(me->comm_.user, buf, bytes, root_rank, stream);
             };
             if (!comm_.broadcast_stream) lc.broadcast = nullptr;
-            const int st = lg_commit_row_relay(ctx_, &lc, 4 * m_, LG_RELAY_BLOCKS, 1, mg_ ? flat_[0].l : nullptr);
+            const int st = lg_commit_row_relay(ctx_, &lc, 4 * m_, LG_RELAY_BLOCKS, 1, mg_ ? (on_device ? dev_rows : flat_[0].l) : nullptr);
             if (st == LG_ERR_COMM) throw std::runtime_error(std::string("the host layer's collective failed (") + lg_last_error(ctx_) + ")");
             check(st, "lg_commit_row_relay");
         });
@@ -1138,6 +1207,7 @@ private:
     PendingOpen pending_[3];       // the three openings of an unsharded proof in flight (open_columns_begin)
     std::vector<std::pair<size_t, E>> assign_buf_;   // prove_arrays' bumped assignment, kept between proofs
     DeviceTrace dtrace_;        // the circuit's trace program is on the device: commits upload the assignment alone
+    lg_tracer* tracer_ = nullptr;   // sharded provers: the program in a tracer of its own (this rank's rows of preenc_u from the assignment)
     bool dtrace_skip_ = false;  // (set for the one host-path retry of an assignment the device call refused)
     bool staged_ = false, staged_failed_ = false;   // prove_arrays staged in_pos_ / in_vals_ itself; ... and the device call refused them
     struct NeedHostTrace {};

@@ -70,6 +70,10 @@ int lg_prove_batch_queue_inputs(lg_ctx*, const uint32_t*, const uint64_t*, uint6
 // (the stub evaluates nothing: the provers under the sanitizers keep the trace on the host, LG_DEVICE_TRACE=0 in their recipe or this status)
 int lg_upload_trace_program(lg_ctx*, uint64_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t, const uint64_t*, uint32_t, const uint32_t*, uint32_t) { return LG_ERR_UNSUPPORTED; }
 int lg_encode_commit_from_inputs(lg_ctx*, const uint32_t*, const uint64_t*, uint64_t, uint64_t*, uint8_t*, uint32_t*) { return LG_ERR_UNSUPPORTED; }
+int lg_tracer_create(lg_tracer** out, int, const lg_trace_program_desc*) { if (out) *out = nullptr; return LG_ERR_UNSUPPORTED; }
+int lg_tracer_rows(lg_tracer*, const uint32_t*, const uint64_t*, uint64_t, const uint64_t*, uint32_t, const uint64_t**, uint32_t*) { return LG_ERR_UNSUPPORTED; }
+void lg_tracer_destroy(lg_tracer*) {}
+const char* lg_tracer_last_error(const lg_tracer*) { return ""; }
 int lg_prove_batch_wait(lg_ctx*, const void*) { return LG_ERR_UNSUPPORTED; }
 int lg_encode_commit(lg_ctx* c, const uint64_t* pre, uint64_t* coeffs, uint8_t* root) {
     const size_t per = (size_t)c->rows * c->k * 32;

@@ -84,9 +84,15 @@ def _worker(rank, world, port, which, out, mode="coset"):
 
 # mode "relay" (round 3): rows end to end in the blocks layout, hash states handed on, sub-proof points = sums of per-rank partial
 # sums, opened columns as row pieces -- the SAME proof, field for field; m = 86 over 4 ranks and m = 4 over 8 (four ranks without rows)
-@pytest.mark.parametrize("which,world,mode", [("poseidon", 2, "coset"), ("poseidon", 4, "coset"), ("small", 8, "coset"),
-                                              ("poseidon", 2, "relay"), ("poseidon", 4, "relay"), ("small", 8, "relay")])
-def test_sharded_proof_equals_the_single_gpu_proof(which, world, mode):
+# trace "device" (round 4): every rank's rows of preenc_u come from a tracer on its device (lg_tracer_rows) instead of the host's
+# evaluation of the whole circuit -- forced here (LG_DEVICE_TRACE=1: the estimate keeps circuits this small on the host; the
+# 2^20-constraint proofs of tests/test_gpu_world8.py take it by themselves); ranks without rows included
+@pytest.mark.parametrize("which,world,mode,trace", [("poseidon", 2, "coset", "host"), ("poseidon", 4, "coset", "host"), ("small", 8, "coset", "host"),
+                                                    ("poseidon", 2, "relay", "host"), ("poseidon", 4, "relay", "host"), ("small", 8, "relay", "host"),
+                                                    ("poseidon", 2, "coset", "device"), ("poseidon", 4, "relay", "device"),
+                                                    ("small", 8, "coset", "device"), ("small", 8, "relay", "device")])
+def test_sharded_proof_equals_the_single_gpu_proof(which, world, mode, trace, monkeypatch):
+    monkeypatch.setenv("LG_DEVICE_TRACE", "1" if trace == "device" else "0")
     if world <= 4:                         # real gloo process groups; the GPU box admits at most six processes on its card,
         import torch.multiprocessing as mp
         mgr = mp.Manager()

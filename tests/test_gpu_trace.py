@@ -195,3 +195,54 @@ def test_provers_make_the_same_proofs_with_the_trace_on_the_device(oracle, model
         monkeypatch.setenv("LG_DEVICE_TRACE", "0")
         with LigeroBatchProver(inst, 5, device_transcript=True) as bp:
             assert all(proofs_equal(ref[b], p) for b, p in enumerate(bp.prove(idx, wit)))
+
+
+def test_tracer_rows_equal_the_host_assembled_rows(oracle, poseidon_inst):
+    """lg_tracer_create / lg_tracer_rows (what a rank of a sharded proof uses): any row ranges of [X; Y; Z; W] from the assignment,
+    in the order asked for, equal the rows of build_preenc_u; a second assignment on the same tracer; the refusals of the commit
+    from inputs"""
+    import ctypes
+    from ligero_amd import _ffi
+    L = _ffi.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    inst = poseidon_inst
+    prog = inst.trace_program()
+
+    class Desc(ctypes.Structure):
+        _fields_ = [("m", ctypes.c_uint64), ("k", ctypes.c_uint32), ("npos", ctypes.c_uint64), ("op", ctypes.c_void_p), ("left", ctypes.c_void_p),
+                    ("right", ctypes.c_void_p), ("constants", ctypes.c_void_p), ("nconst", ctypes.c_uint32), ("order", ctypes.c_void_p),
+                    ("ngates", ctypes.c_uint64), ("level_off", ctypes.c_void_p), ("nlevels", ctypes.c_uint32), ("outputs", ctypes.c_void_p),
+                    ("nout", ctypes.c_uint32)]
+    keep = {k_: np.ascontiguousarray(v) for k_, v in prog.items() if isinstance(v, np.ndarray)}
+    d = Desc(inst.m, inst.k, len(keep["op"]), keep["op"].ctypes.data, keep["left"].ctypes.data, keep["right"].ctypes.data, keep["constants"].ctypes.data,
+             len(keep["constants"]), keep["order"].ctypes.data, len(keep["order"]), keep["level_off"].ctypes.data, len(keep["level_off"]) - 1,
+             keep["outputs"].ctypes.data, len(keep["outputs"]))
+    tr = ctypes.c_void_p()
+    assert L.lg_tracer_create(ctypes.byref(tr), 0, ctypes.byref(d)) == 0, L.lg_tracer_last_error(None)
+    try:
+        idx = list(range(1, 265))
+        pos = inst.input_positions(idx)
+        m = inst.m
+        for b, wit in enumerate(_batch_witnesses(oracle, 2)):
+            pre, ok_host = inst.build_preenc_u(idx, wit)
+            ranges = np.array([[3 * m, m], [0, 5], [m + 3, 7], [2 * m - 1, 2], [4 * m - 1, 1]], dtype=np.uint64)     # W whole, then bits of X, Y, Y|Z, W
+            dev = ctypes.c_void_p()
+            ok = ctypes.c_uint32(7)
+            vals = np.ascontiguousarray(wit)
+            st = L.lg_tracer_rows(tr, pos.ctypes.data, vals.ctypes.data, len(idx), ranges.ctypes.data, len(ranges), ctypes.byref(dev), ctypes.byref(ok))
+            assert st == 0, L.lg_tracer_last_error(tr)
+            total = int(ranges[:, 1].sum())
+            got = np.empty((total, inst.k, 4), dtype=np.uint64)
+            assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), dev, ctypes.c_size_t(got.nbytes), 2) == 0
+            want = np.concatenate([pre[int(a):int(a + n)] for a, n in ranges])
+            assert np.array_equal(got, want), b
+            assert ok.value == int(ok_host) == 1
+        # the same refusals as the commit from the inputs; the tracer stays usable
+        dev = ctypes.c_void_p()
+        assert L.lg_tracer_rows(tr, pos.ctypes.data, vals.ctypes.data, len(idx) - 1, ranges.ctypes.data, 1, ctypes.byref(dev), None) == _ffi.LG_ERR_BAD_ARG
+        assert b"Uninitialised variable" in L.lg_tracer_last_error(tr)
+        outside = np.array([[4 * m, 1]], dtype=np.uint64)
+        assert L.lg_tracer_rows(tr, pos.ctypes.data, vals.ctypes.data, len(idx), outside.ctypes.data, 1, ctypes.byref(dev), None) == _ffi.LG_ERR_BAD_ARG
+        assert L.lg_tracer_rows(tr, pos.ctypes.data, vals.ctypes.data, len(idx), ranges.ctypes.data, 0, ctypes.byref(dev), None) == 0      # a rank without rows
+    finally:
+        L.lg_tracer_destroy(tr)
