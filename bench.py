@@ -596,7 +596,7 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
     return out
 
 
-def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps, witness=None):
+def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps, witness=None, inputs=None):
     """what a drop-in caller gets: lg_encode_commit from host buffers (PCIe inclusive), root read back; with and without the
     coefficient rows coming home, pageable and page-locked (lg_host_register).  witness = (w, gate map) of the SAME matrix:
     also lg_encode_commit_from_witness -- only the W block crosses PCIe, X / Y / Z are gathered on the device (a1 on the
@@ -648,6 +648,17 @@ def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps, witness
             fw["bytes_in"] = int(w.nbytes)
             fw["note"] = "lg_encode_commit_from_witness(host w -> root): a quarter of the bytes; X, Y, Z gathered on the device by the circuit's gate map"
             out["from_witness"] = fw
+            if inputs is not None:
+                # ... and from the ASSIGNMENT alone: the evaluation trace runs on the device too (lg_encode_commit_from_inputs)
+                program, in_pos, in_vals = inputs
+                c.upload_trace_program(program)
+                c.encode_commit_from_inputs(in_pos, in_vals)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    _, ri, ok = c.encode_commit_from_inputs(in_pos, in_vals)
+                out["from_inputs"] = {"pageable_root_only": (time.perf_counter() - t0) / reps * 1e3, "root_equals_host_assembled": bool(ri == root),
+                                      "outputs_all_one": bool(ok.all()), "bytes_in": int(np.asarray(in_vals).nbytes), "levels": int(len(program["level_off"]) - 1),
+                                      "note": "lg_encode_commit_from_inputs(host assignment -> root): w itself is evaluated on the device, level by level"}
     finally:
         c.close()
     return out
@@ -984,7 +995,8 @@ def main():
                 pinst, pidx, pvals = poseidon_batch_inputs()
                 pre_real = np.concatenate([pinst.build_preenc_u(pidx, pvals[i])[0] for i in range(batch)])
                 w_real = np.concatenate([pinst.build_w(pidx, pvals[i])[0] for i in range(batch)])
-                line["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre_real, rows, k, batch, local_rank, 10, witness=(w_real, pinst.gate_map()))
+                line["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre_real, rows, k, batch, local_rank, 10, witness=(w_real, pinst.gate_map()),
+                                                                      inputs=(pinst.trace_program(), pinst.input_positions(pidx), pvals[:batch]))
                 del pre_real, w_real
             except Exception as e:
                 line["host_buffer_commit_ms"] = {"error": f"{type(e).__name__}: {e}"}
@@ -1013,7 +1025,8 @@ def main():
                 pre20r, _ok = inst20.build_preenc_u(idx20, vals20)
                 w20r, _ok = inst20.build_w(idx20, vals20)
                 r20, k20, _ = WORKLOADS["s20"]
-                line["s20"]["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre20r, r20, k20, 1, local_rank, 2, witness=(w20r, inst20.gate_map()))
+                line["s20"]["host_buffer_commit_ms"] = host_buffer_commit_ms(ligero_amd, pre20r, r20, k20, 1, local_rank, 2, witness=(w20r, inst20.gate_map()),
+                                                                             inputs=(inst20.trace_program(), inst20.input_positions(idx20), np.asarray(vals20)[None]))
                 del pre20r, w20r, inst20
             except Exception as e:
                 line["s20"]["host_buffer_commit_ms"] = {"error": f"{type(e).__name__}: {e}"}

@@ -93,7 +93,7 @@ int lg_ctx_destroy_checked(lg_ctx* c) {
     if (c->sub.aux2k) lg_ctx_destroy(c->sub.aux2k);
     hipSetDevice(c->device);
     if (c->gf) gf_destroy(c->gf);
-    for (void* b : {(void*)c->trace.d_op, (void*)c->trace.d_left, (void*)c->trace.d_right, (void*)c->trace.d_order, (void*)c->trace.d_outputs, (void*)c->trace.d_in_pos, (void*)c->trace.d_in_vals, (void*)c->trace.d_ok})
+    for (void* b : {(void*)c->trace.d_op, (void*)c->trace.d_left, (void*)c->trace.d_right, (void*)c->trace.d_order, (void*)c->trace.d_outputs, (void*)c->trace.d_in_pos, (void*)c->trace.d_in_vals, (void*)c->trace.d_ok, (void*)c->trace.d_level_off})
         if (b) hipFree(b);
     if (c->trace.ev_in) hipEventDestroy(c->trace.ev_in);
     if (c->trace.ev_scattered) hipEventDestroy(c->trace.ev_scattered);

@@ -33,6 +33,7 @@
 #include "hash_kernels.h"
 #include "host_fr.h"
 #include "ntt_launch.h"
+#include "trace_plan.h"
 
 using lg::fr;
 
@@ -164,6 +165,8 @@ struct lg_ctx {
     struct TraceProgram {
         uint8_t* d_op = nullptr; uint32_t* d_left = nullptr; uint32_t* d_right = nullptr; uint32_t* d_order = nullptr; uint32_t* d_outputs = nullptr;
         std::vector<uint64_t> level_off;       // [levels + 1] into d_order
+        uint64_t* d_level_off = nullptr;       // the same on the device (the fused launches walk it)
+        std::vector<lg::TraceLaunch> plan;     // wide levels one launch each, runs of narrow ones fused (trace_kernels.h)
         std::vector<uint8_t> h_op;             // host copy: which positions are inputs (checked against every assignment)
         uint64_t npos = 0; uint32_t nout = 0; uint64_t ninputs = 0;
         bool has_one = false;                  // position 0 is the leading constant one

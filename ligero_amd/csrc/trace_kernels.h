@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "fr_gfx950.h"
+#include "trace_plan.h"
 
 namespace lg {
 
@@ -26,12 +27,7 @@ struct TraceLevelArgs {
     uint64_t mk;
     uint32_t batch;
 };
-static __global__ void __launch_bounds__(256) trace_level_kernel(const TraceLevelArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t span = a.end - a.begin;
-    if (gid >= span * a.batch) return;
-    const uint32_t pos = a.order[a.begin + gid % span];
-    fr* w = a.pre + (gid / span) * 4 * a.mk + 3 * a.mk;
+__device__ __forceinline__ void trace_gate(const TraceLevelArgs& a, fr* w, uint32_t pos) {
     const uint32_t l = a.left[pos], r = a.right[pos];
     const fr x = (l & kGateConst) ? fr_load(a.consts + (l & ~kGateConst)) : fr_load(w + l);
     const fr y = (r & kGateConst) ? fr_load(a.consts + (r & ~kGateConst)) : fr_load(w + r);
@@ -40,6 +36,28 @@ static __global__ void __launch_bounds__(256) trace_level_kernel(const TraceLeve
     else fr_add_raw(t, x, y);                    // both < p: the sum < 2p
     fr_reduce(z, t);
     fr_store(w + pos, z);
+}
+static __global__ void __launch_bounds__(256) trace_level_kernel(const TraceLevelArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t span = a.end - a.begin;
+    if (gid >= span * a.batch) return;
+    trace_gate(a, a.pre + (gid / span) * 4 * a.mk + 3 * a.mk, a.order[a.begin + gid % span]);
+}
+// A run of NARROW levels (a few hundred gates each: the tail of a Poseidon circuit is sixty of them, a builder-made chain hundreds) in
+// ONE launch: a workgroup per proof walks the levels with a barrier between them -- a proof's gates read that proof's values only, and
+// the waves of a workgroup share their CU's vector cache, so what one wave stored before the barrier the others load after it.
+struct TraceFusedArgs {
+    TraceLevelArgs lv;            // begin / end unused
+    const uint64_t* level_off;    // device copy
+    uint32_t level0, level1;      // levels [level0, level1) (0-based index into level_off)
+};
+static __global__ void __launch_bounds__(256) trace_fused_kernel(const TraceFusedArgs a) {
+    fr* w = a.lv.pre + (uint64_t)blockIdx.x * 4 * a.lv.mk + 3 * a.lv.mk;
+    for (uint32_t l = a.level0; l < a.level1; l++) {
+        const uint64_t b = a.level_off[l], e = a.level_off[l + 1];
+        for (uint64_t i = b + threadIdx.x; i < e; i += 256) trace_gate(a.lv, w, a.lv.order[i]);
+        __syncthreads();
+    }
 }
 
 struct TraceScatterArgs {

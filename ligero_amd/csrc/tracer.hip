@@ -27,6 +27,8 @@ struct lg_tracer {
     uint8_t* d_op = nullptr; uint32_t* d_left = nullptr; uint32_t* d_right = nullptr; uint32_t* d_order = nullptr; uint32_t* d_outputs = nullptr;
     fr* d_consts = nullptr; fr* d_w = nullptr; uint32_t* d_ok = nullptr;
     std::vector<uint64_t> level_off;
+    uint64_t* d_level_off = nullptr;
+    std::vector<lg::TraceLaunch> plan;
     std::vector<uint8_t> h_op;
     std::vector<uint32_t> h_in_pos;
     uint32_t* d_in_pos = nullptr; fr* d_in_vals = nullptr; size_t in_pos_cap = 0, in_vals_cap = 0;
@@ -94,7 +96,7 @@ void release(lg_tracer* t) {
     (void)hipSetDevice(t->device);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     for (void* b : {(void*)t->d_op, (void*)t->d_left, (void*)t->d_right, (void*)t->d_order, (void*)t->d_outputs, (void*)t->d_consts, (void*)t->d_w, (void*)t->d_ok,
-                    (void*)t->d_in_pos, (void*)t->d_in_vals, (void*)t->d_rows, (void*)t->d_ranges})
+                    (void*)t->d_in_pos, (void*)t->d_in_vals, (void*)t->d_rows, (void*)t->d_ranges, (void*)t->d_level_off})
         if (b) (void)hipFree(b);
     delete t;
 }
@@ -133,6 +135,8 @@ int lg_tracer_create(lg_tracer** out, int device, const lg_trace_program_desc* p
         TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_w), mk * sizeof(fr)));
         TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_ok), 4));
         TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_ranges), 3 * 64 * sizeof(uint64_t)));
+        TR_HIP(t, hipMalloc(reinterpret_cast<void**>(&t->d_level_off), ((size_t)p->nlevels + 1) * 8));
+        TR_HIP(t, hipMemcpy(t->d_level_off, p->level_off, ((size_t)p->nlevels + 1) * 8, hipMemcpyHostToDevice));
         if (p->npos) {
             TR_HIP(t, hipMemcpy(t->d_op, p->op, p->npos, hipMemcpyHostToDevice));
             TR_HIP(t, hipMemcpy(t->d_left, p->left, p->npos * 4, hipMemcpyHostToDevice));
@@ -151,6 +155,7 @@ int lg_tracer_create(lg_tracer** out, int device, const lg_trace_program_desc* p
         return rc;
     }
     t->level_off.assign(p->level_off, p->level_off + p->nlevels + 1);
+    t->plan = lg::trace_launch_plan(t->level_off);
     t->h_op.assign(p->op, p->op + p->npos);
     *out = t;
     return LG_OK;
@@ -234,10 +239,16 @@ int lg_tracer_rows(lg_tracer* t, const uint32_t* in_pos, const uint64_t* in_vals
     }
     lg::TraceLevelArgs la;
     la.pre = pre; la.op = t->d_op; la.left = t->d_left; la.right = t->d_right; la.consts = t->d_consts; la.order = t->d_order; la.mk = t->mk; la.batch = 1;
-    for (size_t l = 0; l + 1 < t->level_off.size(); l++) {
-        la.begin = t->level_off[l]; la.end = t->level_off[l + 1];
-        if (la.end == la.begin) continue;
-        hipLaunchKernelGGL(lg::trace_level_kernel, dim3((uint32_t)((la.end - la.begin + 255) / 256)), dim3(256), 0, s, la);
+    la.begin = la.end = 0;
+    for (const lg::TraceLaunch& pl : t->plan) {
+        if (pl.fused) {
+            lg::TraceFusedArgs fa;
+            fa.lv = la; fa.level_off = t->d_level_off; fa.level0 = pl.level0; fa.level1 = pl.level1;
+            hipLaunchKernelGGL(lg::trace_fused_kernel, dim3(1), dim3(256), 0, s, fa);
+        } else {
+            la.begin = t->level_off[pl.level0]; la.end = t->level_off[pl.level0 + 1];
+            hipLaunchKernelGGL(lg::trace_level_kernel, dim3((uint32_t)((la.end - la.begin + 255) / 256)), dim3(256), 0, s, la);
+        }
         TR_HIP(t, hipGetLastError());
     }
     TR_HIP(t, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(t->d_ok), 1, 1, s));

@@ -331,9 +331,9 @@ extern "C" int lg_upload_trace_program(lg_ctx* c, uint64_t npos, const uint8_t* 
     lg_ctx::TraceProgram& t = c->trace;
     t.loaded = false;
     auto release = [&]() {
-        for (void* b : {(void*)t.d_op, (void*)t.d_left, (void*)t.d_right, (void*)t.d_order, (void*)t.d_outputs, (void*)t.d_ok})
+        for (void* b : {(void*)t.d_op, (void*)t.d_left, (void*)t.d_right, (void*)t.d_order, (void*)t.d_outputs, (void*)t.d_ok, (void*)t.d_level_off})
             if (b) (void)hipFree(b);
-        t.d_op = nullptr; t.d_left = t.d_right = t.d_order = t.d_outputs = t.d_ok = nullptr;
+        t.d_op = nullptr; t.d_left = t.d_right = t.d_order = t.d_outputs = t.d_ok = nullptr; t.d_level_off = nullptr;
     };
     release();
     auto upload = [&]() -> int {
@@ -343,6 +343,8 @@ extern "C" int lg_upload_trace_program(lg_ctx* c, uint64_t npos, const uint8_t* 
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_order), (ngates ? ngates : 1) * 4));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_outputs), (nout ? nout : 1) * 4));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_ok), (size_t)c->batch * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&t.d_level_off), ((size_t)nlevels + 1) * 8));
+        LG_HIP(c, hipMemcpy(t.d_level_off, level_off, ((size_t)nlevels + 1) * 8, hipMemcpyHostToDevice));
         if (npos) {
             LG_HIP(c, hipMemcpy(t.d_op, op, npos, hipMemcpyHostToDevice));
             LG_HIP(c, hipMemcpy(t.d_left, left, npos * 4, hipMemcpyHostToDevice));
@@ -357,6 +359,7 @@ extern "C" int lg_upload_trace_program(lg_ctx* c, uint64_t npos, const uint8_t* 
     const int rc = upload();
     if (rc != LG_OK) { release(); return rc; }
     t.level_off.assign(level_off, level_off + nlevels + 1);
+    t.plan = lg::trace_launch_plan(t.level_off);
     t.h_op.assign(op, op + npos);
     t.h_in_pos.clear();
     t.npos = npos; t.nout = nout; t.ninputs = inputs; t.has_one = npos && op[0] == lg::kTraceOne;
@@ -434,11 +437,17 @@ int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, 
     t.scattered_valid = true;
     lg::TraceLevelArgs la;
     la.pre = c->d_preenc; la.op = t.d_op; la.left = t.d_left; la.right = t.d_right; la.consts = c->gate.d_consts; la.order = t.d_order; la.mk = mk; la.batch = c->batch;
-    for (size_t l = 0; l + 1 < t.level_off.size(); l++) {
-        la.begin = t.level_off[l]; la.end = t.level_off[l + 1];
-        const uint64_t threads = (la.end - la.begin) * c->batch;
-        if (!threads) continue;
-        LG_LAUNCH(c, lg::trace_level_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, la);
+    la.begin = la.end = 0;
+    for (const lg::TraceLaunch& pl : t.plan) {
+        if (pl.fused) {
+            lg::TraceFusedArgs fa;
+            fa.lv = la; fa.level_off = t.d_level_off; fa.level0 = pl.level0; fa.level1 = pl.level1;
+            LG_LAUNCH(c, lg::trace_fused_kernel, dim3(c->batch), dim3(256), 0, s, fa);
+        } else {
+            la.begin = t.level_off[pl.level0]; la.end = t.level_off[pl.level0 + 1];
+            const uint64_t threads = (la.end - la.begin) * c->batch;
+            LG_LAUNCH(c, lg::trace_level_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, la);
+        }
     }
     lg::TraceOutputsArgs oa;
     oa.pre = c->d_preenc; oa.outputs = t.d_outputs; oa.ok = t.d_ok; oa.mk = mk; oa.nout = t.nout; oa.batch = c->batch; oa.one = one;
