@@ -156,6 +156,7 @@ int lg_encode_commit_from_witness_progress(lg_ctx* ctx, const uint64_t* w, const
  *                                 lg_last_error here).  Evaluates w of every proof on the device, gathers X, Y, Z, commits: outputs
  *                                 and residency as lg_encode_commit_from_witness -- the same bytes in LG_BUF_PREENC, the same
  *                                 root.  outputs_all_one (may be NULL): batch words, 1 = every output of that proof is one.
+ *                                 Synchronous like lg_encode_commit: in_pos / in_vals are free again when it returns.
  *   lg_prove_batch_queue_inputs   (further down) the throughput-mode prover fed the same way.
  */
 #define LG_TRACE_INPUT 0
@@ -311,7 +312,8 @@ int lg_prover_setup(lg_ctx* ctx, const lg_sponge_params* sponge, uint32_t t);
 int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
 int lg_prove_batch_queue(lg_ctx* ctx, const uint64_t* w, void* proofs_out);
 /* the same with w evaluated on the device from every proof's inputs (lg_upload_trace_program; in_vals = batch * nin elements,
- * page-locked or the copy blocks the calling thread); status word of a proof whose outputs are not all one: see lg_proof_layout */
+ * page-locked or the copy blocks the calling thread -- and then untouched until lg_prove_batch_wait has returned for this batch; in_pos is
+ * copied before the call returns); status word of a proof whose outputs are not all one: see lg_proof_layout */
 int lg_prove_batch_queue_inputs(lg_ctx* ctx, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin, void* proofs_out);
 int lg_prove_batch_wait(lg_ctx* ctx, const void* proofs_out);
 

@@ -465,7 +465,7 @@ int lg_encode_commit_from_inputs(lg_ctx* c, const uint32_t* in_pos, const uint64
                                  uint32_t* outputs_all_one) {
     if (!c || !root_out) return LG_ERR_BAD_ARG;
     if (c->gf) return LG_ERR_UNSUPPORTED;
-    if (c->shard.on) return LG_ERR_STATE;
+    if (c->shard.on || c->held.staging) return LG_ERR_STATE;      // (a staged commit in progress owns d_preenc)
     // (the trace rewrites d_preenc: the hashes and the tree of the previous commitment are settled by commit_from_witness below before
     // anything of it is overwritten -- they read U and the leaves, not d_preenc)
     int rc = trace_on_device(c, in_pos, in_vals, nin);
@@ -479,7 +479,6 @@ int lg_encode_commit_from_inputs(lg_ctx* c, const uint32_t* in_pos, const uint64
         const uint64_t mk = (uint64_t)(c->rows / 4) * c->k;
         rc = witness_gather(c, 0, mk);
         if (rc != LG_OK) return rc;
-        if (c->held.staging) return LG_ERR_STATE;
         c->held.row0 = 0; c->held.row1 = c->rows;
         rc = commit_resident_matrix(c);
         if (rc != LG_OK) return rc;

@@ -85,6 +85,9 @@ def run_once(seconds, rows, k, seed, batch):
     comm = TorchComm(None)
     c.upload_gate_map(left, right, np.zeros((0, 4), dtype=np.uint64))
     c.upload_constraint_matrix(ncols, a_ri, a_ci, a_vals)
+    all_pos = rng.permutation(m * k).astype(np.uint32)
+    c.upload_trace_program({"op": np.zeros(m * k, dtype=np.uint8), "left": left * 0 + 0xffffffff, "right": left * 0 + 0xffffffff,
+                            "order": np.zeros(0, dtype=np.uint32), "level_off": np.zeros(1, dtype=np.uint64), "outputs": np.zeros(0, dtype=np.uint32)})
     allp = 8 if k <= 4096 else 8 * (k // 4096)
     counts = {}
 
@@ -107,6 +110,10 @@ def run_once(seconds, rows, k, seed, batch):
     def witness(i):
         note("encode_commit_from_witness")
         c.encode_commit_from_witness(mats[i][1])
+
+    def inputs(i):                                            # the trace on the device: here every position is an input (the scatter,
+        note("encode_commit_from_inputs")                      # the gathers and the resident-plan commit between the other entry points)
+        c.encode_commit_from_inputs(all_pos, mats[i][1].reshape(batch, m * k, 4)[:, all_pos])
 
     def staged_all(i):
         be.stage_interpolate(mats[i][0], 0, rows)
@@ -137,7 +144,7 @@ def run_once(seconds, rows, k, seed, batch):
     def relay(i):
         be.commit_native(comm, rows, "contiguous", mats[i][0], plane_groups=int(rng.choice([0, 1, 2])))
 
-    ops = [resident, host, witness, staged_all, staged_rows, sharded, relay] if batch == 1 else [resident, host, witness]
+    ops = [resident, host, witness, inputs, staged_all, staged_rows, sharded, relay] if batch == 1 else [resident, host, witness, inputs]
 
     def check(i, what):
         wnt = want[i]
