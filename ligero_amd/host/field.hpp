@@ -92,17 +92,7 @@ struct Field<Fr> {
     static bool eq(const Fr& a, const Fr& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
     static bool geq_modulus(const Fr& a) { return lg_host::geq(a, lg_host::kP); }
     static Fr neg(const Fr& a) { return is_zero(a) ? a : lg_host::sub_raw(lg_host::kP, a); }
-    static Fr add(const Fr& a, const Fr& b) {
-        Fr r;
-        unsigned __int128 c = 0;
-        for (int i = 0; i < 4; i++) {
-            c += (unsigned __int128)a.l[i] + b.l[i];
-            r.l[i] = (uint64_t)c;
-            c >>= 64;
-        }
-        if (c || lg_host::geq(r, lg_host::kP)) r = lg_host::sub_raw(r, lg_host::kP);
-        return r;
-    }
+    static Fr add(const Fr& a, const Fr& b) { return lg_host::add_mod(a, b); }     // (branch free: host_fr.h)
     static Fr sub(const Fr& a, const Fr& b) { return add(a, neg(b)); }
     static Fr mul(const Fr& a, const Fr& b) { return lg_host::mul(a, b); }
     static Fr to_mont(const Fr& canonical) { return lg_host::to_mont(canonical); }

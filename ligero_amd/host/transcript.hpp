@@ -324,7 +324,20 @@ public:
 private:
     static constexpr size_t kRate = 2, kCapacity = 1, kWidth = 3;
     // x^17: four squarings and one product (alpha is fixed by test_sponge)
+    // (the five products are one dependent chain and the transcript of a large proof is 10^4 permutations in a row: where the host has the
+    // fast product they run without their final subtractions -- values below 2p in, below 2p out -- and the result is reduced once; which
+    // product is decided once per permutation, not per product)
+    template <bool kAdx>
     static Fr sbox17(const Fr& x) {
+#ifdef LG_HOST_HAVE_ADX_PATH
+        if constexpr (kAdx && std::is_same<Fr, lg_host::Fr>::value) {
+            Fr y = lg_host::mul_lazy_adx(x, x);
+            y = lg_host::mul_lazy_adx(y, y);
+            y = lg_host::mul_lazy_adx(y, y);
+            y = lg_host::mul_lazy_adx(y, y);
+            return lg_host::reduce_lazy(lg_host::mul_lazy_adx(y, x));
+        }
+#endif
         Fr y = fr_mul(x, x);
         y = fr_mul(y, y);
         y = fr_mul(y, y);
@@ -332,13 +345,41 @@ private:
         return fr_mul(y, x);
     }
     void permute() {
+#ifdef LG_HOST_HAVE_ADX_PATH
+        if constexpr (std::is_same<Fr, lg_host::Fr>::value) {
+            if (lg_host::have_adx() && alpha_ == 17 && mds_is_test_) { permute_chain(); return; }
+        }
+#endif
+        if (lg_host::have_adx()) permute_impl<true>();
+        else permute_impl<false>();
+    }
+#ifdef LG_HOST_HAVE_ADX_PATH
+    // The configuration every prover of this repository runs (test_sponge: alpha = 17, the additions-only MDS) with the state in three
+    // locals and nothing between the products but what the permutation needs: the transcript of a large proof is one chain of these.
+    void permute_chain() {
+        using lg_host::add_mod;
+        Fr s0 = state_[0], s1 = state_[1], s2 = state_[2];
+        const size_t half = full_rounds_ / 2, rounds = full_rounds_ + partial_rounds_;
+        const std::array<Fr, 3>* ark = ark_.data();
+        for (size_t i = 0; i < rounds; i++) {
+            s0 = add_mod(s0, ark[i][0]); s1 = add_mod(s1, ark[i][1]); s2 = add_mod(s2, ark[i][2]);
+            s0 = sbox17<true>(s0);
+            if (i < half || i >= half + partial_rounds_) { s1 = sbox17<true>(s1); s2 = sbox17<true>(s2); }
+            const Fr n0 = add_mod(s0, s2), n1 = add_mod(s0, s1), n2 = add_mod(s1, s2);
+            s0 = n0; s1 = n1; s2 = n2;
+        }
+        state_[0] = s0; state_[1] = s1; state_[2] = s2;
+    }
+#endif
+    template <bool kAdx>
+    void permute_impl() {
         const size_t half = full_rounds_ / 2;
         for (size_t i = 0; i < full_rounds_ + partial_rounds_; i++) {
             for (size_t j = 0; j < kWidth; j++) state_[j] = fr_add(state_[j], ark_[i][j]);
             const bool full = i < half || i >= half + partial_rounds_;
             if (alpha_ == 17) {
-                state_[0] = sbox17(state_[0]);
-                if (full) { state_[1] = sbox17(state_[1]); state_[2] = sbox17(state_[2]); }
+                state_[0] = sbox17<kAdx>(state_[0]);
+                if (full) { state_[1] = sbox17<kAdx>(state_[1]); state_[2] = sbox17<kAdx>(state_[2]); }
             } else {
                 for (size_t j = 0; j < (full ? kWidth : 1); j++) state_[j] = fr_pow_u64(state_[j], alpha_);
             }

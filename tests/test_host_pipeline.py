@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, mont_matrix, random_mont
+from conftest import GOLDEN, ROOT, mont_matrix, random_mont
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -369,3 +369,25 @@ def test_trace_program_reproduces_build_w(hp, oracle, model):
     w2, _ = inst2.build_w(nodes, v)
     got2 = run_trace_program(oracle, model, inst2.trace_program(), inst2.input_positions(nodes), v, inst2.m * inst2.k)
     assert np.array_equal(got2.reshape(w2.shape), w2)
+
+
+def test_fast_host_product_equals_the_portable_one(tmp_path):
+    """ligero_amd/csrc/host_fr.h: the mulx / adcx / adox Montgomery product (and its chain form without the final subtraction, which the
+    sponge's S-box uses) against the portable CIOS on two million random operands, and the whole sponge with the fast path switched
+    off (LG_HOST_NO_ADX=1) against the default in another process"""
+    import subprocess
+    import sys
+    exe = str(tmp_path / "host_mul_bench")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "ligero_amd", "csrc"), "-o", exe, os.path.join(ROOT, "tools", "host_mul_bench.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatching limbs on 2 M random products: 0" in r.stdout, r.stdout + r.stderr
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from ligero_amd import host_pipeline as hp\n"
+            "el = np.random.default_rng(7).integers(0, 2**62, size=(301, 4), dtype=np.uint64)\n"
+            "s = hp.PoseidonSponge(); s.absorb_bytes(b'x' * 32); s.absorb_elements(el); a = s.squeeze_bytes(48); s.absorb_elements(el[:5]); b = s.squeeze_elements(3)\n"
+            "print(a.hex(), b.tobytes().hex())\n") % ROOT
+    outs = []
+    for no_adx in ("0", "1"):
+        env = dict(os.environ, LG_HOST_NO_ADX=no_adx)
+        outs.append(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) > 100
