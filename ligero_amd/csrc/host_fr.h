@@ -143,6 +143,7 @@ __attribute__((always_inline)) inline void mont_mul_adx(uint64_t r[4], const uin
 inline bool detect_adx() {
     const char* e = std::getenv("LG_HOST_NO_ADX");
     if (e && std::atoi(e) != 0) return false;
+    __builtin_cpu_init();       // (this runs among a shared library's dynamic initialisers)
     return __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
 }
 inline const bool g_have_adx = detect_adx();       // (a plain load per use: a function-local static's guard cost 10 ns per product in a chain)
