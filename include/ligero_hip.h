@@ -326,7 +326,9 @@ int lg_prove_batch_wait(lg_ctx* ctx, const void* proofs_out);
  *   lg_tracer_rows     in_pos / in_vals as for lg_encode_commit_from_inputs (one proof); row_ranges = nranges <= 64 pairs
  *                      (first row, rows).  *device_rows_out is valid until the next call on this tracer and complete when the call
  *                      returns: hand it to lg_commit_sharded / lg_commit_row_relay / lg_stage_interpolate as preenc_rows (they take
- *                      host or device memory).  outputs_all_one as there (one word).
+ *                      host or device memory).  Those calls QUEUE their copy of the rows: let it finish (lg_read_root, lg_sync on the
+ *                      consuming context) before the next lg_tracer_rows, which overwrites -- and may reallocate -- the buffer.
+ *                      outputs_all_one as there (one word).
  * Every rank repeats the same fraction of a millisecond of device work instead of the same host evaluation of the whole circuit.
  */
 typedef struct lg_tracer lg_tracer;
