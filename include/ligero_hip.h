@@ -208,9 +208,11 @@ int lg_open_columns(lg_ctx* ctx, uint32_t proof, const uint32_t* idx, uint32_t t
  * each proof has its own Fiat-Shamir indices), outputs are the per-proof outputs concatenated. */
 int lg_open_columns_batch(lg_ctx* ctx, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out,
                           uint8_t* paths_out);
-/* lg_open_columns without the wait: the gather and the copies are queued on the context's stream and the call returns; the
- * outputs (page-locked memory, or the copies block) are complete after lg_sync or any later call that waits for the stream. */
+/* lg_open_columns without the wait: the gather is queued on the context's stream, the copies home on its download stream -- beside
+ * whatever the context is asked to do next -- and the call returns; the outputs (ALL THREE in page-locked memory, or the copies
+ * block) are complete after lg_open_columns_wait (which waits for every opening queued so far) or lg_sync. */
 int lg_open_columns_async(lg_ctx* ctx, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out);
+int lg_open_columns_wait(lg_ctx* ctx);
 
 /* Row-level operators, independent of the resident commitment (own scratch):
  *   reed_solomon_interpolate  mod.rs:998-1002   nrows * k -> nrows * k

@@ -26,7 +26,7 @@ SYMBOLS = [
     "lg_stage_digests_pack", "lg_stage_digests_unpack", "lg_subproof_points", "lg_subproof_finish",
     "lg_shard_row_ranges", "lg_commit_sharded", "lg_relay_row_ranges", "lg_commit_row_relay", "lg_shard_profile_read",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
-    "lg_ctx_destroy_checked", "lg_last_teardown_error", "lg_open_columns_async", "lg_encode_commit_from_witness_progress", "lg_preenc_mark_filled", "lg_prover_setup", "lg_prover_layout", "lg_prove_batch_queue", "lg_prove_batch_wait",
+    "lg_ctx_destroy_checked", "lg_last_teardown_error", "lg_open_columns_async", "lg_open_columns_wait", "lg_encode_commit_from_witness_progress", "lg_preenc_mark_filled", "lg_prover_setup", "lg_prover_layout", "lg_prove_batch_queue", "lg_prove_batch_wait",
 ]
 
 LG_OK = 0
@@ -125,6 +125,7 @@ def lib():
     L.lg_open_columns.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _vp]
     L.lg_open_columns_batch.argtypes = [_vp, _vp, _u32, _vp, _vp, _vp]
     L.lg_open_columns_async.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _vp]
+    L.lg_open_columns_wait.argtypes = [_vp]
     L.lg_encode_commit_from_witness_progress.argtypes = [_vp, _vp, _vp, _vp, _vp]
     L.lg_reed_solomon_interpolate.argtypes = [_vp, _vp, _u32, _vp]
     L.lg_reed_solomon_evaluate.argtypes = [_vp, _vp, _u32, _vp]

@@ -95,6 +95,8 @@ int lg_ctx_destroy_checked(lg_ctx* c) {
     if (c->gf) gf_destroy(c->gf);
     for (void* b : {(void*)c->trace.d_op, (void*)c->trace.d_left, (void*)c->trace.d_right, (void*)c->trace.d_order, (void*)c->trace.d_outputs, (void*)c->trace.d_in_pos, (void*)c->trace.d_in_vals, (void*)c->trace.d_ok, (void*)c->trace.d_level_off})
         if (b) hipFree(b);
+    if (c->scr.ev_gathered) hipEventDestroy(c->scr.ev_gathered);
+    if (c->scr.ev_copied) hipEventDestroy(c->scr.ev_copied);
     if (c->trace.ev_in) hipEventDestroy(c->trace.ev_in);
     if (c->trace.ev_scattered) hipEventDestroy(c->trace.ev_scattered);
     for (void* b : {(void*)c->gate.d_left, (void*)c->gate.d_right, (void*)c->gate.d_consts})
@@ -618,6 +620,7 @@ int lg_sync(lg_ctx* c) {
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
     { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipStreamSynchronize(c->st.main));
+    if (c->scr.copy_pending) { LG_HIP(c, hipEventSynchronize(c->scr.ev_copied)); c->scr.copy_pending = false; }     // queued openings are home
     return LG_OK;
 }
 

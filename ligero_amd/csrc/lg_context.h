@@ -197,6 +197,10 @@ struct lg_ctx {
         fr* c = nullptr; size_t c_elems = 0;  // natural-order output
         uint32_t* d_idx = nullptr; size_t idx_cap = 0;
         uint8_t* d_path = nullptr; size_t path_cap = 0;
+        // lg_open_columns_async: the way home of an opening runs on st.dn, beside whatever the encode stream does next; whoever writes
+        // c / d_path / d_idx again first lets the encode stream wait for that copy (settle_open_copy)
+        hipEvent_t ev_gathered = nullptr, ev_copied = nullptr;
+        bool copy_pending = false;
     } scr;
     struct Profiler {
         bool on = false;
@@ -420,6 +424,14 @@ inline int grow(lg_ctx* c, fr** p, size_t* cap, size_t need) {
     *cap = 0;
     LG_HIP(c, hipMalloc(reinterpret_cast<void**>(p), need * sizeof(fr)));
     *cap = need;
+    return LG_OK;
+}
+
+// the columns of a queued opening may still be on their way home out of the scratch buffers (st.dn): the encode stream waits for them
+inline int settle_open_copy(lg_ctx* c) {
+    if (!c->scr.copy_pending) return LG_OK;
+    LG_HIP(c, hipStreamWaitEvent(c->st.main, c->scr.ev_copied, 0));
+    c->scr.copy_pending = false;
     return LG_OK;
 }
 

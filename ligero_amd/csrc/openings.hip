@@ -100,6 +100,7 @@ int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nro
     { const int rc_ = need_planes(c, all_planes_mask(c), "lg_read_codeword_rows"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     const size_t elems = (size_t)nrows * c->n;
+    { const int rc_ = settle_open_copy(c); if (rc_ != LG_OK) return rc_; }
     int rc = grow(c, &c->scr.c, &c->scr.c_elems, elems);
     if (rc != LG_OK) return rc;
     const uint64_t threads = elems;
@@ -158,6 +159,7 @@ static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const
     { const int rc_ = need_planes(c, touched, "lg_open_columns"); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipSetDevice(c->device));
     { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
+    { const int rc_ = settle_open_copy(c); if (rc_ != LG_OK) return rc_; }
     const uint32_t plen = (uint32_t)c->logn - 1;
     if (c->scr.idx_cap < nidx) {
         if (c->scr.d_idx) LG_HIP(c, hipFree(c->scr.d_idx));
@@ -179,10 +181,25 @@ static int open_columns_impl(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const
     uint8_t* d_paths = c->scr.d_path + nidx * 32;
     rc = gather_columns_launch(c, proof0, nproofs, c->scr.d_idx, t, c->scr.c, d_sib, d_paths);
     if (rc != LG_OK) return rc;
-    LG_HIP(c, hipMemcpyAsync(cols_out, c->scr.c, nidx * c->rows * sizeof(fr), hipMemcpyDeviceToHost, c->st.main));
-    LG_HIP(c, hipMemcpyAsync(sib_out, d_sib, nidx * 32, hipMemcpyDeviceToHost, c->st.main));
-    if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, d_paths, nidx * plen * 32, hipMemcpyDeviceToHost, c->st.main));
-    if (wait) LG_HIP(c, hipStreamSynchronize(c->st.main));
+    // queued openings travel on the download stream: 50 MB per opening at 2^20 constraints would otherwise sit in front of the next
+    // sub-proof's kernels on the encode stream (0.9 ms each)
+    hipStream_t cs = c->st.main;
+    if (!wait) {
+        if (!c->scr.ev_gathered) LG_HIP(c, hipEventCreateWithFlags(&c->scr.ev_gathered, lg_event_flags()));
+        if (!c->scr.ev_copied) LG_HIP(c, hipEventCreateWithFlags(&c->scr.ev_copied, hipEventDisableTiming));
+        LG_HIP(c, hipEventRecord(c->scr.ev_gathered, c->st.main));
+        LG_HIP(c, hipStreamWaitEvent(c->st.dn, c->scr.ev_gathered, 0));
+        cs = c->st.dn;
+    }
+    LG_HIP(c, hipMemcpyAsync(cols_out, c->scr.c, nidx * c->rows * sizeof(fr), hipMemcpyDeviceToHost, cs));
+    LG_HIP(c, hipMemcpyAsync(sib_out, d_sib, nidx * 32, hipMemcpyDeviceToHost, cs));
+    if (plen) LG_HIP(c, hipMemcpyAsync(paths_out, d_paths, nidx * plen * 32, hipMemcpyDeviceToHost, cs));
+    if (wait) {
+        LG_HIP(c, hipStreamSynchronize(c->st.main));
+    } else {
+        LG_HIP(c, hipEventRecord(c->scr.ev_copied, c->st.dn));
+        c->scr.copy_pending = true;
+    }
     return LG_OK;
 }
 
@@ -194,6 +211,15 @@ int lg_open_columns(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, 
 
 int lg_open_columns_async(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
     return open_columns_impl(c, proof, 1, idx, t, cols_out, sib_out, paths_out, false);
+}
+
+int lg_open_columns_wait(lg_ctx* c) {
+    if (!c) return LG_ERR_BAD_ARG;
+    if (c->gf || !c->scr.ev_copied) return LG_OK;
+    LG_HIP(c, hipSetDevice(c->device));
+    LG_HIP(c, hipEventSynchronize(c->scr.ev_copied));      // (the latest one: the download stream runs the openings in order)
+    c->scr.copy_pending = false;
+    return LG_OK;
 }
 
 int lg_open_columns_batch(lg_ctx* c, const uint32_t* idx, uint32_t t, uint64_t* cols_out, uint8_t* sib_out, uint8_t* paths_out) {
@@ -229,6 +255,7 @@ static int rs_common(lg_ctx* c, const uint64_t* in, uint32_t nrows, uint64_t* ou
     if (!do_eval) return read_back(c, out, coeffs, mat * sizeof(fr));
     rc = grow(c, &c->scr.b, &c->scr.b_elems, 8 * mat);
     if (rc != LG_OK) return rc;
+    { const int rc_ = settle_open_copy(c); if (rc_ != LG_OK) return rc_; }
     rc = grow(c, &c->scr.c, &c->scr.c_elems, 8 * mat);
     if (rc != LG_OK) return rc;
     const uint64_t sstride = (uint64_t)nrows * c->ki;

@@ -287,6 +287,7 @@ int lg_verifier_linear_sums_from_seed(lg_ctx* c, const uint8_t* seed, const uint
         LG_HIP(c, lg::launch_ntt(c->logki, c->logo, true, c->st.main, e));
     }
     // gathered[c][i] = r_i(eta_j) for the opened j (Montgomery), next to the proof's columns
+    { const int rc_ = settle_open_copy(c); if (rc_ != LG_OK) return rc_; }
     rc = grow(c, &c->scr.c, &c->scr.c_elems, 2 * (size_t)t * c->rows);
     if (rc != LG_OK) return rc;
     if (c->scr.idx_cap < t) {

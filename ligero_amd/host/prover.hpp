@@ -968,8 +968,8 @@ private:
     //           (50 MB of freshly faulted vectors per opening at 2^20 constraints) while this thread absorbs the next polynomial
     //   join    before the proof is returned
     struct PendingOpen {
-        std::vector<Fr> cols; bool pinned = false;
-        std::vector<uint8_t> sib, paths;
+        std::vector<Fr> cols; bool pinned = false;      // [t columns | t leaf siblings | t paths], page-locked
+        uint8_t* sib = nullptr; uint8_t* paths = nullptr;   // (into cols)
         std::vector<uint64_t> indices;
         OpenedColumns* dst = nullptr;
         std::thread worker;
@@ -980,18 +980,22 @@ private:
         po.indices = get_distinct_indices_from_prng(n_, t_, sponge.squeeze_seed());
         const size_t t = po.indices.size(), rows = 4 * m_, plen = (size_t)logn_ - 1;
         std::vector<uint32_t> idx(po.indices.begin(), po.indices.end());
-        if (po.cols.size() != t * rows) {
+        // one page-locked block: the columns, then the leaf siblings, then the paths -- a copy into pageable memory is synchronous
+        // (the 32-byte siblings in a plain vector made this "queued" call wait for the 50 MB of columns in front of them: 1 ms each)
+        const size_t tail = (t * 32 + t * plen * 32 + 1 + sizeof(Fr) - 1) / sizeof(Fr);
+        if (po.cols.size() != t * rows + tail) {
             if (po.pinned) lg_host_unregister(ctx_, po.cols.data());
-            po.cols.resize(t * rows);
+            po.cols.resize(t * rows + tail);
             po.pinned = lg_host_register(ctx_, po.cols.data(), po.cols.size() * sizeof(Fr)) == LG_OK;
         }
-        po.sib.resize(t * 32);
-        po.paths.resize(t * plen * 32 + 1);
+        po.sib = reinterpret_cast<uint8_t*>(po.cols.data() + t * rows);
+        po.paths = po.sib + t * 32;
         po.dst = &dst;
-        check(lg_open_columns_async(ctx_, 0, idx.data(), (uint32_t)t, po.cols[0].l, po.sib.data(), po.paths.data()), "lg_open_columns_async");
+        check(lg_open_columns_async(ctx_, 0, idx.data(), (uint32_t)t, po.cols[0].l, po.sib, po.paths), "lg_open_columns_async");
     }
     void open_columns_unpack(int slot) {
         PendingOpen& po = pending_[slot];
+        check(lg_open_columns_wait(ctx_), "lg_open_columns_wait");     // (home long ago, except for the last opening of a proof)
         const size_t rows = 4 * m_, plen = (size_t)logn_ - 1;
         po.worker = std::thread([&po, rows, plen] {
             OpenedColumns& out = *po.dst;

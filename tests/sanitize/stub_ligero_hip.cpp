@@ -60,6 +60,7 @@ int lg_encode_commit_from_witness_progress(lg_ctx* c, const uint64_t* w, const v
         while (__atomic_load_n(const_cast<const uint64_t*>(ready), __ATOMIC_ACQUIRE) < (uint64_t)(c->rows / 4) * c->k) {}
     return lg_encode_commit_from_witness(c, w, coeffs, root);
 }
+int lg_open_columns_wait(lg_ctx*) { return LG_OK; }
 int lg_open_columns_async(lg_ctx* c, uint32_t proof, const uint32_t* idx, uint32_t t, uint64_t* cols, uint8_t* sib, uint8_t* paths) {
     return lg_open_columns(c, proof, idx, t, cols, sib, paths);
 }

@@ -604,3 +604,44 @@ def test_zero_copy_producer_fills_preenc_then_commits_resident(lg, oracle, rows,
             fill()
             c.commit_resident()
             assert c.root() == want
+
+
+def test_queued_openings_come_home_on_the_download_stream(oracle):
+    """lg_open_columns_async / lg_open_columns_wait: three openings queued back to back (the second and third gathers reuse the scratch
+    the first is still being copied out of), other work on the context in between, page-locked outputs -- equal to lg_open_columns"""
+    import ctypes
+    import ligero_amd
+    from ligero_amd import _ffi
+    rows, k = 44, 256
+    pre = random_mont(21, rows * k).reshape(rows, k, 4)
+    sets = [[0, 5, 77, 2047], [1, 2, 3, 1024, 2046], [9, 8, 7]]
+    with ligero_amd.LigeroCommitter(rows=rows, k=k) as c:
+        c.encode_commit(pre, want_coeffs=False)
+        want = [c.open_columns(s) for s in sets]
+        L = _ffi.lib()
+        plen = 10
+        bufs = []
+        for s in sets:
+            t = len(s)
+            block = np.zeros(t * rows * 4 + (t * 32 + t * plen * 32 + 8) // 8 + 1, dtype=np.uint64)       # columns | siblings | paths
+            c.host_register(block)
+            bufs.append(block)
+        try:
+            for s, block in zip(sets, bufs):
+                t = len(s)
+                idx = np.array(s, dtype=np.uint32)
+                base = block.ctypes.data
+                _ffi.check(L.lg_open_columns_async(c._ctx, 0, idx.ctypes.data_as(ctypes.c_void_p), t, ctypes.c_void_p(base), ctypes.c_void_p(base + t * rows * 32),
+                                                   ctypes.c_void_p(base + t * rows * 32 + t * 32)), "lg_open_columns_async", c._ctx)
+            r = random_mont(5, rows).reshape(rows, 4)
+            c.interleaved_row_mul(r)                                                    # the encode stream moves on meanwhile
+            _ffi.check(L.lg_open_columns_wait(c._ctx), "lg_open_columns_wait", c._ctx)
+            for s, block, (cols, sib, paths) in zip(sets, bufs, want):
+                t = len(s)
+                raw = block.view(np.uint8)
+                assert np.array_equal(block[:t * rows * 4].reshape(t, rows, 4), cols)
+                assert raw[t * rows * 32:t * rows * 32 + t * 32].tobytes() == np.ascontiguousarray(sib).tobytes()
+                assert raw[t * rows * 32 + t * 32:t * rows * 32 + t * 32 + t * plen * 32].tobytes() == np.ascontiguousarray(paths).tobytes()
+        finally:
+            for block in bufs:
+                c.host_unregister(block)
