@@ -360,7 +360,10 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
     LG_HIP(c, hipMemsetAsync(c->chal.d_short_flag, 0, 4, s));
     // 1. the commitment (mod.rs:483-551)
     if (in) {       // w itself is made on the device: the evaluation trace of every proof from its inputs (witness.hip)
-        if ((rc = trace_on_device(c, in->pos, in->vals, in->n)) != LG_OK) return rc;
+        if ((rc = trace_on_device(c, in->pos, in->vals, in->n)) != LG_OK) {
+            if (rc == LG_ERR_HIP || rc == LG_ERR_OOM) { c->held.drop(); c->held.row0 = c->held.row1 = 0; }
+            return rc;
+        }
         rc = commit_from_witness(c, nullptr, nullptr, nullptr, true);
     } else {
         rc = commit_from_witness(c, w, nullptr);

@@ -469,7 +469,12 @@ int lg_encode_commit_from_inputs(lg_ctx* c, const uint32_t* in_pos, const uint64
     // (the trace rewrites d_preenc: the hashes and the tree of the previous commitment are settled by commit_from_witness below before
     // anything of it is overwritten -- they read U and the leaves, not d_preenc)
     int rc = trace_on_device(c, in_pos, in_vals, nin);
-    if (rc != LG_OK) return rc;
+    if (rc != LG_OK) {
+        // a refused assignment (LG_ERR_BAD_ARG / LG_ERR_STATE) has touched nothing; a device failure may have left a half-written W
+        // block behind: no commitment, no message rows
+        if (rc == LG_ERR_HIP || rc == LG_ERR_OOM) { c->held.drop(); c->held.row0 = c->held.row1 = 0; }
+        return rc;
+    }
     Chunk plan[lg_ctx::kMaxChunks];
     if (plan_chunks(c, plan) > 1) {
         // a large matrix that is wholly on the device is committed the way lg_commit_resident commits it (every row interpolated in
