@@ -347,6 +347,7 @@ def sharded_prove_leg(torch, dist, world: int, rank: int, device: int, log_n: in
             out[mode] = {"error": merr or "setup failed on another rank"}
             continue
         with sp:
+            trace_where = "every rank's device (lg_tracer_rows)" if sp.device_trace else "every rank's host"
             proof = sp.prove(idx, vals)                           # first proof: buffers, tables
             dist.barrier()
             torch.cuda.synchronize()
@@ -360,7 +361,8 @@ def sharded_prove_leg(torch, dist, world: int, rank: int, device: int, log_n: in
             dt = float(dt.item()) / proofs
             accepted = sp.verify(proof) if rank == 0 else None
             roots[mode] = proof.info()["u_root"].hex()
-        out[mode] = {"value": 1.0 / dt, "s_per_proof": dt, "u_root": roots[mode], "verifies": accepted, "prover_create_s": t_create}
+        out[mode] = {"value": 1.0 / dt, "s_per_proof": dt, "u_root": roots[mode], "verifies": accepted, "prover_create_s": t_create,
+                     "evaluation_trace": trace_where}
     ok = [m for m in ("coset", "relay") if "value" in out.get(m, {})]
     if ok:
         best = max(ok, key=lambda m: out[m]["value"])

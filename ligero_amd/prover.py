@@ -96,6 +96,12 @@ class LigeroProver:
     def _create(self, instance, device):
         _check(self._L.lgp_prover_create(ctypes.byref(self._h), instance._h, device), "lgp_prover_create")
 
+    @property
+    def device_trace(self) -> bool:
+        """the circuit's evaluation trace runs on the device for this prover (single prover: lg_encode_commit_from_inputs; a rank of a
+        sharded proof: its own lg_tracer); decided by a cost estimate, LG_DEVICE_TRACE=0 / 1 overrides"""
+        return bool(self._L.lgp_prover_device_trace(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.lgp_prover_destroy(self._h)
