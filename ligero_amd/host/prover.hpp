@@ -414,16 +414,15 @@ public:
     LigeroProof prove_arrays(const uint64_t* node_idx, const uint64_t* values, uint64_t count, PoseidonSponge& sponge) {
         static_assert(sizeof(E) % 8 == 0, "elements are whole 64-bit limbs");
         constexpr size_t limbs = sizeof(E) / 8;
+        bool host_trace_only = false;
         if constexpr (kDeviceChallenges) {
             // with the circuit's trace program on the device the arrays go there almost as they are: positions instead of node
             // indices (kept while the caller passes the same indices), the values into page-locked memory
             if (dtrace_.on && !sharded_ && !preenc_on_host() && stage_input_arrays(node_idx, values, count)) {
-                staged_ = true;
-                struct Reset { bool& f; ~Reset() { f = false; } } reset{staged_};
                 try {
-                    return prove_inner(assign_buf_, sponge);           // (the assignment itself is not looked at)
+                    return prove_inner(assign_buf_, sponge, TraceOn::DeviceStaged);     // (the pairs themselves are not looked at)
                 } catch (const NeedHostTrace&) {
-                    // a variable named twice: the host evaluates (below)
+                    host_trace_only = true;        // a variable named twice: the host evaluates (below)
                 }
             }
         }
@@ -442,9 +441,7 @@ public:
             for (unsigned t = 0; t < nt; t++) ts.emplace_back(fill, count * t / nt, count * (t + 1) / nt);
             for (auto& t : ts) t.join();
         }
-        dtrace_skip_ = staged_failed_;
-        struct Reset { bool& a; bool& b; ~Reset() { a = false; b = false; } } reset{dtrace_skip_, staged_failed_};
-        return prove_inner(assign_buf_, sponge);
+        return prove_inner(assign_buf_, sponge, host_trace_only ? TraceOn::Host : TraceOn::Auto);
     }
     // mod.rs:580-611: labels resolve in the formatted circuit's variable map; "Variable not found: <label>" otherwise
     LigeroProof prove_with_labels(const std::vector<std::pair<std::string, E>>& var_assignment, PoseidonSponge& sponge) {
@@ -452,7 +449,11 @@ public:
     }
 
 private:
-    LigeroProof prove_inner(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge) {   // mod.rs:457-578
+    // where the evaluation trace of this proof runs: Auto = on the device if the circuit's program is there and the assignment is "every
+    // variable once" (else the host's way); DeviceStaged = prove_arrays has put the assignment into in_pos_ / in_vals_ already; Host
+    enum class TraceOn { Auto, DeviceStaged, Host };
+    struct NeedHostTrace {};    // thrown out of a DeviceStaged proof whose assignment the device call refused: the caller holds the arrays
+    LigeroProof prove_inner(const std::vector<std::pair<size_t, E>>& formatted_assignment, PoseidonSponge& sponge, TraceOn trace = TraceOn::Auto) {   // mod.rs:457-578
         // preenc_u straight into a buffer this prover keeps (and page-locks, so that lg_encode_commit's PCIe chunks overlap
         // the encoding): at 2^20 constraints the matrix is 1.3 GB and fresh memory for it costs more than the commitment
         if constexpr (kDeviceChallenges) {
@@ -464,7 +465,8 @@ private:
         // ... and with the circuit's trace program there too, only the ASSIGNMENT is: w is evaluated on the device
         // (lg_encode_commit_from_inputs).  Anything but "every variable once" goes the host's way, which words the reference's panics.
         bool inputs_only = false;
-        if constexpr (kDeviceChallenges) inputs_only = witness_only && (staged_ || stage_inputs(formatted_assignment));
+        if constexpr (kDeviceChallenges)
+            inputs_only = witness_only && trace != TraceOn::Host && (trace == TraceOn::DeviceStaged || stage_inputs(formatted_assignment));
         const size_t want = inputs_only ? flat_.size() : (witness_only ? m_ * k_ : 4 * m_ * k_);
         if (flat_.size() != want) {
             if (pinned_) lg_host_unregister(ctx_, flat_.data());
@@ -483,10 +485,8 @@ private:
         if (inputs_only) {
             const int st = lg_encode_commit_from_inputs(ctx_, in_pos_.data(), in_vals_.empty() ? nullptr : in_vals_[0].l, in_pos_.size(), nullptr, proof.u_root.data(), nullptr);
             if (st == LG_ERR_BAD_ARG) {     // (a variable named twice: legal for the reference -- the last value wins -- so the host evaluates)
-                if (staged_) { staged_failed_ = true; throw NeedHostTrace(); }
-                dtrace_skip_ = true;
-                struct Reset { bool& f; ~Reset() { f = false; } } reset{dtrace_skip_};
-                return prove_inner(formatted_assignment, sponge);
+                if (trace == TraceOn::DeviceStaged) throw NeedHostTrace();
+                return prove_inner(formatted_assignment, sponge, TraceOn::Host);
             }
             check(st, "lg_encode_commit_from_inputs");
             tm.mark("assignment H2D, evaluation trace + gathers on the device, commit");
@@ -1212,9 +1212,6 @@ private:
     std::vector<std::pair<size_t, E>> assign_buf_;   // prove_arrays' bumped assignment, kept between proofs
     DeviceTrace dtrace_;        // the circuit's trace program is on the device: commits upload the assignment alone
     lg_tracer* tracer_ = nullptr;   // sharded provers: the program in a tracer of its own (this rank's rows of preenc_u from the assignment)
-    bool dtrace_skip_ = false;  // (set for the one host-path retry of an assignment the device call refused)
-    bool staged_ = false, staged_failed_ = false;   // prove_arrays staged in_pos_ / in_vals_ itself; ... and the device call refused them
-    struct NeedHostTrace {};
     std::vector<uint64_t> last_node_idx_;           // the indices in_pos_ was made from
     bool stage_input_arrays(const uint64_t* node_idx, const uint64_t* values, uint64_t count) {
         const bool same = last_node_idx_.size() == count && in_pos_.size() == count && (count == 0 || std::memcmp(last_node_idx_.data(), node_idx, count * 8) == 0);
@@ -1241,7 +1238,7 @@ private:
     bool in_vals_pinned_ = false;
     // the assignment as the device wants it; false = not "every variable, nothing else" (or no trace program): the host's way
     bool stage_inputs(const std::vector<std::pair<size_t, E>>& fa) {
-        if (dtrace_skip_ || !dtrace_.on) return false;
+        if (!dtrace_.on) return false;
         last_node_idx_.clear();      // (in_pos_ is rewritten)
         if (!device_trace_positions(dtrace_, fa.size(), [&](size_t i) { return fa[i].first; }, in_pos_)) return false;
         if (in_vals_.size() != fa.size()) {
