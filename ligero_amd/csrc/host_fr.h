@@ -207,6 +207,54 @@ __attribute__((always_inline)) inline Fr mul_lazy_adx(const Fr& a, const Fr& b) 
 }
 #endif
 inline Fr reduce_lazy(const Fr& a) { return cond_sub_p(a); }     // [0, 2p) -> [0, p)
+#ifdef LG_HOST_HAVE_ADX_PATH
+// x^17 (four squarings and a product, every one without its final subtraction) as ONE block of instructions: the running value never
+// leaves its four registers between the products -- as five separate blocks the compiler moves it through the stack in between and
+// reloads the modulus (15 registers for 16 live values), on the critical path of a chain that is nothing but these.  Input below 2p,
+// output below 2p (reduce_lazy afterwards).
+#define LG_SBOX_REDUCE                                                                                   \
+    "movq %[t0], %%rdx\n\t" "imulq %[inv], %%rdx\n\t"                                                    \
+    "xorq %[lo], %[lo]\n\t"                                                                              \
+    "mulxq %[p0], %[lo], %[m2]\n\t" "adcxq %[t0], %[lo]\n\t" "movq %[m2], %[t0]\n\t"                    \
+    "adcxq %[t1], %[t0]\n\t" "mulxq %[p1], %[lo], %[t1]\n\t" "adoxq %[lo], %[t0]\n\t"                   \
+    "adcxq %[t2], %[t1]\n\t" "mulxq %[p2], %[lo], %[t2]\n\t" "adoxq %[lo], %[t1]\n\t"                   \
+    "adcxq %[t3], %[t2]\n\t" "mulxq %[p3], %[lo], %[t3]\n\t" "adoxq %[lo], %[t2]\n\t"                   \
+    "movl $0, %k[lo]\n\t" "adcxq %[lo], %[t3]\n\t" "adoxq %[A], %[t3]\n\t"
+#define LG_SBOX_ROUND0(B)                                                                                \
+    "movq " B ", %%rdx\n\t" "xorq %[lo], %[lo]\n\t"                                                      \
+    "mulxq %[y0], %[t0], %[t1]\n\t"                                                                      \
+    "mulxq %[y1], %[lo], %[t2]\n\t" "adoxq %[lo], %[t1]\n\t"                                             \
+    "mulxq %[y2], %[lo], %[t3]\n\t" "adoxq %[lo], %[t2]\n\t"                                             \
+    "mulxq %[y3], %[lo], %[A]\n\t"  "adoxq %[lo], %[t3]\n\t"                                             \
+    "movl $0, %k[lo]\n\t" "adoxq %[lo], %[A]\n\t" LG_SBOX_REDUCE
+#define LG_SBOX_ROUND(B)                                                                                 \
+    "movq " B ", %%rdx\n\t" "xorq %[lo], %[lo]\n\t"                                                      \
+    "mulxq %[y0], %[lo], %[A]\n\t" "adoxq %[lo], %[t0]\n\t"                                              \
+    "adcxq %[A], %[t1]\n\t" "mulxq %[y1], %[lo], %[A]\n\t" "adoxq %[lo], %[t1]\n\t"                     \
+    "adcxq %[A], %[t2]\n\t" "mulxq %[y2], %[lo], %[A]\n\t" "adoxq %[lo], %[t2]\n\t"                     \
+    "adcxq %[A], %[t3]\n\t" "mulxq %[y3], %[lo], %[A]\n\t" "adoxq %[lo], %[t3]\n\t"                     \
+    "movl $0, %k[lo]\n\t" "adcxq %[lo], %[A]\n\t" "adoxq %[lo], %[A]\n\t" LG_SBOX_REDUCE
+#define LG_SBOX_SQUARE                                                                                   \
+    LG_SBOX_ROUND0("%[y0]") LG_SBOX_ROUND("%[y1]") LG_SBOX_ROUND("%[y2]") LG_SBOX_ROUND("%[y3]")         \
+    "movq %[t0], %[y0]\n\t" "movq %[t1], %[y1]\n\t" "movq %[t2], %[y2]\n\t" "movq %[t3], %[y3]\n\t"
+__attribute__((always_inline)) inline Fr sbox17_lazy_adx(const Fr& x) {
+    uint64_t y0 = x.l[0], y1 = x.l[1], y2 = x.l[2], y3 = x.l[3];
+    uint64_t t0, t1, t2, t3, A, lo, m2;
+    __asm__(
+        LG_SBOX_SQUARE LG_SBOX_SQUARE LG_SBOX_SQUARE LG_SBOX_SQUARE
+        LG_SBOX_ROUND0("%[x0]") LG_SBOX_ROUND("%[x1]") LG_SBOX_ROUND("%[x2]") LG_SBOX_ROUND("%[x3]")
+        : [y0] "+&r"(y0), [y1] "+&r"(y1), [y2] "+&r"(y2), [y3] "+&r"(y3), [t0] "=&r"(t0), [t1] "=&r"(t1), [t2] "=&r"(t2), [t3] "=&r"(t3),
+          [A] "=&r"(A), [lo] "=&r"(lo), [m2] "=&r"(m2)
+        : [x0] "m"(x.l[0]), [x1] "m"(x.l[1]), [x2] "m"(x.l[2]), [x3] "m"(x.l[3]), [p0] "m"(kP.l[0]), [p1] "m"(kP.l[1]), [p2] "m"(kP.l[2]),
+          [p3] "m"(kP.l[3]), [inv] "m"(kInv64)
+        : "cc", "rdx");
+    return Fr{{t0, t1, t2, t3}};
+}
+#undef LG_SBOX_SQUARE
+#undef LG_SBOX_ROUND
+#undef LG_SBOX_ROUND0
+#undef LG_SBOX_REDUCE
+#endif
 inline Fr to_mont(const Fr& a) { return mul(a, kR2); }
 inline Fr from_mont(const Fr& a) {
     Fr one = {{1, 0, 0, 0}};

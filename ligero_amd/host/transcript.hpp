@@ -375,7 +375,7 @@ private:
                 a = mul_lazy_adx(a, a); b = mul_lazy_adx(b, b); c = mul_lazy_adx(c, c);
                 s0 = lg_host::reduce_lazy(mul_lazy_adx(a, s0)); s1 = lg_host::reduce_lazy(mul_lazy_adx(b, s1)); s2 = lg_host::reduce_lazy(mul_lazy_adx(c, s2));
             } else {
-                s0 = sbox17<true>(s0);
+                s0 = lg_host::reduce_lazy(lg_host::sbox17_lazy_adx(s0));     // (one block of instructions: the value stays in its registers)
             }
             const Fr n0 = add_mod(s0, s2), n1 = add_mod(s0, s1), n2 = add_mod(s1, s2);
             s0 = n0; s1 = n1; s2 = n2;
