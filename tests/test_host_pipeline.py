@@ -381,6 +381,10 @@ def test_fast_host_product_equals_the_portable_one(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "ligero_amd", "csrc"), "-o", exe, os.path.join(ROOT, "tools", "host_mul_bench.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "mismatching limbs on 2 M random products: 0" in r.stdout, r.stdout + r.stderr
+    exe2 = str(tmp_path / "host_sbox_check")                 # the single-block x^17 (sbox17_lazy_adx), canonical and lazy inputs
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "ligero_amd", "csrc"), "-o", exe2, os.path.join(ROOT, "tools", "host_sbox_check.cpp")], check=True)
+    r = subprocess.run([exe2], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatching limbs: 0" in r.stdout, r.stdout + r.stderr
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "from ligero_amd import host_pipeline as hp\n"
             "el = np.random.default_rng(7).integers(0, 2**62, size=(301, 4), dtype=np.uint64)\n"
