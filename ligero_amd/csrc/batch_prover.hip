@@ -123,6 +123,7 @@ static int chacha_elements(lg_ctx* c, const uint32_t* d_seeds, fr* d_out, uint32
     a.seeds = d_seeds; a.out = d_out; a.counts = c->chal.d_counts; a.short_flag = c->chal.d_short_flag;
     a.n = n; a.blocks = blocks; a.wgs = wgs;
     LG_LAUNCH(c, lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
+    LG_LAUNCH(c, lg::chacha_scan_kernel, dim3(c->batch), dim3(1024), 0, c->st.main, a);
     LG_LAUNCH(c, lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
     return LG_OK;
 }

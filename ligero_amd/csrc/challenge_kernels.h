@@ -6,8 +6,9 @@
 //
 // F::rand (ark-ff 0.4) is rejection sampling: 32 stream bytes per attempt, top two bits masked, accepted when
 // below p (75.6 % of attempts), the limbs ARE the Montgomery representation.  Element i is therefore the i-th
-// ACCEPTED 32-byte chunk of the ChaCha20 stream: a stream compaction.  Two launches, no stored candidates:
+// ACCEPTED 32-byte chunk of the ChaCha20 stream: a stream compaction.  Three launches, no stored candidates:
 //   chacha_count_kernel     accepted chunks per workgroup (256 blocks = 512 chunks each)
+//   chacha_scan_kernel      exclusive prefix sums of those counts (one workgroup per proof)
 //   chacha_scatter_kernel   recomputes the blocks, prefix-sums the flags (wave ballots + LDS), writes element i
 // The same restatement as ligero_amd/host/transcript.hpp (PARITY UNPINNED against the Rust crates, see there);
 // tests compare the two bit for bit.
@@ -102,19 +103,35 @@ static __global__ void __launch_bounds__(256) chacha_count_kernel(ChaChaArgs a) 
     if (threadIdx.x == 0) a.counts[(uint64_t)proof * a.wgs + blockIdx.x] = total;
 }
 
-static __global__ void __launch_bounds__(256) chacha_scatter_kernel(ChaChaArgs a) {
-    __shared__ uint32_t part[256];
-    const uint32_t proof = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
-    // accepted chunks in the workgroups before this one
+// counts[proof][w] -> accepted chunks in the workgroups BEFORE w (exclusive prefix sums, in place): one workgroup per proof, every
+// thread a contiguous run.  (Until round 4 every scatter workgroup summed the counts in front of it itself: quadratic in the length of
+// the challenge vector -- 22 GB of L2 reads at 2^20 constraints, 360 GB and 20 of the kernel's 21 ms at 2^22.)
+static __global__ void __launch_bounds__(1024) chacha_scan_kernel(ChaChaArgs a) {
+    __shared__ uint32_t part[1024];
+    uint32_t* cnt = a.counts + (uint64_t)blockIdx.x * a.wgs;
+    const uint32_t per = (a.wgs + 1023) / 1024;
+    const uint32_t w0 = min(a.wgs, threadIdx.x * per), w1 = min(a.wgs, w0 + per);
     uint32_t s = 0;
-    for (uint32_t w = threadIdx.x; w < blockIdx.x; w += 256) s += a.counts[(uint64_t)proof * a.wgs + w];
+    for (uint32_t w = w0; w < w1; w++) s += cnt[w];
     part[threadIdx.x] = s;
     __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+    for (int d = 1; d < 1024; d <<= 1) {               // inclusive scan of the threads' sums
+        const uint32_t v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
         __syncthreads();
     }
-    const uint32_t offset = part[0];
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (uint32_t w = w0; w < w1; w++) {
+        const uint32_t c = cnt[w];
+        cnt[w] = run;
+        run += c;
+    }
+}
+
+static __global__ void __launch_bounds__(256) chacha_scatter_kernel(ChaChaArgs a) {      // counts = what chacha_scan_kernel left
+    const uint32_t proof = blockIdx.y, blk = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t offset = a.counts[(uint64_t)proof * a.wgs + blockIdx.x];
     uint32_t x[16];
     fr e0, e1;
     bool a0 = false, a1 = false;

@@ -213,6 +213,7 @@ static int linear_ra_from_seeds(lg_ctx* c, const uint8_t* seeds, uint32_t* per_o
     a.seeds = c->chal.d_seeds; a.out = c->chal.d_rlin; a.counts = c->chal.d_counts; a.short_flag = c->chal.d_short_flag;
     a.n = (uint32_t)rlen; a.blocks = blocks; a.wgs = wgs;
     LG_LAUNCH(c, lg::chacha_count_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
+    LG_LAUNCH(c, lg::chacha_scan_kernel, dim3(c->batch), dim3(1024), 0, c->st.main, a);
     LG_LAUNCH(c, lg::chacha_scatter_kernel, dim3(wgs, c->batch), dim3(256), 0, c->st.main, a);
     lg::SparseRowMulArgs m;
     m.col_ptr = c->amat.d_colptr; m.ent_row = c->amat.d_row; m.ent_val = c->amat.d_val;
