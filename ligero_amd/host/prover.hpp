@@ -997,19 +997,29 @@ private:
         PendingOpen& po = pending_[slot];
         check(lg_open_columns_wait(ctx_), "lg_open_columns_wait");     // (home long ago, except for the last opening of a proof)
         const size_t rows = 4 * m_, plen = (size_t)logn_ - 1;
-        po.worker = std::thread([&po, rows, plen] {
+        // The proof owns its columns (Vec<Vec<F>>): 50 MB of freshly faulted memory per opening at 2^20 constraints.  The first two
+        // openings are unpacked behind the next polynomial's absorb; the LAST has nothing to hide behind, and page faults are what it
+        // costs (2 - 9 ms on one thread, by the allocator's mood) -- so large openings are unpacked by a few threads side by side.
+        const unsigned helpers = (po.indices.size() * rows * sizeof(Fr) >= (size_t{8} << 20)) ? std::min(4u, std::max(1u, usable_cpus())) : 1u;
+        po.worker = std::thread([&po, rows, plen, helpers] {
             OpenedColumns& out = *po.dst;
             const size_t t = po.indices.size();
             out.columns.resize(t);
             out.paths.resize(t);
-            for (size_t c = 0; c < t; c++) {
-                out.columns[c].assign(po.cols.begin() + c * rows, po.cols.begin() + (c + 1) * rows);
-                MerklePath& p = out.paths[c];
-                p.leaf_index = po.indices[c];
-                memcpy(p.leaf_sibling_hash.data(), &po.sib[32 * c], 32);
-                p.auth_path.resize(plen);
-                for (size_t l = 0; l < plen; l++) memcpy(p.auth_path[l].data(), &po.paths[32 * (c * plen + l)], 32);
-            }
+            auto some = [&](size_t c0, size_t c1) {
+                for (size_t c = c0; c < c1; c++) {
+                    out.columns[c].assign(po.cols.begin() + c * rows, po.cols.begin() + (c + 1) * rows);
+                    MerklePath& p = out.paths[c];
+                    p.leaf_index = po.indices[c];
+                    memcpy(p.leaf_sibling_hash.data(), &po.sib[32 * c], 32);
+                    p.auth_path.resize(plen);
+                    for (size_t l = 0; l < plen; l++) memcpy(p.auth_path[l].data(), &po.paths[32 * (c * plen + l)], 32);
+                }
+            };
+            std::vector<std::thread> more;
+            for (unsigned h = 1; h < helpers; h++) more.emplace_back(some, t * h / helpers, t * (h + 1) / helpers);
+            some(0, t / helpers);
+            for (auto& th : more) th.join();
         });
     }
     void open_columns_join() {
