@@ -6,6 +6,8 @@
 #      copies of the same child command bench.py runs, and tools/device_transcript_probe.py's table
 #   3. one proof over the "ranks" of this box: RCCL itself at world 1 (all four modes), two gloo ranks sharing the GPU
 #   4. the default bench line (what the driver runs)
+#   5. the large proofs (2^20 / 2^22 constraints: phases, kernels, three provers in flight), the commit from the assignment, the stream
+#      placement A/B and the host's field-arithmetic microbenchmarks
 # Usage: tools/collect_profiles.sh <round tag, e.g. r04>      (copy gpurun_out/profiles/* into profiles/ afterwards;
 #        profiles/pmc_traffic.json is rewritten in place by tools/pmc_traffic.py -- set its _source.commit when committing)
 set -u
@@ -52,6 +54,17 @@ LIGERO_NO_TORCH_PRELOAD=1 LG_SHIP_BLOCKS=8 python3 tools/device_transcript_probe
 LIGERO_NO_TORCH_PRELOAD=1 LG_COPY_STREAM_PRIORITY=none python3 tools/device_transcript_probe.py pipe:1x1024 pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [copy stream at the encode stream'"'"'s priority: the second prover of a process may share its hardware queue, EXPERIMENTS L]/' >> "$OUT/${TAG}_device_transcript_probe.log"
 echo "prover done"
 python3 tools/s20_prove_timing.py 20 6 2>&1 | grep -v amdgpu > "$OUT/${TAG}_s20_prove_timing.log"
+timeout -k 10 600 python3 tools/s20_prove_timing.py 22 3 2>&1 | grep -v amdgpu > "$OUT/${TAG}_s22_prove_timing.log"
+python3 tools/large_proofs_in_flight.py 20 3 6 2>&1 | grep -v amdgpu > "$OUT/${TAG}_large_proofs_in_flight.log"
+python3 tools/poseidon_proof_latency.py 2>&1 | grep Poseidon > "$OUT/${TAG}_poseidon_proof_latency.log"
+python3 tools/from_inputs_probe.py 2>&1 | grep batch > "$OUT/${TAG}_from_inputs_probe.log"
+python3 tools/stream_order_probe.py 0 1 2 3 5 > "$OUT/${TAG}_stream_pick_ab.log" 2>&1
+g++ -O2 -std=c++17 -I ligero_amd/csrc -o /tmp/host_mul_bench tools/host_mul_bench.cpp && /tmp/host_mul_bench > "$OUT/${TAG}_host_mul_bench.log"
+(g++ -O2 -std=c++17 -I ligero_amd/csrc -o /tmp/host_sbox_bench tools/host_sbox_bench.cpp && /tmp/host_sbox_bench; g++ -O2 -std=c++17 -I ligero_amd/host -I ligero_amd/csrc -I include -o /tmp/host_sponge_bench tools/host_sponge_bench.cpp && /tmp/host_sponge_bench) > "$OUT/${TAG}_host_sbox_bench.log"
+D=/tmp/prof_s20_proof; rm -rf $D      # the kernels of one large proof: trace, gathers, commit, the three sub-proofs
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 tools/s20_prove_timing.py 20 4 > /dev/null 2>&1
+cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_s20_proof_kernel_stats.csv"
+python3 tools/timeline_summary.py $(find $D -name '*kernel_trace.csv' | head -1) > "$OUT/${TAG}_s20_proof_timeline_summary.log" 2>&1
 # one proof over the "ranks" of this box
 LIGERO_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload s22 --steps 5 --warmup 2 --no-cpu-baseline \
     2> "$OUT/${TAG}_s22_rccl_world1.err" | grep '^{' > "$OUT/${TAG}_s22_rccl_world1_four_modes.json"
