@@ -109,23 +109,30 @@ static __global__ void __launch_bounds__(256) chacha_count_kernel(ChaChaArgs a) 
 static __global__ void __launch_bounds__(1024) chacha_scan_kernel(ChaChaArgs a) {
     __shared__ uint32_t part[1024];
     uint32_t* cnt = a.counts + (uint64_t)blockIdx.x * a.wgs;
-    const uint32_t per = (a.wgs + 1023) / 1024;
-    const uint32_t w0 = min(a.wgs, threadIdx.x * per), w1 = min(a.wgs, w0 + per);
-    uint32_t s = 0;
-    for (uint32_t w = w0; w < w1; w++) s += cnt[w];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {               // inclusive scan of the threads' sums
-        const uint32_t v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    uint32_t carry = 0;                                   // accepted chunks in the tiles before this one
+    for (uint32_t base = 0; base < a.wgs; base += 4096) {       // tiles of 4096 counts, four consecutive ones per thread: coalesced
+        const uint32_t i0 = base + 4 * threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = i0 + j < a.wgs ? cnt[i0 + j] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        part[threadIdx.x] = mine;
         __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (uint32_t w = w0; w < w1; w++) {
-        const uint32_t c = cnt[w];
-        cnt[w] = run;
-        run += c;
+        for (int d = 1; d < 1024; d <<= 1) {              // inclusive scan of the threads' sums
+            const uint32_t u = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += u;
+            __syncthreads();
+        }
+        uint32_t run = carry + part[threadIdx.x] - mine;
+        const uint32_t tile_total = part[1023];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j < a.wgs) cnt[i0 + j] = run;
+            run += v[j];
+        }
+        carry += tile_total;
+        __syncthreads();                                  // part[] is rewritten by the next tile
     }
 }
 
