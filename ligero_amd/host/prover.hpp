@@ -1068,22 +1068,26 @@ private:
         }
         // column hashes: independent, and at 2^20 constraints 156 columns of 10 036 elements each (three times per proof) are
         // most of what is left of verify() on one thread
+        // (and the walk up each column's path with them; from a megabyte of columns on -- a Poseidon opening is 1.7 MB -- a few threads
+        // are worth their start: Blake2s runs at under a gigabyte a second on one core)
         const size_t nc = indices.size();
-        std::vector<Digest> hashes(nc);
-        const size_t workers = (4 * m_ >= 2048 && nc > 1) ? std::min<size_t>({(size_t)usable_cpus(), 16, nc}) : 1;
-        auto hash_some = [&](size_t w) {
-            for (size_t c = w; c < nc; c += workers) hashes[c] = column_hash(open.columns[c]);
+        const size_t bytes = nc * 4 * m_ * sizeof(Fr);
+        const size_t workers = (bytes >= (size_t{1} << 20) && nc > 1) ? std::min<size_t>({(size_t)usable_cpus(), bytes >= (size_t{32} << 20) ? 16u : 4u, nc}) : 1;
+        std::vector<uint8_t> ok(workers, 1);
+        auto check_some = [&](size_t w) {
+            for (size_t c = w; c < nc; c += workers)
+                if (!merkle_path_verify(open.paths[c], root, column_hash(open.columns[c]))) ok[w] = 0;
         };
         if (workers > 1) {
             std::vector<std::thread> th;
-            for (size_t w = 1; w < workers; w++) th.emplace_back(hash_some, w);
-            hash_some(0);
+            for (size_t w = 1; w < workers; w++) th.emplace_back(check_some, w);
+            check_some(0);
             for (auto& t : th) t.join();
         } else {
-            hash_some(0);
+            check_some(0);
         }
-        for (size_t c = 0; c < nc; c++)
-            if (!merkle_path_verify(open.paths[c], root, hashes[c])) return false;
+        for (uint8_t o : ok)
+            if (!o) return false;
         return true;
     }
 
