@@ -946,10 +946,15 @@ private:
 public:
     // ---------------------------------------------------------------- verify (mod.rs:613-644)
     bool verify(const LigeroProof& proof, PoseidonSponge& sponge) {
+        PhaseTimer tm;
         sponge.absorb_bytes(proof.u_root.data(), 32);
-        return verify_interleaved(proof.interleaved_proof, proof.u_root, sponge) &&
-               verify_linear(proof.linear_constraints_proof, proof.u_root, sponge) &&
-               verify_quadratic_constraints(proof.quadratic_constraints_proof, proof.u_root, sponge);
+        if (!verify_interleaved(proof.interleaved_proof, proof.u_root, sponge)) return false;
+        tm.mark("verify: interleaved test");
+        if (!verify_linear(proof.linear_constraints_proof, proof.u_root, sponge)) return false;
+        tm.mark("verify: linear test");
+        const bool ok = verify_quadratic_constraints(proof.quadratic_constraints_proof, proof.u_root, sponge);
+        tm.mark("verify: quadratic test");
+        return ok;
     }
 
     size_t m() const { return m_; }
