@@ -246,3 +246,19 @@ def test_tracer_rows_equal_the_host_assembled_rows(oracle, poseidon_inst):
         assert L.lg_tracer_rows(tr, pos.ctypes.data, vals.ctypes.data, len(idx), ranges.ctypes.data, 0, ctypes.byref(dev), None) == 0      # a rank without rows
     finally:
         L.lg_tracer_destroy(tr)
+
+
+def test_smallest_circuit():
+    """two gates (the reference refuses an output that is not a gate): the scatter, two one-gate levels, the gathers and the commit"""
+    from ligero_amd import host_pipeline as hp
+    c = hp.ArithmeticCircuit()
+    var = c.new_variables(3)
+    inst = hp.LigeroInstance(c, outputs=[c.add(c.mul(var[0], var[1]), var[2])])
+    prog = inst.trace_program()
+    assert len(prog["order"]) == 2 and len(prog["level_off"]) - 1 == 2
+    vals = random_mont(31, 3).reshape(1, 3, 4)
+    w, ok_host = inst.build_w(var, vals[0])
+    ref, dev = _committers(inst, 1)
+    with ref, dev:
+        _, root, ok = dev.encode_commit_from_inputs(inst.input_positions(var), vals)
+        assert root == ref.encode_commit_from_witness(w)[1] and bool(ok[0]) == ok_host
