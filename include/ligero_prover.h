@@ -115,6 +115,27 @@ const lgp_proof* lgp_batch_proof(const lgp_batch_prover* p, uint32_t index);
 int lgp_proof_info(const lgp_proof* proof, uint64_t info_out[6], uint8_t root_out[32]);
 /* field-by-field equality of two proofs (u_root, preenc_u_lc, both polynomials, every opened column and path) */
 int lgp_proof_equal(const lgp_proof* a, const lgp_proof* b, int* equal_out);
+/*
+ * The proof's fields as bytes -- how a host in another language reads a LigeroProof (src/ligero/mod.rs:96-144) out of the
+ * handle, and what the parity tests compare with the oracle's proofs byte for byte (oracle/model_prover.py proof_field_bytes).
+ * The reference defines no serialisation of a LigeroProof, so this is the layout of the FIELDS, in declaration order:
+ *   LGP_FIELD_U_ROOT                                        the 32 digest bytes
+ *   *_PREENC_U_LC / *_POLYNOMIAL                            the elements in order (a polynomial: its trimmed coefficients)
+ *   *_COLUMNS                                               the opened columns in order, each its 4m elements in order
+ *   *_PATHS   per opening: LE64(leaf_index) || leaf_sibling_hash (32 B) || auth_path digests, root side first
+ * An element is 32 bytes: with LGP_BYTES_CANONICAL its CanonicalSerialize form (the canonical integer, little-endian), with
+ * LGP_BYTES_MONTGOMERY the four u64 limbs as ark-ff keeps them in memory (little-endian limbs of a R mod r).
+ * out may be NULL to ask for the length alone; LGP_ERR_BAD_ARG if cap is smaller than the field.
+ */
+enum { LGP_FIELD_U_ROOT = 0, LGP_FIELD_INTERLEAVED_PREENC_U_LC = 1, LGP_FIELD_INTERLEAVED_COLUMNS = 2, LGP_FIELD_INTERLEAVED_PATHS = 3,
+       LGP_FIELD_LINEAR_POLYNOMIAL = 4, LGP_FIELD_LINEAR_COLUMNS = 5, LGP_FIELD_LINEAR_PATHS = 6, LGP_FIELD_QUADRATIC_POLYNOMIAL = 7,
+       LGP_FIELD_QUADRATIC_COLUMNS = 8, LGP_FIELD_QUADRATIC_PATHS = 9, LGP_FIELD_COUNT = 10 };
+enum { LGP_BYTES_CANONICAL = 0, LGP_BYTES_MONTGOMERY = 1 };
+int lgp_proof_field_bytes(const lgp_proof* proof, int field, int form, uint8_t* out, uint64_t cap, uint64_t* len_out);
+/* the inverse: a proof handle (owned; lgp_proof_destroy) from the ten fields -- a proof made elsewhere (the reference's prover,
+ * the oracle) for lgp_verify.  column_len = elements per opened column, auth_path_len = digests per path; a field whose length
+ * does not divide into whole items, or a canonical element that is not below the modulus, is LGP_ERR_BAD_ARG. */
+int lgp_proof_from_fields(lgp_proof** proof_out, const uint8_t* const fields[10], const uint64_t lens[10], int form, uint64_t column_len, uint64_t auth_path_len);
 /* (the proof-corruption hook the tamper tests use lives in a separate test-only library: ligero_amd/host/ligero_prover_testhooks.cpp) */
 
 #ifdef __cplusplus

@@ -1,6 +1,7 @@
 // C ABI over prover.hpp (include/ligero_prover.h): links the device library.
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <new>
 #include <string>
 
@@ -240,6 +241,118 @@ int lgp_proof_equal(const lgp_proof* a, const lgp_proof* b, int* equal_out) {
                  same_elems(x.quadratic_constraints_proof.polynomial, y.quadratic_constraints_proof.polynomial) &&
                  same_open(x.quadratic_constraints_proof.open, y.quadratic_constraints_proof.open);
     return LGP_OK;
+}
+
+// ---- the proof's fields as bytes (include/ligero_prover.h: lgp_proof_field_bytes / lgp_proof_from_fields)
+namespace {
+using F = ligero::Field<Fr>;
+struct FieldRef {
+    const std::vector<Fr>* elems = nullptr;          // *_PREENC_U_LC / *_POLYNOMIAL
+    const ligero::OpenedColumns* open = nullptr;     // *_COLUMNS / *_PATHS
+    bool paths = false;
+};
+FieldRef field_ref(const LigeroProof& p, int field) {
+    FieldRef r;
+    switch (field) {
+        case LGP_FIELD_INTERLEAVED_PREENC_U_LC: r.elems = &p.interleaved_proof.preenc_u_lc; break;
+        case LGP_FIELD_LINEAR_POLYNOMIAL: r.elems = &p.linear_constraints_proof.polynomial; break;
+        case LGP_FIELD_QUADRATIC_POLYNOMIAL: r.elems = &p.quadratic_constraints_proof.polynomial; break;
+        case LGP_FIELD_INTERLEAVED_COLUMNS: r.open = &p.interleaved_proof.open; break;
+        case LGP_FIELD_LINEAR_COLUMNS: r.open = &p.linear_constraints_proof.open; break;
+        case LGP_FIELD_QUADRATIC_COLUMNS: r.open = &p.quadratic_constraints_proof.open; break;
+        case LGP_FIELD_INTERLEAVED_PATHS: r.open = &p.interleaved_proof.open; r.paths = true; break;
+        case LGP_FIELD_LINEAR_PATHS: r.open = &p.linear_constraints_proof.open; r.paths = true; break;
+        case LGP_FIELD_QUADRATIC_PATHS: r.open = &p.quadratic_constraints_proof.open; r.paths = true; break;
+        default: break;
+    }
+    return r;
+}
+void put_elem(const Fr& e, int form, uint8_t* out) {
+    const Fr c = form == LGP_BYTES_CANONICAL ? F::from_mont(e) : e;
+    for (int i = 0; i < 32; i++) out[i] = (uint8_t)(c.l[i / 8] >> (8 * (i % 8)));
+}
+bool get_elem(const uint8_t* in, int form, Fr& e) {
+    Fr c{};
+    for (int i = 0; i < 32; i++) c.l[i / 8] |= (uint64_t)in[i] << (8 * (i % 8));
+    if (F::geq_modulus(c)) return false;
+    e = form == LGP_BYTES_CANONICAL ? F::to_mont(c) : c;
+    return true;
+}
+}  // namespace
+
+int lgp_proof_field_bytes(const lgp_proof* proof, int field, int form, uint8_t* out, uint64_t cap, uint64_t* len_out) {
+    if (!proof || !len_out || field < 0 || field >= LGP_FIELD_COUNT || (form != LGP_BYTES_CANONICAL && form != LGP_BYTES_MONTGOMERY)) return LGP_ERR_BAD_ARG;
+    return guarded([&] {
+        const LigeroProof& p = *proof->view;
+        const FieldRef r = field_ref(p, field);
+        uint64_t len = 32;
+        if (r.elems) len = 32 * (uint64_t)r.elems->size();
+        else if (r.open && !r.paths) { len = 0; for (const auto& c : r.open->columns) len += 32 * (uint64_t)c.size(); }
+        else if (r.open) { len = 0; for (const auto& ph : r.open->paths) len += 8 + 32 + 32 * (uint64_t)ph.auth_path.size(); }
+        *len_out = len;
+        if (!out) return (int)LGP_OK;
+        if (cap < len) { g_err = "lgp_proof_field_bytes: buffer too small"; return (int)LGP_ERR_BAD_ARG; }
+        if (field == LGP_FIELD_U_ROOT) std::memcpy(out, p.u_root.data(), 32);
+        else if (r.elems) for (const Fr& e : *r.elems) { put_elem(e, form, out); out += 32; }
+        else if (!r.paths) { for (const auto& c : r.open->columns) for (const Fr& e : c) { put_elem(e, form, out); out += 32; } }
+        else for (const auto& ph : r.open->paths) {
+            for (int i = 0; i < 8; i++) out[i] = (uint8_t)(ph.leaf_index >> (8 * i));
+            std::memcpy(out + 8, ph.leaf_sibling_hash.data(), 32);
+            out += 40;
+            for (const auto& d : ph.auth_path) { std::memcpy(out, d.data(), 32); out += 32; }
+        }
+        return (int)LGP_OK;
+    });
+}
+
+int lgp_proof_from_fields(lgp_proof** proof_out, const uint8_t* const fields[10], const uint64_t lens[10], int form, uint64_t column_len, uint64_t auth_path_len) {
+    if (!proof_out || !fields || !lens || (form != LGP_BYTES_CANONICAL && form != LGP_BYTES_MONTGOMERY)) return LGP_ERR_BAD_ARG;
+    *proof_out = nullptr;
+    for (int f = 0; f < LGP_FIELD_COUNT; f++)
+        if (lens[f] && !fields[f]) return LGP_ERR_BAD_ARG;
+    return guarded([&] {
+        auto bad = [&](const char* what) { g_err = std::string("lgp_proof_from_fields: ") + what; return (int)LGP_ERR_BAD_ARG; };
+        if (lens[LGP_FIELD_U_ROOT] != 32) return bad("u_root is not 32 bytes");
+        auto h = std::make_unique<lgp_proof>();
+        LigeroProof& p = h->own;
+        std::memcpy(p.u_root.data(), fields[LGP_FIELD_U_ROOT], 32);
+        auto elems = [&](int f, std::vector<Fr>& v) {
+            if (lens[f] % 32) return false;
+            v.resize(lens[f] / 32);
+            for (size_t i = 0; i < v.size(); i++)
+                if (!get_elem(fields[f] + 32 * i, form, v[i])) return false;
+            return true;
+        };
+        auto open = [&](int fc, int fp, ligero::OpenedColumns& o) {
+            std::vector<Fr> flat;
+            if (!elems(fc, flat)) return false;
+            if (column_len == 0 ? !flat.empty() : flat.size() % column_len != 0) return false;
+            o.columns.clear();
+            for (size_t i = 0; column_len && i < flat.size(); i += column_len) o.columns.emplace_back(flat.begin() + i, flat.begin() + i + column_len);
+            const uint64_t step = 8 + 32 + 32 * auth_path_len;
+            if (lens[fp] % step) return false;
+            o.paths.assign(lens[fp] / step, ligero::MerklePath{});
+            const uint8_t* in = fields[fp];
+            for (auto& ph : o.paths) {
+                ph.leaf_index = 0;
+                for (int i = 0; i < 8; i++) ph.leaf_index |= (uint64_t)in[i] << (8 * i);
+                std::memcpy(ph.leaf_sibling_hash.data(), in + 8, 32);
+                ph.auth_path.resize(auth_path_len);
+                for (uint64_t a = 0; a < auth_path_len; a++) std::memcpy(ph.auth_path[a].data(), in + 40 + 32 * a, 32);
+                in += step;
+            }
+            return true;
+        };
+        if (!elems(LGP_FIELD_INTERLEAVED_PREENC_U_LC, p.interleaved_proof.preenc_u_lc) || !elems(LGP_FIELD_LINEAR_POLYNOMIAL, p.linear_constraints_proof.polynomial) ||
+            !elems(LGP_FIELD_QUADRATIC_POLYNOMIAL, p.quadratic_constraints_proof.polynomial))
+            return bad("an element field is not whole elements below the modulus");
+        if (!open(LGP_FIELD_INTERLEAVED_COLUMNS, LGP_FIELD_INTERLEAVED_PATHS, p.interleaved_proof.open) ||
+            !open(LGP_FIELD_LINEAR_COLUMNS, LGP_FIELD_LINEAR_PATHS, p.linear_constraints_proof.open) ||
+            !open(LGP_FIELD_QUADRATIC_COLUMNS, LGP_FIELD_QUADRATIC_PATHS, p.quadratic_constraints_proof.open))
+            return bad("an opening field does not divide into whole columns / paths of the stated shape");
+        *proof_out = h.release();
+        return (int)LGP_OK;
+    });
 }
 
 }  // extern "C"

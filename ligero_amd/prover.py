@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads", "lgp_batch_prover_device_trace", "lgp_prover_device_trace",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal", "lgp_proof_field_bytes", "lgp_proof_from_fields"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -38,6 +38,8 @@ def lib():
         L.lgp_verify.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         L.lgp_sharded_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_int, _vp]
         L.lgp_proof_equal.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
+        L.lgp_proof_field_bytes.argtypes = [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        L.lgp_proof_from_fields.argtypes = [ctypes.POINTER(_vp), _vp, _vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]
         L.lgp_proof_destroy.argtypes = [_vp]
         L.lgp_proof_destroy.restype = None
         L.lgp_proof_info.argtypes = [_vp, _vp, _vp]
@@ -65,6 +67,12 @@ def _check(rc, what):
         raise RuntimeError(f"{what}: status {rc} ({lib().lgp_last_error().decode()})")
 
 
+# the ten fields of a LigeroProof in declaration order (include/ligero_prover.h LGP_FIELD_*)
+PROOF_FIELDS = ("u_root", "interleaved.preenc_u_lc", "interleaved.columns", "interleaved.paths", "linear.polynomial", "linear.columns",
+                "linear.paths", "quadratic.polynomial", "quadratic.columns", "quadratic.paths")
+BYTES_CANONICAL, BYTES_MONTGOMERY = 0, 1
+
+
 class Proof:
     def __init__(self, handle, owner=None):
         self._L = lib()
@@ -75,6 +83,28 @@ class Proof:
         if getattr(self, "_h", None) and self._owner is None:
             self._L.lgp_proof_destroy(self._h)
         self._h = None
+
+    def field_bytes(self, form: int = BYTES_CANONICAL) -> dict:
+        """the proof, field by field, as bytes (lgp_proof_field_bytes): {name of PROOF_FIELDS: bytes}"""
+        out = {}
+        for f, name in enumerate(PROOF_FIELDS):
+            n = ctypes.c_uint64(0)
+            _check(self._L.lgp_proof_field_bytes(self._h, f, form, None, 0, ctypes.byref(n)), "lgp_proof_field_bytes")
+            buf = (ctypes.c_uint8 * max(1, n.value))()
+            _check(self._L.lgp_proof_field_bytes(self._h, f, form, ctypes.cast(buf, _vp), n.value, ctypes.byref(n)), "lgp_proof_field_bytes")
+            out[name] = bytes(buf[:n.value])
+        return out
+
+    @classmethod
+    def from_fields(cls, fields: dict, column_len: int, auth_path_len: int, form: int = BYTES_CANONICAL) -> "Proof":
+        """a proof made elsewhere (lgp_proof_from_fields), for LigeroProver.verify"""
+        L = lib()
+        blobs = [bytes(fields[name]) for name in PROOF_FIELDS]
+        ptrs = (ctypes.c_char_p * 10)(*blobs)
+        lens = (ctypes.c_uint64 * 10)(*[len(b) for b in blobs])
+        h = _vp()
+        _check(L.lgp_proof_from_fields(ctypes.byref(h), ctypes.cast(ptrs, _vp), ctypes.cast(lens, _vp), form, column_len, auth_path_len), "lgp_proof_from_fields")
+        return cls(h)
 
     def info(self):
         info = np.zeros(6, dtype=np.uint64)

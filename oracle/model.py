@@ -299,8 +299,9 @@ class ArithmeticCircuit:
     from_constraint_system uses)."""
 
     def __init__(self):
-        self.nodes: List[tuple] = []        # ('V',), ('C', v), ('A', l, r), ('M', l, r)
+        self.nodes: List[tuple] = []        # ('V', label), ('C', v), ('A', l, r), ('M', l, r)
         self.constants = {}
+        self.variables = {}                 # label -> node index (mod.rs:33-34)
 
     def constant(self, v: int) -> int:      # mod.rs:76-84
         v %= P
@@ -310,8 +311,20 @@ class ArithmeticCircuit:
         self.constants[v] = len(self.nodes) - 1
         return len(self.nodes) - 1
 
+    def new_variable_with_label(self, label: str) -> int:   # mod.rs:92-100
+        self.nodes.append(("V", label))
+        if label in self.variables:
+            raise ValueError(f"Variable label already in use: {label}")
+        self.variables[label] = len(self.nodes) - 1
+        return len(self.nodes) - 1
+
     def new_variable(self) -> int:          # mod.rs:107-109
-        self.nodes.append(("V",))
+        return self.new_variable_with_label(f"var_{len(self.variables)}")
+
+    def new_variables(self, num: int) -> List[int]:   # mod.rs:111-113
+        return [self.new_variable() for _ in range(num)]
+
+    def last(self) -> int:                  # mod.rs:51-53
         return len(self.nodes) - 1
 
     def add(self, l: int, r: int) -> int:   # mod.rs:125-131
@@ -327,6 +340,23 @@ class ArithmeticCircuit:
         for i in idx[1:]:
             acc = self.add(acc, i)
         return acc
+
+    def mul_nodes(self, idx: Sequence[int]) -> int:   # mod.rs:156-161
+        acc = idx[0]
+        for i in idx[1:]:
+            acc = self.mul(acc, i)
+        return acc
+
+    def pow(self, node: int, exponent: int) -> int:   # mod.rs:164-205: square-and-multiply over the bits after the leading one
+        cur = node
+        for bit in bin(exponent)[3:]:
+            cur = self.mul(cur, cur)
+            if bit == "1":
+                cur = self.mul(cur, node)
+        return cur
+
+    def minus(self, node: int) -> int:      # mod.rs:225-228
+        return self.mul(self.constant(P - 1), node)
 
     def compile_sparse_scalar_product(self, row) -> int:   # mod.rs:501-520
         consts = [(self.constant(c), w) for c, w in row]

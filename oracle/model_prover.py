@@ -1,0 +1,645 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/): a big-int restatement of the reference's WHOLE prover and verifier --
+``LigeroCircuit::new`` / ``prove`` / ``prove_with_labels`` / ``prove_inner`` / ``verify`` and the three sub-protocols -- written
+line by line from /root/reference/src/ligero/mod.rs and /root/reference/src/utils.rs (each function cites the lines it
+follows), composed from ``oracle/model.py`` (field, NTT, hashes, tree, circuit) and ``oracle/transcript_model.py`` (ChaCha,
+F::rand, gen_range, the Poseidon sponge).  It shares no code with the product (ligero_amd/host/prover.hpp, transcript.hpp,
+the device transcript): it is what the ``-m gpu`` prover tests compare proofs with, byte for byte, and what verifies them.
+
+PARITY UNPINNED against a run of the Rust crate (no cargo here; the reference's tests hold no proof bytes): the protocol
+algebra follows the reference's source, the transcript framing follows the published arkworks / rand algorithms
+(oracle/transcript_model.py), and nothing has been compared with bytes the Rust code produced.
+
+Values are canonical integers mod P throughout; a proof is a plain dict (see ``prove_inner``)."""
+from __future__ import annotations
+
+import hashlib
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from . import model as M
+from . import transcript_model as T
+
+P = M.P
+CHACHA_SEED_BYTES = 32                                   # src/lib.rs:9
+DEFAULT_SECURITY_LEVEL = 128                             # src/lib.rs:8
+
+
+class Panic(Exception):
+    """the reference panics here (message = the reference's)"""
+
+
+def _mont_to_value(v: int) -> int:
+    """F::rand keeps the drawn limbs as the Montgomery representation (oracle/transcript_model.py fr_rand): the element's value"""
+    return v * M.RINV % P
+
+
+def get_field_elements_from_prng(n: int, seed: bytes) -> List[int]:
+    """src/utils.rs:23-29"""
+    return [_mont_to_value(v) for v in T.field_elements_from_seed(seed, n)]
+
+
+def get_distinct_indices_from_prng(n: int, t: int, seed: bytes) -> List[int]:
+    """src/utils.rs:31-55"""
+    return T.distinct_indices_from_seed(seed, n, t)
+
+
+def scalar_product_checked(a: Sequence[int], b: Sequence[int]) -> int:
+    """src/utils.rs:12-21"""
+    if len(a) != len(b):
+        raise Panic("assertion failed: a.len() == b.len()")
+    return sum(x * y for x, y in zip(a, b)) % P
+
+
+class Sponge(T.PoseidonSponge):
+    """the `impl CryptographicSponge` the reference's tests pass in (test_sponge(), tests.rs:151, 399) with the two absorb
+    shapes the protocol uses: a digest (Vec<u8>) and a Vec<F>"""
+
+    def absorb_digest(self, d: bytes):          # sponge.absorb(&u_root), mod.rs:560, 634
+        self.absorb_bytes(d)
+
+    def absorb_field_vec(self, v: Sequence[int]):   # sponge.absorb(&Vec<F>), mod.rs:660, 696, 738, 798, 850, 903
+        self.absorb_elements(list(v))
+
+    def clone(self) -> "Sponge":
+        c = Sponge.__new__(Sponge)
+        c.__dict__.update(self.__dict__)
+        c.state = list(self.state)
+        return c
+
+
+_SPONGE0: Optional[Sponge] = None
+
+
+def test_sponge() -> Sponge:
+    """ark_poly_commit::test_sponge() (tests.rs:151, 399); the round constants are drawn once"""
+    global _SPONGE0
+    if _SPONGE0 is None:
+        _SPONGE0 = Sponge()
+    return _SPONGE0.clone()
+
+
+class SparseMatrix:
+    """src/matrices/mod.rs:6-126 (what LigeroCircuit uses)"""
+
+    def __init__(self, num_cols: int, rows: Optional[List[List[Tuple[int, int]]]] = None):
+        self.num_cols = num_cols
+        self.rows: List[List[Tuple[int, int]]] = rows if rows is not None else []
+
+    def num_rows(self) -> int:
+        return len(self.rows)
+
+    def push_row(self, row):
+        self.rows.append(list(row))
+
+    def push_empty_row(self):
+        self.rows.append([])
+
+    def push_empty_rows(self, count: int):
+        self.rows.extend([] for _ in range(count))
+
+    @staticmethod
+    def identity(size: int) -> "SparseMatrix":           # matrices/mod.rs:56-61
+        return SparseMatrix(size, [[(1, i)] for i in range(size)])
+
+    @staticmethod
+    def zero(num_rows: int, num_cols: int) -> "SparseMatrix":   # matrices/mod.rs:63-68
+        return SparseMatrix(num_cols, [[] for _ in range(num_rows)])
+
+    def h_stack(self, other: "SparseMatrix") -> "SparseMatrix":  # matrices/mod.rs:70-88
+        if self.num_rows() != other.num_rows():
+            raise Panic("Row number mismatch in when stacking matrices horizontally")
+        shift = self.num_cols
+        return SparseMatrix(self.num_cols + other.num_cols,
+                            [a + [(v, j + shift) for v, j in b] for a, b in zip(self.rows, other.rows)])
+
+    def v_stack(self, other: "SparseMatrix") -> "SparseMatrix":  # matrices/mod.rs:90-101
+        if self.num_cols != other.num_cols:
+            raise Panic("Column number mismatch in when stacking matrices vertically")
+        return SparseMatrix(self.num_cols, self.rows + other.rows)
+
+    def neg(self) -> "SparseMatrix":                     # matrices/mod.rs:113-126
+        return SparseMatrix(self.num_cols, [[((P - v) % P, j) for v, j in row] for row in self.rows])
+
+    def row_mul(self, row: Sequence[int]) -> List[int]:  # matrices/mod.rs:103-111
+        out = [0] * self.num_cols
+        for c, own in zip(row, self.rows):
+            for v, col in own:
+                out[col] = (out[col] + c * v) % P
+        return out
+
+    def __eq__(self, o):
+        return isinstance(o, SparseMatrix) and self.num_cols == o.num_cols and self.rows == o.rows
+
+
+def _bump_index(one_index: int, one_found: bool, index: int) -> int:
+    """mod.rs:230-242"""
+    if one_found:
+        if index < one_index:
+            return index + 1
+        if index == one_index:
+            return 0
+        return index
+    return index + 1
+
+
+def poly_trim(c: Sequence[int]) -> List[int]:
+    """DensePolynomial::from_coefficients_vec: trailing zeros dropped"""
+    c = list(c)
+    while c and c[-1] == 0:
+        c.pop()
+    return c
+
+
+def poly_add(a: Sequence[int], b: Sequence[int]) -> List[int]:
+    n = max(len(a), len(b))
+    return poly_trim([((a[i] if i < len(a) else 0) + (b[i] if i < len(b) else 0)) % P for i in range(n)])
+
+
+def poly_sub(a: Sequence[int], b: Sequence[int]) -> List[int]:
+    n = max(len(a), len(b))
+    return poly_trim([((a[i] if i < len(a) else 0) - (b[i] if i < len(b) else 0)) % P for i in range(n)])
+
+
+def poly_mul(a: Sequence[int], b: Sequence[int]) -> List[int]:
+    """&DensePolynomial * &DensePolynomial: zero if either is zero, else the product's coefficients (exact; arkworks uses an
+    FFT over a domain of size >= deg + 1, any algorithm yields these values)"""
+    if not a or not b:
+        return []
+    return poly_trim(M.poly_mul(a, b))
+
+
+def poly_scale(a: Sequence[int], r: int) -> List[int]:
+    """&DensePolynomial * F: zero if either is zero"""
+    if not a or r % P == 0:
+        return []
+    return poly_trim([x * r % P for x in a])
+
+
+def poly_degree(c: Sequence[int]) -> int:
+    """Polynomial::degree: 0 for the zero polynomial"""
+    return len(c) - 1 if c else 0
+
+
+def poly_evaluate(c: Sequence[int], x: int) -> int:
+    acc = 0
+    for v in reversed(c):
+        acc = (acc * x + v) % P
+    return acc
+
+
+class LigeroCircuit:
+    """src/ligero/mod.rs:49-94, 146-228"""
+
+    def __init__(self, circuit: M.ArithmeticCircuit, outputs: Sequence[int], lam: int = DEFAULT_SECURITY_LEVEL):
+        # mod.rs:160-169: where the constant 1 sits; move it to the front
+        if 1 in circuit.constants:
+            one_index, one_found = circuit.constants[1], True
+        else:
+            one_index, one_found = 1, False
+        circ = M.ArithmeticCircuit()
+        circ.nodes = list(circuit.nodes)
+        circ.constants = dict(circuit.constants)
+        circ.variables = dict(circuit.variables)
+        if one_index != 0:
+            self._insert_one(circ, one_index, one_found)
+        self.circuit, self.one_index, self.one_found = circ, one_index, one_found
+        # mod.rs:171-175
+        sol_vec_length = 1 + len(circ.nodes) - len(circ.constants) + len(outputs)
+        self.m, self.k = M.compute_dimensions(sol_vec_length)
+        self.n, self.t = M.reed_solomon_parameters(self.m, self.k, lam)
+        # mod.rs:177-194: original index -> index once every constant but the leading 1 is dropped
+        index_map: Dict[int, int] = {0: 0}
+        seen_constants = 0
+        for i, node in enumerate(circ.nodes):
+            if i == 0:
+                continue
+            if node[0] == "C":
+                seen_constants += 1
+            else:
+                index_map[i] = i - seen_constants
+        # mod.rs:197-202
+        self.outputs = [_bump_index(one_index, one_found, i) for i in outputs]
+        self.a = self._generate_matrices(circ, self.outputs, self.m * self.k, index_map)
+        # mod.rs:204-212
+        self.omega_n = M.domain_generator(self.n)
+        self.omega_k = M.domain_generator(self.k)
+        self.omega_2k = M.domain_generator(2 * self.k)
+
+    @staticmethod
+    def _insert_one(circ: M.ArithmeticCircuit, one_index: int, one_found: bool):
+        """mod.rs:244-271"""
+        if one_found:
+            del circ.nodes[one_index]
+        circ.nodes.insert(0, ("C", 1))
+        bump = lambda i: _bump_index(one_index, one_found, i)
+        circ.nodes = [(nd[0], bump(nd[1]), bump(nd[2])) if nd[0] in ("A", "M") else nd for nd in circ.nodes]
+        circ.constants = {v: bump(i) for v, i in circ.constants.items()}
+        circ.constants[1] = 0
+        circ.variables = {s: bump(i) for s, i in circ.variables.items()}
+
+    @staticmethod
+    def _generate_matrices(circ: M.ArithmeticCircuit, outputs: Sequence[int], num_cols: int, index_map: Dict[int, int]) -> SparseMatrix:
+        """mod.rs:296-433"""
+        nodes = circ.nodes
+        p_x, p_y, p_z, p_add = (SparseMatrix(num_cols) for _ in range(4))
+
+        def at(i):                                   # *index_map.get(i).unwrap()
+            if i not in index_map:
+                raise Panic("called `Option::unwrap()` on a `None` value")
+            return index_map[i]
+
+        def add_row(l, r):                           # mod.rs:324-336 and 377-389
+            if nodes[l][0] == "C":
+                return [(nodes[l][1], 0), (1, at(r))]
+            if nodes[r][0] == "C":
+                return [(1, at(l)), (nodes[r][1], 0)]
+            return [(1, at(l)), (1, at(r))]
+
+        def mul_rows(l, r):                          # mod.rs:343-355 and 397-409
+            if nodes[l][0] == "C":
+                p_x.push_row([(nodes[l][1], 0)])
+                p_y.push_row([(1, at(r))])
+            elif nodes[r][0] == "C":
+                p_x.push_row([(1, at(l))])
+                p_y.push_row([(nodes[r][1], 0)])
+            else:
+                p_x.push_row([(1, at(l))])
+                p_y.push_row([(1, at(r))])
+
+        for i, node in enumerate(nodes):             # mod.rs:309-367
+            if node[0] == "V":
+                for mtx in (p_x, p_y, p_z, p_add):
+                    mtx.push_empty_row()
+            elif node[0] == "A":
+                for mtx in (p_x, p_y, p_z):
+                    mtx.push_empty_row()
+                p_add.push_row(add_row(node[1], node[2]) + [(P - 1, at(i))])
+            elif node[0] == "M":
+                p_add.push_empty_row()
+                mul_rows(node[1], node[2])
+                p_z.push_row([(1, at(i))])
+            elif i == 0:
+                for mtx in (p_x, p_y, p_z, p_add):
+                    mtx.push_empty_row()
+        for o in outputs:                            # mod.rs:369-414: the constraint o = 1 per output
+            node = nodes[o]
+            if node[0] == "A":
+                for mtx in (p_x, p_y, p_z):
+                    mtx.push_empty_row()
+                p_add.push_row(add_row(node[1], node[2]) + [(P - 1, 0)])
+            elif node[0] == "M":
+                p_add.push_empty_row()
+                mul_rows(node[1], node[2])
+                p_z.push_row([(1, 0)])
+            else:
+                raise Panic("The output node must be an addition or multiplication gate")
+        padding = num_cols - p_x.num_rows()          # mod.rs:416-421
+        if padding < 0:
+            raise Panic("attempt to subtract with overflow")
+        for mtx in (p_x, p_y, p_z, p_add):
+            mtx.push_empty_rows(padding)
+        upper_right = p_x.v_stack(p_y).v_stack(p_z).neg()            # mod.rs:429-432
+        upper = SparseMatrix.identity(3 * num_cols).h_stack(upper_right)
+        lower = SparseMatrix.zero(num_cols, 3 * num_cols).h_stack(p_add)
+        return upper.v_stack(lower)
+
+    # ---- Reed-Solomon, mod.rs:998-1017
+    def reed_solomon_interpolate(self, msg):
+        return M.reed_solomon_interpolate(msg, self.k)
+
+    def reed_solomon_evaluate(self, msg):
+        return M.reed_solomon_evaluate(msg, self.n)
+
+    def reed_solomon(self, msg):
+        return self.reed_solomon_evaluate(self.reed_solomon_interpolate(msg))
+
+    def as_matrix(self, vec):
+        return [list(vec[i:i + self.k]) for i in range(0, len(vec) - len(vec) % self.k, self.k)]
+
+    # ---- prove, mod.rs:435-455, 580-611
+    def prove(self, var_assignment: Sequence[Tuple[int, int]], sponge: Sponge) -> dict:
+        return self.prove_inner([(_bump_index(self.one_index, self.one_found, i), f) for i, f in var_assignment], sponge)
+
+    def prove_with_labels(self, var_assignment: Sequence[Tuple[str, int]], sponge: Sponge) -> dict:
+        va = []
+        for label, value in var_assignment:
+            if label not in self.circuit.variables:
+                raise Panic(f"Variable not found: {label}")
+            va.append((self.circuit.variables[label], value))
+        return self.prove_inner(va, sponge)
+
+    def evaluation_trace_multioutput(self, var_assignment, outputs) -> List[Optional[int]]:
+        """src/arithmetic_circuit/mod.rs:325-358 with inner_evaluate 247-271 (recursion unrolled onto a stack)"""
+        nodes = self.circuit.nodes
+        vals: List[Optional[int]] = [nd[1] if nd[0] == "C" else None for nd in nodes]
+        for index, value in var_assignment:
+            if nodes[index][0] != "V":
+                raise Panic("Value supplied for non-variable node")
+            vals[index] = value % P
+        for out in outputs:
+            stack = [out]
+            while stack:
+                i = stack[-1]
+                if vals[i] is not None:
+                    stack.pop()
+                    continue
+                nd = nodes[i]
+                if nd[0] == "V":
+                    raise Panic("Uninitialised variable")
+                if nd[0] == "C":
+                    raise Panic("Uninitialised constant")
+                l, r = nd[1], nd[2]
+                if vals[l] is None:
+                    stack.append(l)
+                    continue
+                if vals[r] is None:
+                    stack.append(r)
+                    continue
+                vals[i] = (vals[l] + vals[r]) % P if nd[0] == "A" else vals[l] * vals[r] % P
+                stack.pop()
+        return vals
+
+    def prove_inner(self, var_assignment: Sequence[Tuple[int, int]], sponge: Sponge) -> dict:
+        """mod.rs:457-578.  Returns
+        {"u_root", "interleaved": {"preenc_u_lc", "columns", "paths"}, "linear": {"polynomial", "columns", "paths"},
+         "quadratic": {...}} with paths = [(leaf_index, leaf_sibling_hash, auth_path)]"""
+        m, k = self.m, self.k
+        sol = self.evaluation_trace_multioutput(var_assignment, self.outputs)          # mod.rs:476-478
+        if any(v is None for v in sol):
+            raise Panic("Uninitialised variable. Make sure the circuit only contains nodes upon which the final output truly depends")
+        x, y, z, w = [], [], [], []                                                   # mod.rs:483-504
+        for i, (val, node) in enumerate(zip(sol, self.circuit.nodes)):
+            if node[0] == "C" and i != 0:
+                continue
+            w.append(val)
+            if node[0] == "M":
+                x.append(sol[node[1]]); y.append(sol[node[2]]); z.append(val)
+            else:
+                x.append(0); y.append(0); z.append(0)
+        def resize(v):                                                                # mod.rs:506-509 (Vec::resize truncates too)
+            return v[:m * k] + [0] * (m * k - len(v))
+        preenc_u = self.as_matrix(resize(x)) + self.as_matrix(resize(y)) + self.as_matrix(resize(z)) + self.as_matrix(resize(w))   # 511-516
+        u_polynomial_coeffs = [self.reed_solomon_interpolate(row) for row in preenc_u]  # mod.rs:521-526
+        u = [self.reed_solomon_evaluate(row) for row in u_polynomial_coeffs]            # mod.rs:528-533
+        leaves = [M.col_hash([row[j] for row in u]) for j in range(self.n)]             # mod.rs:536-542
+        nodes = M.merkle_tree(leaves)                                                   # mod.rs:544-549
+        u_root = nodes[0]                                                               # mod.rs:551
+        tree = (leaves, nodes)
+        u_polys = [poly_trim(c) for c in u_polynomial_coeffs]                           # mod.rs:555-558
+        sponge.absorb_digest(u_root)                                                    # mod.rs:560
+        interleaved = self.prove_interleaved(preenc_u, u, tree, sponge)                 # mod.rs:562
+        linear = self.prove_linear_constraints(u_polys, u, tree, sponge)                # mod.rs:564
+        quadratic = self.prove_quadratic_constraints(u_polys[:3 * m], u, tree, sponge)  # mod.rs:566-570
+        return {"u_root": u_root, "interleaved": interleaved, "linear": linear, "quadratic": quadratic}
+
+    def open_columns(self, u, tree, sponge: Sponge):
+        """mod.rs:935-955"""
+        seed_cols = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        indices = get_distinct_indices_from_prng(self.n, self.t, seed_cols)
+        columns = [[row[i] for row in u] for i in indices]
+        leaves, nodes = tree
+        paths = []
+        for i in indices:
+            sib, auth = M.merkle_path(leaves, nodes, i)
+            paths.append((i, sib, auth))
+        return columns, paths
+
+    def prove_interleaved(self, preenc_u, u, tree, sponge: Sponge) -> dict:
+        """mod.rs:646-669"""
+        seed_r = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        r_interleaved = get_field_elements_from_prng(4 * self.m, seed_r)
+        preenc_u_lc = M.dense_row_mul(preenc_u, r_interleaved)
+        sponge.absorb_field_vec(preenc_u_lc)
+        columns, paths = self.open_columns(u, tree, sponge)
+        return {"preenc_u_lc": preenc_u_lc, "columns": columns, "paths": paths}
+
+    def _r_polys(self, r_linear):
+        """mod.rs:722-729 = 774-780: r_a = A.row_mul(r_linear), split into rows of k, each interpolated over the small domain"""
+        r_a = self.a.row_mul(r_linear)
+        rows = [r_a[i:i + self.k] for i in range(0, len(r_a) - len(r_a) % self.k, self.k)]
+        return [poly_trim(M.intt(row, self.omega_k)) for row in rows]
+
+    def prove_linear_constraints(self, u_polys, u, tree, sponge: Sponge) -> dict:
+        """mod.rs:712-747"""
+        seed = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        r_linear = get_field_elements_from_prng(4 * self.m * self.k, seed)
+        r_polys = self._r_polys(r_linear)
+        acc = None                                                                       # mod.rs:731-736
+        for up, rp in zip(u_polys, r_polys):
+            prod = poly_mul(up, rp)
+            acc = prod if acc is None else poly_add(acc, prod)
+        if acc is None:
+            raise Panic("called `Option::unwrap()` on a `None` value")
+        sponge.absorb_field_vec(acc)
+        columns, paths = self.open_columns(u, tree, sponge)
+        return {"polynomial": acc, "columns": columns, "paths": paths}
+
+    def prove_quadratic_constraints(self, u_xyz_polys, u, tree, sponge: Sponge) -> dict:
+        """mod.rs:832-859"""
+        m = self.m
+        seed = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        r_quadratic = get_field_elements_from_prng(m, seed)
+        p_x, p_y, p_z = u_xyz_polys[:m], u_xyz_polys[m:2 * m], u_xyz_polys[2 * m:3 * m]
+        acc = None                                                                       # mod.rs:845-848
+        for px, py, pz, r in zip(p_x, p_y, p_z, r_quadratic):
+            term = poly_scale(poly_sub(poly_mul(px, py), pz), r)
+            acc = term if acc is None else poly_add(acc, term)
+        if acc is None:
+            raise Panic("called `Option::unwrap()` on a `None` value")
+        sponge.absorb_field_vec(acc)
+        columns, paths = self.open_columns(u, tree, sponge)
+        return {"polynomial": acc, "columns": columns, "paths": paths}
+
+    # ---- verify, mod.rs:613-644
+    def verify(self, proof: dict, sponge: Sponge) -> bool:
+        u_root = proof["u_root"]
+        sponge.absorb_digest(u_root)
+        return (self.verify_interleaved(proof["interleaved"], u_root, sponge)
+                and self.verify_linear(proof["linear"], u_root, sponge)
+                and self.verify_quadratic_constraints(proof["quadratic"], u_root, sponge))
+
+    def verify_column_openings(self, columns, paths, u_root, sponge: Sponge) -> bool:
+        """mod.rs:957-996 (izip! stops at the shortest of the three)"""
+        seed_cols = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        indices = get_distinct_indices_from_prng(self.n, self.t, seed_cols)
+        col_hashes = [M.col_hash(col) for col in columns]
+        for col_hash, i, (leaf_index, sib, auth) in zip(col_hashes, indices, paths):
+            if leaf_index != i or not path_verify(u_root, col_hash, leaf_index, sib, auth):
+                return False
+        return True
+
+    def verify_interleaved(self, ip: dict, u_root, sponge: Sponge) -> bool:
+        """mod.rs:671-708"""
+        preenc_u_lc, columns, paths = ip["preenc_u_lc"], ip["columns"], ip["paths"]
+        seed = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        r_interleaved = get_field_elements_from_prng(4 * self.m, seed)
+        sponge.absorb_field_vec(preenc_u_lc)
+        if not self.verify_column_openings(columns, paths, u_root, sponge):
+            return False
+        w = self.reed_solomon(list(preenc_u_lc)[:self.k])       # resize(k) at mod.rs:1000 truncates a longer vector too
+        return all(w[path[0]] == scalar_product_checked(r_interleaved, col) for path, col in zip(paths, columns))
+
+    def verify_linear(self, lp: dict, u_root, sponge: Sponge) -> bool:
+        """mod.rs:749-830"""
+        poly, columns, paths = poly_trim(lp["polynomial"]), lp["columns"], lp["paths"]
+        k, n = self.k, self.n
+        seed = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        r_linear = get_field_elements_from_prng(4 * self.m * k, seed)
+        r_polys = self._r_polys(r_linear)
+        if poly_degree(poly) >= 2 * k - 1:
+            return False
+        q_coeffs = (list(lp["polynomial"]) + [0] * (2 * k))[:2 * k]
+        intermediate_evals = M.ntt(q_coeffs, self.omega_2k)
+        cofactor = n // (2 * k)
+        if sum(intermediate_evals[::2]) % P != 0:
+            return False
+        sponge.absorb_field_vec(lp["polynomial"])
+        if not self.verify_column_openings(columns, paths, u_root, sponge):
+            return False
+        r_polys_evals = [self.reed_solomon_evaluate(rp) for rp in r_polys]
+        for (j, _, _), column in zip(paths, columns):
+            ev = intermediate_evals[j // cofactor] if j % cofactor == 0 else poly_evaluate(poly, pow(self.omega_n, j, P))
+            if sum(r_i[j] * column[i] for i, r_i in enumerate(r_polys_evals)) % P != ev:
+                return False
+        return True
+
+    def verify_quadratic_constraints(self, qp: dict, u_root, sponge: Sponge) -> bool:
+        """mod.rs:861-933"""
+        poly, columns, paths = poly_trim(qp["polynomial"]), qp["columns"], qp["paths"]
+        k, n, m = self.k, self.n, self.m
+        seed = sponge.squeeze_bytes(CHACHA_SEED_BYTES)
+        r_quadratic = get_field_elements_from_prng(m, seed)
+        if poly_degree(poly) >= 2 * k - 1:
+            return False
+        p_0 = (list(qp["polynomial"]) + [0] * (2 * k))[:2 * k]
+        intermediate_evals = M.ntt(p_0, self.omega_2k)
+        if any(intermediate_evals[2 * c] != 0 for c in range(k)):
+            return False
+        cofactor = n // (2 * k)
+        sponge.absorb_field_vec(qp["polynomial"])
+        if not self.verify_column_openings(columns, paths, u_root, sponge):
+            return False
+        for (col, _, _), column in zip(paths, columns):
+            lhs = intermediate_evals[col // cofactor] if col % cofactor == 0 else poly_evaluate(poly, pow(self.omega_n, col, P))
+            rhs = sum(r_i * (column[i] * column[i + m] - column[i + 2 * m]) for i, r_i in enumerate(r_quadratic)) % P
+            if lhs != rhs:
+                return False
+        return True
+
+
+def path_verify(root: bytes, leaf: bytes, index: int, sib: bytes, auth: Sequence[bytes]) -> bool:
+    """ark-crypto-primitives Path::verify with TestMerkleTreeParams (call site mod.rs:985-995)"""
+    return M.merkle_verify(root, leaf, index, sib, auth)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# A byte form of a proof, to compare and to fingerprint.  The reference defines none (LigeroProof derives no
+# CanonicalSerialize): this is the oracle's own -- every F as its CanonicalSerialize bytes (32 LE bytes of the canonical
+# integer), vectors concatenated in order, a Path as LE64(leaf_index) || leaf_sibling_hash || auth_path digests root-side
+# first.  The product exports the same ten fields through lgp_proof_field_bytes (include/ligero_prover.h).
+# --------------------------------------------------------------------------------------------------------------------
+FIELDS = ("u_root", "interleaved.preenc_u_lc", "interleaved.columns", "interleaved.paths", "linear.polynomial", "linear.columns",
+          "linear.paths", "quadratic.polynomial", "quadratic.columns", "quadratic.paths")
+
+
+def _elems(v: Sequence[int]) -> bytes:
+    return b"".join(M.fr_to_bytes(x) for x in v)
+
+
+def _paths(paths) -> bytes:
+    return b"".join(struct.pack("<Q", i) + sib + b"".join(auth) for i, sib, auth in paths)
+
+
+def proof_field_bytes(proof: dict) -> Dict[str, bytes]:
+    out = {"u_root": proof["u_root"]}
+    for name, key in (("interleaved", "preenc_u_lc"), ("linear", "polynomial"), ("quadratic", "polynomial")):
+        sub = proof[name]
+        out[f"{name}.{key}"] = _elems(sub[key])
+        out[f"{name}.columns"] = b"".join(_elems(c) for c in sub["columns"])
+        out[f"{name}.paths"] = _paths(sub["paths"])
+    return out
+
+
+def proof_fingerprint(proof: dict) -> Dict[str, str]:
+    """per-field SHA-256 plus the shape: what tests/golden/proofs.json records per case"""
+    fb = proof_field_bytes(proof)
+    fp = {name: hashlib.sha256(fb[name]).hexdigest() for name in FIELDS}
+    fp["lens"] = {name: len(fb[name]) for name in FIELDS}
+    return fp
+
+
+def proof_from_field_bytes(fb: Dict[str, bytes], column_len: int, auth_path_len: int) -> dict:
+    """inverse of proof_field_bytes (what a GPU-made proof, exported field by field, becomes for this model's verify)"""
+    def elems(b):
+        return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+    def cols(b):
+        e = elems(b)
+        return [e[i:i + column_len] for i in range(0, len(e), column_len)] if column_len else []
+
+    def paths(b):
+        step = 8 + 32 + 32 * auth_path_len
+        out = []
+        for o in range(0, len(b), step):
+            out.append((struct.unpack_from("<Q", b, o)[0], b[o + 8:o + 40], [b[o + 40 + 32 * i:o + 72 + 32 * i] for i in range(auth_path_len)]))
+        return out
+    proof = {"u_root": fb["u_root"]}
+    for name, key in (("interleaved", "preenc_u_lc"), ("linear", "polynomial"), ("quadratic", "polynomial")):
+        proof[name] = {key: elems(fb[f"{name}.{key}"]), "columns": cols(fb[f"{name}.columns"]), "paths": paths(fb[f"{name}.paths"])}
+    return proof
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The reference's own prove-and-verify cases (src/ligero/tests.rs:186-415; circuits src/arithmetic_circuit/tests.rs:51-108)
+# --------------------------------------------------------------------------------------------------------------------
+def lemniscate_circuit():
+    """src/arithmetic_circuit/tests.rs:51-77 with the assignment of src/ligero/tests.rs:196-199"""
+    c = M.ArithmeticCircuit()
+    one = c.constant(1)
+    x, y = c.new_variable(), c.new_variable()
+    a, b = c.constant(120), c.constant(80)
+    x_2, y_2 = c.mul(x, x), c.mul(y, y)
+    a_x_2, b_y_2 = c.mul(a, x_2), c.mul(b, y_2)
+    minus_a_x_2 = c.minus(a_x_2)
+    x_2_plus_y_2 = c.add(x_2, y_2)
+    b_y_2_minus_a_x_2 = c.add(b_y_2, minus_a_x_2)
+    x_2_plus_y_2_2 = c.mul(x_2_plus_y_2, x_2_plus_y_2)
+    c.add_nodes([x_2_plus_y_2_2, b_y_2_minus_a_x_2, one])
+    return c, [c.last()], [(1, 8), (2, 4)]
+
+
+def determinant_circuit():
+    """src/arithmetic_circuit/tests.rs:79-108 with the assignment of src/ligero/tests.rs:209-226"""
+    c = M.ArithmeticCircuit()
+    one = c.constant(1)
+    v = c.new_variables(9)
+    det = c.new_variable()
+    aei, bfg, cdh = c.mul_nodes([v[0], v[4], v[8]]), c.mul_nodes([v[1], v[5], v[6]]), c.mul_nodes([v[2], v[3], v[7]])
+    ceg, bdi, afh = c.mul_nodes([v[2], v[4], v[6]]), c.mul_nodes([v[1], v[3], v[8]]), c.mul_nodes([v[0], v[5], v[7]])
+    sum1 = c.add_nodes([aei, bfg, cdh])
+    sum2 = c.add_nodes([ceg, bdi, afh])
+    minus_sum2 = c.minus(sum2)
+    minus_det = c.minus(det)
+    c.add_nodes([sum1, minus_sum2, minus_det, one])
+    vals = [2, 0, -1, 3, 5, 2, -4, 1, 4]
+    return c, [c.last()], [(i + 1, vals[i] % P) for i in range(9)] + [(10, 13)]
+
+
+def multioutput_circuit():
+    """src/ligero/tests.rs:245-266 (no constant 1 in the circuit: insert_one prepends it); assignment by label, 350-354"""
+    c = M.ArithmeticCircuit()
+    x, y = c.new_variable_with_label("x"), c.new_variable_with_label("y")
+    c_1, c_2, c_3 = c.constant((-9 + 1) % P), c.constant((-64 + 1) % P), c.constant((-7 + 1) % P)
+    x2 = c.mul(x, x)
+    y2 = c.pow(y, 3)
+    s = c.add(x, y)
+    outs = [c.add(x2, c_1), c.add(y2, c_2), c.add(s, c_3)]
+    return c, outs, [("x", 3), ("y", 4)]
+
+
+def r1cs_circuit(r1cs_path: str, witness: Sequence[int]):
+    """src/ligero/tests.rs:364-398: from_constraint_system + `cs_witness.into_iter().enumerate().skip(1)`"""
+    prime, n_wires, cons = M.read_r1cs(r1cs_path)
+    assert prime == P and len(witness) == n_wires
+    circ, outputs = M.from_constraint_system(n_wires, cons)
+    return circ, outputs, [(i, v % P) for i, v in enumerate(witness) if i >= 1]

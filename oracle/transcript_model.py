@@ -1,8 +1,19 @@
-"""TEST INFRASTRUCTURE: an independent Python restatement of the Fiat-Shamir pieces that
-ligero_amd/host/transcript.hpp restates in C++ (rand_chacha ChaCha20Rng / rand StdRng, ark-ff F::rand,
-rand gen_range, ark-crypto-primitives PoseidonSponge with ark-poly-commit's test_sponge() parameters).
-PARITY UNPINNED against the Rust crates (not vendored, no transcript bytes in the reference's tests):
-the two restatements only check each other, plus the RFC 8439 vector for the block function."""
+"""TEST INFRASTRUCTURE ONLY (oracle/): a Python restatement of the Fiat-Shamir pieces the reference's prover and verifier
+draw on -- written from the crates' published algorithms, NOT from ligero_amd/host/transcript.hpp:
+
+* ``ChaChaRng``            rand_chacha 0.3 ChaCha20Rng / ChaCha12Rng (`from_seed`, 64-bit block counter in words 12-13, stream id 0,
+                           `next_u32` / `next_u64` off a 16-word block buffer) -- /root/reference/src/utils.rs:27, 36
+* ``fr_rand``              ark-ff `UniformRand for Fp<MontBackend<_, 4>>`: four u64, the top limb masked to the modulus' bit length,
+                           accepted when below the modulus, and kept AS the Montgomery limbs -- utils.rs:28
+* ``gen_range``            rand 0.8 `UniformInt<usize>::sample_single` (widening multiply against a zone) -- utils.rs:47
+* ``field_elements_from_seed`` / ``distinct_indices_from_seed``   utils.rs:23-29, 31-55
+* ``PoseidonSponge``       ark-crypto-primitives `PoseidonSponge` with ark-poly-commit's `test_sponge()` parameters (rate 2, capacity 1,
+                           8 full + 31 partial rounds, alpha 17, the fixed MDS, round constants from `test_rng()`), `absorb` of a
+                           `Vec<u8>` and of a `Vec<F>`, `squeeze_bytes` -- /root/reference/src/ligero/tests.rs:151, 399 and the
+                           call sites src/ligero/mod.rs:560, 653, 660, 719, 738, 839, 850, 941
+
+PARITY UNPINNED against the Rust crates (un-vendored; the reference's tests hold no transcript bytes): pinned here are only the
+RFC 8439 vector of the block function and agreement of independent restatements with each other."""
 import struct
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617

@@ -51,7 +51,7 @@ def expected_case(name: str):
     """everything the dump records, from this repository's stack"""
     from ligero_amd import host_pipeline as hp
     from oracle import binding as orc
-    import transcript_model as tm
+    from oracle import transcript_model as tm
     g = os.path.join(ROOT, "tests", "golden")
     if name == "poseidon":
         circ = hp.ArithmeticCircuit.from_r1cs(os.path.join(g, "poseidon.r1cs"))

@@ -15,6 +15,7 @@ from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # spawned ranks import tests/proof_fp.py
 
 
 def _free_port():
@@ -40,12 +41,14 @@ def _small_case():
     c = hp.ArithmeticCircuit()
     x, y = c.new_variable_with_label("x"), c.new_variable_with_label("y")
     c1, c2, c3 = (c.constant(hp.fr_mont(v)) for v in (-8, -63, -6))
-    outs = [c.add(c.mul(x, x), c1), c.add(c.pow(y, 3), c2), c.add(c.add(x, y), c3)]
+    x2, y3, xy = c.mul(x, x), c.pow(y, 3), c.add(x, y)          # the reference's order of construction: the golden "multioutput" case
+    outs = [c.add(x2, c1), c.add(y3, c2), c.add(xy, c3)]
     return hp.LigeroInstance(c, outs), ["x", "y"], np.stack([hp.fr_mont(3), hp.fr_mont(4)])
 
 
 def _rank_body(rank, world, dist, which, mode="coset"):
     from ligero_amd.prover import LigeroProver, ShardedLigeroProver, proofs_equal
+    from proof_fp import fingerprint
     inst, names, vals = _poseidon_case() if which == "poseidon" else _small_case()
     by_label = isinstance(names[0], str)
     with ShardedLigeroProver(inst, dist, device=0, mode=mode) as sp:
@@ -53,7 +56,7 @@ def _rank_body(rank, world, dist, which, mode="coset"):
         again = sp.prove_with_labels(names, vals) if by_label else sp.prove(names, vals)        # the context is reused
         accepted_by_sharded = sp.verify(proof)
         res = {"root": proof.info()["u_root"], "info": {k: v for k, v in proof.info().items() if k != "u_root"},
-               "again": proofs_equal(proof, again), "accepted_by_sharded": accepted_by_sharded}
+               "again": proofs_equal(proof, again), "accepted_by_sharded": accepted_by_sharded, "fingerprint": fingerprint(proof)}
         if rank == world - 1:                                          # one rank compares with the unsharded prover
             with LigeroProver(inst) as single:
                 ref = single.prove_with_labels(names, vals) if by_label else single.prove(names, vals)
@@ -107,8 +110,13 @@ def test_sharded_proof_equals_the_single_gpu_proof(which, world, mode, trace, mo
     assert last["accepted"]
     if which == "poseidon":
         assert last["ref_root"].hex() == json.load(open(os.path.join(GOLDEN, "vectors.json")))["poseidon"]["root"]
+    # round 5: every rank's proof is the ORACLE's proof of this statement, byte for byte (tests/golden/proofs.json, made by
+    # oracle/model_prover.py from the reference's source) -- not only the proof the single-GPU product prover makes
+    import proof_fp
+    want = proof_fp.golden()["cases"]["poseidon" if which == "poseidon" else "multioutput"]
     for rank in range(world):
         r = out[rank]
+        assert proof_fp.same(r["fingerprint"], want), (rank, proof_fp.diff(r["fingerprint"], want))
         assert r["root"] == last["ref_root"], rank                        # every rank holds the complete, same proof
         assert r["info"] == last["info"], rank
         assert r["again"] and r["accepted_by_sharded"] and r["wrong_rejected"], (rank, r)

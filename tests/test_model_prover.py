@@ -1,0 +1,173 @@
+"""CPU tests of the whole-proof oracle (oracle/model_prover.py): the restatement of LigeroCircuit::new / prove / verify the GPU
+prover tests compare with.  Pinned against what the reference's tests DO hold: the constraint matrix A of test_multioutput_1
+(src/ligero/tests.rs:267-343), accept / reject of the reference's prove-and-verify cases (tests.rs:153-243, 345-361), and the
+committed fingerprints (tests/golden/proofs.json reproduces).  The product's host pipeline is compared with the model where no
+GPU is needed (dimensions, A entry for entry)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import model as M
+from oracle import model_prover as MP
+
+P = M.P
+
+
+@pytest.fixture(scope="module")
+def golden_proofs():
+    return json.load(open(os.path.join(GOLDEN, "proofs.json")))
+
+
+def test_multioutput_matrix_is_the_reference_table():
+    """src/ligero/tests.rs:267-343: the expected A, entry for entry and in the reference's in-row order"""
+    c, outs, _ = MP.multioutput_circuit()
+    lc = MP.LigeroCircuit(c, outs)
+    assert (lc.m, lc.k) == (4, 4)
+    e = lambda *rows: [list(r) for r in rows]
+    p_x = MP.SparseMatrix(16, e(*[[]] * 3, [(1, 1)], [(1, 2)], [(1, 4)], *[[]] * 4, *[[]] * 6))
+    p_y = MP.SparseMatrix(16, e(*[[]] * 3, [(1, 1)], [(1, 2)], [(1, 2)], *[[]] * 4, *[[]] * 6))
+    p_z = MP.SparseMatrix(16, e(*[[]] * 3, [(1, 3)], [(1, 4)], [(1, 5)], *[[]] * 4, *[[]] * 6))
+    neg = lambda v: (P - v) % P
+    p_add = MP.SparseMatrix(16, e(*[[]] * 6,
+                                  [(1, 1), (1, 2), (neg(1), 6)], [(1, 3), (neg(8), 0), (neg(1), 7)], [(1, 5), (neg(63), 0), (neg(1), 8)],
+                                  [(1, 6), (neg(6), 0), (neg(1), 9)], [(1, 3), (neg(8), 0), (neg(1), 0)], [(1, 5), (neg(63), 0), (neg(1), 0)],
+                                  [(1, 6), (neg(6), 0), (neg(1), 0)], *[[]] * 3))
+    p_column = p_x.v_stack(p_y.v_stack(p_z)).neg()
+    expected = MP.SparseMatrix.identity(3 * 16).h_stack(p_column).v_stack(MP.SparseMatrix.zero(16, 3 * 16).h_stack(p_add))
+    assert lc.a == expected
+
+
+@pytest.mark.parametrize("which", ["lemniscate", "determinant"])
+def test_reference_prove_and_verify_cases(which, golden_proofs):
+    """test_proof_and_verify (tests.rs:153-170): the assignment verifies, the first variable + 1 does not; fingerprints reproduce"""
+    c, outs, va = (MP.lemniscate_circuit if which == "lemniscate" else MP.determinant_circuit)()
+    lc = MP.LigeroCircuit(c, outs)
+    proof = lc.prove(va, MP.test_sponge())
+    assert lc.verify(proof, MP.test_sponge())
+    bad = lc.prove([(va[0][0], va[0][1] + 1)] + va[1:], MP.test_sponge())
+    assert not lc.verify(bad, MP.test_sponge())
+    for name, pr in ((which, proof), (which + "_invalid", bad)):
+        want = golden_proofs["cases"][name]
+        got = MP.proof_fingerprint(pr)
+        assert {f: got[f] for f in MP.FIELDS} == {f: want[f] for f in MP.FIELDS} and got["lens"] == want["lens"]
+    # a proof survives its byte form
+    info = (len(proof["interleaved"]["columns"][0]), len(proof["interleaved"]["paths"][0][2]))
+    assert MP.proof_from_field_bytes(MP.proof_field_bytes(proof), *info) == proof
+
+
+def test_multioutput_by_label(golden_proofs):
+    """tests.rs:345-361: prove_with_labels after insert_one moved every index"""
+    c, outs, va = MP.multioutput_circuit()
+    lc = MP.LigeroCircuit(c, outs)
+    assert not lc.one_found and lc.circuit.nodes[0] == ("C", 1) and lc.circuit.variables == {"x": 1, "y": 2}
+    proof = lc.prove_with_labels(va, MP.test_sponge())
+    assert lc.verify(proof, MP.test_sponge())
+    assert MP.proof_fingerprint(proof)["u_root"] == golden_proofs["cases"]["multioutput"]["u_root"]
+    assert proof == lc.prove([(0, 3), (1, 4)], MP.test_sponge())            # the same statement by ORIGINAL index (prove bumps it)
+    assert not lc.verify(lc.prove_with_labels([("x", 3), ("y", 5)], MP.test_sponge()), MP.test_sponge())
+    with pytest.raises(MP.Panic, match="Variable not found: z"):
+        lc.prove_with_labels([("x", 3), ("z", 4)], MP.test_sponge())
+    with pytest.raises(MP.Panic, match="Uninitialised variable"):
+        lc.prove_with_labels([("x", 3)], MP.test_sponge())
+
+
+def _tampers(proof):
+    """one changed item per proof field, as the product's tamper hook does (ligero_amd/host/ligero_prover_testhooks.cpp)"""
+    import copy
+
+    def variant(fn):
+        p = copy.deepcopy(proof)
+        fn(p)
+        return p
+    bump = lambda v, i: v.__setitem__(i, (v[i] + 1) % P)
+    yield "u_root", variant(lambda p: p.__setitem__("u_root", bytes([p["u_root"][0] ^ 1]) + p["u_root"][1:]))
+    yield "preenc_u_lc", variant(lambda p: bump(p["interleaved"]["preenc_u_lc"], 1))
+    yield "linear poly", variant(lambda p: bump(p["linear"]["polynomial"], 0))
+    yield "quadratic poly", variant(lambda p: bump(p["quadratic"]["polynomial"], 3))
+    for sub in ("interleaved", "linear", "quadratic"):
+        yield sub + " column", variant(lambda p: bump(p[sub]["columns"][2], 5))
+    yield "auth path", variant(lambda p: p["interleaved"]["paths"].__setitem__(0, (p["interleaved"]["paths"][0][0], p["interleaved"]["paths"][0][1],
+                                                                                  [bytes(32)] + p["interleaved"]["paths"][0][2][1:])))
+    yield "leaf index", variant(lambda p: p["linear"]["paths"].__setitem__(3, (p["linear"]["paths"][3][0] ^ 1,) + p["linear"]["paths"][3][1:]))
+    yield "sibling", variant(lambda p: p["quadratic"]["paths"].__setitem__(1, (p["quadratic"]["paths"][1][0], bytes(32), p["quadratic"]["paths"][1][2])))
+
+
+def test_model_verifier_rejects_every_tamper():
+    c, outs, va = MP.determinant_circuit()
+    lc = MP.LigeroCircuit(c, outs)
+    proof = lc.prove(va, MP.test_sponge())
+    assert lc.verify(proof, MP.test_sponge())
+    for what, bad in _tampers(proof):
+        assert not lc.verify(bad, MP.test_sponge()), what
+
+
+def test_multiplication_r1cs(golden_proofs):
+    c, outs, va = MP.r1cs_circuit(os.path.join(GOLDEN, "multiplication.r1cs"), [1, 33, 3, 11])
+    lc = MP.LigeroCircuit(c, outs)
+    proof = lc.prove(va, MP.test_sponge())
+    assert lc.verify(proof, MP.test_sponge())
+    want = golden_proofs["cases"]["multiplication"]
+    assert all(MP.proof_fingerprint(proof)[f] == want[f] for f in MP.FIELDS)
+
+
+def test_product_host_pipeline_builds_the_models_instance():
+    """LigeroCircuit::new of the product's C++ host side (ligero_amd/host/circuit.hpp) and of the model: same dimensions, same A
+    entry for entry, on the Poseidon fixture and on a circuit that needs insert_one"""
+    from ligero_amd import host_pipeline as hp
+    circ = hp.ArithmeticCircuit.from_r1cs(os.path.join(GOLDEN, "poseidon.r1cs"))
+    inst = hp.LigeroInstance(circ)
+    w = M.load_witness_json(os.path.join(GOLDEN, "poseidon_witness.json"))
+    c, outs, _ = MP.r1cs_circuit(os.path.join(GOLDEN, "poseidon.r1cs"), w)
+    lc = MP.LigeroCircuit(c, outs)
+    assert (inst.m, inst.k, inst.n, inst.t) == (lc.m, lc.k, lc.n, lc.t) == (86, 128, 1024, 156)
+
+    def coo(rows, cols, vals):
+        ints = [int(v[0]) | int(v[1]) << 64 | int(v[2]) << 128 | int(v[3]) << 192 for v in vals]
+        return [(int(r), int(cc), v * M.RINV % P) for r, cc, v in zip(rows, cols, ints)]
+    want = [(r, col, v) for r, row in enumerate(lc.a.rows) for v, col in row]
+    assert coo(*inst.a_entries()) == want
+    c2 = hp.ArithmeticCircuit()
+    x, y = c2.new_variable_with_label("x"), c2.new_variable_with_label("y")
+    c1, c2_, c3 = (c2.constant(hp.fr_mont(v)) for v in (-8, -63, -6))
+    x2, y3, xy = c2.mul(x, x), c2.pow(y, 3), c2.add(x, y)                  # the reference's order of construction (tests.rs:258-264)
+    outs2 = [c2.add(x2, c1), c2.add(y3, c2_), c2.add(xy, c3)]
+    inst2 = hp.LigeroInstance(c2, outs2)
+    mc, mouts, _ = MP.multioutput_circuit()
+    lc2 = MP.LigeroCircuit(mc, mouts)
+    assert coo(*inst2.a_entries()) == [(r, col, v) for r, row in enumerate(lc2.a.rows) for v, col in row]
+
+
+def test_golden_file_shape(golden_proofs):
+    assert golden_proofs["fields"] == list(MP.FIELDS)
+    assert len(golden_proofs["poseidon_batch64"]) == 64
+    vectors = json.load(open(os.path.join(GOLDEN, "vectors.json")))
+    assert [p["u_root"] for p in golden_proofs["poseidon_batch64"]] == [__import__("hashlib").sha256(bytes.fromhex(r)).hexdigest() for r in vectors["poseidon_batch64_roots"]]
+    pos = golden_proofs["cases"]["poseidon"]
+    assert pos["dims"] == {"m": 86, "k": 128, "n": 1024, "t": 156} and pos["accepted"]
+    assert pos["lens"]["interleaved.columns"] == 156 * 344 * 32 and pos["lens"]["linear.paths"] == 156 * (8 + 32 + 9 * 32)
+    assert not golden_proofs["cases"]["lemniscate_invalid"]["accepted"]
+
+
+def test_proof_handle_round_trip_without_a_gpu():
+    """lgp_proof_from_fields / lgp_proof_field_bytes (include/ligero_prover.h): an oracle-made proof through the product's handle and
+    back, both byte forms; the exported layout IS the oracle's proof_field_bytes"""
+    from ligero_amd.prover import BYTES_MONTGOMERY, Proof
+    c, outs, va = MP.determinant_circuit()
+    lc = MP.LigeroCircuit(c, outs)
+    proof = lc.prove(va, MP.test_sponge())
+    fb = MP.proof_field_bytes(proof)
+    shape = (4 * lc.m, len(proof["interleaved"]["paths"][0][2]))
+    h = Proof.from_fields(fb, *shape)
+    assert h.field_bytes() == fb
+    info = h.info()
+    assert (info["column_len"], info["auth_path_len"], info["opened_columns"], info["u_root"]) == (*shape, lc.t, proof["u_root"])
+    mont = h.field_bytes(BYTES_MONTGOMERY)
+    assert mont["interleaved.preenc_u_lc"][:32] == (proof["interleaved"]["preenc_u_lc"][0] * M.R % P).to_bytes(32, "little")
+    assert Proof.from_fields(mont, *shape, form=BYTES_MONTGOMERY).field_bytes() == fb
+    with pytest.raises(RuntimeError):
+        Proof.from_fields({**fb, "u_root": fb["u_root"][:31]}, *shape)
+    with pytest.raises(RuntimeError):
+        Proof.from_fields({**fb, "quadratic.paths": fb["quadratic.paths"] + b"\0"}, *shape)

@@ -1,13 +1,13 @@
 """CPU tests of the Fiat-Shamir pieces (ligero_amd/host/transcript.hpp through libligero_host.so).
 Pinned: the ChaCha20 block function (RFC 8439 section 2.3.2).  Everything else is checked against an
-independent Python restatement (tests/transcript_model.py) -- both are UNPINNED against the Rust
+independent Python restatement (oracle/transcript_model.py) -- both are UNPINNED against the Rust
 crates, so these tests catch implementation slips, not misreadings of the crates."""
 import random
 
 import numpy as np
 import pytest
 
-import transcript_model as tm
+from oracle import transcript_model as tm
 from ligero_amd import host_pipeline as hp
 
 R = 1 << 256
