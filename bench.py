@@ -111,6 +111,21 @@ def device_copy_gbs(torch, nbytes: int = 1 << 30, reps: int = 5) -> float:
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def device_d2h_gbs(torch, nbytes: int = 1 << 30, reps: int = 4) -> float:
+    """device -> page-locked host copy rate of this box (GB/s): the practical ceiling of the proofs/s leg's PCIe roof"""
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del src, dst
+    return reps * nbytes / dt / 1e9
+
+
 def usable_cpus() -> int:
     """CPUs this process may use: os.cpu_count() capped by a cgroup v2 quota (the GPU boxes give 16 of 256), divided by the ranks
     a launcher started on this box (LOCAL_WORLD_SIZE)"""
@@ -162,6 +177,7 @@ def commit_leg(workload, e, st, launches, root, steps, tfile):
     return leg
 
 
+PCIE_D2H_PEAK_GBS = 63.0   # PCIe 5.0 x16 per direction (32 GT/s x 16 x 128/130 / 8)
 PROVER_BATCH = 1024      # proofs per batch of the throughput-mode prover (device transcript); two batches in flight
 
 
@@ -183,6 +199,7 @@ def prover_child(argv):
         try:
             bp_device_trace = bp.device_trace
             bp.prove(idx, allv, copy=False)                      # warm-up: buffers, page-locking, the first launches
+            out["d2h_bytes_per_proof"] = bp.arena_bytes() / batch   # what the device writes to the page-locked arena per proof (lg_proof_layout)
             h0 = bp.host_stats()
             c0, t0, m0 = time.process_time(), time.perf_counter(), time.thread_time()
             bp.submit(idx, allv)
@@ -257,12 +274,24 @@ def full_prover_rate(device: int, steps: int = 6, extras: bool = True):
     try:
         res = _run_prover_child(device, "device", PROVER_BATCH, steps)
     except Exception as e:      # (e.g. the box will not page-lock two 5.6 GB arenas per rank: a quarter of the batch still hides the chain)
-        res = _run_prover_child(device, "device", PROVER_BATCH // 4, steps * 4)
+        try:
+            res = _run_prover_child(device, "device", PROVER_BATCH // 4, steps * 4)
+        except Exception as e2:
+            return {"error": f"batch {PROVER_BATCH}: {type(e).__name__}: {str(e)[-200:]}; batch {PROVER_BATCH // 4}: {type(e2).__name__}: {str(e2)[-200:]}",
+                    "proofs": 0, "seconds": 0.0}
         res["first_attempt"] = f"batch {PROVER_BATCH} failed ({type(e).__name__}: {str(e)[-200:]}); measured with batch {PROVER_BATCH // 4}"
     res["note"] = ("full prove() per proof, transcript on the device (one lane per proof), proofs delivered to page-locked host memory; "
                    "PCIe bound (5.4 MB of opened columns per proof); transcript unpinned vs the Rust crates; measured in a child process "
                    "on the system HIP runtime (see prover_child)")
-    res["pcie_GBs"] = res["value"] * 5.44e6 / 1e9
+    bpp = float(res.get("d2h_bytes_per_proof") or 5.44e6)
+    res["pcie_GBs"] = res["value"] * bpp / 1e9
+    # the roof of THIS leg: every proof crosses PCIe once, device -> page-locked host memory (three sets of t opened columns are 99 % of it)
+    res["roofline"] = {"bound": "pcie-d2h", "bytes_per_proof": bpp, "achieved_GBs": res["value"] * bpp / 1e9, "peak_GBs": PCIE_D2H_PEAK_GBS,
+                       "frac": res["value"] * bpp / 1e9 / PCIE_D2H_PEAK_GBS, "unit": "GB/s",
+                       "peak_source": "PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130 / 8 = 63.0 GB/s before packet overhead "
+                                      "(MI355X host interface, /opt/skills/guides/MI355X_MICROARCH.md); measured_d2h_GBs beside it is a 1 GiB "
+                                      "page-locked device-to-host copy timed in this run",
+                       "bytes_source": "lg_proof_layout.total_bytes / batch of the prover's arena (include/ligero_hip.h)"}
     if extras:
         try:
             two = _run_prover_child(device, "device", PROVER_BATCH, steps, cpus=2)
@@ -473,6 +502,65 @@ def cpu_baseline(rows: int, k: int, n: int, batch: int, budget_s: float = 20.0, 
                 break
         out["all_cores"] = {"value": done * sample_rows * n / dt2, "cores": nthr,
                             "sample": f"{done} x ({sample_rows} rows x {k} -> {n}), rows / columns over OpenMP threads, {dt2:.1f} s"}
+    return out
+
+
+def cpu_baseline_prover(budget_s: float = 10.0, verify_budget_s: float = 3.0, all_cores_budget_s: float = 6.0):
+    """The WHOLE prove() / verify() of the reference on the host's cores, beside proofs/sec (the reference's own timing site,
+    src/ligero/tests.rs:399-414): the serial reference-shaped C restatement (oracle/ligero_oracle.c orc_prove / orc_verify --
+    evaluation trace, x/y/z/w, encode + commit, the three sub-proofs with one FFT product per row as DensePolynomial does, sparse
+    A.row_mul, the Poseidon sponge and the ChaCha draws, openings) on the committed Poseidon witnesses, one core; then the same
+    proofs spread over the usable cores, one independent proof per thread.  The proofs equal the GPU's byte for byte
+    (tests/test_oracle_prover.py, tests/test_gpu_prover_oracle.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as orc        # cpu_baseline leg only: the checker, never the product
+    from oracle import model as M
+    from oracle import model_prover as MP
+    g = os.path.join(ROOT, "tests", "golden")
+    blob = open(os.path.join(g, "poseidon_witness_batch64.bin"), "rb").read()
+    wits = [[int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") for j in range(265)] for i in range(64)]
+    circ, outs, _ = MP.r1cs_circuit(os.path.join(g, "poseidon.r1cs"), wits[0])
+    lc = MP.LigeroCircuit(circ, outs)         # LigeroCircuit::new: once per circuit, outside the reference's timed region too
+    st = orc.Statement(lc)
+    assigns = [st.assignment([(j, w[j]) for j in range(1, 265)]) for w in wits]
+    fb = st.prove([(j, wits[0][j]) for j in range(1, 265)])       # warm-up (tables, sponge constants) and a self-check
+    assert st.verify(fb)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        assert st.prove_raw(*assigns[done % 64]) == 0
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    out = {"value": done / dt, "unit": "proofs/s", "cores": 1, "kind": "port", "s_per_proof": dt / done,
+           "sample": f"{done} whole proofs of the Poseidon R1CS (m 86, k 128, n 1024, t 156) on the committed witnesses, serial reference-shaped "
+                     f"C restatement (oracle/ligero_oracle.c orc_prove), {dt:.1f} s",
+           "host_cores_available": os.cpu_count(), "host_cores_usable": usable_cpus()}
+    vdone, t0 = 0, time.perf_counter()
+    while True:
+        assert st.verify(fb)
+        vdone += 1
+        vdt = time.perf_counter() - t0
+        if vdt >= verify_budget_s:
+            break
+    out["verify"] = {"value": vdone / vdt, "unit": "verifications/s", "cores": 1, "kind": "port", "s_per_verify": vdt / vdone,
+                     "sample": f"{vdone} x orc_verify of one Poseidon proof, {vdt:.1f} s"}
+    nthr = min(usable_cpus(), 64)
+    if nthr > 1:
+        sts = [st] + [orc.Statement(lc) for _ in range(nthr - 1)]
+
+        def worker(i):
+            n_, t_end = 0, time.perf_counter() + all_cores_budget_s
+            while time.perf_counter() < t_end:
+                assert sts[i].prove_raw(*assigns[(i + n_ * nthr) % 64]) == 0
+                n_ += 1
+            return n_
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nthr) as ex:
+            counts = list(ex.map(worker, range(nthr)))
+        adt = time.perf_counter() - t0
+        out["all_cores"] = {"value": sum(counts) / adt, "unit": "proofs/s", "cores": nthr, "kind": "port",
+                            "sample": f"{sum(counts)} proofs, one independent orc_prove per thread (ctypes releases the GIL), {adt:.1f} s"}
     return out
 
 
@@ -1051,7 +1139,22 @@ def main():
                 line["s22"] = commit_leg("s22", e22, st22, l22, root22, 3, tfile)
             except Exception as e:
                 line["s22"] = {"error": f"{type(e).__name__}: {e}"}
-            line["full_prover"] = full_prover_rate(local_rank)
+            try:
+                line["full_prover"] = full_prover_rate(local_rank)
+            except Exception as e:
+                line["full_prover"] = {"error": f"{type(e).__name__}: {e}"}
+            if "roofline" in line["full_prover"]:
+                try:
+                    line["full_prover"]["roofline"]["measured_d2h_GBs"] = device_d2h_gbs(torch)
+                except Exception as e:
+                    line["full_prover"]["roofline"]["measured_d2h_GBs"] = None
+            try:      # the reference's whole prove() / verify() on this host's cores, beside proofs/s
+                line["full_prover"]["cpu_baseline"] = cpu_baseline_prover()
+                if line["full_prover"].get("value"):
+                    line["full_prover"]["vs_cpu_baseline"] = {"ratio": line["full_prover"]["value"] / line["full_prover"]["cpu_baseline"]["value"],
+                                                               "of": "full_prover.cpu_baseline.value (1 core); a reported ratio, not the target"}
+            except Exception as e:
+                line["full_prover"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             # the 2^20-constraint R1CS itself: the drop-in entry points on its matrix (host-assembled preenc_u against w + gate map),
             # then the complete proof
             try:

@@ -355,6 +355,14 @@ class LigeroBatchProver:
         _check(self._L.lgp_batch_prover_host_stats(self._h, ctypes.cast(out, _vp)), "lgp_batch_prover_host_stats")
         return {"batches": int(out[0]), "w_core_ms": out[1], "w_wall_ms": out[2], "queue_ms": out[3], "wait_ms": out[4]}
 
+    def arena_bytes(self) -> int:
+        """bytes of ONE batch's proofs as the device delivers them to page-locked host memory (lg_proof_layout.total_bytes);
+        device-transcript provers only, after the first batch"""
+        base = _vp()
+        layout = (ctypes.c_uint64 * 40)()            # lg_proof_layout begins with `uint64_t total_bytes` (include/ligero_hip.h)
+        _check(self._L.lgp_batch_proof_arena(self._h, ctypes.byref(base), ctypes.cast(layout, _vp)), "lgp_batch_proof_arena")
+        return int(layout[0])
+
     def collect(self):
         """wait for the oldest batch in flight; returns its proofs, read lazily out of the prover's arena"""
         _check(self._L.lgp_prove_batch_collect(self._h), "prove_batch_collect")

@@ -54,6 +54,13 @@ def lib():
         L.orc_linear_constraint_poly.argtypes = [_u32, _u32, _vp, _vp, _vp]
         L.orc_quadratic_constraint_poly.argtypes = [_u32, _u32, _vp, _vp, _vp]
         L.orc_max_threads.restype = ctypes.c_int
+        L.orc_field_elements_from_seed.argtypes = [_vp, ctypes.c_uint64, _vp]
+        L.orc_field_elements_from_seed.restype = None
+        L.orc_distinct_indices_from_seed.argtypes = [_vp, _u32, _u32, _vp]
+        L.orc_sponge_script.argtypes = [_vp, _vp, _sz, _vp, _vp]
+        L.orc_sponge_script.restype = None
+        L.orc_prove.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, _vp]
+        L.orc_verify.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         _lib = L
     return _lib
 
@@ -212,3 +219,117 @@ def quadratic_constraint_poly(coeffs: np.ndarray, r: np.ndarray) -> np.ndarray:
     out = np.empty((2 * k, 4), dtype=np.uint64)
     assert lib().orc_quadratic_constraint_poly(rows // 4, k, _p(coeffs), _p(r), _p(out)) == 0
     return out
+
+
+# ---- the whole prover / verifier (ligero_oracle.c orc_prove / orc_verify): the serial reference-shaped CPU baseline beside proofs/sec ----
+FIELDS = ("u_root", "interleaved.preenc_u_lc", "interleaved.columns", "interleaved.paths", "linear.polynomial", "linear.columns",
+          "linear.paths", "quadratic.polynomial", "quadratic.columns", "quadratic.paths")
+
+
+class _OrcCircuit(ctypes.Structure):
+    _fields_ = [("m", _u32), ("k", _u32), ("n", _u32), ("t", _u32), ("num_nodes", ctypes.c_uint64), ("kind", _vp), ("left", _vp),
+                ("right", _vp), ("const_val", _vp), ("num_outputs", ctypes.c_uint64), ("outputs", _vp), ("a_row_ptr", _vp),
+                ("a_col", _vp), ("a_val", _vp)]
+
+
+class _OrcProof(ctypes.Structure):
+    _fields_ = [("field", _vp * 10), ("cap", ctypes.c_uint64 * 10), ("len", ctypes.c_uint64 * 10)]
+
+
+class Statement:
+    """a LigeroCircuit of the big-int model (oracle/model_prover.py: the circuit after insert_one, the outputs, A, the dimensions)
+    packed into the arrays orc_prove / orc_verify read"""
+
+    def __init__(self, lc):
+        R = (1 << 256) % lc_modulus()
+        nodes = lc.circuit.nodes
+        self.m, self.k, self.n, self.t = lc.m, lc.k, lc.n, lc.t
+        self.kind = np.array([{"V": 0, "C": 1, "A": 2, "M": 3}[nd[0]] for nd in nodes], dtype=np.uint8)
+        self.left = np.array([nd[1] if nd[0] in "AM" else 0 for nd in nodes], dtype=np.uint64)
+        self.right = np.array([nd[2] if nd[0] in "AM" else 0 for nd in nodes], dtype=np.uint64)
+        self.const_val = ints_to_limbs([nd[1] * R % lc_modulus() if nd[0] == "C" else 0 for nd in nodes])
+        self.outputs = np.array(lc.outputs, dtype=np.uint64)
+        self.a_row_ptr = np.zeros(len(lc.a.rows) + 1, dtype=np.uint64)
+        self.a_row_ptr[1:] = np.cumsum([len(r) for r in lc.a.rows])
+        self.a_col = np.array([col for r in lc.a.rows for _, col in r], dtype=np.uint32)
+        self.a_val = ints_to_limbs([v * R % lc_modulus() for r in lc.a.rows for v, _ in r]).reshape(-1, 4)
+        self.one_index, self.one_found = lc.one_index, lc.one_found
+        self.variables = dict(lc.circuit.variables)
+        self.c = _OrcCircuit(self.m, self.k, self.n, self.t, len(nodes), _p(self.kind), _p(self.left), _p(self.right), _p(self.const_val),
+                             len(lc.outputs), _p(self.outputs), _p(self.a_row_ptr), _p(self.a_col), _p(self.a_val))
+        plen = self.n.bit_length() - 2
+        self.caps = [32, 32 * self.k, 32 * self.t * 4 * self.m, self.t * (40 + 32 * plen), 32 * 2 * self.k, 32 * self.t * 4 * self.m,
+                     self.t * (40 + 32 * plen), 32 * 2 * self.k, 32 * self.t * 4 * self.m, self.t * (40 + 32 * plen)]
+        self.path_len = plen
+        self._bufs = [np.zeros(max(1, c), dtype=np.uint8) for c in self.caps]     # reused from proof to proof (the timed loop allocates nothing here)
+
+    def bump(self, index: int) -> int:
+        """LigeroCircuit::bump_index (src/ligero/mod.rs:230-242): what `prove` applies to the caller's node indices"""
+        if self.one_found:
+            return index + 1 if index < self.one_index else (0 if index == self.one_index else index)
+        return index + 1
+
+    def assignment(self, var_assignment):
+        """[(original node index | label, canonical value)] -> (idx array, Montgomery values) as prove / prove_with_labels pass down"""
+        idx = np.array([self.variables[i] if isinstance(i, str) else self.bump(i) for i, _ in var_assignment], dtype=np.uint64)
+        R = (1 << 256) % lc_modulus()
+        return idx, ints_to_limbs([v % lc_modulus() * R % lc_modulus() for _, v in var_assignment])
+
+    def prove_raw(self, idx: np.ndarray, vals: np.ndarray) -> int:
+        """one orc_prove into the statement's reused buffers; returns the status (what the baseline times)"""
+        pr = _OrcProof()
+        for f in range(10):
+            pr.field[f] = self._bufs[f].ctypes.data
+            pr.cap[f] = self.caps[f]
+        self._last = pr
+        return lib().orc_prove(ctypes.byref(self.c), _p(idx), _p(vals), idx.shape[0], ctypes.byref(pr))
+
+    def prove(self, var_assignment) -> dict:
+        """-> {field name: bytes}, the layout of oracle/model_prover.py proof_field_bytes"""
+        idx, vals = self.assignment(var_assignment)
+        rc = self.prove_raw(idx, vals)
+        if rc == -4:
+            raise RuntimeError("Uninitialised variable")
+        assert rc == 0, rc
+        return {name: self._bufs[f][:self._last.len[f]].tobytes() for f, name in enumerate(FIELDS)}
+
+    def verify(self, fields: dict) -> bool:
+        blobs = [np.frombuffer(bytes(fields[name]) or b"\0", dtype=np.uint8) for name in FIELDS]
+        pr = _OrcProof()
+        for f, name in enumerate(FIELDS):
+            pr.field[f] = blobs[f].ctypes.data
+            pr.cap[f] = pr.len[f] = len(fields[name])
+        ok = ctypes.c_int(0)
+        rc = lib().orc_verify(ctypes.byref(self.c), ctypes.byref(pr), ctypes.byref(ok))
+        return rc == 0 and bool(ok.value)
+
+
+def lc_modulus() -> int:
+    return 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def field_elements_from_seed(seed: bytes, count: int) -> np.ndarray:
+    """src/utils.rs:23-29: (count, 4) Montgomery limbs"""
+    out = np.empty((count, 4), dtype=np.uint64)
+    s = np.frombuffer(seed, dtype=np.uint8)
+    lib().orc_field_elements_from_seed(_p(s), count, _p(out))
+    return out
+
+
+def distinct_indices_from_seed(seed: bytes, n: int, t: int):
+    out = np.empty(max(1, t), dtype=np.uint32)
+    s = np.frombuffer(seed, dtype=np.uint8)
+    assert lib().orc_distinct_indices_from_seed(_p(s), n, t, _p(out)) == 0
+    return [int(x) for x in out[:t]]
+
+
+def sponge_script(ops):
+    """ops: list of ("bytes", b) / ("elems", [canonical ints]) / ("seed",) on one fresh test_sponge(); returns the squeezed 32-byte seeds"""
+    code = np.array([{"bytes": 0, "elems": 1, "seed": 2}[o[0]] for o in ops], dtype=np.uint8)
+    lens = np.array([len(o[1]) if o[0] != "seed" else 0 for o in ops], dtype=np.uint64)
+    data = b"".join(o[1] if o[0] == "bytes" else b"".join(int(v).to_bytes(32, "little") for v in o[1]) for o in ops if o[0] != "seed")
+    d = np.frombuffer(data or b"\0", dtype=np.uint8)
+    nseeds = int((code == 2).sum())
+    out = np.zeros(max(1, 32 * nseeds), dtype=np.uint8)
+    lib().orc_sponge_script(_p(code), _p(lens), len(ops), _p(d), _p(out))
+    return [out[32 * i:32 * i + 32].tobytes() for i in range(nseeds)]

@@ -591,3 +591,610 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+
+/* =====================================================================================================================
+ * The WHOLE prover and verifier, reference-shaped and serial: LigeroCircuit::prove_inner (src/ligero/mod.rs:457-578),
+ * prove_interleaved / prove_linear_constraints / prove_quadratic_constraints (646-669, 712-747, 832-859), open_columns
+ * (935-955), verify and its three tests (613-644, 671-708, 749-830, 861-933), verify_column_openings (957-996), the PRNG
+ * helpers (src/utils.rs:23-55) and the transcript they draw on (rand_chacha ChaCha20Rng, ark-ff F::rand, rand gen_range,
+ * ark-crypto-primitives PoseidonSponge with ark-poly-commit's test_sponge() parameters -- the crates' published algorithms;
+ * PARITY UNPINNED as above).  This is the CPU baseline beside proofs/sec (bench.py cpu_baseline leg), shaped as the
+ * reference computes: one DensePolynomial product = two forward FFTs over the 2k domain, a point-wise product and an
+ * inverse FFT, summed coefficient-wise (mod.rs:731-736, 845-848); A.row_mul over the sparse rows on the host (matrices/
+ * mod.rs:103-111); the verifier's 4m full size-n FFTs of the r polynomials (mod.rs:816-819).  Checked against the big-int
+ * model (oracle/model_prover.py) field for field in tests/test_oracle_prover.py.
+ * ===================================================================================================================== */
+
+static inline int fr_is_zero(const fr_t *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fr_eq(const fr_t *a, const fr_t *b) { return memcmp(a, b, sizeof(fr_t)) == 0; }
+static void fr_to_bytes(const fr_t *mont, uint8_t out[32]) { /* CanonicalSerialize: the canonical integer, little-endian */
+    fr_t c;
+    fr_from_mont(&c, mont);
+    for (int w = 0; w < 4; w++)
+        for (int b = 0; b < 8; b++) out[8 * w + b] = (uint8_t)(c.l[w] >> (8 * b));
+}
+static int fr_from_bytes(const uint8_t in[32], fr_t *mont) {
+    fr_t c = {{0, 0, 0, 0}};
+    for (int i = 0; i < 32; i++) c.l[i / 8] |= (uint64_t)in[i] << (8 * (i % 8));
+    if (fr_geq(&c, &FR_P)) return -1;
+    fr_to_mont(mont, &c);
+    return 0;
+}
+
+/* ---- rand_chacha: ChaCha with a 64-bit block counter in words 12-13, stream 0, words consumed in order ---- */
+typedef struct { uint32_t key[8]; uint64_t counter; uint32_t buf[16]; int pos, rounds; } chacha_t;
+static inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define CHACHA_QR(a, b, c, d) \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+static void chacha_refill(chacha_t *c) {
+    uint32_t s[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574}, x[16];
+    memcpy(s + 4, c->key, 32);
+    s[12] = (uint32_t)c->counter; s[13] = (uint32_t)(c->counter >> 32); s[14] = 0; s[15] = 0;
+    memcpy(x, s, sizeof(x));
+    for (int r = 0; r < c->rounds; r += 2) {
+        CHACHA_QR(0, 4, 8, 12) CHACHA_QR(1, 5, 9, 13) CHACHA_QR(2, 6, 10, 14) CHACHA_QR(3, 7, 11, 15)
+        CHACHA_QR(0, 5, 10, 15) CHACHA_QR(1, 6, 11, 12) CHACHA_QR(2, 7, 8, 13) CHACHA_QR(3, 4, 9, 14)
+    }
+    for (int i = 0; i < 16; i++) c->buf[i] = x[i] + s[i];
+    c->counter++;
+    c->pos = 0;
+}
+static void chacha_init(chacha_t *c, const uint8_t seed[32], int rounds) {
+    for (int i = 0; i < 8; i++) c->key[i] = (uint32_t)seed[4 * i] | (uint32_t)seed[4 * i + 1] << 8 | (uint32_t)seed[4 * i + 2] << 16 | (uint32_t)seed[4 * i + 3] << 24;
+    c->counter = 0; c->pos = 16; c->rounds = rounds;
+}
+static inline uint32_t chacha_u32(chacha_t *c) {
+    if (c->pos == 16) chacha_refill(c);
+    return c->buf[c->pos++];
+}
+static inline uint64_t chacha_u64(chacha_t *c) {
+    uint64_t lo = chacha_u32(c);
+    return lo | (uint64_t)chacha_u32(c) << 32;
+}
+/* ark-ff UniformRand for Fp<MontBackend, 4>: four u64, top limb masked to 254 bits, accepted below the modulus, and used AS the
+ * Montgomery representation */
+static void fr_rand(chacha_t *c, fr_t *out) {
+    for (;;) {
+        fr_t t;
+        for (int i = 0; i < 4; i++) t.l[i] = chacha_u64(c);
+        t.l[3] &= 0x3fffffffffffffffULL;
+        if (!fr_geq(&t, &FR_P)) { *out = t; return; }
+    }
+}
+/* rand 0.8 UniformInt<usize>::sample_single(0, n) */
+static uint64_t gen_range(chacha_t *c, uint64_t n) {
+    const uint64_t zone = (n << __builtin_clzll(n)) - 1;
+    for (;;) {
+        u128 m = (u128)chacha_u64(c) * n;
+        if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
+    }
+}
+/* src/utils.rs:23-29 */
+static void field_elements_from_prng(uint64_t count, const uint8_t seed[32], fr_t *out) {
+    chacha_t c;
+    chacha_init(&c, seed, 20);
+    for (uint64_t i = 0; i < count; i++) fr_rand(&c, &out[i]);
+}
+/* src/utils.rs:31-55 (the BTreeSet is a membership map read in ascending order) */
+static int distinct_indices_from_prng(uint32_t n, uint32_t t, const uint8_t seed[32], uint32_t *out) {
+    chacha_t c;
+    chacha_init(&c, seed, 20);
+    uint8_t *in = (uint8_t *)calloc(n ? n : 1, 1);
+    if (!in) return -2;
+    const uint32_t to_select = t < n - t ? t : n - t;
+    for (uint32_t have = 0; have < to_select;) {
+        uint64_t j = gen_range(&c, n);
+        if (!in[j]) { in[j] = 1; have++; }
+    }
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (in[i] == (to_select == t)) out[o++] = i;
+    free(in);
+    return o == t ? 0 : -1;
+}
+void orc_field_elements_from_seed(const uint8_t seed[32], uint64_t count, uint64_t *out) { field_elements_from_prng(count, seed, (fr_t *)out); }
+int orc_distinct_indices_from_seed(const uint8_t seed[32], uint32_t n, uint32_t t, uint32_t *out) { return t > n ? -1 : distinct_indices_from_prng(n, t, seed, out); }
+
+/* ---- PoseidonSponge<Fr> as test_sponge() builds it (src/ligero/tests.rs:151, 399): rate 2, capacity 1, 8 full + 31 partial
+ * rounds, alpha 17, MDS [[1,0,1],[1,1,0],[0,1,1]], 39 x 3 round constants F::rand(test_rng()) (ChaCha12, ark-std's fixed seed) ---- */
+enum { SP_RATE = 2, SP_CAP = 1, SP_T = 3, SP_FULL = 8, SP_PARTIAL = 31 };
+typedef struct { fr_t state[SP_T]; int squeezing, idx; } sponge_t;
+static fr_t SP_ARK[SP_FULL + SP_PARTIAL][SP_T], SP_MDS[SP_T][SP_T];
+static int sp_ready = 0;
+static void sponge_params(void) {
+    if (sp_ready) return;
+    static const uint8_t seed[32] = {1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0};
+    chacha_t c;
+    chacha_init(&c, seed, 12);
+    for (int i = 0; i < SP_FULL + SP_PARTIAL; i++)
+        for (int j = 0; j < SP_T; j++) fr_rand(&c, &SP_ARK[i][j]);
+    static const int mds[3][3] = {{1, 0, 1}, {1, 1, 0}, {0, 1, 1}};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            memset(&SP_MDS[i][j], 0, sizeof(fr_t));
+            if (mds[i][j]) SP_MDS[i][j] = FR_R;
+        }
+    sp_ready = 1;
+}
+static void sponge_init(sponge_t *s) {
+#pragma omp critical(orc_sponge_params)
+    sponge_params();
+    memset(s, 0, sizeof(*s));
+}
+static inline void sbox17(fr_t *x) {
+    fr_t x2, x4, x8, x16;
+    fr_mul(&x2, x, x); fr_mul(&x4, &x2, &x2); fr_mul(&x8, &x4, &x4); fr_mul(&x16, &x8, &x8);
+    fr_mul(x, &x16, x);
+}
+static void sponge_permute(sponge_t *s) {
+    for (int r = 0; r < SP_FULL + SP_PARTIAL; r++) {
+        for (int j = 0; j < SP_T; j++) fr_add(&s->state[j], &s->state[j], &SP_ARK[r][j]);
+        if (r < SP_FULL / 2 || r >= SP_FULL / 2 + SP_PARTIAL)
+            for (int j = 0; j < SP_T; j++) sbox17(&s->state[j]);
+        else
+            sbox17(&s->state[0]);
+        fr_t n[SP_T];
+        for (int i = 0; i < SP_T; i++) {          /* apply_mds: products with the matrix entries, as upstream computes them */
+            memset(&n[i], 0, sizeof(fr_t));
+            for (int j = 0; j < SP_T; j++) {
+                fr_t t;
+                fr_mul(&t, &s->state[j], &SP_MDS[i][j]);
+                fr_add(&n[i], &n[i], &t);
+            }
+        }
+        memcpy(s->state, n, sizeof(n));
+    }
+}
+static void sponge_absorb_internal(sponge_t *s, int start, const fr_t *e, size_t count) {
+    for (;;) {
+        if (start + count <= SP_RATE) {
+            for (size_t i = 0; i < count; i++) fr_add(&s->state[SP_CAP + start + i], &s->state[SP_CAP + start + i], &e[i]);
+            s->squeezing = 0; s->idx = start + (int)count;
+            return;
+        }
+        const int take = SP_RATE - start;
+        for (int i = 0; i < take; i++) fr_add(&s->state[SP_CAP + start + i], &s->state[SP_CAP + start + i], &e[i]);
+        sponge_permute(s);
+        e += take; count -= take; start = 0;
+    }
+}
+static void sponge_absorb_elements(sponge_t *s, const fr_t *e, size_t count) {
+    if (!count) return;
+    if (s->squeezing) {
+        sponge_permute(s);
+        sponge_absorb_internal(s, 0, e, count);
+    } else {
+        int idx = s->idx;
+        if (idx == SP_RATE) { sponge_permute(s); idx = 0; }
+        sponge_absorb_internal(s, idx, e, count);
+    }
+}
+/* Absorb for Vec<u8>: LE64(len) || bytes packed 31 bytes per element, little-endian */
+static void sponge_absorb_bytes(sponge_t *s, const uint8_t *data, size_t len) {
+    const size_t total = 8 + len, ne = (total + 30) / 31;
+    uint8_t *b = (uint8_t *)calloc(ne * 31 + 1, 1);
+    fr_t *e = (fr_t *)malloc(sizeof(fr_t) * ne);
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)((uint64_t)len >> (8 * i));
+    memcpy(b + 8, data, len);
+    for (size_t i = 0; i < ne; i++) {
+        uint8_t le[32] = {0};
+        memcpy(le, b + 31 * i, 31);
+        fr_from_bytes(le, &e[i]);
+    }
+    sponge_absorb_elements(s, e, ne);
+    free(b); free(e);
+}
+static void sponge_squeeze_internal(sponge_t *s, int start, fr_t *out, size_t count) {
+    for (;;) {
+        if (start + count <= SP_RATE) {
+            memcpy(out, &s->state[SP_CAP + start], sizeof(fr_t) * count);
+            s->squeezing = 1; s->idx = start + (int)count;
+            return;
+        }
+        const int take = SP_RATE - start;
+        memcpy(out, &s->state[SP_CAP + start], sizeof(fr_t) * take);
+        if (count != SP_RATE) sponge_permute(s);
+        out += take; count -= take; start = 0;
+    }
+}
+static void sponge_squeeze_elements(sponge_t *s, fr_t *out, size_t count) {
+    if (!s->squeezing) {
+        sponge_permute(s);
+        sponge_squeeze_internal(s, 0, out, count);
+    } else {
+        int idx = s->idx;
+        if (idx == SP_RATE) { sponge_permute(s); idx = 0; }
+        sponge_squeeze_internal(s, idx, out, count);
+    }
+}
+static void sponge_squeeze_seed(sponge_t *s, uint8_t seed[32]) { /* squeeze_bytes(CHACHA_SEED_BYTES): 2 elements, 31 bytes each, cut to 32 */
+    fr_t e[2];
+    uint8_t b[64];
+    sponge_squeeze_elements(s, e, 2);
+    fr_to_bytes(&e[0], b);
+    fr_to_bytes(&e[1], b + 31);      /* (overwrites byte 31 of the first: only its low 31 bytes are kept) */
+    memcpy(seed, b, 32);
+}
+/* test hooks of the sponge alone: a script of operations, for tests/test_oracle_prover.py against the Python model */
+void orc_sponge_script(const uint8_t *ops, const uint64_t *lens, size_t nops, const uint8_t *data, uint8_t *out) {
+    /* op 0: absorb bytes (lens[i] of data); 1: absorb elements (lens[i] x 32 canonical bytes); 2: squeeze a 32-byte seed to out */
+    sponge_t s;
+    sponge_init(&s);
+    for (size_t i = 0; i < nops; i++) {
+        if (ops[i] == 0) { sponge_absorb_bytes(&s, data, lens[i]); data += lens[i]; }
+        else if (ops[i] == 1) {
+            fr_t *e = (fr_t *)malloc(sizeof(fr_t) * (lens[i] ? lens[i] : 1));
+            for (uint64_t j = 0; j < lens[i]; j++) fr_from_bytes(data + 32 * j, &e[j]);
+            sponge_absorb_elements(&s, e, lens[i]);
+            data += 32 * lens[i];
+            free(e);
+        } else { sponge_squeeze_seed(&s, out); out += 32; }
+    }
+}
+
+/* ---- the statement: LigeroCircuit after `new` (mod.rs:147-228), handed over as arrays ---- */
+typedef struct {
+    uint32_t m, k, n, t;
+    uint64_t num_nodes;            /* the circuit after insert_one: kind 0 Variable, 1 Constant, 2 Add, 3 Mul */
+    const uint8_t *kind;
+    const uint64_t *left, *right;  /* operands of Add / Mul */
+    const uint64_t *const_val;     /* num_nodes x 4 Montgomery limbs, read for Constant nodes */
+    uint64_t num_outputs;
+    const uint64_t *outputs;
+    const uint64_t *a_row_ptr;     /* A in CSR over its 4mk rows (in-row order as the reference builds them) */
+    const uint32_t *a_col;
+    const uint64_t *a_val;         /* nnz x 4 Montgomery limbs */
+} orc_circuit;
+
+/* proof fields as bytes, the layout of oracle/model_prover.py proof_field_bytes / include/ligero_prover.h lgp_proof_field_bytes:
+ * field[f] is caller-allocated with cap[f] bytes; len[f] is written */
+typedef struct { uint8_t *field[10]; uint64_t cap[10], len[10]; } orc_proof;
+enum { F_ROOT = 0, F_LC = 1, F_ICOLS = 2, F_IPATHS = 3, F_LPOLY = 4, F_LCOLS = 5, F_LPATHS = 6, F_QPOLY = 7, F_QCOLS = 8, F_QPATHS = 9 };
+
+typedef struct { const orc_circuit *c; fr_t *preenc, *coeffs, *u; uint8_t *leaves, *nodes; sponge_t sp; } prover_t;
+
+static int put_elems(orc_proof *p, int f, const fr_t *e, size_t count) {
+    if (p->cap[f] < 32 * count) return -3;
+    for (size_t i = 0; i < count; i++) fr_to_bytes(&e[i], p->field[f] + 32 * i);
+    p->len[f] = 32 * count;
+    return 0;
+}
+/* open_columns, mod.rs:935-955 */
+static int open_columns_into(prover_t *P, orc_proof *out, int fcols, int fpaths) {
+    const orc_circuit *c = P->c;
+    const uint32_t rows = 4 * c->m, plen = (uint32_t)log2_exact(c->n) - 1;
+    uint8_t seed[32];
+    sponge_squeeze_seed(&P->sp, seed);
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (c->t ? c->t : 1));
+    fr_t *cols = (fr_t *)malloc(sizeof(fr_t) * (size_t)c->t * rows);
+    uint8_t *sib = (uint8_t *)malloc((size_t)c->t * 32 + 1), *paths = (uint8_t *)malloc((size_t)c->t * plen * 32 + 1);
+    int rc = distinct_indices_from_prng(c->n, c->t, seed, idx);
+    if (!rc) rc = orc_open_columns(rows, c->n, (const uint64_t *)P->u, P->leaves, P->nodes, idx, c->t, (uint64_t *)cols, sib, paths);
+    if (!rc) rc = put_elems(out, fcols, cols, (size_t)c->t * rows);
+    const uint64_t step = 8 + 32 + 32 * (uint64_t)plen;
+    if (!rc && out->cap[fpaths] < step * c->t) rc = -3;
+    if (!rc) {
+        uint8_t *o = out->field[fpaths];
+        for (uint32_t i = 0; i < c->t; i++, o += step) {
+            for (int b = 0; b < 8; b++) o[b] = (uint8_t)((uint64_t)idx[i] >> (8 * b));
+            memcpy(o + 8, sib + 32 * (size_t)i, 32);
+            memcpy(o + 40, paths + 32 * (size_t)i * plen, 32 * (size_t)plen);
+        }
+        out->len[fpaths] = step * c->t;
+    }
+    free(idx); free(cols); free(sib); free(paths);
+    return rc;
+}
+static size_t trimmed_len(const fr_t *c, size_t len) { /* DensePolynomial::from_coefficients_vec */
+    while (len && fr_is_zero(&c[len - 1])) len--;
+    return len;
+}
+/* &DensePolynomial * &DensePolynomial as ark-poly computes it: zero if either is zero; else both evaluated over the domain of
+ * size >= len_a + len_b - 1, multiplied point-wise, interpolated.  prod: d coefficients (d = that domain's size) */
+static void poly_mul_fft(const fr_t *a, size_t la, const fr_t *b, size_t lb, fr_t *prod, fr_t *tmp, uint32_t d) {
+    memset(prod, 0, sizeof(fr_t) * d);
+    la = trimmed_len(a, la); lb = trimmed_len(b, lb);
+    if (!la || !lb) return;
+    memset(tmp, 0, sizeof(fr_t) * d);
+    memcpy(prod, a, sizeof(fr_t) * la);
+    memcpy(tmp, b, sizeof(fr_t) * lb);
+    orc_fft(d, (uint64_t *)prod);
+    orc_fft(d, (uint64_t *)tmp);
+    for (uint32_t j = 0; j < d; j++) fr_mul(&prod[j], &prod[j], &tmp[j]);
+    orc_ifft(d, (uint64_t *)prod);
+}
+/* r_polys (mod.rs:722-729 = 774-780): r_a = A.row_mul(r_linear) over the sparse rows, split into rows of k, each through small_domain.ifft */
+static fr_t *r_polys_from_seed(const orc_circuit *c, const uint8_t seed[32]) {
+    const size_t len = 4 * (size_t)c->m * c->k;
+    fr_t *r = (fr_t *)malloc(sizeof(fr_t) * len), *ra = (fr_t *)calloc(len, sizeof(fr_t));
+    if (!r || !ra) { free(r); free(ra); return NULL; }
+    field_elements_from_prng(len, seed, r);
+    for (size_t row = 0; row < len; row++)
+        for (uint64_t e = c->a_row_ptr[row]; e < c->a_row_ptr[row + 1]; e++) {
+            fr_t t;
+            fr_mul(&t, &r[row], (const fr_t *)c->a_val + e);
+            fr_add(&ra[c->a_col[e]], &ra[c->a_col[e]], &t);
+        }
+    for (uint32_t i = 0; i < 4 * c->m; i++) orc_ifft(c->k, (uint64_t *)(ra + (size_t)i * c->k));
+    free(r);
+    return ra;
+}
+
+/* evaluation_trace_multioutput + inner_evaluate (src/arithmetic_circuit/mod.rs:247-271, 325-358), the recursion on an explicit stack.
+ * Returns 0, or -4 "Uninitialised variable" / -5 "Value supplied for non-variable node" */
+static int evaluation_trace(const orc_circuit *c, const uint64_t *var_idx, const uint64_t *var_val, uint64_t nvars, fr_t *sol, uint8_t *set) {
+    for (uint64_t i = 0; i < c->num_nodes; i++) {
+        set[i] = c->kind[i] == 1;
+        if (set[i]) memcpy(&sol[i], c->const_val + 4 * i, sizeof(fr_t));
+    }
+    for (uint64_t v = 0; v < nvars; v++) {
+        if (var_idx[v] >= c->num_nodes || c->kind[var_idx[v]] != 0) return -5;
+        memcpy(&sol[var_idx[v]], var_val + 4 * v, sizeof(fr_t));
+        set[var_idx[v]] = 1;
+    }
+    uint64_t *stack = (uint64_t *)malloc(sizeof(uint64_t) * (c->num_nodes + 1));
+    int rc = 0;
+    for (uint64_t o = 0; o < c->num_outputs && !rc; o++) {
+        size_t sp = 0;
+        stack[sp++] = c->outputs[o];
+        while (sp && !rc) {
+            const uint64_t i = stack[sp - 1];
+            if (set[i]) { sp--; continue; }
+            if (c->kind[i] < 2) { rc = -4; break; }
+            const uint64_t l = c->left[i], r = c->right[i];
+            if (!set[l]) { stack[sp++] = l; continue; }
+            if (!set[r]) { stack[sp++] = r; continue; }
+            if (c->kind[i] == 2) fr_add(&sol[i], &sol[l], &sol[r]); else fr_mul(&sol[i], &sol[l], &sol[r]);
+            set[i] = 1;
+            sp--;
+        }
+    }
+    free(stack);
+    return rc;
+}
+
+/* prove_inner, mod.rs:457-578, with the test_sponge() transcript.  var_idx are node indices of the circuit as handed over (after
+ * insert_one: what `prove` passes down, mod.rs:449-454) */
+int orc_prove(const orc_circuit *c, const uint64_t *var_idx, const uint64_t *var_val, uint64_t nvars, orc_proof *out) {
+    const uint32_t m = c->m, k = c->k, n = c->n, rows = 4 * m, d = 2 * k;
+    if (log2_exact(k) < 0 || n != 8 * k || m == 0) return -1;
+    const size_t mk = (size_t)m * k;
+    int rc = 0;
+    prover_t P;
+    memset(&P, 0, sizeof(P));
+    P.c = c;
+    fr_t *sol = (fr_t *)malloc(sizeof(fr_t) * (c->num_nodes + 1));
+    uint8_t *set = (uint8_t *)malloc(c->num_nodes + 1);
+    P.preenc = (fr_t *)calloc(4 * mk, sizeof(fr_t));
+    P.coeffs = (fr_t *)malloc(sizeof(fr_t) * 4 * mk);
+    P.u = (fr_t *)malloc(sizeof(fr_t) * (size_t)rows * n);
+    P.leaves = (uint8_t *)malloc((size_t)n * 32);
+    P.nodes = (uint8_t *)malloc((size_t)n * 32);
+    fr_t *acc = (fr_t *)calloc(d, sizeof(fr_t)), *prod = (fr_t *)malloc(sizeof(fr_t) * d), *tmp = (fr_t *)malloc(sizeof(fr_t) * d);
+    fr_t *r = (fr_t *)malloc(sizeof(fr_t) * (rows > m ? rows : m)), *lc = (fr_t *)malloc(sizeof(fr_t) * k), *rp = NULL;
+    uint8_t seed[32], root[32];
+    if (!sol || !set || !P.preenc || !P.coeffs || !P.u || !P.leaves || !P.nodes || !acc || !prod || !tmp || !r || !lc) { rc = -2; goto done; }
+    /* mod.rs:476-478 */
+    rc = evaluation_trace(c, var_idx, var_val, nvars, sol, set);
+    if (rc) goto done;
+    for (uint64_t i = 0; i < c->num_nodes; i++)
+        if (!set[i]) { rc = -4; goto done; }
+    /* mod.rs:483-516: x, y, z, w over the kept nodes, zero padded to m k, as the rows of [X; Y; Z; W] */
+    {
+        size_t pos = 0;
+        for (uint64_t i = 0; i < c->num_nodes; i++) {
+            if (c->kind[i] == 1 && i != 0) continue;
+            if (pos < mk) {          /* Vec::resize(m k) cuts a longer vector */
+                P.preenc[3 * mk + pos] = sol[i];
+                if (c->kind[i] == 3) {
+                    P.preenc[pos] = sol[c->left[i]];
+                    P.preenc[mk + pos] = sol[c->right[i]];
+                    P.preenc[2 * mk + pos] = sol[i];
+                }
+            }
+            pos++;
+        }
+    }
+    /* mod.rs:521-551 */
+    rc = orc_encode_commit(rows, k, n, (const uint64_t *)P.preenc, (uint64_t *)P.coeffs, (uint64_t *)P.u, P.leaves, P.nodes, root, 1);
+    if (rc) goto done;
+    if (out->cap[F_ROOT] < 32) { rc = -3; goto done; }
+    memcpy(out->field[F_ROOT], root, 32);
+    out->len[F_ROOT] = 32;
+    sponge_init(&P.sp);
+    sponge_absorb_bytes(&P.sp, root, 32);                                  /* mod.rs:560 */
+    /* prove_interleaved, mod.rs:646-669 */
+    sponge_squeeze_seed(&P.sp, seed);
+    field_elements_from_prng(rows, seed, r);
+    orc_dense_row_mul(rows, k, (const uint64_t *)P.preenc, (const uint64_t *)r, (uint64_t *)lc);
+    sponge_absorb_elements(&P.sp, lc, k);
+    if ((rc = put_elems(out, F_LC, lc, k)) || (rc = open_columns_into(&P, out, F_ICOLS, F_IPATHS))) goto done;
+    /* prove_linear_constraints, mod.rs:712-747 */
+    sponge_squeeze_seed(&P.sp, seed);
+    rp = r_polys_from_seed(c, seed);
+    if (!rp) { rc = -2; goto done; }
+    for (uint32_t i = 0; i < rows; i++) {                                  /* mod.rs:731-736 */
+        poly_mul_fft(P.coeffs + (size_t)i * k, k, rp + (size_t)i * k, k, prod, tmp, d);
+        for (uint32_t j = 0; j < d; j++) fr_add(&acc[j], &acc[j], &prod[j]);
+    }
+    {
+        const size_t len = trimmed_len(acc, d);
+        sponge_absorb_elements(&P.sp, acc, len);
+        if ((rc = put_elems(out, F_LPOLY, acc, len)) || (rc = open_columns_into(&P, out, F_LCOLS, F_LPATHS))) goto done;
+    }
+    /* prove_quadratic_constraints, mod.rs:832-859 */
+    sponge_squeeze_seed(&P.sp, seed);
+    field_elements_from_prng(m, seed, r);
+    memset(acc, 0, sizeof(fr_t) * d);
+    for (uint32_t i = 0; i < m; i++) {                                     /* mod.rs:845-848: &(&(p_x * p_y) - p_z) * r */
+        poly_mul_fft(P.coeffs + (size_t)i * k, k, P.coeffs + (size_t)(m + i) * k, k, prod, tmp, d);
+        for (uint32_t j = 0; j < k; j++) fr_sub(&prod[j], &prod[j], &P.coeffs[(size_t)(2 * m + i) * k + j]);
+        for (uint32_t j = 0; j < d; j++) {
+            fr_mul(&prod[j], &prod[j], &r[i]);
+            fr_add(&acc[j], &acc[j], &prod[j]);
+        }
+    }
+    {
+        const size_t len = trimmed_len(acc, d);
+        sponge_absorb_elements(&P.sp, acc, len);
+        if ((rc = put_elems(out, F_QPOLY, acc, len)) || (rc = open_columns_into(&P, out, F_QCOLS, F_QPATHS))) goto done;
+    }
+done:
+    free(sol); free(set); free(P.preenc); free(P.coeffs); free(P.u); free(P.leaves); free(P.nodes);
+    free(acc); free(prod); free(tmp); free(r); free(lc); free(rp);
+    return rc;
+}
+
+/* Path::verify with TestMerkleTreeParams (call site mod.rs:985-995): bottom level SHA-256(LE64(32) || L || LE64(32) || R), above SHA-256(L || R) */
+static int path_verify(const uint8_t root[32], const uint8_t leaf[32], uint64_t index, const uint8_t *sib, const uint8_t *auth, uint32_t plen) {
+    uint8_t msg[80], cur[32];
+    static const uint8_t pre[8] = {32, 0, 0, 0, 0, 0, 0, 0};
+    const uint8_t *l = (index & 1) ? sib : leaf, *r = (index & 1) ? leaf : sib;
+    memcpy(msg, pre, 8); memcpy(msg + 8, l, 32); memcpy(msg + 40, pre, 8); memcpy(msg + 48, r, 32);
+    orc_sha256(msg, 80, cur);
+    uint64_t idx = index >> 1;
+    for (uint32_t lev = plen; lev-- > 0; idx >>= 1) {
+        const uint8_t *s = auth + 32 * (size_t)lev;
+        if (idx & 1) { memcpy(msg, s, 32); memcpy(msg + 32, cur, 32); } else { memcpy(msg, cur, 32); memcpy(msg + 32, s, 32); }
+        orc_sha256(msg, 64, cur);
+    }
+    return memcmp(cur, root, 32) == 0;
+}
+typedef struct { fr_t *cols; uint64_t *leaf_index; uint32_t count; } opening_t;
+/* verify_column_openings, mod.rs:957-996; reads the columns / paths fields into `o` (columns as Montgomery elements) */
+static int verify_openings(const orc_circuit *c, sponge_t *sp, const uint8_t root[32], const orc_proof *p, int fcols, int fpaths, opening_t *o) {
+    const uint32_t rows = 4 * c->m, plen = (uint32_t)log2_exact(c->n) - 1;
+    const uint64_t step = 8 + 32 + 32 * (uint64_t)plen;
+    uint8_t seed[32];
+    sponge_squeeze_seed(sp, seed);
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (c->t ? c->t : 1));
+    int ok = distinct_indices_from_prng(c->n, c->t, seed, idx) == 0;
+    if (p->len[fcols] % (32 * (uint64_t)rows) || p->len[fpaths] % step) ok = 0;
+    const uint64_t ncols = ok ? p->len[fcols] / (32 * (uint64_t)rows) : 0, npaths = ok ? p->len[fpaths] / step : 0;
+    uint64_t count = ncols < npaths ? ncols : npaths;               /* izip! stops at the shortest */
+    if (count > c->t) count = c->t;
+    o->cols = (fr_t *)malloc(sizeof(fr_t) * (size_t)(count ? count : 1) * rows);
+    o->leaf_index = (uint64_t *)malloc(sizeof(uint64_t) * (count ? count : 1));
+    o->count = (uint32_t)count;
+    for (uint64_t i = 0; i < count && ok; i++) {
+        const uint8_t *ph = p->field[fpaths] + step * i;
+        uint64_t li = 0;
+        for (int b = 0; b < 8; b++) li |= (uint64_t)ph[b] << (8 * b);
+        o->leaf_index[i] = li;
+        for (uint32_t e = 0; e < rows && ok; e++)
+            if (fr_from_bytes(p->field[fcols] + 32 * ((size_t)i * rows + e), &o->cols[(size_t)i * rows + e])) ok = 0;
+        uint8_t h[32];
+        if (ok) orc_col_hash((const uint64_t *)(o->cols + (size_t)i * rows), rows, h);
+        if (ok && (li != idx[i] || !path_verify(root, h, li, ph + 8, ph + 40, plen))) ok = 0;
+    }
+    free(idx);
+    return ok;
+}
+static int read_elems(const orc_proof *p, int f, fr_t **out, size_t *count) {
+    if (p->len[f] % 32) return -1;
+    *count = p->len[f] / 32;
+    *out = (fr_t *)malloc(sizeof(fr_t) * (*count ? *count : 1));
+    for (size_t i = 0; i < *count; i++)
+        if (fr_from_bytes(p->field[f] + 32 * i, *out + i)) return -1;
+    return 0;
+}
+static void poly_eval(const fr_t *c, size_t len, const fr_t *x, fr_t *out) {
+    fr_t acc = {{0, 0, 0, 0}};
+    for (size_t i = len; i-- > 0;) { fr_mul(&acc, &acc, x); fr_add(&acc, &acc, &c[i]); }
+    *out = acc;
+}
+
+/* verify, mod.rs:613-644 and the three tests.  accepted_out: 1 / 0.  Returns 0, or < 0 for a malformed proof buffer */
+int orc_verify(const orc_circuit *c, const orc_proof *p, int *accepted_out) {
+    const uint32_t m = c->m, k = c->k, n = c->n, rows = 4 * m, d = 2 * k, cof = n / d;
+    *accepted_out = 0;
+    if (log2_exact(k) < 0 || n != 8 * k || p->len[F_ROOT] != 32) return -1;
+    const uint8_t *root = p->field[F_ROOT];
+    sponge_t sp;
+    sponge_init(&sp);
+    sponge_absorb_bytes(&sp, root, 32);                                     /* mod.rs:634 */
+    uint8_t seed[32];
+    fr_t *lc = NULL, *lp = NULL, *qp = NULL, *r = (fr_t *)malloc(sizeof(fr_t) * rows), *w = (fr_t *)malloc(sizeof(fr_t) * n);
+    fr_t *ie = (fr_t *)malloc(sizeof(fr_t) * d), *rp = NULL, *rpe = NULL, wn;
+    size_t nlc = 0, nlp = 0, nqp = 0;
+    opening_t o = {NULL, NULL, 0};
+    int ok = 0, rc = 0;
+    domain_group_gen(&wn, n);
+    if (read_elems(p, F_LC, &lc, &nlc) || read_elems(p, F_LPOLY, &lp, &nlp) || read_elems(p, F_QPOLY, &qp, &nqp)) { rc = -1; goto done; }
+    /* ---- verify_interleaved, mod.rs:671-708 */
+    sponge_squeeze_seed(&sp, seed);
+    field_elements_from_prng(rows, seed, r);
+    sponge_absorb_elements(&sp, lc, nlc);
+    if (!verify_openings(c, &sp, root, p, F_ICOLS, F_IPATHS, &o)) goto done;
+    {
+        fr_t *msg = (fr_t *)calloc(k, sizeof(fr_t));
+        memcpy(msg, lc, sizeof(fr_t) * (nlc < k ? nlc : k));
+        orc_ifft(k, (uint64_t *)msg);
+        orc_reed_solomon_evaluate(n, (const uint64_t *)msg, k, (uint64_t *)w);
+        free(msg);
+        for (uint32_t i = 0; i < o.count; i++) {
+            fr_t s = {{0, 0, 0, 0}}, t;
+            for (uint32_t e = 0; e < rows; e++) { fr_mul(&t, &r[e], &o.cols[(size_t)i * rows + e]); fr_add(&s, &s, &t); }
+            if (!fr_eq(&w[o.leaf_index[i]], &s)) goto done;
+        }
+    }
+    free(o.cols); free(o.leaf_index); o.cols = NULL; o.leaf_index = NULL;
+    /* ---- verify_linear, mod.rs:749-830 */
+    sponge_squeeze_seed(&sp, seed);
+    rp = r_polys_from_seed(c, seed);
+    if (!rp) { rc = -2; goto done; }
+    if ((nlp ? nlp - 1 : 0) >= (size_t)d - 1) goto done;                     /* degree() >= 2k - 1 */
+    memset(ie, 0, sizeof(fr_t) * d);
+    memcpy(ie, lp, sizeof(fr_t) * nlp);
+    orc_fft(d, (uint64_t *)ie);
+    {
+        fr_t s = {{0, 0, 0, 0}};
+        for (uint32_t j = 0; j < d; j += 2) fr_add(&s, &s, &ie[j]);
+        if (!fr_is_zero(&s)) goto done;
+    }
+    sponge_absorb_elements(&sp, lp, nlp);
+    if (!verify_openings(c, &sp, root, p, F_LCOLS, F_LPATHS, &o)) goto done;
+    rpe = (fr_t *)malloc(sizeof(fr_t) * (size_t)rows * n);                  /* mod.rs:816-819: every r polynomial over the large domain */
+    if (!rpe) { rc = -2; goto done; }
+    for (uint32_t i = 0; i < rows; i++) orc_reed_solomon_evaluate(n, (const uint64_t *)(rp + (size_t)i * k), k, (uint64_t *)(rpe + (size_t)i * n));
+    for (uint32_t i = 0; i < o.count; i++) {
+        const uint64_t j = o.leaf_index[i];
+        fr_t ev, s = {{0, 0, 0, 0}}, t;
+        if (j % cof == 0) ev = ie[j / cof];
+        else { fr_t pt; fr_pow_u64(&pt, &wn, j); poly_eval(lp, nlp, &pt, &ev); }
+        for (uint32_t e = 0; e < rows; e++) { fr_mul(&t, &rpe[(size_t)e * n + j], &o.cols[(size_t)i * rows + e]); fr_add(&s, &s, &t); }
+        if (!fr_eq(&s, &ev)) goto done;
+    }
+    free(o.cols); free(o.leaf_index); o.cols = NULL; o.leaf_index = NULL;
+    /* ---- verify_quadratic_constraints, mod.rs:861-933 */
+    sponge_squeeze_seed(&sp, seed);
+    field_elements_from_prng(m, seed, r);
+    if ((nqp ? nqp - 1 : 0) >= (size_t)d - 1) goto done;
+    memset(ie, 0, sizeof(fr_t) * d);
+    memcpy(ie, qp, sizeof(fr_t) * nqp);
+    orc_fft(d, (uint64_t *)ie);
+    for (uint32_t cc = 0; cc < k; cc++)
+        if (!fr_is_zero(&ie[2 * cc])) goto done;
+    sponge_absorb_elements(&sp, qp, nqp);
+    if (!verify_openings(c, &sp, root, p, F_QCOLS, F_QPATHS, &o)) goto done;
+    for (uint32_t i = 0; i < o.count; i++) {
+        const uint64_t j = o.leaf_index[i];
+        const fr_t *col = o.cols + (size_t)i * rows;
+        fr_t lhs, rhs = {{0, 0, 0, 0}}, t;
+        if (j % cof == 0) lhs = ie[j / cof];
+        else { fr_t pt; fr_pow_u64(&pt, &wn, j); poly_eval(qp, nqp, &pt, &lhs); }
+        for (uint32_t e = 0; e < m; e++) {
+            fr_mul(&t, &col[e], &col[e + m]);
+            fr_sub(&t, &t, &col[e + 2 * m]);
+            fr_mul(&t, &t, &r[e]);
+            fr_add(&rhs, &rhs, &t);
+        }
+        if (!fr_eq(&lhs, &rhs)) goto done;
+    }
+    ok = 1;
+done:
+    *accepted_out = ok && !rc;
+    free(lc); free(lp); free(qp); free(r); free(w); free(ie); free(rp); free(rpe); free(o.cols); free(o.leaf_index);
+    return rc;
+}
