@@ -121,3 +121,111 @@ def test_row_ownership_rules_of_the_library_equal_the_host_layer():
     assert L.lg_relay_row_ranges(10, 2, 0, _ffi.LG_RELAY_BLOCKS, bad.ctypes.data_as(vp), ctypes.cast(ctypes.byref(ctypes.c_uint32(0)), vp)) == _ffi.LG_ERR_BAD_ARG
     for code in (_ffi.LG_RELAY_ROUND_ROBIN_BASE, _ffi.LG_RELAY_ROUND_ROBIN_BASE + 9, 7):      # no such layout
         assert L.lg_relay_row_ranges(10, 2, 0, code, bad.ctypes.data_as(vp), ctypes.cast(ctypes.byref(ctypes.c_uint32(0)), vp)) == _ffi.LG_ERR_BAD_ARG
+
+
+# ---- the Rust side of the boundary, as source (no Rust toolchain in this image): rust-shim/ligero-hip-sys is GENERATED from the header
+RUST_SYS = os.path.join(ROOT, "rust-shim", "ligero-hip-sys", "src", "lib.rs")
+_C_WIDTH = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "int": "c_int", "float": "f32", "double": "f64", "char": "c_char",
+            "size_t": "usize", "void": "c_void"}
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        depth += ch == "("
+        depth -= ch == ")"
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    return out + ([cur.strip()] if cur.strip() else [])
+
+
+def _c_shape(decl):
+    """a C parameter / return type -> (pointer depth, base as the Rust spelling); an array parameter is one pointer level"""
+    decl = re.sub(r"\b(const|volatile|struct)\b", " ", decl)
+    depth = decl.count("*") + (1 if "[" in decl else 0)
+    decl = re.sub(r"\[.*?\]", "", decl).replace("*", " ")
+    words = decl.split()
+    base = next(w for w in words if w in _C_WIDTH or w.startswith("lg_"))
+    return depth, _C_WIDTH.get(base, base)
+
+
+def _rust_shape(ty):
+    ty = ty.strip()
+    depth = len(re.findall(r"\*(?:const|mut)\s", ty))
+    return depth, re.sub(r"\*(?:const|mut)\s", "", ty).strip()
+
+
+def test_rust_extern_block_matches_header():
+    """(1) the committed lib.rs is exactly what tools/gen_rust_sys.py makes of the header today; (2) parsed here independently of that
+    generator: the same functions, the same number of arguments, the same pointer depth and integer / float width per argument
+    and for the return value; (3) enum constants and numeric #defines carry the header's values"""
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_rust_sys.py"), "--check"])
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)        # callbacks inside structs are not exports
+    c_funcs = {}
+    for m in re.finditer(r"([\w \t\*]+?)\b(lg_\w+)\s*\(([^;{}]*)\)\s*;", body):
+        args = [] if m.group(3).strip() in ("", "void") else _split_top(m.group(3))
+        c_funcs[m.group(2)] = (_c_shape(m.group(1)) if m.group(1).strip() != "void" else None, [_c_shape(a) for a in args])
+    assert sorted(c_funcs) == _declared_symbols()
+    rust = open(RUST_SYS).read()
+    block = rust[rust.index('extern "C" {'):]
+    r_funcs = {}
+    for m in re.finditer(r"pub fn (lg_\w+)\((.*?)\)(?:\s*->\s*([^;]+))?;", block):
+        args = [a.split(":", 1)[1] for a in _split_top(m.group(2))] if m.group(2).strip() else []
+        r_funcs[m.group(1)] = (_rust_shape(m.group(3)) if m.group(3) else None, [_rust_shape(a) for a in args])
+    assert sorted(r_funcs) == sorted(c_funcs)
+    for name in c_funcs:
+        assert r_funcs[name] == c_funcs[name], (name, r_funcs[name], c_funcs[name])
+    for m in re.finditer(r"\b(LG_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))", src):                # enum constants
+        rm = re.search(rf"pub const {m.group(1)}: \w+ = (-?(?:0x[0-9a-fA-F]+|\d+));", rust)
+        assert rm and int(rm.group(1), 0) == int(m.group(2), 0), m.group(1)
+    for m in re.finditer(r"^#define\s+(LG_\w+)\s+((?:0x[0-9a-fA-F]+|\d+))u?\s*$", src, flags=re.M):
+        rm = re.search(rf"pub const {m.group(1)}: u32 = ((?:0x[0-9a-fA-F]+|\d+));", rust)
+        assert rm and int(rm.group(1), 0) == int(m.group(2), 0), m.group(1)
+    # struct fields: same names in the same order (layout follows from #[repr(C)] and the widths checked by the generator)
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*\1\s*;", src, flags=re.S):
+        c_names = []
+        for decl in [d for d in m.group(2).split(";") if d.strip()]:
+            fm = re.search(r"\(\s*\*\s*(\w+)\s*\)", decl)
+            c_names += [fm.group(1)] if fm else [re.sub(r"\[.*?\]", "", d).replace("*", " ").split()[-1] for d in _split_top(decl)]
+        rs = re.search(rf"pub struct {m.group(1)} \{{(.*?)\n\}}", rust, flags=re.S)
+        assert rs and re.findall(r"pub (?:r#)?(\w+):", rs.group(1)) == c_names, m.group(1)
+
+
+def test_reference_patch_names_only_generated_items_and_applies():
+    """rust-shim/reference.patch (the reference's prove_inner / open_columns behind `feature = "hip"`): every `sys::` item it uses
+    exists in the generated crate with the argument count used, and -- where the reference tree is present (the build container) -- the
+    patch applies cleanly to it"""
+    import shutil
+    import tempfile
+    patch = open(os.path.join(ROOT, "rust-shim", "reference.patch")).read()
+    rust = open(RUST_SYS).read()
+    added = "\n".join(l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    used = set(re.findall(r"\bsys::(\w+)", added))
+    assert {"lg_ctx_create", "lg_encode_commit", "lg_open_columns", "lg_ctx_destroy"} <= used
+    for item in used:
+        assert re.search(rf"\b(?:pub fn|pub const|pub struct|pub type) {item}\b", rust), item
+    for m in re.finditer(r"sys::(lg_\w+)\(", added):
+        depth, i, args = 1, m.end(), 0
+        has_any = False
+        while depth:
+            ch = added[i]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if ch == "," and depth == 1:
+                args += 1
+            has_any |= not ch.isspace() and depth >= 1 and ch != ")"
+            i += 1
+        n_used = args + 1 if has_any else 0
+        decl = re.search(rf"pub fn {m.group(1)}\((.*?)\)", rust).group(1)
+        assert n_used == (len(_split_top(decl)) if decl.strip() else 0), m.group(1)
+    ref = "/root/reference"
+    if not (os.path.isdir(ref) and shutil.which("patch")):
+        pytest.skip("no reference tree here (GPU box): the patch is applied in the build container's run of this test")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(os.path.join(ref, "Cargo.toml"), tmp)
+        shutil.copytree(os.path.join(ref, "src"), os.path.join(tmp, "src"))
+        subprocess.check_call(["patch", "-p1", "--dry-run", "-s", "-i", os.path.join(ROOT, "rust-shim", "reference.patch")], cwd=tmp)
