@@ -76,9 +76,34 @@ def algorithmic_bytes(rows: int, k: int, n: int, batch: int):
     return commit, evaluate
 
 
+ISA_COUNTS = os.path.join(ROOT, "profiles", "isa_counts.json")
+
+
+def isa_counts_of(k: int):
+    """the evaluate kernel's entry of profiles/isa_counts.json for transforms of size k (tools/isa_counts.py: dynamic instruction
+    counts from the assembly of the tree named in its _source), or None"""
+    try:
+        d = json.load(open(ISA_COUNTS))
+    except (OSError, ValueError):
+        return None
+    for shape, e in d.items():
+        if not shape.startswith("_") and e.get("k") == k:
+            return {"shape": shape, "source": d.get("_source", {}), **e["evaluate"]}
+    return None
+
+
 def multiplier_instr_per_element(k: int):
-    """v_mad_u64_u32 / v_mul_lo_u32 instructions the evaluate kernel executes per output element
-    (ligero_amd/csrc/ntt_kernels.h): shoup29 = 143, reduce29 = 10, Montgomery dot<2> = 261, dot<4> = 423"""
+    """v_mad_u64_u32 / v_mul_lo_u32 instructions the evaluate kernel executes per output element: counted in the kernel's ISA for the
+    three reported shapes (profiles/isa_counts.json); for any other k the closed form over the building blocks of
+    ligero_amd/csrc/ntt_kernels.h (shoup29 = 143, reduce29 = 10, Montgomery dot<2> = 261, dot<4> = 423), which the counted shapes
+    match to 1 %"""
+    counted = isa_counts_of(k)
+    if counted:
+        return counted["multiplier_per_element"]
+    return multiplier_model_per_element(k)
+
+
+def multiplier_model_per_element(k: int):
     lg = k.bit_length() - 1
     if lg < 4 or lg > 14:
         return None
@@ -863,10 +888,22 @@ def valu_roofline_of(workload, stage):
     if mi is None:
         return None
     rate = batch * rows * 7 * k * mi / (stage["evaluate"] * 1e-3) / 1e12
-    return {"unit": "T multiplier lane-instr/s", "kernel": "ntt_rows_kernel<evaluate>",
-            "multiplier_instr_per_element": mi, "achieved": rate, "peak": MAD_PEAK_T, "frac": rate / MAD_PEAK_T,
-            "peak_source": "measured v_mad_u64_u32 issue rate, whole chip (tools/microbench2.hip)",
-            "note": "the remaining issue slots go to carries, butterflies, packing and LDS traffic (DESIGN.md 4.2)"}
+    out = {"unit": "T multiplier lane-instr/s", "kernel": "ntt_rows_kernel<evaluate>",
+           "multiplier_instr_per_element": mi, "achieved": rate, "peak": MAD_PEAK_T, "frac": rate / MAD_PEAK_T,
+           "peak_source": "measured v_mad_u64_u32 issue rate, whole chip (tools/microbench2.hip)",
+           "note": "the remaining issue slots go to carries, butterflies, packing and LDS traffic (DESIGN.md 4.2)"}
+    counted = isa_counts_of(k)
+    if counted:
+        src = counted["source"]
+        out["instr_source"] = f"profiles/isa_counts.json @ {src.get('tree')} (tools/isa_counts.py: dynamic counts from this kernel's ISA, {src.get('compiler')})"
+        out["instr_mix_per_element"] = {"multiplier": counted["multiplier_per_element"], "carry": counted["carry_per_element"], "lds": counted["lds_per_element"],
+                                        "valu_all": counted["valu_per_element"]}
+        out["closed_form_per_element"] = multiplier_model_per_element(k)
+        if "pmc_cross_check" in counted:
+            out["pmc_cross_check"] = counted["pmc_cross_check"]
+    else:
+        out["instr_source"] = "closed form over the kernel's building blocks (bench.py multiplier_model_per_element): no counted entry for this k"
+    return out
 
 
 def main():

@@ -58,9 +58,13 @@ struct lg_batch_prover_state {
     lg_proof_layout layout;
 };
 
+// Frees the prover's state.  The CALLER has drained every stream that touches it -- the context's main stream and the prover's own
+// copy stream (batch_prover_copy_stream) -- under its deadline (lg_ctx_destroy_checked, lg_prover_setup): nothing below waits, and
+// the copy stream goes FIRST, before the staging buffers it reads are freed.
 static void bp_free(lg_ctx* c) {
     lg_batch_prover_state* b = c->bp;
     if (!b) return;
+    if (b->copy) (void)hipStreamDestroy(b->copy);
     for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_small[0], (void*)b->d_small[1]})
         if (p) (void)hipFree(p);
     for (int o = 0; o < 3; o++) {
@@ -68,7 +72,6 @@ static void bp_free(lg_ctx* c) {
         if (b->ev_gathered[o]) (void)hipEventDestroy(b->ev_gathered[o]);
         if (b->ev_copied[o]) (void)hipEventDestroy(b->ev_copied[o]);
     }
-    if (b->copy) { (void)hipStreamSynchronize(b->copy); (void)hipStreamDestroy(b->copy); }
     for (auto& sl : b->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.small_copied) (void)hipEventDestroy(sl.small_copied);
@@ -78,6 +81,8 @@ static void bp_free(lg_ctx* c) {
 }
 // (context.hip calls this from lg_ctx_destroy, after the streams have drained)
 void batch_prover_release(lg_ctx* c) { bp_free(c); }
+// the prover's own stream (copies of the proofs to the host), for the teardown's drain list and lg_sync; null without a prover
+hipStream_t batch_prover_copy_stream(const lg_ctx* c) { return c->bp ? c->bp->copy : nullptr; }
 
 static uint64_t align64(uint64_t x) { return (x + 63) & ~uint64_t{63}; }
 
@@ -183,6 +188,7 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
     if (c->logk + 1 > 14) return LG_ERR_UNSUPPORTED;
     LG_HIP(c, hipSetDevice(c->device));
     LG_HIP(c, hipStreamSynchronize(c->st.main));
+    if (c->bp && c->bp->copy) LG_HIP(c, hipStreamSynchronize(c->bp->copy));      // a re-setup: the old prover's copies are home before its staging is freed
     bp_free(c);
     lg_batch_prover_state* b = new (std::nothrow) lg_batch_prover_state();
     if (!b) return LG_ERR_OOM;
@@ -456,12 +462,20 @@ int lg_prove_batch_wait(lg_ctx* c, const void* proofs_out) {
         // query every 200 us with the thread asleep in between -- LG_WAIT_POLL_US=0 restores the runtime's wait.
         static const long poll_us = [] { const char* e = getenv("LG_WAIT_POLL_US"); return e ? atol(e) : 200L; }();
         if (poll_us <= 0) {
-            LG_HIP(c, hipEventSynchronize(b->slot[si].done));
+            if (const hipError_t q = hipEventSynchronize(b->slot[si].done); q != hipSuccess) {
+                b->slot[si].busy = false;
+                b->slot[si].out = nullptr;
+                return fail_hip(c, q, "hipEventSynchronize(batch done)");
+            }
         } else {
             for (;;) {
                 const hipError_t q = hipEventQuery(b->slot[si].done);
                 if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) return fail_hip(c, q, "hipEventQuery(batch done)");
+                if (q != hipErrorNotReady) {       // the batch is void: its slot (and the caller's buffer) must not stay "in flight" for good
+                    b->slot[si].busy = false;
+                    b->slot[si].out = nullptr;
+                    return fail_hip(c, q, "hipEventQuery(batch done)");
+                }
                 (void)hipGetLastError();
                 std::this_thread::sleep_for(std::chrono::microseconds(poll_us));
             }

@@ -81,7 +81,8 @@ int lg_ctx_destroy_checked(lg_ctx* c) {
     hipSetDevice(c->device);
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(teardown_deadline_ms());
     const struct { hipStream_t s; const char* name; } all[] = {{c->st.main, "main"}, {c->st.hash, "hash"}, {c->st.up, "up"}, {c->st.dn, "dn"},
-                                                               {c->st.tree, "tree"}, {c->st.hash2, "hash2"}, {c->st.xchg, "xchg"}};
+                                                               {c->st.tree, "tree"}, {c->st.hash2, "hash2"}, {c->st.xchg, "xchg"},
+                                                               {batch_prover_copy_stream(c), "prover-copy"}};
     for (const auto& st : all)
         if (!drain_stream(c, st.s, st.name, deadline)) {
             teardown_mark(c, "a stream did not drain: the context is leaked, nothing is freed");
@@ -621,6 +622,7 @@ int lg_sync(lg_ctx* c) {
     { const int rc_ = settle_hash(c); if (rc_ != LG_OK) return rc_; }
     LG_HIP(c, hipStreamSynchronize(c->st.main));
     if (c->scr.copy_pending) { LG_HIP(c, hipEventSynchronize(c->scr.ev_copied)); c->scr.copy_pending = false; }     // queued openings are home
+    if (hipStream_t bc = batch_prover_copy_stream(c)) LG_HIP(c, hipStreamSynchronize(bc));                          // and the throughput prover's proofs
     return LG_OK;
 }
 

@@ -465,3 +465,4 @@ int quadratic_on_device(lg_ctx* c);
 int sub_aux2k(lg_ctx* c);
 // batch_prover.hip
 void batch_prover_release(lg_ctx* c);
+hipStream_t batch_prover_copy_stream(const lg_ctx* c);

@@ -7,9 +7,12 @@
 // the same 0.2 ms of device work instead of the same 61 ms (2^20 constraints) of host evaluation.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/ligero_hip.h"
@@ -94,7 +97,26 @@ fr mont_one() {
 
 void release(lg_tracer* t) {
     (void)hipSetDevice(t->device);
-    if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
+    if (t->stream) {
+        // lg_tracer_rows leaves the stream idle (it waits before it returns); only a call that failed half way can have left work
+        // behind.  Wait for that under a deadline (LG_TEARDOWN_TIMEOUT_MS, as lg_ctx_destroy_checked does): a wedged stream leaks the
+        // tracer -- its buffers stay allocated, named on stderr -- instead of blocking the caller for good.
+        const char* e = getenv("LG_TEARDOWN_TIMEOUT_MS");
+        const long ms = e && atol(e) > 0 ? atol(e) : 120000;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+        for (unsigned spins = 0;; spins++) {
+            const hipError_t q = hipStreamQuery(t->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady || std::chrono::steady_clock::now() > deadline) {
+                (void)hipGetLastError();
+                fprintf(stderr, "libligero_hip: tracer %p not destroyed: its stream %s after %ld ms; leaked\n", static_cast<void*>(t),
+                        q == hipErrorNotReady ? "still holds unfinished work" : hipGetErrorString(q), ms);
+                return;
+            }
+            if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 1000 : 50));
+        }
+        (void)hipStreamDestroy(t->stream);
+    }
     for (void* b : {(void*)t->d_op, (void*)t->d_left, (void*)t->d_right, (void*)t->d_order, (void*)t->d_outputs, (void*)t->d_consts, (void*)t->d_w, (void*)t->d_ok,
                     (void*)t->d_in_pos, (void*)t->d_in_vals, (void*)t->d_rows, (void*)t->d_ranges, (void*)t->d_level_off})
         if (b) (void)hipFree(b);
@@ -172,7 +194,7 @@ int lg_tracer_rows(lg_tracer* t, const uint32_t* in_pos, const uint64_t* in_vals
     if (!t || !device_rows_out || (nin && (!in_pos || !in_vals)) || (nranges && !row_ranges) || nranges > 64 || nin > 0xffffffffull) return LG_ERR_BAD_ARG;
     *device_rows_out = nullptr;
     // every variable exactly once and nothing else, in the reference's words (mod.rs:476-478; arithmetic_circuit/mod.rs:341)
-    const bool same = t->h_in_pos.size() == nin && (nin == 0 || memcmp(t->h_in_pos.data(), in_pos, nin * 4) == 0);
+    const bool same = nin == t->ninputs && t->h_in_pos.size() == nin && (nin == 0 || memcmp(t->h_in_pos.data(), in_pos, nin * 4) == 0);   // (the count: see trace_on_device)
     if (!same) {
         std::vector<uint8_t> seen(t->npos, 0);
         for (uint64_t i = 0; i < nin; i++) {

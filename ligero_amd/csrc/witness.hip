@@ -381,7 +381,9 @@ int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, 
     const uint64_t mk = (uint64_t)m * c->k;
     // the assignment must name every variable once and nothing else (mod.rs:476-478; "Value supplied for non-variable node",
     // arithmetic_circuit/mod.rs:341).  The same positions as last time (the usual case) are not looked at again.
-    const bool same = t.h_in_pos.size() == nin && (nin == 0 || memcmp(t.h_in_pos.data(), in_pos, nin * 4) == 0);
+    // (an assignment is only ever remembered after it passed the checks below, so `same` implies nin == t.ninputs -- except for the empty
+    // one, which a freshly uploaded program "remembers" trivially: the count is therefore part of the shortcut)
+    const bool same = nin == t.ninputs && t.h_in_pos.size() == nin && (nin == 0 || memcmp(t.h_in_pos.data(), in_pos, nin * 4) == 0);
     if (!same) {
         std::vector<uint8_t> seen(t.npos, 0);
         for (uint64_t i = 0; i < nin; i++) {

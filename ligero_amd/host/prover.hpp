@@ -385,6 +385,11 @@ public:
         }
     }
     ~HipLigeroT() {
+        // openings queued and not yet home (lg_open_columns_async; an exception in the middle of a proof leaves them so) still write
+        // into pending_[].cols on the download stream: lg_sync waits for them -- and for every other stream of the context -- before
+        // any page-locked block is unregistered
+        (void)lg_open_columns_wait(ctx_);
+        (void)lg_sync(ctx_);
         for (auto& po : pending_) {
             if (po.worker.joinable()) po.worker.join();
             if (po.pinned) lg_host_unregister(ctx_, po.cols.data());
@@ -1526,7 +1531,9 @@ public:
         const int slot = (int)(collected_ & 1);
         PhaseTimer tm;
         const auto t0 = std::chrono::steady_clock::now();
-        check(lg_prove_batch_wait(ctx_, arena_[slot].data()), "lg_prove_batch_wait");
+        const int st = lg_prove_batch_wait(ctx_, arena_[slot].data());
+        if (st != LG_OK && st != LG_ERR_STATE) collected_++;      // a hard error voids the batch and frees its slot (batch_prover.hip): the host side moves on with it
+        check(st, "lg_prove_batch_wait");
         stats_.wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         tm.mark("proofs (device)");
         collected_++;
@@ -1665,6 +1672,14 @@ public:
 private:
     void release() {
         if (!ctx_) return;
+        // Up to two batches may be submitted and not collected (an exception between submit() and collect() lands here): the encode
+        // stream, the prover's copy stream and the upload stream are then still reading and writing the page-locked blocks
+        // unregistered below.  Collect what is in flight; should that fail, lg_sync waits for every stream of the context (the
+        // prover's copy stream included) -- only then is host memory handed back.
+        while (in_flight()) {
+            try { collect(); } catch (...) { collected_ = submitted_; break; }
+        }
+        (void)lg_sync(ctx_);
         if (pinned_mat_) lg_host_unregister(ctx_, mat_.data());
         if (pinned_cols_) lg_host_unregister(ctx_, cols_.data());
         if (pinned_mat2_) lg_host_unregister(ctx_, mat2_.data());

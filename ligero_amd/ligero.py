@@ -124,8 +124,14 @@ class LigeroCommitter:
     def __enter__(self):
         return self
 
-    def __exit__(self, *exc):
-        self.close()
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            self.close()
+        except RuntimeError as teardown:
+            if exc_type is None:
+                raise
+            # the with-block is already unwinding with an exception of its own: that one must reach the caller; the leak is said on stderr
+            os.write(2, f"[LigeroCommitter.__exit__] {teardown} (while handling {exc_type.__name__})\n".encode())
 
     def _chk(self, st, what):
         _ffi.check(st, what, self._ctx)

@@ -262,3 +262,29 @@ def test_smallest_circuit():
     with ref, dev:
         _, root, ok = dev.encode_commit_from_inputs(inst.input_positions(var), vals)
         assert root == ref.encode_commit_from_witness(w)[1] and bool(ok[0]) == ok_host
+
+
+def test_an_empty_assignment_on_a_fresh_program_is_refused(poseidon_inst):
+    """round 5 (ADVICE): a freshly uploaded program remembers no assignment; an EMPTY one must not pass as "the same as last time" --
+    the header promises LG_ERR_BAD_ARG ("Uninitialised variable", mod.rs:477) for a circuit that has variables, through the commitment
+    entry point and through a rank's tracer, and the context must still work afterwards"""
+    import ligero_amd
+    from ligero_amd import _ffi
+    inst = poseidon_inst
+    left, right, consts = inst.gate_map()
+    none_pos, none_vals = np.zeros(0, dtype=np.uint32), np.zeros((1, 0, 4), dtype=np.uint64)
+    with ligero_amd.LigeroCommitter(rows=inst.rows, k=inst.k) as c:
+        c.upload_gate_map(left, right, consts)
+        c.upload_trace_program(inst.trace_program())
+        with pytest.raises(ligero_amd.LigeroHipError) as e:
+            c.encode_commit_from_inputs(none_pos, none_vals)
+        assert e.value.status == _ffi.LG_ERR_BAD_ARG and "Uninitialised variable" in str(e.value)
+        idx = list(range(1, 265))
+        from test_gpu_witness import _batch_witnesses
+        from oracle import binding as orc
+        vals = np.stack(_batch_witnesses(orc, 1))
+        _, root, ok = c.encode_commit_from_inputs(inst.input_positions(idx), vals)
+        assert ok.all()
+        with pytest.raises(ligero_amd.LigeroHipError):                       # and after a good assignment too
+            c.encode_commit_from_inputs(none_pos, none_vals)
+        assert c.encode_commit_from_inputs(inst.input_positions(idx), vals)[1] == root

@@ -39,6 +39,20 @@ for WL in poseidon s20 s22; do
   python3 tools/pmc_traffic.py $WL /tmp/pq_${WL}_FETCH_SIZE.csv /tmp/pq_${WL}_WRITE_SIZE.csv > /dev/null
 done
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
+# the numerator of bench.py's valu_roofline: dynamic instruction counts from the ISA of THIS tree (profiles/isa_counts.json), with the
+# hardware's own count of VALU instructions per wave beside them (one PMC pass per shape; counters in a run of their own)
+python3 tools/isa_counts.py > "$OUT/${TAG}_isa_counts.log" 2>&1
+PMCARGS=""
+for WL in poseidon s20 s22; do
+  D=/tmp/prof_${WL}_insts; rm -rf $D
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $D -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline \
+      > /dev/null 2> "$OUT/${TAG}_${WL}_pmc_insts.err"
+  f=$(find $D -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && (head -1 "$f"; grep -E 'ntt_rows_kernel' "$f") > "$OUT/${TAG}_${WL}_pmc_insts.csv" && PMCARGS="$PMCARGS $WL=$OUT/${TAG}_${WL}_pmc_insts.csv"
+  echo "pmc insts $WL done"
+done
+python3 tools/isa_counts.py --pmc $PMCARGS >> "$OUT/${TAG}_isa_counts.log" 2>&1
+cp profiles/isa_counts.json "$OUT/isa_counts.json"
 # the proofs/s leg: the child bench.py runs, under the profiler (the program itself after `--`, no torch in it)
 D=/tmp/prof_prover; rm -rf $D
 LIGERO_NO_TORCH_PRELOAD=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $D -- python3 bench.py --prover-child 0 device 1024 6 0 \
