@@ -463,6 +463,34 @@ typedef struct lg_comm {
 } lg_comm;
 enum { LG_COMM_EXCHANGE_AT_WORLD_1 = 1 };
 /*
+ * A second provider of lg_comm::all_gather beside the caller's RCCL binding: PEER PUSH.  Every rank writes its block straight
+ * into the other ranks' buffers (a device-to-device copy per peer, queued on the stream the library names: on a node each of
+ * them goes out over its own xGMI link, where a ring is bound by one), the buffers being mapped into every process once through
+ * HIP IPC (hipIpcGetMemHandle / hipIpcOpenMemHandle of the allocation that holds device_buf, on first use) and the hand-over
+ * ordered by two interprocess events per rank ("my old contents are consumed", "my pushes are done") with a host barrier before
+ * each is waited for -- the device is never waited for on the host.  SURVEY section 5 / 8(e) step 2 asked for this shape of the
+ * coefficient all-gather (5.26 GB at 2^22 constraints).
+ *   lg_push_comm_create    collective over the `world` ranks.  boot: the caller's out-of-band channel -- an all-gather of equal HOST
+ *                          blocks (recv = world blocks of `bytes`, block r from rank r; used when a buffer is first mapped) and a
+ *                          barrier (twice per exchange); both return 0 on success.  One process per rank; the ranks' devices may
+ *                          be one device (how the tests run it) or peers.
+ *   lg_push_comm_bind      fills comm->world, rank, flags, user and all_gather; send / recv / broadcast are left as they are.
+ *                          The exchanged buffers must outlive the push comm (destroy it before the contexts it served).
+ *   lg_push_comm_destroy   collective (it begins with a barrier: nobody unmaps while a peer may still push).
+ * Functional on this pool with two processes on one GPU (tests/test_gpu_sharded.py); NOT timed against RCCL on a node -- no
+ * 8-GPU node was available to this build.
+ */
+typedef struct lg_push_comm lg_push_comm;
+typedef struct lg_push_bootstrap {
+    void* user;
+    int (*all_gather_host)(void* user, const void* send, void* recv, uint64_t bytes);
+    int (*barrier)(void* user);
+} lg_push_bootstrap;
+int lg_push_comm_create(lg_push_comm** out, int device, uint32_t world, uint32_t rank, const lg_push_bootstrap* boot);
+int lg_push_comm_bind(lg_push_comm* pc, lg_comm* comm, uint32_t flags);
+const char* lg_push_comm_last_error(const lg_push_comm* pc);
+void lg_push_comm_destroy(lg_push_comm* pc);
+/*
  * Coset-sharded commit (steps 1-5 of lg_stage_*; ctx from lg_ctx_create_sharded with the plane run [rank np/world, (rank + 1)
  * np/world)).  Row ownership: the rows are cut into `pieces` (1..8) pieces of world * sub rows and rank g owns sub-block g of
  * every piece (lg_shard_row_ranges; pieces = 1: equal shards of ceil(rows / world) rows) -- so piece p of the coefficient

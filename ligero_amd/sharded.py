@@ -23,6 +23,7 @@ gloo at world_size 2 without a GPU.
 from __future__ import annotations
 
 import ctypes
+import os
 import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -192,6 +193,72 @@ class TorchComm:
         return self._guard("broadcast", go)
 
 
+class _LgPushBootstrap(ctypes.Structure):
+    _fields_ = [("user", _vp), ("all_gather_host", ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64)), ("barrier", ctypes.CFUNCTYPE(ctypes.c_int, _vp))]
+
+
+class PushComm(TorchComm):
+    """`lg_comm` with the all-gather served by the library's PEER-PUSH provider (include/ligero_hip.h lg_push_comm: every rank
+    copies its block into the peers' buffers, mapped through HIP IPC; interprocess events order the hand-over) instead of
+    `dist.all_gather_into_tensor`; send / recv / broadcast stay torch.distributed's.  torch.distributed is only the out-of-band
+    channel here: an all-gather of small host blocks when a buffer is first mapped and two barriers per exchange, on `boot_group`
+    (a gloo group: host tensors; under an "nccl" default group one is made with dist.new_group(backend="gloo") -- collectively).
+    Select with LIGERO_ALLGATHER=push (make_comm).  close() is collective and must run before the contexts it served are destroyed."""
+
+    def __init__(self, dist, group=None, device: int = 0, exchange_at_world_1: bool = False, boot_group=None):
+        super().__init__(dist, group, device, exchange_at_world_1)
+        if dist is None:
+            raise ValueError("PushComm needs a process group (its bootstrap channel)")
+        self._L = _ffi.lib()
+        if boot_group is None and dist.get_backend(group) != "gloo":
+            boot_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend="gloo")
+        self._boot_group = boot_group if boot_group is not None else group
+        self._boot_cbs = (_LgPushBootstrap._fields_[1][1](self._boot_all_gather), _LgPushBootstrap._fields_[2][1](self._boot_barrier))
+        self._boot = _LgPushBootstrap(None, *self._boot_cbs)
+        self._pc = _vp()
+        st = self._L.lg_push_comm_create(ctypes.byref(self._pc), device, self.world, self.rank, ctypes.cast(ctypes.byref(self._boot), _vp))
+        if st != _ffi.LG_OK:
+            raise RuntimeError(f"lg_push_comm_create: status {st} ({self._L.lg_push_comm_last_error(None).decode()}) [{self.error}]")
+        flags = _ffi.LG_COMM_EXCHANGE_AT_WORLD_1 if exchange_at_world_1 else 0
+        st = self._L.lg_push_comm_bind(self._pc, self.ptr(), flags)
+        if st != _ffi.LG_OK:
+            raise RuntimeError(f"lg_push_comm_bind: status {st}")
+        self.provider = "push"
+
+    def _boot_all_gather(self, _user, send, recv, nbytes):
+        def go():
+            import torch
+            n = int(nbytes)
+            src = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(int(send)))).clone()
+            parts = [torch.empty(n, dtype=torch.uint8) for _ in range(self.world)]
+            self.dist.all_gather(parts, src, group=self._boot_group)
+            dst = np.ctypeslib.as_array((ctypes.c_uint8 * (n * self.world)).from_address(int(recv)))
+            for r, p_ in enumerate(parts):
+                dst[r * n:(r + 1) * n] = p_.numpy()
+        return self._guard("push bootstrap all_gather", go)
+
+    def _boot_barrier(self, _user):
+        return self._guard("push bootstrap barrier", lambda: self.dist.barrier(group=self._boot_group))
+
+    def last_error(self) -> str:
+        return self._L.lg_push_comm_last_error(self._pc).decode() if self._pc else ""
+
+    def close(self):
+        if getattr(self, "_pc", None):
+            self._L.lg_push_comm_destroy(self._pc)
+            self._pc = _vp()
+
+    __del__ = close
+
+
+def make_comm(dist, group=None, device: int = 0, exchange_at_world_1: bool = False):
+    """the lg_comm provider of a sharded commit: LIGERO_ALLGATHER=push -> PushComm (peer push over HIP IPC), anything else -> TorchComm
+    (RCCL under backend "nccl")"""
+    if dist is not None and os.environ.get("LIGERO_ALLGATHER", "").lower() == "push":
+        return PushComm(dist, group, device, exchange_at_world_1)
+    return TorchComm(dist, group, device, exchange_at_world_1)
+
+
 def shard_row_ranges(rows: int, world: int, rank: int, pieces: int = 1) -> List[Tuple[int, int]]:
     """[(first row, rows)] of the ranges `rank` owns in the coset-sharded commit, in the order its rows are handed over
     (lg_shard_row_ranges): the rows are cut into `pieces` pieces of world * sub rows, the rank owns sub-block `rank` of every
@@ -359,8 +426,13 @@ class CosetShardedCommitter:
         self.stage_ms: Dict[str, float] = {}      # per-stage ms of the last commit(s): HIP events (native) or host laps (stage by stage)
         self._digest_buf = None
         self.native = hasattr(backend, "commit_native")
-        self._comm = TorchComm(dist, group, backend.device, exchange_at_world_1=self.force) if self.native else None
+        self._comm = make_comm(dist, group, backend.device, exchange_at_world_1=self.force) if self.native else None
         self._profiling = False
+
+    def close_comm(self):
+        """collective: releases a peer-push provider's mappings (PushComm); call it before the backend's context is destroyed"""
+        if self._comm is not None and hasattr(self._comm, "close"):
+            self._comm.close()
 
     def row_ranges(self, rank: Optional[int] = None) -> List[Tuple[int, int]]:
         """the row ranges this rank hands to commit(), concatenated in this order"""

@@ -43,8 +43,13 @@ def _rank_body(rank, world, dist, rows, k, pieces=1):
             refused = False
         except Exception as e:                                              # LigeroHipError(status = LG_ERR_STATE)
             refused = getattr(e, "status", None) == -6
-        return (root, {j: (c.tobytes(), s.tobytes(), p.tobytes()) for j, (c, s, p) in opened.items()}, refused, dict(sc.stage_ms))
+        stage_ms = dict(sc.stage_ms)
+        if os.environ.get("LIGERO_ALLGATHER") == "push":                      # which lg_comm provider served the all-gathers (make_comm)
+            stage_ms["_provider"] = getattr(sc._comm, "provider", "torch")
+        return (root, {j: (c.tobytes(), s.tobytes(), p.tobytes()) for j, (c, s, p) in opened.items()}, refused, stage_ms)
     finally:
+        if "sc" in locals():
+            sc.close_comm()          # a peer-push provider unmaps the peers' buffers (collectively) before the context goes
         be.close()
 
 
@@ -153,6 +158,32 @@ def test_pipelined_exchange_on_the_real_backend(oracle, world, rows, k, pieces):
         assert root == ref["root"], rank
         assert refused
         assert set(stage_ms) == {"interpolate", "allgather_coeffs", "evaluate_hash", "allgather_digests", "merkle"}
+        got.update(opened)
+    assert got == want
+
+
+@pytest.mark.parametrize("world,rows,k,pieces", [(2, 21, 128, 1), (2, 21, 128, 3), (2, 5, 8192, 2), (4, 10, 128, 4)])
+def test_peer_push_all_gather_over_hip_ipc(oracle, monkeypatch, world, rows, k, pieces):
+    """round 5: lg_commit_sharded with its all-gathers served by the library's PEER-PUSH provider (lg_push_comm, LIGERO_ALLGATHER=push:
+    every rank copies its block of the coefficient rows -- and of the leaf digests -- straight into the other ranks' buffers, mapped
+    through HIP IPC on first use; interprocess events order the hand-over, the hosts meet at two barriers per exchange over gloo).
+    Separate PROCESSES sharing the one GPU, as the RCCL-free path of an 8-GPU node would run one per GPU.  Root and owner-served
+    openings equal the oracle's; one piece and pipelined pieces, a ragged shard, folded k = 8192, a second commit on the same mappings."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("LIGERO_ALLGATHER", "push")
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), rows, k, out, pieces), nprocs=world, join=True)
+    pre = random_mont(515, rows * k).reshape(rows, k, 4)
+    ref = oracle.encode_commit(pre, k, 8 * k)
+    ecols, esib, epaths = oracle.open_columns(ref["u"], ref["leaves"], ref["nodes"], [0, 5, 8 * k - 1])
+    want = {j: (ecols[i].tobytes(), esib[i].tobytes(), epaths[i].tobytes()) for i, j in enumerate([0, 5, 8 * k - 1])}
+    got = {}
+    for rank in range(world):
+        root, opened, refused, stage_ms = out[rank]
+        assert stage_ms["_provider"] == "push", rank
+        assert root == ref["root"], rank
+        assert refused
         got.update(opened)
     assert got == want
 
