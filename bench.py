@@ -607,7 +607,7 @@ def golden_large(workload: str):
 
 
 def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, rank: int, local_rank: int, steps: int, warmup: int,
-                       partial: dict = None):
+                       partial: dict = None, only_first_mode: bool = False):
     """ONE proof of the `workload` shape over `world` ranks (BASELINE configs[3]); returns the result dict on every rank.
     Timed region: barrier + sync, `steps` commits QUEUED back to back with the message rows resident (each commit is one
     library call -- lg_commit_sharded / lg_commit_row_relay -- whose exchanges come back through TorchComm on the library's own
@@ -674,9 +674,13 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
             "mode": "coset-sharded: one all-gather, then evaluate + hash",
         }
         out["coset_one_allgather_ms_per_commit"] = out["ms_per_commit"]
+        out["allgather_provider"] = getattr(sc._comm, "provider", "torch.distributed (RCCL under nccl)") if sc._comm is not None else None
+        out["rccl_ranks_seen"] = world if (dist is not None and backend == "nccl") else 0
         if partial is not None:
             partial["sharded_commit"] = dict(out)
         best = elapsed
+        if only_first_mode:
+            return out
         if pieces > 1:
             try:
                 sp = CosetShardedCommitter(be, dist, collectives_at_world_1=True, exchange_pieces=pieces)
@@ -694,6 +698,9 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
             except Exception as e:
                 out["pipelined"] = {"error": f"{type(e).__name__}: {e}"}
     finally:
+        for c_ in (locals().get("sc"), locals().get("sp")):
+            if c_ is not None:
+                c_.close_comm()          # a peer-push provider unmaps (collectively) before the context goes
         be.close()
     if os.environ.get("LIGERO_BENCH_ROW_RELAY", "1") != "0":
         rc = None
@@ -741,6 +748,36 @@ def sharded_commit_leg(torch, dist, backend: str, workload: str, world: int, ran
             if rr is not None:
                 rr.be.close()
     return out
+
+
+def push_allgather_leg(torch, dist, backend, workload, world, rank, local_rank, steps, warmup, finish):
+    """The coset-sharded commit once more with its all-gathers served by the library's PEER-PUSH provider (lg_push_comm over HIP IPC:
+    every rank copies its coefficient rows straight into the peers' buffers, one copy per peer = one xGMI link each) instead of RCCL's
+    all-gather -- SURVEY section 5 / 8(e): a ring is bound by one link.  LIGERO_BENCH_ALLGATHER = both (default: this leg runs beside the
+    RCCL-served one whenever there is more than one rank) | rccl (skip it) | push.  Runs LAST, under its own timer: should it hang
+    on a machine this build never saw (it has run with two and four PROCESSES on one GPU only), `finish` is called with an error
+    record and every rank leaves with status 0 -- everything the contract asks for has been measured by then."""
+    import threading
+
+    def bail():
+        finish({"error": "the peer-push leg did not finish in time; dropped", "rccl_ranks_seen": world if backend == "nccl" else 0})
+        os._exit(0)
+    timer = threading.Timer(float(os.environ.get("LIGERO_BENCH_PUSH_TIMEOUT", "150")), bail)
+    timer.daemon = True
+    timer.start()
+    os.environ["LIGERO_ALLGATHER"] = "push"
+    try:
+        res = sharded_commit_leg(torch, dist, backend, workload, world, rank, local_rank, steps, warmup, None, only_first_mode=True)
+        res = {k_: res[k_] for k_ in ("workload", "ms_per_commit", "value", "unit", "stage_ms_max_over_ranks", "allgather_coeffs_GBs_per_rank_ingress",
+                                      "root_matches_golden", "allgather_provider", "rccl_ranks_seen", "mode") if k_ in res}
+        res["note"] = ("same commit, all-gathers by peer push over HIP IPC (include/ligero_hip.h lg_push_comm); compare ms_per_commit / allgather_coeffs with "
+                       "sharded_commit.coset_one_allgather_ms_per_commit of the RCCL-served run above")
+    except Exception as e:
+        res = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        os.environ.pop("LIGERO_ALLGATHER", None)
+        timer.cancel()
+    return res
 
 
 def host_buffer_commit_ms(ligero_amd, pre, rows, k, batch, device, reps, witness=None, inputs=None):
@@ -999,6 +1036,14 @@ def main():
             watchdog.cancel()
             if rank == 0:
                 line["sharded_prove"] = sp_res
+            if world > 1 and os.environ.get("LIGERO_BENCH_ALLGATHER", "both") in ("both", "push"):
+                def finish(res_):
+                    if rank == 0:
+                        line["sharded_commit_peer_push"] = res_
+                        emit(line)
+                pres = push_allgather_leg(torch, dist, backend, args.workload, world, rank, local_rank, min(steps, 5), 2, finish)
+                if rank == 0:
+                    line["sharded_commit_peer_push"] = pres
         if rank == 0:
             emit(line)
         dist.barrier()
@@ -1208,6 +1253,17 @@ def main():
                 line["s20"]["full_prover_from_r1cs"] = s20_prover_rate(local_rank)
             except Exception as e:
                 line["s20"]["full_prover_from_r1cs"] = {"error": f"{type(e).__name__}: {e}"}
+    if (dist is not None and world > 1 and args.sharded_leg != "none" and not args.no_cpu_baseline
+            and os.environ.get("LIGERO_BENCH_ALLGATHER", "both") in ("both", "push")):
+        # last of all (see push_allgather_leg): the same sharded commit with the peer-push all-gather instead of RCCL's
+        def finish(res_):
+            if rank == 0:
+                line["sharded_commit_peer_push"] = res_
+                emit(line)
+        pres = push_allgather_leg(torch, dist, backend, args.sharded_leg, world, rank, local_rank, 5, 2, finish)
+        if rank == 0:
+            line["sharded_commit_peer_push"] = pres
+    if rank == 0:
         emit(line)
     if dist is not None:
         dist.barrier()
