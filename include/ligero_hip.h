@@ -312,6 +312,16 @@ typedef struct lg_proof_layout {
 } lg_proof_layout;
 int lg_prover_setup(lg_ctx* ctx, const lg_sponge_params* sponge, uint32_t t);
 int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
+/*
+ * RESIDENT mode of the throughput prover: the three openings of every proof -- 99 % of a proof's bytes -- stay in the device staging
+ * (a consumer on the device, or a measurement of what the device can prove when PCIe is not the bound); what lg_prove_batch_queue*
+ * then delivers is the small region as before (roots, preenc_u_lc, both polynomials, lengths, status: exact) and, per sub-proof
+ * o, `batch` records of four SHA-256 digests at off_idx[o] of the layout -- record b = [ SHA-256(the t indices, LE32 each) |
+ * SHA-256(SHA-256(column 0) || ... || SHA-256(column t - 1)), a column being its 4m elements as 32-byte Montgomery words |
+ * SHA-256(the t sibling digests) | SHA-256(the t paths) ] -- so that a test can check, without the bytes, that the same proofs were
+ * made (tests/test_gpu_prover.py).  Nothing else of the layout's opening regions is written.  Not while a batch is in flight.
+ */
+int lg_prover_set_resident(lg_ctx* ctx, int on);
 int lg_prove_batch_queue(lg_ctx* ctx, const uint64_t* w, void* proofs_out);
 /* the same with w evaluated on the device from every proof's inputs (lg_upload_trace_program; in_vals = batch * nin elements,
  * page-locked or the copy blocks the calling thread -- and then untouched until lg_prove_batch_wait has returned for this batch; in_pos is

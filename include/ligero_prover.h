@@ -89,6 +89,10 @@ int lgp_batch_prover_create(lgp_batch_prover** out, const lgh_instance* inst, ui
 enum { LGP_BATCH_DEVICE_TRANSCRIPT = 1 };
 int lgp_batch_prover_create_ex(lgp_batch_prover** out, const lgh_instance* inst, uint32_t batch, int device, uint32_t threads, uint32_t flags);
 int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_proof_layout* layout_out);
+/* RESIDENT mode of a device-transcript prover (include/ligero_hip.h lg_prover_set_resident): the openings stay on the device; a batch's
+ * arena then holds the small items and, per sub-proof, `batch` records of four SHA-256 digests at off_idx[o].  lgp_batch_proof is
+ * refused for such a batch.  Waits for the batches in flight. */
+int lgp_batch_prover_set_resident(lgp_batch_prover* p, int on);
 /* lgp_prove_batch in two halves (device-transcript provers only): submit assembles w on the host threads and queues the batch
  * on the device, collect waits for the OLDEST batch queued; at most two may be in flight.  submit(i + 1) before collect(i)
  * keeps the device and PCIe busy while the host works.  After collect, lgp_batch_proof_arena / lgp_batch_proof show that batch

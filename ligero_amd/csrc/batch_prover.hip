@@ -25,6 +25,7 @@
 
 #include "lg_context.h"
 #include "challenge_kernels.h"
+#include "hash_kernels.h"
 #include "sponge_kernels.h"
 
 struct lg_batch_prover_state {
@@ -56,6 +57,11 @@ struct lg_batch_prover_state {
     // priority levels never share a queue.  (It carries copies, not kernels -- unless the small-grid ship kernel is in use.)
     hipStream_t copy = nullptr;
     lg_proof_layout layout;
+    // RESIDENT mode (lg_prover_set_resident): the opened columns and their paths stay in the device staging; what goes home per
+    // sub-proof and proof is a record of four SHA-256 digests (indices, columns, siblings, paths) -- 128 bytes instead of 1.8 MB
+    bool resident = false;
+    uint8_t* d_digest[3] = {nullptr, nullptr, nullptr};   // [batch][4][32]
+    uint8_t* d_coldig = nullptr;                            // [batch][t][32]: per-column digests, scratch of the column record
 };
 
 // Frees the prover's state.  The CALLER has drained every stream that touches it -- the context's main stream and the prover's own
@@ -67,7 +73,9 @@ static void bp_free(lg_ctx* c) {
     if (b->copy) (void)hipStreamDestroy(b->copy);
     for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_small[0], (void*)b->d_small[1]})
         if (p) (void)hipFree(p);
+    if (b->d_coldig) (void)hipFree(b->d_coldig);
     for (int o = 0; o < 3; o++) {
+        if (b->d_digest[o]) (void)hipFree(b->d_digest[o]);
         if (b->d_open[o]) (void)hipFree(b->d_open[o]);
         if (b->ev_gathered[o]) (void)hipEventDestroy(b->ev_gathered[o]);
         if (b->ev_copied[o]) (void)hipEventDestroy(b->ev_copied[o]);
@@ -112,6 +120,64 @@ static __global__ void __launch_bounds__(256) ship_kernel(const ShipArgs a) {
         }
         for (; i < n; i += nthreads) __builtin_nontemporal_store(src[i], dst + i);
     }
+}
+}  // namespace lg
+
+// ---- resident mode: SHA-256 of byte ranges that stay on the device (one lane per range; ranges are multiples of 4 bytes)
+namespace lg {
+__device__ __forceinline__ void sha256_range(const uint8_t* p, uint64_t bytes, uint8_t* out32) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p);
+    uint32_t st[8], w[16];
+    sha256_init(st);
+    const uint64_t words = bytes / 4, full = words / 16;
+    for (uint64_t blk = 0; blk < full; blk++) {
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const uint4* q = reinterpret_cast<const uint4*>(src + 16 * blk);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const uint4 v = q[i]; w[4 * i] = bswap32(v.x); w[4 * i + 1] = bswap32(v.y); w[4 * i + 2] = bswap32(v.z); w[4 * i + 3] = bswap32(v.w); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) w[i] = bswap32(src[16 * blk + i]);
+        }
+        sha256_block(st, w);
+    }
+    const uint32_t rem = (uint32_t)(words - 16 * full);       // 0..15 words left, then the padding
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)i < rem ? bswap32(src[16 * full + i]) : 0u;
+    w[rem] = 0x80000000u;
+    if (rem >= 14) {
+        sha256_block(st, w);
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = 0;
+    }
+    w[14] = (uint32_t)((bytes * 8) >> 32);
+    w[15] = (uint32_t)(bytes * 8);
+    sha256_block(st, w);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = bswap32(st[i]);
+}
+struct DigestArgs {
+    const uint8_t* idx; const uint8_t* cols; const uint8_t* sib; const uint8_t* paths;   // the staging regions of one sub-proof
+    uint8_t* coldig;    // [batch][t][32]
+    uint8_t* out;       // [batch][4][32]
+    uint32_t batch, t, rows, plen;
+};
+// one lane per opened column: SHA-256 of its rows * 32 bytes as they lie in the staging (Montgomery words)
+static __global__ void __launch_bounds__(64) digest_columns_kernel(const DigestArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= (uint64_t)a.batch * a.t) return;
+    sha256_range(a.cols + i * a.rows * 32, (uint64_t)a.rows * 32, a.coldig + i * 32);
+}
+// one lane per (proof, item): 0 the t indices, 1 the t column digests, 2 the t sibling digests, 3 the t paths
+static __global__ void __launch_bounds__(64) digest_records_kernel(const DigestArgs a) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.batch * 4) return;
+    const uint32_t b = i >> 2, item = i & 3;
+    const uint8_t* p = item == 0 ? a.idx + (uint64_t)b * a.t * 4 : item == 1 ? a.coldig + (uint64_t)b * a.t * 32
+                     : item == 2 ? a.sib + (uint64_t)b * a.t * 32 : a.paths + (uint64_t)b * a.t * a.plen * 32;
+    const uint64_t bytes = item == 0 ? (uint64_t)a.t * 4 : item == 3 ? (uint64_t)a.t * a.plen * 32 : (uint64_t)a.t * 32;
+    sha256_range(p, bytes, a.out + (uint64_t)i * 32);
 }
 }  // namespace lg
 
@@ -293,6 +359,23 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
     return rc;
 }
 
+int lg_prover_set_resident(lg_ctx* c, int on) {
+    if (!c) return LG_ERR_BAD_ARG;
+    lg_batch_prover_state* b = c->bp;
+    if (!b) return LG_ERR_STATE;
+    if (b->slot[0].busy || b->slot[1].busy) {
+        snprintf(c->err, sizeof(c->err), "lg_prover_set_resident: a batch is in flight (lg_prove_batch_wait first)");
+        return LG_ERR_STATE;
+    }
+    LG_HIP(c, hipSetDevice(c->device));
+    if (on && !b->d_coldig) {
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_coldig), (size_t)c->batch * b->t * 32));
+        for (int o = 0; o < 3; o++) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_digest[o]), (size_t)c->batch * 128));
+    }
+    b->resident = on != 0;
+    return LG_OK;
+}
+
 int lg_prover_layout(const lg_ctx* c, lg_proof_layout* out) {
     if (!c || !out) return LG_ERR_BAD_ARG;
     if (!c->bp) return LG_ERR_STATE;
@@ -403,6 +486,16 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
         LG_LAUNCH(c, lg::distinct_indices_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ia);
         { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
         { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, reinterpret_cast<fr*>(st + b->open_cols), st + b->open_sib, st + b->open_paths); if (rc_ != LG_OK) return rc_; }
+        if (b->resident) {      // the opening stays here: its four digests per proof go home in its place (the first batch * 128 bytes of the region)
+            lg::DigestArgs da{st + b->open_idx, st + b->open_cols, st + b->open_sib, st + b->open_paths, b->d_coldig, b->d_digest[o], B, t, c->rows, b->plen};
+            LG_LAUNCH(c, lg::digest_columns_kernel, dim3((uint32_t)(((uint64_t)B * t + 63) / 64)), dim3(64), 0, s, da);
+            LG_LAUNCH(c, lg::digest_records_kernel, dim3((B * 4 + 63) / 64), dim3(64), 0, s, da);
+            LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
+            LG_HIP(c, hipStreamWaitEvent(b->copy, b->ev_gathered[o], 0));
+            LG_HIP(c, hipMemcpyAsync(out + L.off_idx[o], b->d_digest[o], (size_t)B * 128, hipMemcpyDeviceToHost, b->copy));
+            LG_HIP(c, hipEventRecord(b->ev_copied[o], b->copy));
+            return LG_OK;
+        }
         LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
         LG_HIP(c, hipStreamWaitEvent(b->copy, b->ev_gathered[o], 0));
         const ShipSeg seg = {st, out + L.off_idx[o], b->open_bytes};   // (staging and the layout's region of sub-proof o are laid out alike)

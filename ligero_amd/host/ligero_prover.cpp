@@ -130,6 +130,10 @@ int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_p
     *layout_out = p->hip.layout();
     return LGP_OK;
 }
+int lgp_batch_prover_set_resident(lgp_batch_prover* p, int on) {
+    if (!p) return LGP_ERR_BAD_ARG;
+    return guarded([&] { p->hip.set_resident(on != 0); return LGP_OK; });
+}
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p) { return p ? p->hip.threads() : 0; }
 int lgp_batch_prover_device_trace(const lgp_batch_prover* p) { return p && p->hip.device_trace() ? 1 : 0; }
 int lgp_prover_device_trace(const lgp_prover* p) { return p && p->hip.device_trace() ? 1 : 0; }

@@ -1453,6 +1453,15 @@ public:
     // valid until the second submit() after the collect() that returned it
     const uint8_t* arena() const { return arena_[last_collected_].data(); }
     const lg_proof_layout& layout() const { return layout_; }
+    // RESIDENT mode (include/ligero_hip.h lg_prover_set_resident): the openings stay on the device, the arena receives the small items and
+    // four digests per sub-proof and proof; proof objects cannot be made from such a batch (proof_from_arena is refused)
+    void set_resident(bool on) {
+        if (!device_transcript_) throw std::runtime_error("resident mode needs the device transcript");
+        while (in_flight()) collect();
+        check(lg_prover_set_resident(ctx_, on ? 1 : 0), "lg_prover_set_resident");
+        resident_ = on;
+    }
+    bool resident() const { return resident_; }
     // Two batches may be in flight: submit() builds w on the host threads and queues the whole batch on the device, collect()
     // waits for the OLDEST batch queued.  submit(i + 1) before collect(i) keeps the device (and PCIe) busy while the host
     // assembles the next w.
@@ -1557,6 +1566,7 @@ public:
     }
     // proof b of the arena as the host's proof object (a copy: tests, the verifier)
     LigeroProof materialize(size_t b) const {
+        if (resident_) throw std::runtime_error("this batch was proved in resident mode: its openings are on the device, the arena holds their digests");
         const lg_proof_layout& L = layout_;
         const uint8_t* A = arena();
         const size_t rows = 4 * m_, plen = L.path_len;
@@ -1768,6 +1778,7 @@ private:
     std::vector<uint8_t> arena_[2];   // device transcript: batches of proofs as the device wrote them (two in flight)
     std::vector<Fr> mat2_;            // ... and the second w buffer
     uint64_t submitted_ = 0, collected_ = 0;
+    bool resident_ = false;
     HostStats stats_;
     int last_collected_ = 0;
     lg_ctx* ctx_ = nullptr;

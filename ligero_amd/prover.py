@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads", "lgp_batch_prover_device_trace", "lgp_prover_device_trace",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal", "lgp_proof_field_bytes", "lgp_proof_from_fields"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal", "lgp_proof_field_bytes", "lgp_proof_from_fields", "lgp_batch_prover_set_resident"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -46,6 +46,7 @@ def lib():
         L.lgp_batch_prover_create.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.lgp_batch_prover_create_ex.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.lgp_batch_proof_arena.argtypes = [_vp, ctypes.POINTER(_vp), _vp]
+        L.lgp_batch_prover_set_resident.argtypes = [_vp, ctypes.c_int]
         L.lgp_prove_batch_submit.argtypes = [_vp, _vp, _vp, ctypes.c_uint64]
         L.lgp_prove_batch_collect.argtypes = [_vp]
         L.lgp_batch_prover_host_stats.argtypes = [_vp, _vp]
@@ -354,6 +355,54 @@ class LigeroBatchProver:
         out = (ctypes.c_double * 5)()
         _check(self._L.lgp_batch_prover_host_stats(self._h, ctypes.cast(out, _vp)), "lgp_batch_prover_host_stats")
         return {"batches": int(out[0]), "w_core_ms": out[1], "w_wall_ms": out[2], "queue_ms": out[3], "wait_ms": out[4]}
+
+    def set_resident(self, on: bool = True):
+        """RESIDENT mode (lgp_batch_prover_set_resident): the openings stay on the device, the arena receives their digests"""
+        _check(self._L.lgp_batch_prover_set_resident(self._h, 1 if on else 0), "lgp_batch_prover_set_resident")
+
+    def arena(self):
+        """(base address, layout dict) of the batch last collected (lgp_batch_proof_arena; include/ligero_hip.h lg_proof_layout)"""
+        base = _vp()
+        raw = (ctypes.c_uint64 * 40)()
+        _check(self._L.lgp_batch_proof_arena(self._h, ctypes.byref(base), ctypes.cast(raw, _vp)), "lgp_batch_proof_arena")
+        u64 = list(raw)
+        names = ["total_bytes", "off_roots", "off_lc", "off_linear_poly", "off_quadratic_poly", "off_poly_lens", "off_status"]
+        lay = dict(zip(names, u64[:7]))
+        for j, key in enumerate(("off_idx", "off_columns", "off_siblings", "off_paths")):
+            lay[key] = u64[7 + 3 * j:10 + 3 * j]
+        words = (ctypes.c_uint32 * 6).from_buffer_copy(bytes((ctypes.c_uint64 * 3)(*u64[19:22])))
+        lay["batch"], lay["k"], lay["rows"], lay["t"], lay["path_len"] = (int(x) for x in words[:5])
+        lay["off_outputs_ok"] = u64[22]
+        return int(base.value), lay
+
+    def arena_read(self, offset: int, nbytes: int) -> bytes:
+        base, _ = self.arena()
+        return ctypes.string_at(base + offset, nbytes)
+
+    def opening_digests(self, from_bytes: bool):
+        """[sub-proof o][proof b] -> 4 x 32 bytes: the digest records of resident mode, read out of the arena (from_bytes = False) or
+        computed here from the openings a non-resident batch delivered (from_bytes = True): the definition in include/ligero_hip.h"""
+        import hashlib
+        _, L = self.arena()
+        B, t, rows, plen = L["batch"], L["t"], L["rows"], L["path_len"]
+        out = []
+        for o in range(3):
+            recs = []
+            if not from_bytes:
+                blob = self.arena_read(L["off_idx"][o], B * 128)
+                recs = [blob[128 * b:128 * (b + 1)] for b in range(B)]
+            else:
+                idx = self.arena_read(L["off_idx"][o], B * t * 4)
+                cols = self.arena_read(L["off_columns"][o], B * t * rows * 32)
+                sib = self.arena_read(L["off_siblings"][o], B * t * 32)
+                paths = self.arena_read(L["off_paths"][o], B * t * plen * 32)
+                for b in range(B):
+                    cd = b"".join(hashlib.sha256(cols[(b * t + i) * rows * 32:(b * t + i + 1) * rows * 32]).digest() for i in range(t))
+                    recs.append(hashlib.sha256(idx[b * t * 4:(b + 1) * t * 4]).digest() + hashlib.sha256(cd).digest()
+                                + hashlib.sha256(sib[b * t * 32:(b + 1) * t * 32]).digest()
+                                + hashlib.sha256(paths[b * t * plen * 32:(b + 1) * t * plen * 32]).digest())
+            out.append(recs)
+        return out
 
     def arena_bytes(self) -> int:
         """bytes of ONE batch's proofs as the device delivers them to page-locked host memory (lg_proof_layout.total_bytes);

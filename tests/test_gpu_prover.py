@@ -168,6 +168,50 @@ def test_device_transcript_batch_prover_equals_the_host_transcript_provers(posei
         assert proofs_equal(proofs[B // 2], third[B // 2])
 
 
+@pytest.mark.parametrize("B", [3, 70])
+def test_resident_mode_delivers_the_digests_of_the_same_proofs(poseidon, oracle, B):
+    """round 5: lg_prover_set_resident -- the three openings of every proof stay on the device and four SHA-256 digests per sub-proof and
+    proof come home in their place (128 bytes instead of 1.8 MB).  The digests equal the ones computed on the host from the bytes a
+    shipped batch of the same statements delivered; the small items (roots, preenc_u_lc, polynomials, lengths, status) still arrive
+    and are identical; switching back ships whole proofs again (golden fingerprints)"""
+    import proof_fp
+    from ligero_amd.prover import LigeroBatchProver
+    inst, prover, idx, vals = poseidon
+    blob = open(os.path.join(GOLDEN, "poseidon_witness_batch64.bin"), "rb").read()
+    ws = [[int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") for j in range(265)] for i in range(64)]
+    allv = np.stack([oracle.to_mont(oracle.ints_to_limbs(w[1:])) for w in ws])
+    sel = (np.arange(B) * 7) % 64
+    with LigeroBatchProver(inst, B, device_transcript=True) as bp:
+        bp.prove(idx, allv[sel], copy=False)
+        _, L = bp.arena()
+        assert (L["batch"], L["t"], L["rows"], L["path_len"]) == (B, 156, 344, 9)
+        want = bp.opening_digests(from_bytes=True)
+        small_len = L["off_idx"][0]
+        small_want = bp.arena_read(0, small_len)
+        bp.set_resident(True)
+        views = bp.prove(idx, allv[sel], copy=False)
+        assert bp.arena_read(0, small_len) == small_want
+        got = bp.opening_digests(from_bytes=False)
+        for o in range(3):
+            for b in range(B):
+                assert got[o][b] == want[o][b], (o, b)
+        with pytest.raises(RuntimeError):                 # no proof object without the bytes
+            views[0].info()
+        # two resident batches in flight, other statements: digests follow the statements
+        sel2 = (sel + 11) % 64
+        bp.submit(idx, allv[sel2])
+        bp.submit(idx, allv[sel])
+        bp.collect()
+        first = bp.opening_digests(from_bytes=False)
+        bp.collect()
+        assert bp.opening_digests(from_bytes=False) == want and first != want
+        bp.set_resident(False)
+        shipped = bp.prove(idx, allv[sel2], copy=False)
+        assert bp.opening_digests(from_bytes=True) == first
+        gold = proof_fp.golden()["poseidon_batch64"]
+        assert proof_fp.same(proof_fp.fingerprint(shipped[B - 1]), gold[sel2[B - 1]])
+
+
 # ---- the reference's own prove-and-verify tests on BN254 (src/ligero/tests.rs:144-170, 195-243, 245-362), same circuits
 # (src/arithmetic_circuit/tests.rs:51-108), same assignments, same negative case (first variable + 1)
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
