@@ -218,13 +218,18 @@ def prover_child(argv):
     from ligero_amd.prover import LigeroBatchProver
     inst, idx, vals = poseidon_batch_inputs()
     out = {"mode": mode, "batch": batch, "host_cpus": ncpu}
-    if mode == "device":
+    if mode in ("device", "resident"):
         allv = np.ascontiguousarray(vals[np.arange(batch) % 64])
         bp = LigeroBatchProver(inst, batch, device=device, threads=ncpu, device_transcript=True)
         try:
             bp_device_trace = bp.device_trace
             bp.prove(idx, allv, copy=False)                      # warm-up: buffers, page-locking, the first launches
             out["d2h_bytes_per_proof"] = bp.arena_bytes() / batch   # what the device writes to the page-locked arena per proof (lg_proof_layout)
+            if mode == "resident":      # the openings stay on the device: digests come home (lg_prover_set_resident)
+                _, L_ = bp.arena()
+                out["d2h_bytes_per_proof"] = (L_["off_idx"][0] + 3 * batch * 128) / batch
+                bp.set_resident(True)
+                bp.prove(idx, allv, copy=False)
             h0 = bp.host_stats()
             c0, t0, m0 = time.process_time(), time.perf_counter(), time.thread_time()
             bp.submit(idx, allv)
@@ -323,6 +328,15 @@ def full_prover_rate(device: int, steps: int = 6, extras: bool = True):
             res["two_core_cap"] = {k_: two[k_] for k_ in ("value", "unit", "host_cpus", "ms_per_batch", "host_core_ms_per_proof")}
         except Exception as e:
             res["two_core_cap"] = {"error": f"{type(e).__name__}: {e}"}
+        try:      # what the DEVICE can prove when the proofs are not shipped (openings stay in HBM, their digests come home): not the headline
+            rs = _run_prover_child(device, "resident", PROVER_BATCH, steps)
+            res["device_resident"] = {"value": rs["value"], "unit": "proofs/s", "ms_per_batch": rs["ms_per_batch"], "batch": rs["batch"],
+                                      "d2h_bytes_per_proof": rs["d2h_bytes_per_proof"], "host_core_ms_per_proof": rs["host_core_ms_per_proof"]["total"],
+                                      "note": "lg_prover_set_resident: the same proofs (their SHA-256 digests equal the shipped proofs', tests/test_gpu_prover.py), the three "
+                                              "openings left in device memory; the sponge chain, the gathers and the digest kernels are now the critical path. "
+                                              "NOT the headline: a proof that stays on the device has not been delivered"}
+        except Exception as e:
+            res["device_resident"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             host = _run_prover_child(device, "host", 64, 8)
             res["host_transcript"] = {k_: host[k_] for k_ in ("value", "unit", "concurrent_batch_provers", "host_threads_each", "host_cpus", "host_core_ms_per_proof")}

@@ -318,7 +318,8 @@ int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
  * then delivers is the small region as before (roots, preenc_u_lc, both polynomials, lengths, status: exact) and, per sub-proof
  * o, `batch` records of four SHA-256 digests at off_idx[o] of the layout -- record b = [ SHA-256(the t indices, LE32 each) |
  * SHA-256(SHA-256(column 0) || ... || SHA-256(column t - 1)), a column being its 4m elements as 32-byte Montgomery words |
- * SHA-256(the t sibling digests) | SHA-256(the t paths) ] -- so that a test can check, without the bytes, that the same proofs were
+ * SHA-256(the t sibling digests) | SHA-256(SHA-256(path 0) || ... || SHA-256(path t - 1)), a path being its path_len digests root
+ * side first ] -- so that a test can check, without the bytes, that the same proofs were
  * made (tests/test_gpu_prover.py).  Nothing else of the layout's opening regions is written.  Not while a batch is in flight.
  */
 int lg_prover_set_resident(lg_ctx* ctx, int on);

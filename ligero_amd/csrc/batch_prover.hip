@@ -61,7 +61,7 @@ struct lg_batch_prover_state {
     // sub-proof and proof is a record of four SHA-256 digests (indices, columns, siblings, paths) -- 128 bytes instead of 1.8 MB
     bool resident = false;
     uint8_t* d_digest[3] = {nullptr, nullptr, nullptr};   // [batch][4][32]
-    uint8_t* d_coldig = nullptr;                            // [batch][t][32]: per-column digests, scratch of the column record
+    uint8_t* d_coldig = nullptr;                            // [2][batch][t][32]: per-column and per-path digests, scratch of the records
 };
 
 // Frees the prover's state.  The CALLER has drained every stream that touches it -- the context's main stream and the prover's own
@@ -159,25 +159,27 @@ __device__ __forceinline__ void sha256_range(const uint8_t* p, uint64_t bytes, u
 }
 struct DigestArgs {
     const uint8_t* idx; const uint8_t* cols; const uint8_t* sib; const uint8_t* paths;   // the staging regions of one sub-proof
-    uint8_t* coldig;    // [batch][t][32]
+    uint8_t* coldig;    // [batch][2][t][32]: per-column digests, then per-path digests
     uint8_t* out;       // [batch][4][32]
     uint32_t batch, t, rows, plen;
 };
-// one lane per opened column: SHA-256 of its rows * 32 bytes as they lie in the staging (Montgomery words)
+// one lane per opened column (blockIdx.y = 0: SHA-256 of its rows * 32 bytes as they lie in the staging, Montgomery words) or per
+// authentication path (blockIdx.y = 1: its plen * 32 bytes)
 static __global__ void __launch_bounds__(64) digest_columns_kernel(const DigestArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= (uint64_t)a.batch * a.t) return;
-    sha256_range(a.cols + i * a.rows * 32, (uint64_t)a.rows * 32, a.coldig + i * 32);
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x, bt = (uint64_t)a.batch * a.t;
+    if (i >= bt) return;
+    if (blockIdx.y == 0) sha256_range(a.cols + i * a.rows * 32, (uint64_t)a.rows * 32, a.coldig + i * 32);
+    else sha256_range(a.paths + i * a.plen * 32, (uint64_t)a.plen * 32, a.coldig + (bt + i) * 32);
 }
-// one lane per (proof, item): 0 the t indices, 1 the t column digests, 2 the t sibling digests, 3 the t paths
+// one lane per (proof, item): 0 the t indices, 1 the t column digests, 2 the t sibling digests, 3 the t path digests
 static __global__ void __launch_bounds__(64) digest_records_kernel(const DigestArgs a) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.batch * 4) return;
     const uint32_t b = i >> 2, item = i & 3;
+    const uint64_t bt = (uint64_t)a.batch * a.t;
     const uint8_t* p = item == 0 ? a.idx + (uint64_t)b * a.t * 4 : item == 1 ? a.coldig + (uint64_t)b * a.t * 32
-                     : item == 2 ? a.sib + (uint64_t)b * a.t * 32 : a.paths + (uint64_t)b * a.t * a.plen * 32;
-    const uint64_t bytes = item == 0 ? (uint64_t)a.t * 4 : item == 3 ? (uint64_t)a.t * a.plen * 32 : (uint64_t)a.t * 32;
-    sha256_range(p, bytes, a.out + (uint64_t)i * 32);
+                     : item == 2 ? a.sib + (uint64_t)b * a.t * 32 : a.coldig + (bt + (uint64_t)b * a.t) * 32;
+    sha256_range(p, item == 0 ? (uint64_t)a.t * 4 : (uint64_t)a.t * 32, a.out + (uint64_t)i * 32);
 }
 }  // namespace lg
 
@@ -369,7 +371,7 @@ int lg_prover_set_resident(lg_ctx* c, int on) {
     }
     LG_HIP(c, hipSetDevice(c->device));
     if (on && !b->d_coldig) {
-        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_coldig), (size_t)c->batch * b->t * 32));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_coldig), (size_t)c->batch * b->t * 64));
         for (int o = 0; o < 3; o++) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_digest[o]), (size_t)c->batch * 128));
     }
     b->resident = on != 0;
@@ -488,7 +490,7 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
         { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, reinterpret_cast<fr*>(st + b->open_cols), st + b->open_sib, st + b->open_paths); if (rc_ != LG_OK) return rc_; }
         if (b->resident) {      // the opening stays here: its four digests per proof go home in its place (the first batch * 128 bytes of the region)
             lg::DigestArgs da{st + b->open_idx, st + b->open_cols, st + b->open_sib, st + b->open_paths, b->d_coldig, b->d_digest[o], B, t, c->rows, b->plen};
-            LG_LAUNCH(c, lg::digest_columns_kernel, dim3((uint32_t)(((uint64_t)B * t + 63) / 64)), dim3(64), 0, s, da);
+            LG_LAUNCH(c, lg::digest_columns_kernel, dim3((uint32_t)(((uint64_t)B * t + 63) / 64), 2), dim3(64), 0, s, da);
             LG_LAUNCH(c, lg::digest_records_kernel, dim3((B * 4 + 63) / 64), dim3(64), 0, s, da);
             LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
             LG_HIP(c, hipStreamWaitEvent(b->copy, b->ev_gathered[o], 0));

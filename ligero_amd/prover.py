@@ -400,7 +400,7 @@ class LigeroBatchProver:
                     cd = b"".join(hashlib.sha256(cols[(b * t + i) * rows * 32:(b * t + i + 1) * rows * 32]).digest() for i in range(t))
                     recs.append(hashlib.sha256(idx[b * t * 4:(b + 1) * t * 4]).digest() + hashlib.sha256(cd).digest()
                                 + hashlib.sha256(sib[b * t * 32:(b + 1) * t * 32]).digest()
-                                + hashlib.sha256(paths[b * t * plen * 32:(b + 1) * t * plen * 32]).digest())
+                                + hashlib.sha256(b"".join(hashlib.sha256(paths[(b * t + i) * plen * 32:(b * t + i + 1) * plen * 32]).digest() for i in range(t))).digest())
             out.append(recs)
         return out
 
