@@ -2,7 +2,8 @@
 batch) splits on one GPU; `host` = the host-transcript batch prover for comparison.
     python tools/device_transcript_probe.py 2x256 pipe:1x1024 host:4x64 [--steps=6] [--threads=N] [--cpus=C]
 PxB = P provers in flight (one thread each) of B proofs per batch; pipe:PxB = each prover keeps two batches in flight.
---cpus C pins the process to C CPUs first (what one rank of an 8-GPU node gets of this box's quota: C = 2)."""
+--cpus C pins the process to C CPUs first (what one rank of an 8-GPU node gets of this box's quota: C = 2).
+--resident: the openings stay on the device (lg_prover_set_resident): what the device can prove when PCIe is not the bound."""
 import os
 import sys
 import threading
@@ -34,6 +35,9 @@ def main():
         try:
             for bp in provers:
                 bp.prove(idx, allv, copy=False)
+                if "--resident" in sys.argv and not host:
+                    bp.set_resident(True)
+                    bp.prove(idx, allv, copy=False)
 
             def work(bp):
                 if pipe:
