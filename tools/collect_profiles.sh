@@ -8,14 +8,17 @@
 #   4. the default bench line (what the driver runs)
 #   5. the large proofs (2^20 / 2^22 constraints: phases, kernels, three provers in flight), the commit from the assignment, the stream
 #      placement A/B and the host's field-arithmetic microbenchmarks
-# Usage: tools/collect_profiles.sh <round tag, e.g. r04>      (copy gpurun_out/profiles/* into profiles/ afterwards;
-#        profiles/pmc_traffic.json is rewritten in place by tools/pmc_traffic.py -- set its _source.commit when committing)
+# Usage: tools/collect_profiles.sh <round tag, e.g. r05> [commit|prover|all]      (copy gpurun_out/profiles/* into profiles/ afterwards;
+#        profiles/pmc_traffic.json is rewritten in place by tools/pmc_traffic.py -- set its _source.commit when committing).
+#        The whole collection outlasts one gpurun call (20 min): `commit` = steps 1 and the ISA counts, `prover` = steps 2-5.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
+PART=${2:-all}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+if [ "$PART" = all ] || [ "$PART" = commit ]; then
 for WL in poseidon s20 s22; do
   STEPS=200; WARM=10                        # Poseidon: bench.py's defaults, so the profiler's average is of the driver's command
   [ "$WL" = s20 ] && STEPS=5 && WARM=3; [ "$WL" = s22 ] && STEPS=3 && WARM=3
@@ -53,6 +56,8 @@ for WL in poseidon s20 s22; do
 done
 python3 tools/isa_counts.py --pmc $PMCARGS >> "$OUT/${TAG}_isa_counts.log" 2>&1
 cp profiles/isa_counts.json "$OUT/isa_counts.json"
+fi
+if [ "$PART" = commit ]; then ls -la "$OUT"; exit 0; fi
 # the proofs/s leg: the child bench.py runs, under the profiler (the program itself after `--`, no torch in it)
 D=/tmp/prof_prover; rm -rf $D
 LIGERO_NO_TORCH_PRELOAD=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $D -- python3 bench.py --prover-child 0 device 1024 6 0 \
@@ -60,6 +65,13 @@ LIGERO_NO_TORCH_PRELOAD=1 rocprofv3 --kernel-trace --memory-copy-trace --stats -
 cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_prover_kernel_stats.csv"
 cp $(find $D -name '*memory_copy_stats.csv' | head -1) "$OUT/${TAG}_prover_memory_copy_stats.csv"
 python3 tools/timeline_summary.py $(find $D -name '*kernel_trace.csv' | head -1) > "$OUT/${TAG}_prover_timeline_summary.log" 2>&1
+# the same child in RESIDENT mode (lg_prover_set_resident: the openings stay on the device, their digests come home): the sponge chain,
+# the gathers and the digest kernels on the critical path; then how batch depth and several contexts change it
+D=/tmp/prof_prover_res; rm -rf $D
+LIGERO_NO_TORCH_PRELOAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --prover-child 0 resident 2048 4 0 \
+    > "$OUT/${TAG}_prover_child_resident_under_rocprof.json" 2> "$OUT/${TAG}_prover_resident_rocprof.err"
+cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_prover_resident_kernel_stats.csv"
+LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py pipe:1x1024 pipe:1x2048 pipe:1x4096 pipe:2x512 pipe:2x1024 --steps=6 --resident 2>&1 | grep -v amdgpu > "$OUT/${TAG}_resident_contexts_probe.log"
 LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py host:4x64 1x64 1x256 1x1024 pipe:1x256 pipe:1x512 pipe:1x1024 pipe:1x2048 2x256 2x512 --steps=8 \
     2>&1 | grep -v amdgpu > "$OUT/${TAG}_device_transcript_probe.log"
 LIGERO_NO_TORCH_PRELOAD=1 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 --cpus=2 2>&1 | grep proofs/s >> "$OUT/${TAG}_device_transcript_probe.log"
