@@ -48,7 +48,7 @@ struct lg_batch_prover_state {
     hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr};     // on the copy stream: staging o has left for the host
     bool copied_valid = false;
     // two batches may be in flight (the second queued before the first is waited for): a slot per batch
-    struct Slot { const void* out = nullptr; hipEvent_t done = nullptr; hipEvent_t small_copied = nullptr; bool busy = false, used = false; } slot[2];
+    struct Slot { const void* out = nullptr; hipEvent_t done = nullptr; hipEvent_t small_copied = nullptr; hipEvent_t chain_done = nullptr; bool busy = false, used = false; } slot[2];
     uint64_t batches = 0;
     uint32_t ship_blocks = 0;           // workgroups of the ship kernel; 0 = the runtime's copy (default_ship_blocks)
     // The copy stream is the prover's own, created at ANOTHER PRIORITY than the encode stream: the runtime maps streams onto a
@@ -83,6 +83,7 @@ static void bp_free(lg_ctx* c) {
     for (auto& sl : b->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.small_copied) (void)hipEventDestroy(sl.small_copied);
+        if (sl.chain_done) (void)hipEventDestroy(sl.chain_done);
     }
     delete b;
     c->bp = nullptr;
@@ -337,6 +338,7 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
             LG_HIP(c, hipMemset(b->d_small[i], 0, b->small_bytes));
             LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].done, hipEventDisableTiming | hipEventBlockingSync));
             LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].small_copied, hipEventDisableTiming));
+            LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].chain_done, hipEventDisableTiming));
         }
         for (int o = 0; o < 3; o++) {
             LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_open[o]), b->open_bytes));
@@ -531,8 +533,11 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
     LG_HIP(c, hipMemcpyAsync(small + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToDevice, s));
     if (in) LG_HIP(c, hipMemcpyAsync(small + L.off_outputs_ok, c->trace.d_ok, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     else LG_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(small + L.off_outputs_ok), 1, B, s));     // the caller evaluated the circuit itself
-    LG_HIP(c, hipEventRecord(c->evt.done, s));
-    LG_HIP(c, hipStreamWaitEvent(b->copy, c->evt.done, 0));
+    // (an event of this slot's own: the context's shared evt.done is recorded again by the NEXT batch -- queued before the copy stream
+    // gets here -- and the small items of batch i were then seen to leave only when the chain of batch i + 1 had ended, every opening
+    // of batch i + 1 queued behind them: copies a whole batch late and a gather on the copy engine's critical path, tools/copy_gaps.py)
+    LG_HIP(c, hipEventRecord(slot.chain_done, s));
+    LG_HIP(c, hipStreamWaitEvent(b->copy, slot.chain_done, 0));
     const ShipSeg seg = {small, out, b->small_bytes};
     if ((rc = ship(c, &seg, 1)) != LG_OK) return rc;
     LG_HIP(c, hipEventRecord(slot.small_copied, b->copy));

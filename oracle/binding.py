@@ -60,6 +60,8 @@ def lib():
         L.orc_sponge_script.argtypes = [_vp, _vp, _sz, _vp, _vp]
         L.orc_sponge_script.restype = None
         L.orc_prove.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, _vp]
+        L.orc_prover_set_threads.argtypes = [ctypes.c_int]
+        L.orc_prover_set_threads.restype = None
         L.orc_verify.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         _lib = L
     return _lib

@@ -605,6 +605,11 @@ int orc_max_threads(void) {
  * model (oracle/model_prover.py) field for field in tests/test_oracle_prover.py.
  * ===================================================================================================================== */
 
+/* threads for orc_prove / orc_verify's row loops (encode, r polynomials, products): 1 = the serial reference shape bench.py times; more
+ * only to GENERATE goldens of large shapes in reasonable time (tests/golden/make_golden_proofs_large.py) -- same bytes either way */
+static int g_prover_threads = 1;
+void orc_prover_set_threads(int n) { g_prover_threads = n > 1 ? n : 1; }
+
 static inline int fr_is_zero(const fr_t *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
 static inline int fr_eq(const fr_t *a, const fr_t *b) { return memcmp(a, b, sizeof(fr_t)) == 0; }
 static void fr_to_bytes(const fr_t *mont, uint8_t out[32]) { /* CanonicalSerialize: the canonical integer, little-endian */
@@ -916,7 +921,8 @@ static fr_t *r_polys_from_seed(const orc_circuit *c, const uint8_t seed[32]) {
             fr_mul(&t, &r[row], (const fr_t *)c->a_val + e);
             fr_add(&ra[c->a_col[e]], &ra[c->a_col[e]], &t);
         }
-    for (uint32_t i = 0; i < 4 * c->m; i++) orc_ifft(c->k, (uint64_t *)(ra + (size_t)i * c->k));
+#pragma omp parallel for schedule(static) if (g_prover_threads > 1) num_threads(g_prover_threads > 1 ? g_prover_threads : 1)
+    for (long i = 0; i < (long)(4 * c->m); i++) orc_ifft(c->k, (uint64_t *)(ra + (size_t)i * c->k));
     free(r);
     return ra;
 }
@@ -997,7 +1003,7 @@ int orc_prove(const orc_circuit *c, const uint64_t *var_idx, const uint64_t *var
         }
     }
     /* mod.rs:521-551 */
-    rc = orc_encode_commit(rows, k, n, (const uint64_t *)P.preenc, (uint64_t *)P.coeffs, (uint64_t *)P.u, P.leaves, P.nodes, root, 1);
+    rc = orc_encode_commit(rows, k, n, (const uint64_t *)P.preenc, (uint64_t *)P.coeffs, (uint64_t *)P.u, P.leaves, P.nodes, root, g_prover_threads);
     if (rc) goto done;
     if (out->cap[F_ROOT] < 32) { rc = -3; goto done; }
     memcpy(out->field[F_ROOT], root, 32);
@@ -1014,9 +1020,24 @@ int orc_prove(const orc_circuit *c, const uint64_t *var_idx, const uint64_t *var
     sponge_squeeze_seed(&P.sp, seed);
     rp = r_polys_from_seed(c, seed);
     if (!rp) { rc = -2; goto done; }
-    for (uint32_t i = 0; i < rows; i++) {                                  /* mod.rs:731-736 */
-        poly_mul_fft(P.coeffs + (size_t)i * k, k, rp + (size_t)i * k, k, prod, tmp, d);
-        for (uint32_t j = 0; j < d; j++) fr_add(&acc[j], &acc[j], &prod[j]);
+    if (g_prover_threads <= 1) {
+        for (uint32_t i = 0; i < rows; i++) {                              /* mod.rs:731-736 */
+            poly_mul_fft(P.coeffs + (size_t)i * k, k, rp + (size_t)i * k, k, prod, tmp, d);
+            for (uint32_t j = 0; j < d; j++) fr_add(&acc[j], &acc[j], &prod[j]);
+        }
+    } else {                                                               /* the same sum, rows dealt to threads (field addition commutes) */
+#pragma omp parallel num_threads(g_prover_threads)
+        {
+            fr_t *pa = (fr_t *)calloc(d, sizeof(fr_t)), *pp = (fr_t *)malloc(sizeof(fr_t) * d), *pt = (fr_t *)malloc(sizeof(fr_t) * d);
+#pragma omp for schedule(static)
+            for (long i = 0; i < (long)rows; i++) {
+                poly_mul_fft(P.coeffs + (size_t)i * k, k, rp + (size_t)i * k, k, pp, pt, d);
+                for (uint32_t j = 0; j < d; j++) fr_add(&pa[j], &pa[j], &pp[j]);
+            }
+#pragma omp critical(orc_linear_acc)
+            for (uint32_t j = 0; j < d; j++) fr_add(&acc[j], &acc[j], &pa[j]);
+            free(pa); free(pp); free(pt);
+        }
     }
     {
         const size_t len = trimmed_len(acc, d);

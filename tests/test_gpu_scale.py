@@ -68,6 +68,14 @@ def test_s20_from_r1cs_commit_prove_verify(oracle, tmp_path):
         info = proof.info()
         assert info["u_root"] == root
         assert info["opened_columns"] == 156 and info["column_len"] == rows and info["auth_path_len"] == 14
+        # round 5: the WHOLE proof of BASELINE configs[2] is the oracle's proof, byte for byte in all ten fields (tests/golden/proofs_large.json:
+        # oracle/model_prover.py's LigeroCircuit::new + oracle/ligero_oracle.c's orc_prove, made without the product)
+        import json
+        import proof_fp
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs_large.json")))["s20"]
+        assert gold["dims"] == {"m": 2509, "k": 4096, "n": 32768, "t": 156} and gold["accepted"]
+        fp = proof_fp.fingerprint(proof)
+        assert proof_fp.same(fp, gold), proof_fp.diff(fp, gold)
         t1 = time.time()
         assert prover.verify(proof)
         t_verify = time.time() - t1
@@ -77,6 +85,29 @@ def test_s20_from_r1cs_commit_prove_verify(oracle, tmp_path):
         bad = w[1:].copy()
         bad[777] = bad[778]                                        # break one squaring
         assert not prover.verify(prover.prove(idx, bad))
+
+
+@pytest.mark.parametrize("log_n", [10, 14])
+def test_small_members_of_the_family_equal_the_oracles_proofs(tmp_path, log_n):
+    """the same circuit family at 2^10 and 2^14 constraints (k = 128, 512): whole proofs = tests/golden/proofs_large.json, which the CPU
+    suite regenerates from the oracle (tests/test_oracle_prover.py)"""
+    import json
+    import proof_fp
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroProver
+    gen = _gen()
+    r1cs, wtns = str(tmp_path / "rs.r1cs"), str(tmp_path / "rs.wtns")
+    gen.write_r1cs(r1cs, log_n)
+    gen.write_wtns(wtns, gen.witness(log_n, 1))
+    inst = hp.LigeroInstance(hp.ArithmeticCircuit.from_r1cs(r1cs))
+    w = hp.read_witness(wtns)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs_large.json")))[f"s{log_n}"]
+    assert (inst.m, inst.k, inst.n, inst.t) == tuple(gold["dims"][d] for d in "mknt")
+    with LigeroProver(inst) as prover:
+        proof = prover.prove(np.arange(1, w.shape[0], dtype=np.uint64), w[1:])
+        fp = proof_fp.fingerprint(proof)
+        assert proof_fp.same(fp, gold), proof_fp.diff(fp, gold)
+        assert prover.verify(proof)
 
 
 def test_s22_from_r1cs_prove_verify(tmp_path):

@@ -84,3 +84,17 @@ def test_c_prover_on_poseidon_equals_the_golden_fingerprint():
     flipped = dict(fb)
     flipped["quadratic.columns"] = fb["quadratic.columns"][:64] + bytes([fb["quadratic.columns"][64] ^ 1]) + fb["quadratic.columns"][65:]
     assert not st.verify(flipped)
+
+
+@pytest.mark.parametrize("log_n", [10, 14])
+def test_large_family_goldens_reproduce(log_n):
+    """tests/golden/proofs_large.json (the repeated-squaring family of BASELINE configs[2]; 2^20 itself takes ten minutes to make and is
+    checked on the GPU box against the product): the small members regenerate from the oracle, serial and threaded alike"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgl", os.path.join(GOLDEN, "make_golden_proofs_large.py"))
+    mgl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgl)
+    gold = json.load(open(os.path.join(GOLDEN, "proofs_large.json")))
+    assert gold[f"s{log_n}"] == mgl.fingerprint(log_n, threads=1 if log_n == 10 else 4)
+    if "s20" in gold:
+        assert gold["s20"]["dims"] == {"m": 2509, "k": 4096, "n": 32768, "t": 156} and gold["s20"]["accepted"]

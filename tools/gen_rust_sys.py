@@ -98,7 +98,8 @@ def ident(name: str) -> str:
 def parse_header(src: str):
     src = strip_comments(src)
     defines = [(m.group(1), m.group(2)) for m in re.finditer(r"^#define\s+(LG_\w+)\s+((?:0x[0-9a-fA-F]+|\d+)u?)\s*$", src, flags=re.M)]
-    skipped_macros = re.findall(r"^#define\s+(LG_\w+)\(", src, flags=re.M)
+    # function-like macros of the one shape the header uses -- NAME(arg) (EXPR over + and identifiers) -- become const fns
+    skipped_macros = [(m.group(1), m.group(2), m.group(3)) for m in re.finditer(r"^#define\s+(LG_\w+)\((\w+)\)\s+\((.+)\)\s*$", src, flags=re.M)]
     body = re.sub(r"^\s*#.*$", "", src, flags=re.M)
     body = body.replace('extern "C" {', "")
     opaque = re.findall(r"typedef\s+struct\s+(\w+)\s+\1\s*;", body)
@@ -164,8 +165,7 @@ def generate() -> str:
     for name, val in defines:
         v = val.rstrip("u")
         o.append(f"pub const {name}: u32 = {v};")
-    for mname in skipped:
-        o.append(f"// (function-like macro {mname}(..) of the header has no constant form: see the enum base it adds to)")
+    macro_fns = skipped
     o.append("")
     for name in opaque:
         o.append("#[repr(C)]")
@@ -186,6 +186,14 @@ def generate() -> str:
         o.append(f"pub struct {name} {{")
         for fname, fty in fields:
             o.append(f"    pub {ident(fname)}: {fty},")
+        o.append("}")
+        o.append("")
+    for mname, arg, body in macro_fns:
+        expr = re.sub(r"\((\w+)\)", r"\1", body)
+        if not re.fullmatch(r"[\w\s+]+", expr):
+            raise ValueError(f"macro {mname}: body {body!r} is not a sum of identifiers")
+        o.append(f"pub const fn {mname}({arg}: c_int) -> c_int {{")
+        o.append(f"    {expr}")
         o.append("}")
         o.append("")
     o.append('#[link(name = "ligero_hip")]')
