@@ -295,7 +295,7 @@ def _run_prover_child(device: int, mode: str, batch: int, steps: int, cpus: int 
     return json.loads(lines[-1])
 
 
-def full_prover_rate(device: int, steps: int = 6, extras: bool = True):
+def full_prover_rate(device: int, steps: int = 12, extras: bool = True):
     """proofs/s of the complete prove() on the committed Poseidon witnesses in throughput mode: batches of PROVER_BATCH proofs, two
     in flight, commit + three sub-proofs + openings AND the Fiat-Shamir transcript on the device (lg_prove_batch_queue), the host
     assembling w only.  The transcript is the restated test_sponge() -- unpinned against the Rust crates -- so this
@@ -1083,7 +1083,7 @@ def main():
     if dist is not None and args.workload == "poseidon" and not args.no_cpu_baseline:
         dist.barrier()
         try:                                        # (local work only inside the try: every rank must reach the reductions below)
-            fp = full_prover_rate(local_rank, steps=4, extras=(rank == 0))
+            fp = full_prover_rate(local_rank, steps=8, extras=(rank == 0))
         except Exception as e:
             fp = {"error": f"{type(e).__name__}: {e}", "proofs": 0, "seconds": 0.0}
         dev_ = "cuda" if backend == "nccl" else "cpu"

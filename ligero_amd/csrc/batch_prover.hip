@@ -533,9 +533,8 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
     LG_HIP(c, hipMemcpyAsync(small + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToDevice, s));
     if (in) LG_HIP(c, hipMemcpyAsync(small + L.off_outputs_ok, c->trace.d_ok, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     else LG_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(small + L.off_outputs_ok), 1, B, s));     // the caller evaluated the circuit itself
-    // (an event of this slot's own: the context's shared evt.done is recorded again by the NEXT batch -- queued before the copy stream
-    // gets here -- and the small items of batch i were then seen to leave only when the chain of batch i + 1 had ended, every opening
-    // of batch i + 1 queued behind them: copies a whole batch late and a gather on the copy engine's critical path, tools/copy_gaps.py)
+    // (an event of this slot's own rather than the context's shared evt.done, which the next batch's commit -- queued before the copy
+    // stream gets here -- records again)
     LG_HIP(c, hipEventRecord(slot.chain_done, s));
     LG_HIP(c, hipStreamWaitEvent(b->copy, slot.chain_done, 0));
     const ShipSeg seg = {small, out, b->small_bytes};
