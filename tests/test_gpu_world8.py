@@ -135,3 +135,11 @@ def test_s20_proof_sharded_over_eight_rank_contexts_equals_the_single_gpu_proof(
         for rank, p in enumerate(proofs):
             assert proofs_equal(ref, p), rank
         assert single.verify(proofs[WORLD - 1])
+        # round 5: ... and it is the ORACLE's proof of this statement, byte for byte (tests/golden/proofs_large.json, made by
+        # oracle/model_prover.py + oracle/ligero_oracle.c without the product): the eight-rank proof of BASELINE configs[2] is pinned by it
+        import json
+        import proof_fp
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs_large.json")))["s20"]
+        for p in (proofs[0], proofs[WORLD - 1]):
+            fp = proof_fp.fingerprint(p)
+            assert proof_fp.same(fp, gold), proof_fp.diff(fp, gold)
