@@ -643,3 +643,59 @@ def r1cs_circuit(r1cs_path: str, witness: Sequence[int]):
     assert prime == P and len(witness) == n_wires
     circ, outputs = M.from_constraint_system(n_wires, cons)
     return circ, outputs, [(i, v % P) for i, v in enumerate(witness) if i >= 1]
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Random circuits for differential tests (model against C oracle on the CPU, product against C oracle on the GPU): every circuit is
+# one `LigeroCircuit::new` accepts and `prove` does not panic on -- no gate of two constants, every output a gate, every
+# non-constant node in the cone of an output -- with the constant 1 first, somewhere else or absent (the three paths of
+# mod.rs:160-169), and outputs that evaluate to 1 (satisfied) or not.
+# --------------------------------------------------------------------------------------------------------------------
+def random_circuit(seed: int, nvars: int, ngates: int, one: str = "first", satisfied: bool = True, nconsts: int = 3):
+    """-> (circuit, outputs, assignment [(node, value)]).  one: "first" | "middle" | "absent" """
+    import random
+    rng = random.Random(seed)
+    c = M.ArithmeticCircuit()
+    if one == "first":
+        c.constant(1)
+    variables = [c.new_variable() for _ in range(nvars)]
+    consts = [c.constant(rng.randrange(2, P)) for _ in range(nconsts)]
+    if one == "middle":
+        c.constant(1)
+    values = {v: rng.randrange(P) for v in variables}
+    val = lambda i: c.nodes[i][1] if c.nodes[i][0] == "C" else values[i]
+    unused = list(variables)
+    live = list(variables)                       # non-constant nodes so far
+    for _ in range(ngates):
+        a = unused.pop(rng.randrange(len(unused))) if unused and rng.random() < 0.7 else rng.choice(live)
+        pick = rng.random()
+        if pick < 0.2:
+            b = rng.choice(consts + ([c.constants[1]] if 1 in c.constants else []))
+        elif unused and pick < 0.6:
+            b = unused.pop(rng.randrange(len(unused)))
+        else:
+            b = rng.choice(live)
+        l, r = (a, b) if rng.random() < 0.5 else (b, a)
+        g = c.mul(l, r) if rng.random() < 0.5 else c.add(l, r)
+        values[g] = val(l) * val(r) % P if c.nodes[g][0] == "M" else (val(l) + val(r)) % P
+        if a in unused:
+            unused.remove(a)
+        unused.append(g)
+        live.append(g)
+    outputs = []
+    for s in [u for u in unused if c.nodes[u][0] in ("A", "M")]:          # every sink becomes (or feeds) an output
+        if satisfied:
+            k = c.constant((1 - values[s]) % P)                             # out = s + (1 - value(s)) = 1
+            o = c.add(s, k)
+            values[o] = 1
+            outputs.append(o)
+        else:
+            outputs.append(s)
+    for v in [u for u in unused if c.nodes[u][0] == "V"]:                  # a variable nothing used: hang it on the first output's cone
+        g = c.mul(v, outputs[0])
+        values[g] = values[v] * values[outputs[0]] % P
+        k = c.constant((1 - values[g]) % P) if satisfied else consts[0]
+        o = c.add(g, k)
+        values[o] = (values[g] + val(k)) % P
+        outputs[0] = o
+    return c, outputs, [(v, values[v]) for v in variables]

@@ -175,3 +175,40 @@ def test_product_verifier_on_oracle_made_proofs(name):
     big["interleaved.preenc_u_lc"] = P.to_bytes(32, "little") + fb["interleaved.preenc_u_lc"][32:]
     with pytest.raises(RuntimeError):
         Proof.from_fields(big, column_len, path_len)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_circuits_whole_proofs_equal_the_c_oracle(block):
+    """48 random circuits (oracle/model_prover.py random_circuit: the constant 1 first / elsewhere / absent, satisfied and not, 4 to
+    ~1000 gates: k = 4 ... 64, i.e. every column opened and t = 155 of n = 256 / 512) through LigeroCircuit::new, the trace, the commit,
+    the three sub-proofs and the transcript of the PRODUCT -- every proof equals, in all ten fields, the one the C oracle's
+    reference-shaped prover makes (itself equal to the big-int model on such circuits, tests/test_oracle_prover.py), and both
+    verifiers agree on it; every fourth circuit also goes through the two batch provers"""
+    from ligero_amd import host_pipeline as hp
+    from ligero_amd.prover import LigeroBatchProver, LigeroProver
+    from oracle import binding as orc
+    from oracle import model_prover as MP
+    for seed in range(12 * block, 12 * block + 12):
+        one = ("first", "middle", "absent")[seed % 3]
+        sat = seed % 4 != 3
+        mc, outs, va = MP.random_circuit(5000 + seed, nvars=1 + seed % 9, ngates=3 + (seed * 97) % 1000, one=one, satisfied=sat)
+        lc = MP.LigeroCircuit(mc, outs)
+        st = orc.Statement(lc)
+        want = st.prove(va)
+        inst = hp.LigeroInstance(hp_circuit(hp, mc), outputs=outs)
+        assert (inst.m, inst.k, inst.n, inst.t) == (lc.m, lc.k, lc.n, lc.t), seed
+        idx, vals = [i for i, _ in va], mont_rows(hp, [v for _, v in va])
+        with LigeroProver(inst) as prover:
+            proof = prover.prove(idx, vals)
+            got = proof.field_bytes()
+            assert got == want, (seed, [f for f in got if got[f] != want[f]])
+            assert prover.verify(proof) == sat == st.verify(got), seed
+        if seed % 4 == 0:
+            other = [(i, (v * 3 + 1) % P) for i, v in va]                    # a second statement of the same circuit (unsatisfied)
+            want2 = st.prove(other)
+            allv = np.stack([vals, mont_rows(hp, [v for _, v in other]), vals])
+            for device_transcript in (False, True):
+                with LigeroBatchProver(inst, 3, device_transcript=device_transcript) as bp:
+                    proofs = bp.prove(idx, allv)
+                    assert proofs[0].field_bytes() == want and proofs[2].field_bytes() == want, (seed, device_transcript)
+                    assert proofs[1].field_bytes() == want2, (seed, device_transcript)

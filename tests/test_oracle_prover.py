@@ -98,3 +98,20 @@ def test_large_family_goldens_reproduce(log_n):
     assert gold[f"s{log_n}"] == mgl.fingerprint(log_n, threads=1 if log_n == 10 else 4)
     if "s20" in gold:
         assert gold["s20"]["dims"] == {"m": 2509, "k": 4096, "n": 32768, "t": 156} and gold["s20"]["accepted"]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_circuits_model_and_c_prover_agree(seed):
+    """random circuits LigeroCircuit::new accepts (the constant 1 first, elsewhere or absent: the three paths of mod.rs:160-169;
+    satisfied and unsatisfied outputs; k = 4 ... 64, so t = n and t = 155 < n): the two restatements make the same proof bytes and
+    reach the same verdicts"""
+    one = ("first", "middle", "absent")[seed % 3]
+    sat = seed % 4 != 3
+    c, outs, va = MP.random_circuit(1000 + seed, nvars=1 + seed % 7, ngates=3 + (seed * 53) % 900, one=one, satisfied=sat)
+    lc = MP.LigeroCircuit(c, outs)
+    proof = lc.prove(va, MP.test_sponge())
+    assert lc.verify(proof, MP.test_sponge()) == sat
+    st = orc.Statement(lc)
+    fb = st.prove(va)
+    assert fb == MP.proof_field_bytes(proof)
+    assert st.verify(fb) == sat
