@@ -925,14 +925,14 @@ def roofline_of(workload, stage, launches, traffic_file):
                      "overlapped_span": bool(overlapped.get(sname, False))}
         if sname == dom:
             src = tall_src.get("_source", {})
-            dom_rl = {"bound": "valu-issue (hbm fraction reported per contract)", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
+            dom_rl = {"bound": "hbm", "limited_by": "valu-issue", "kernel": {"evaluate": "ntt_rows_kernel<evaluate>", "interpolate": "ntt_rows_kernel<interpolate>",
                                                  "colhash": "blake2s_columns_kernel", "merkle": "merkle_subtree_kernel"}[dom],
                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tall.get(sname),
                       "algorithmic_bytes_per_launch": per_stage_bytes[sname] / nl, "ms_per_launch": ms, "launches_per_step": nl,
                       "samples": stage["samples"] * nl,
                       "traffic_source": (f"{src.get('file', 'profiles/pmc_traffic.json')} @ {src.get('commit', '?')} (round {src.get('round', '?')}): a committed rocprofv3 PMC "
                                          "measurement of this kernel on this shape, replayed -- not measured in this process") if tall.get(sname) is not None else None,
-                      "bound_note": "the kernel is limited by vector-ALU issue, not by HBM (valu_roofline, DESIGN.md 4.2); frac is the algorithmic-bytes rate over the 8 TB/s HBM peak as the bench contract defines it"}
+                      "bound_note": "`bound` names the roof frac is taken against, as the bench contract defines it (algorithmic bytes over the 8 TB/s HBM peak); what the kernel is actually limited by is vector-ALU issue (`limited_by`; valu_roofline, DESIGN.md 4.2)"}
     return dom_rl, rl
 
 

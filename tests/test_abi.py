@@ -229,3 +229,26 @@ def test_reference_patch_names_only_generated_items_and_applies():
         shutil.copy(os.path.join(ref, "Cargo.toml"), tmp)
         shutil.copytree(os.path.join(ref, "src"), os.path.join(tmp, "src"))
         subprocess.check_call(["patch", "-p1", "--dry-run", "-s", "-i", os.path.join(ROOT, "rust-shim", "reference.patch")], cwd=tmp)
+
+
+def test_rust_sources_have_balanced_delimiters():
+    """no Rust compiler here: at least every (, [, { of the generated crate, its build script and the new file of the reference patch
+    closes in order (string and comment contents skipped)"""
+    def check(name, text):
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)
+        text = re.sub(r"'(?:\\.|[^'\\])'", "' '", text)
+        stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+        for i, ch in enumerate(text):
+            if ch in "([{":
+                stack.append((ch, i))
+            elif ch in pairs:
+                assert stack and stack[-1][0] == pairs[ch], (name, "unbalanced", ch, text[max(0, i - 60):i + 20])
+                stack.pop()
+        assert not stack, (name, "unclosed", stack[-1])
+    base = os.path.join(ROOT, "rust-shim")
+    check("lib.rs", open(os.path.join(base, "ligero-hip-sys", "src", "lib.rs")).read())
+    check("build.rs", open(os.path.join(base, "ligero-hip-sys", "build.rs")).read())
+    patch = open(os.path.join(base, "reference.patch")).read()
+    hip = patch[patch.index("+++ b/src/ligero/hip.rs"):patch.index("diff -ruN a/src/ligero/mod.rs")]
+    check("hip.rs", "\n".join(l[1:] for l in hip.splitlines()[2:] if l.startswith("+")))
