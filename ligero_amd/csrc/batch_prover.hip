@@ -203,6 +203,13 @@ static int chacha_elements(lg_ctx* c, const uint32_t* d_seeds, fr* d_out, uint32
 }
 
 static int sponge_launch(lg_ctx* c, const lg::SpongeArgs& a) {
+    // test_sponge()'s additions-only matrix: four lanes per proof (the S-boxes of a full round side by side: 195 instead of 275
+    // product-times per permutation, sponge_kernels.h); LG_SPONGE_LANES=1 keeps the one-lane kernel (A/B; any other matrix uses it)
+    static const bool quad = [] { const char* e = getenv("LG_SPONGE_LANES"); return !(e && atoi(e) == 1); }();
+    if (!c->bp->d_mds && quad) {
+        LG_LAUNCH(c, lg::sponge_quad_kernel, dim3((c->batch + 15) / 16), dim3(64), 0, c->st.main, a);
+        return LG_OK;
+    }
     const dim3 grid((c->batch + 63) / 64);
     if (c->bp->d_mds)
         LG_LAUNCH(c, lg::sponge_kernel<false>, grid, dim3(64), 0, c->st.main, a);

@@ -59,12 +59,16 @@ struct PoseidonParams {
 
 // x^17: four squarings and one product.  x: limbs 0..7 < 2^29, value < 8p.  Result < 1.1p, limbs 0..7 < 2^29.
 __device__ __forceinline__ void sbox17(f29& x) {
-    f29 y;
-    mul29(y, x, x);
-    mul29(y, y, y);
-    mul29(y, y, y);
-    mul29(y, y, y);
-    mul29(x, y, x);
+    f29 y, z;
+#ifdef LG_SBOX_NO_SQR      // A/B: the squarings as general products
+    mul29(y, x, x); mul29(z, y, y); mul29(y, z, z); mul29(z, y, y);
+#else
+    sqr29(y, x);
+    sqr29(z, y);
+    sqr29(y, z);
+    sqr29(z, y);
+#endif
+    mul29(x, z, x);
 }
 
 // one permutation; s[j]: limbs 0..7 < 2^29, value < 2p on entry and on exit.  TEST_MDS: the additions-only matrix (P.mds unused).
@@ -273,6 +277,139 @@ static __global__ void __launch_bounds__(64) sponge_kernel(const SpongeArgs a) {
             for (int i = 0; i < 9; i++) st[9 * jj + i] = s[jj].v[i];
         }
         st[27] = squeezing; st[28] = idx;
+    }
+}
+
+// ---- the same sponge with FOUR LANES PER PROOF (round 5).  The one-lane kernel's wave is alone on its SIMD and issues one instruction
+// every ~4.4 cycles whatever their dependences, so a permutation costs its instruction count: 275 products (8 full rounds x 3 S-boxes
+// + 31 partial x 1, five products each).  Here lane e = 0, 1, 2 of a quad owns state element e (lane 3 shadows lane 0 and is never
+// read): the three S-boxes of a full round run side by side, a partial round's single S-box runs on lane 0 with the others masked
+// -- 39 x 5 = 195 product-times per permutation, 1.4 x fewer -- the additions-only mixing of test_sponge() ([[1,0,1],[1,1,0],[0,1,1]]:
+// n_e = x_e + x_{(e + 2) mod 3}) takes the neighbour's nine limbs through DPP quad_perm [2, 0, 1, 3], and the two rate elements of an
+// absorb step are loaded and converted by lanes 1 and 2 at once.  Every element goes through exactly the operations of the one-lane
+// kernel: the states are bit-identical (the proofs are compared byte for byte with the oracle's either way).  Test parameters only
+// (the general matrix keeps the one-lane kernel).  16 proofs per wave: four times the waves, still a sliver of the chip.
+template <uint32_t CTRL>
+__device__ __forceinline__ uint32_t quad_dpp(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void poseidon_permute_quad(f29& x, const uint32_t e, const PoseidonParams& P) {
+    const uint32_t half = P.full_rounds / 2, rounds = P.full_rounds + P.partial_rounds;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t* ark = P.ark + 27 * r + 9 * e;
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.v[i] += ark[i];     // < 3p, limbs < 2^30
+        norm29_strict(x);
+        const bool full = r < half || r >= half + P.partial_rounds;
+        if (full || e == 0u) sbox17(x);
+        f29 nb, n;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nb.v[i] = quad_dpp<0xD2>(x.v[i]);      // lanes 0, 1, 2, 3 read lanes 2, 0, 1, 3
+        add29(n, x, nb);
+        reduce29(x, n);
+    }
+}
+
+static __global__ void __launch_bounds__(64) sponge_quad_kernel(const SpongeArgs a) {
+    __shared__ uint32_t ark_lds[27 * kSpongeMaxRounds];
+    {
+        const uint32_t words = 27 * (a.P.full_rounds + a.P.partial_rounds);
+        for (uint32_t i = threadIdx.x; i < words; i += 64) ark_lds[i] = a.P.ark[i];
+        __syncthreads();
+    }
+    const PoseidonParams P{ark_lds, nullptr, a.P.full_rounds, a.P.partial_rounds};
+    const uint32_t b = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const uint32_t lane = threadIdx.x & 3u, e = lane == 3u ? 0u : lane;     // the state element this lane owns
+    const bool live = b < a.batch;
+    const uint32_t bb = live ? b : 0;
+    uint32_t* st = a.state + (uint64_t)bb * kSpongeWords;
+    f29 x;
+    uint32_t squeezing, idx;
+    if (a.reset) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.v[i] = 0;
+        squeezing = 0; idx = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.v[i] = st[9 * e + i];
+        squeezing = st[27]; idx = st[28];
+    }
+    uint32_t len = 0;
+    uint32_t rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const fr* src = a.src + (uint64_t)bb * a.src_proof;
+    if (a.kind == kAbsorbDigest) {
+        const uint32_t* d = reinterpret_cast<const uint32_t*>(a.digests + (uint64_t)bb * a.digest_stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) rw[i] = d[i];
+        len = 2;
+    } else if (a.kind == kAbsorbElems) {
+        len = a.count;
+        if (a.trim)
+            while (len > 0 && fr_is_zero_words(fr_load(src + (len - 1)))) len--;
+        if (a.lens_out && live && lane == 0u) a.lens_out[b] = len;
+    }
+    // the duplex state machine as in sponge_kernel; every lane of a quad walks it identically (phase, pos, start, j are the proof's)
+    uint32_t phase = live ? 0u : 4u;
+    uint32_t pos = 0, start = 0, j = 0;
+    bool need_perm = false;
+    for (;;) {
+        if (need_perm) {
+            poseidon_permute_quad(x, e, P);
+            need_perm = false;
+        }
+        while (!need_perm && phase != 4u) {
+            if (phase == 0u) {
+                if (len == 0) { phase = 2u; continue; }
+                if (squeezing || idx == 2u) { start = 0; need_perm = true; } else { start = idx; }
+                phase = 1u;
+            } else if (phase == 1u) {
+                const uint32_t left = len - pos, room = 2u - start, cnt = left < room ? left : room;
+                // rate slot t = state element 1 + t belongs to lane 1 + t: it takes element pos + (t - start) if the step reaches its slot
+                const uint32_t t = lane - 1u;                           // lanes 1, 2 -> 0, 1 (lanes 0, 3: out of range below)
+                if (lane - 1u < 2u && t >= start && t - start < cnt) {
+                    const uint32_t i = t - start;
+                    f29 el, xin;
+                    if (a.kind == kAbsorbDigest) {
+                        xin = unpack29(digest_element(rw, pos + i));
+                        mul29(el, xin, const29<kC522>());
+                    } else {
+                        xin = unpack29(fr_load(src + pos + i));
+                        mul29(el, xin, const29<kC266>());
+                    }
+#pragma unroll
+                    for (int l = 0; l < 9; l++) x.v[l] += el.v[l];
+                }
+                if (start + left <= 2u) {
+                    squeezing = 0; idx = start + left; phase = 2u;
+                } else {
+                    pos += cnt; start = 0; need_perm = true;
+                }
+            } else if (phase == 2u) {
+                if (j == a.nsqueeze) { phase = 4u; continue; }
+                if (!squeezing || idx == 2u) { start = 0; need_perm = true; } else { start = idx; }
+                phase = 3u;
+            } else {   // phase 3: squeeze_bytes(32): element state[1 + start] then the other rate element; the low 31 bytes of each, cut to 32
+                f29 c;
+                mul29(c, x, const29<kOne29>());
+                const fr mine = pack29_reduced(c);
+                const uint32_t other0 = quad_dpp<0xD8>(mine.v[0]);       // lanes 1 and 2 trade their first word
+                if (lane == 1u + start) {                                // the lane of the FIRST squeezed element writes the seed
+                    uint32_t* out = a.seeds + ((uint64_t)j * a.batch + b) * 8;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) out[i] = mine.v[i];
+                    out[7] = (mine.v[7] & 0x00ffffffu) | (other0 << 24);
+                }
+                squeezing = 1; idx = start == 0u ? 2u : 1u;
+                j++; phase = 2u;
+            }
+        }
+        if (!__any(need_perm)) break;
+    }
+    if (live && lane < 3u) {
+        norm29_strict(x);
+#pragma unroll
+        for (int i = 0; i < 9; i++) st[9 * e + i] = x.v[i];
+        if (lane == 0u) { st[27] = squeezing; st[28] = idx; }
     }
 }
 
