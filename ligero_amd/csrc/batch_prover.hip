@@ -206,7 +206,10 @@ static int sponge_launch(lg_ctx* c, const lg::SpongeArgs& a) {
     // test_sponge()'s additions-only matrix: four lanes per proof (the S-boxes of a full round side by side: 195 instead of 275
     // product-times per permutation, sponge_kernels.h); LG_SPONGE_LANES=1 keeps the one-lane kernel (A/B; any other matrix uses it)
     static const bool quad = [] { const char* e = getenv("LG_SPONGE_LANES"); return !(e && atoi(e) == 1); }();
-    if (!c->bp->d_mds && quad) {
+    // (up to 16 384 proofs per batch: beyond that the chip has no idle SIMDs left for the extra lanes and the one-lane kernel's higher
+    // throughput per proof wins -- tools/microbench9.hip, profiles/r05_microbench9_sponge_quad.log: 77 against 116 us per permutation up to
+    // 16 384 proofs, 376 against 117 at 65 536)
+    if (!c->bp->d_mds && quad && c->batch <= 16384) {
         LG_LAUNCH(c, lg::sponge_quad_kernel, dim3((c->batch + 15) / 16), dim3(64), 0, c->st.main, a);
         return LG_OK;
     }

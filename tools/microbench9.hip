@@ -129,7 +129,15 @@ __global__ void __launch_bounds__(256) valu_load_kernel(uint32_t* sink, uint32_t
     if (x.v[0] == 0xdeadbeefu) sink[0] = y.v[1];
 }
 
+// MB9_QUAD=1: the four-lanes-per-proof kernel of round 5 (sponge_quad_kernel: 16 proofs per wave) in the correctness and timing legs
+static bool g_quad = false;
+#define LAUNCH_SPONGE(B_, stream_, args_) do { \
+        if (g_quad) hipLaunchKernelGGL(sponge_quad_kernel, dim3(((B_) + 15) / 16), dim3(64), 0, stream_, args_); \
+        else hipLaunchKernelGGL(sponge_kernel<true>, dim3(((B_) + 63) / 64), dim3(64), 0, stream_, args_); } while (0)
+
 int main(int argc, char** argv) {
+    g_quad = getenv("MB9_QUAD") && atoi(getenv("MB9_QUAD")) == 1;
+    printf("kernel: %s\n", g_quad ? "sponge_quad_kernel (four lanes per proof)" : "sponge_kernel (one lane per proof)");
     const uint32_t FULL = 8, PART = 31, ROUNDS = FULL + PART;
     HostSponge proto;
     proto.ark.resize(ROUNDS);
@@ -176,19 +184,19 @@ int main(int argc, char** argv) {
         a.state = d_state; a.P = P; a.batch = B; a.seeds = d_seeds;
         // absorb(root), squeeze
         a.kind = kAbsorbDigest; a.digests = d_dig; a.digest_stride = 32; a.nsqueeze = 1; a.reset = 1;
-        hipLaunchKernelGGL(sponge_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, 0, a);
+        LAUNCH_SPONGE(B, 0, a);
         CK(hipDeviceSynchronize());
         for (uint32_t b = 0; b < B; b++) hs[b].absorb_bytes(&dig[32 * b], 32);
         check(1, "digest");
         // absorb(K elements), squeeze twice
         a.kind = kAbsorbElems; a.src = d_el; a.src_proof = K; a.count = K; a.trim = 0; a.nsqueeze = 2; a.reset = 0;
-        hipLaunchKernelGGL(sponge_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, 0, a);
+        LAUNCH_SPONGE(B, 0, a);
         CK(hipDeviceSynchronize());
         for (uint32_t b = 0; b < B; b++) hs[b].absorb(std::vector<Fr>(el.begin() + (size_t)b * K, el.begin() + (size_t)(b + 1) * K));
         check(2, "elements");
         // absorb(trimmed polynomial), squeeze three times (lanes now differ in length, mode and position)
         a.src = d_el2; a.trim = 1; a.lens_out = d_lens; a.nsqueeze = 3;
-        hipLaunchKernelGGL(sponge_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, 0, a);
+        LAUNCH_SPONGE(B, 0, a);
         CK(hipDeviceSynchronize());
         hipMemcpy(lens.data(), d_lens, B * 4, hipMemcpyDeviceToHost);
         for (uint32_t b = 0; b < B; b++) {
@@ -200,7 +208,7 @@ int main(int argc, char** argv) {
         check(3, "trimmed");
         // one more absorb of ONE element then an odd squeeze position is not reachable through squeeze_bytes(32); absorb 3 (odd) elements
         a.src = d_el; a.src_proof = K; a.count = 3; a.trim = 0; a.lens_out = nullptr; a.nsqueeze = 1;
-        hipLaunchKernelGGL(sponge_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, 0, a);
+        LAUNCH_SPONGE(B, 0, a);
         CK(hipDeviceSynchronize());
         for (uint32_t b = 0; b < B; b++) hs[b].absorb(std::vector<Fr>(el.begin() + (size_t)b * K, el.begin() + (size_t)b * K + 3));
         check(1, "odd count");
@@ -242,11 +250,11 @@ int main(int argc, char** argv) {
             CK(hipMemset(d_el, 1, (size_t)B * K * 32));   // 0x0101.. < p
             SpongeArgs a{};
             a.state = d_state; a.P = P; a.batch = B; a.kind = kAbsorbElems; a.src = d_el; a.src_proof = K; a.count = K; a.reset = 1;
-            hipLaunchKernelGGL(sponge_kernel<true>, dim3(waves), dim3(64), 0, s1, a);   // warm-up
+            LAUNCH_SPONGE(B, s1, a);   // warm-up
             CK(hipStreamSynchronize(s1));
             if (loaded) hipLaunchKernelGGL(valu_load_kernel, dim3(4096), dim3(256), 0, s2, d_sink, 60000u / 16);
             CK(hipEventRecord(e0, s1));
-            hipLaunchKernelGGL(sponge_kernel<true>, dim3(waves), dim3(64), 0, s1, a);
+            LAUNCH_SPONGE(B, s1, a);
             CK(hipEventRecord(e1, s1));
             CK(hipStreamSynchronize(s1));
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
