@@ -606,6 +606,28 @@ def cpu_baseline_prover(budget_s: float = 10.0, verify_budget_s: float = 3.0, al
     return out
 
 
+def verify_rate(device: int, reps: int = 30):
+    """verify() of one Poseidon-R1CS proof through the product's verifier (ligero_amd/host/prover.hpp over the device library: the
+    reference's verify_interleaved / verify_linear / verify_quadratic_constraints / verify_column_openings, src/ligero/mod.rs:613-996),
+    one proof at a time -- the other half of the reference's timing site (src/ligero/tests.rs:410-414)"""
+    from ligero_amd.prover import LigeroProver
+    inst, idx, vals = poseidon_batch_inputs()
+    with LigeroProver(inst, device=device) as prover:
+        proof = prover.prove(idx, vals[0])
+        assert prover.verify(proof)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ok = prover.verify(proof)
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            prover.prove(idx, vals[0])
+        dtp = time.perf_counter() - t0
+    return {"value": reps / dt, "unit": "verifications/s", "ms_per_verify": dt / reps * 1e3, "accepted": bool(ok),
+            "single_proof_ms": dtp / reps * 1e3,
+            "note": "one proof at a time on the single prover (host transcript): latency, not throughput; single_proof_ms = prove() of one Poseidon-R1CS proof the same way"}
+
+
 def shard_rows_of_seeded_matrix(seed: int, k: int, r0: int, r1: int) -> np.ndarray:
     """rows [r0, r1) of synthetic_preenc(seed, rows * k) without generating the rest: PCG64.advance skips the 4 k
     64-bit draws of each earlier row (full-range uint64 draws consume one output each)"""
@@ -1247,6 +1269,10 @@ def main():
                     line["full_prover"]["roofline"]["measured_d2h_GBs"] = device_d2h_gbs(torch)
                 except Exception as e:
                     line["full_prover"]["roofline"]["measured_d2h_GBs"] = None
+            try:
+                line["full_prover"]["verify"] = verify_rate(local_rank)
+            except Exception as e:
+                line["full_prover"]["verify"] = {"error": f"{type(e).__name__}: {e}"}
             try:      # the reference's whole prove() / verify() on this host's cores, beside proofs/s
                 line["full_prover"]["cpu_baseline"] = cpu_baseline_prover()
                 if line["full_prover"].get("value"):
