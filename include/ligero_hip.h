@@ -313,7 +313,8 @@ typedef struct lg_proof_layout {
 int lg_prover_setup(lg_ctx* ctx, const lg_sponge_params* sponge, uint32_t t);
 int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
 /*
- * RESIDENT mode of the throughput prover: the three openings of every proof -- 99 % of a proof's bytes -- stay in the device staging
+ * RESIDENT mode of the throughput prover: the three openings of every proof (open_columns at src/ligero/mod.rs:662, 740, 852 -> 935-955:
+ * columns and paths, 99 % of a proof's bytes) stay in the device staging
  * (a consumer on the device, or a measurement of what the device can prove when PCIe is not the bound); what lg_prove_batch_queue*
  * then delivers is the small region as before (roots, preenc_u_lc, both polynomials, lengths, status: exact) and, per sub-proof
  * o, `batch` records of four SHA-256 digests at off_idx[o] of the layout -- record b = [ SHA-256(the t indices, LE32 each) |
@@ -474,7 +475,8 @@ typedef struct lg_comm {
 } lg_comm;
 enum { LG_COMM_EXCHANGE_AT_WORLD_1 = 1 };
 /*
- * A second provider of lg_comm::all_gather beside the caller's RCCL binding: PEER PUSH.  Every rank writes its block straight
+ * A second provider of lg_comm::all_gather beside the caller's RCCL binding: PEER PUSH (the exchange between the row-sharded
+ * interpolation, src/ligero/mod.rs:521-526, and the plane-sharded evaluation, 528-533, of one proof over several GPUs).  Every rank writes its block straight
  * into the other ranks' buffers (a device-to-device copy per peer, queued on the stream the library names: on a node each of
  * them goes out over its own xGMI link, where a ring is bound by one), the buffers being mapped into every process once through
  * HIP IPC (hipIpcGetMemHandle / hipIpcOpenMemHandle of the allocation that holds device_buf, on first use) and the hand-over
