@@ -60,6 +60,14 @@ def test_argument_errors_need_no_gpu():
     assert L.lg_open_columns(None, 0, None, 0, None, None, None) == _ffi.LG_ERR_BAD_ARG
     assert L.lg_sync(None) == _ffi.LG_ERR_BAD_ARG
     L.lg_ctx_destroy(None)
+    # round 5 entry points
+    pc = ctypes.c_void_p()
+    assert L.lg_push_comm_create(None, 0, 2, 0, None) == _ffi.LG_ERR_BAD_ARG
+    assert L.lg_push_comm_create(ctypes.byref(pc), 0, 2, 0, None) == _ffi.LG_ERR_BAD_ARG        # more than one rank needs the bootstrap
+    assert L.lg_push_comm_create(ctypes.byref(pc), 0, 2, 2, None) == _ffi.LG_ERR_BAD_ARG        # rank outside the world
+    assert L.lg_push_comm_bind(None, None, 0) == _ffi.LG_ERR_BAD_ARG
+    L.lg_push_comm_destroy(None)
+    assert L.lg_prover_set_resident(None, 1) == _ffi.LG_ERR_BAD_ARG
 
 
 def test_no_fallback_without_gpu():
