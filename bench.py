@@ -224,9 +224,14 @@ def prover_child(argv):
         try:
             bp_device_trace = bp.device_trace
             bp.prove(idx, allv, copy=False)                      # warm-up: buffers, page-locking, the first launches
-            out["d2h_bytes_per_proof"] = bp.arena_bytes() / batch   # what the device writes to the page-locked arena per proof (lg_proof_layout)
+            _, L_ = bp.arena()
+            # what the queued copies of a batch move to the page-locked arena, per proof (lg_proof_layout.shipped_bytes: a column that several
+            # sub-proofs of a proof open travels once); as_separate_sets: the same proofs with every opening shipping all of its t columns
+            out["d2h_bytes_per_proof"] = L_["shipped_bytes"] / batch
+            out["d2h_bytes_per_proof_as_separate_sets"] = (L_["off_idx"][0] + 3 * (L_["off_columns"][0] - L_["off_idx"][0]) + 3 * batch * L_["t"] * L_["rows"] * 32) / batch
+            out["columns_per_proof"] = {"opened": 3 * L_["t"], "shipped_slots": sum(L_["cap_columns"]) / batch,
+                                        "in_use": [int(x) for x in np.frombuffer(bp.arena_read(L_["off_open_totals"], 12), dtype=np.uint32)]}
             if mode == "resident":      # the openings stay on the device: digests come home (lg_prover_set_resident)
-                _, L_ = bp.arena()
                 out["d2h_bytes_per_proof"] = (L_["off_idx"][0] + 3 * batch * 128) / batch
                 bp.set_resident(True)
                 bp.prove(idx, allv, copy=False)
@@ -239,6 +244,7 @@ def prover_child(argv):
             bp.collect()
             dt, cpu, cpu_main = time.perf_counter() - t0, time.process_time() - c0, time.thread_time() - m0
             h1 = bp.host_stats()
+            out["late_columns"] = bp.late_columns()      # columns fetched after a batch's queued copies (cap_columns exceeded): 0 in the normal course
         finally:
             bp.close()
         n = batch * steps
@@ -311,9 +317,9 @@ def full_prover_rate(device: int, steps: int = 12, extras: bool = True):
                     "proofs": 0, "seconds": 0.0}
         res["first_attempt"] = f"batch {PROVER_BATCH} failed ({type(e).__name__}: {str(e)[-200:]}); measured with batch {PROVER_BATCH // 4}"
     res["note"] = ("full prove() per proof, transcript on the device (one lane per proof), proofs delivered to page-locked host memory; "
-                   "PCIe bound (5.4 MB of opened columns per proof); transcript unpinned vs the Rust crates; measured in a child process "
+                   "PCIe bound (4.6 MB per proof: every opened column once); transcript unpinned vs the Rust crates; measured in a child process "
                    "on the system HIP runtime (see prover_child)")
-    bpp = float(res.get("d2h_bytes_per_proof") or 5.44e6)
+    bpp = float(res.get("d2h_bytes_per_proof") or 4.62e6)
     res["pcie_GBs"] = res["value"] * bpp / 1e9
     # the roof of THIS leg: every proof crosses PCIe once, device -> page-locked host memory (three sets of t opened columns are 99 % of it)
     res["roofline"] = {"bound": "pcie-d2h", "bytes_per_proof": bpp, "achieved_GBs": res["value"] * bpp / 1e9, "peak_GBs": PCIE_D2H_PEAK_GBS,
@@ -321,7 +327,8 @@ def full_prover_rate(device: int, steps: int = 12, extras: bool = True):
                        "peak_source": "PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130 / 8 = 63.0 GB/s before packet overhead "
                                       "(MI355X host interface, /opt/skills/guides/MI355X_MICROARCH.md); measured_d2h_GBs beside it is a 1 GiB "
                                       "page-locked device-to-host copy timed in this run",
-                       "bytes_source": "lg_proof_layout.total_bytes / batch of the prover's arena (include/ligero_hip.h)"}
+                       "bytes_source": "lg_proof_layout.shipped_bytes / batch of the prover's arena (include/ligero_hip.h): what the queued copies "
+                                       "of a batch move; an opened column that several sub-proofs of a proof share travels once"}
     if extras:
         try:
             two = _run_prover_child(device, "device", PROVER_BATCH, steps, cpus=2)

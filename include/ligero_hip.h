@@ -285,13 +285,14 @@ int lg_verifier_linear_sums_from_seed(lg_ctx* ctx, const uint8_t* seed, const ui
  *                          proof-major: roots [batch][32], preenc_u_lc [batch][k], the polynomials [batch][2k] with their
  *                          lengths AFTER DensePolynomial's trimming of trailing zeros in poly_lens [2][batch] (linear,
  *                          quadratic); per sub-proof o = 0 interleaved, 1 linear, 2 quadratic: idx [batch][t] (ascending),
- *                          columns [batch][t][rows] Montgomery words, siblings [batch][t][32], paths [batch][t][path_len][32]
- *                          root side first).  The field layout of LigeroProof (src/ligero/types.rs:29-46) item for item.
+ *                          refs [batch][t], siblings [batch][t][32], paths [batch][t][path_len][32] root side first, and the
+ *                          columns (rows Montgomery words each) each proof opens for the first time in o -- see off_refs below).
+ *                          The field layout of LigeroProof (src/ligero/types.rs:29-46) item for item.
  *   lg_prove_batch_queue   queues the whole batch and returns; w = [batch][m k] elements (the W block of every proof, as for
  *                          lg_encode_commit_from_witness) in host memory, proofs_out = total_bytes of host memory.  Page-lock
  *                          both (lg_host_register) or the copies block the calling thread.  Neither buffer may be touched
- *                          until lg_prove_batch_wait returns; one batch per context is in flight at a time (several contexts
- *                          overlap: a proof's transcript is a latency chain of ~40 ms that other contexts' work hides).
+ *                          until lg_prove_batch_wait returns; up to two batches per context are in flight (into different
+ *                          buffers): the second keeps the device and the link busy while the first is waited for.
  *   lg_prove_batch_wait    blocks until the proofs are in proofs_out.
  * The transcript restates the same unpinned crates as ligero_amd/host/transcript.hpp; the proofs equal the host-transcript
  * provers' field for field.
@@ -309,9 +310,24 @@ typedef struct lg_proof_layout {
     uint32_t batch, k, rows, t, path_len;
     uint64_t off_outputs_ok;   /* [batch] words: 1 = every output of the proof's circuit evaluated to one (lg_prove_batch_queue_inputs;
                                   all 1 for lg_prove_batch_queue, whose caller evaluated the circuit) */
+    /* EVERY OPENED COLUMN TRAVELS ONCE.  The three openings of a proof draw their t leaves independently, so a column is often opened
+     * again (Poseidon, t = 156 of n = 1024: 68 of the 468).  The columns region of sub-proof o holds only the columns no earlier
+     * sub-proof of the same proof has opened, proof-major, in the order of their indices; refs [batch][t] words say where column c
+     * of sub-proof o of proof b lies: region = ref >> 30 (a sub-proof number <= o), slot = ref & 0x3fffffff, at
+     * off_columns[region] + slot * rows * 32.  open_totals [3] words: the slots in use per region.  cap_columns[o]: how many slots
+     * the stream-ordered copy of a batch carries (mean + six standard deviations of the batch's total; batch * t with
+     * LG_PROVER_COMPACT=0, where refs are the identity) -- a batch that needs more has the rest fetched inside lg_prove_batch_wait.
+     * shipped_bytes: what the queued copies of one batch move (small items + per sub-proof idx, refs, siblings, paths and
+     * cap_columns[o] columns); total_bytes is the size of the buffer (every region at full capacity). */
+    uint64_t off_refs[3];
+    uint64_t off_open_totals;
+    uint64_t cap_columns[3];
+    uint64_t shipped_bytes;
 } lg_proof_layout;
 int lg_prover_setup(lg_ctx* ctx, const lg_sponge_params* sponge, uint32_t t);
 int lg_prover_layout(const lg_ctx* ctx, lg_proof_layout* out);
+/* columns that lg_prove_batch_wait fetched itself so far because a batch's new columns exceeded cap_columns[o] (0 in the normal course) */
+int lg_prover_late_columns(const lg_ctx* ctx, uint64_t* out);
 /*
  * RESIDENT mode of the throughput prover: the three openings of every proof (open_columns at src/ligero/mod.rs:662, 740, 852 -> 935-955:
  * columns and paths, 99 % of a proof's bytes) stay in the device staging

@@ -93,6 +93,9 @@ int lgp_batch_proof_arena(const lgp_batch_prover* p, const void** base_out, lg_p
  * arena then holds the small items and, per sub-proof, `batch` records of four SHA-256 digests at off_idx[o].  lgp_batch_proof is
  * refused for such a batch.  Waits for the batches in flight. */
 int lgp_batch_prover_set_resident(lgp_batch_prover* p, int on);
+/* columns the prover fetched after a batch's queued copies because the batch opened more new columns than they carry
+ * (include/ligero_hip.h lg_proof_layout.cap_columns, lg_prover_late_columns): 0 in the normal course */
+int lgp_batch_prover_late_columns(const lgp_batch_prover* p, uint64_t* out);
 /* lgp_prove_batch in two halves (device-transcript provers only): submit assembles w on the host threads and queues the batch
  * on the device, collect waits for the OLDEST batch queued; at most two may be in flight.  submit(i + 1) before collect(i)
  * keeps the device and PCIe busy while the host works.  After collect, lgp_batch_proof_arena / lgp_batch_proof show that batch

@@ -27,7 +27,7 @@ SYMBOLS = [
     "lg_shard_row_ranges", "lg_commit_sharded", "lg_relay_row_ranges", "lg_commit_row_relay", "lg_shard_profile_read",
     "lg_ctx_dims", "lg_ctx_pipeline_chunks", "lg_profile_enable", "lg_profile_read",
     "lg_ctx_destroy_checked", "lg_last_teardown_error", "lg_open_columns_async", "lg_open_columns_wait", "lg_encode_commit_from_witness_progress", "lg_preenc_mark_filled", "lg_prover_setup", "lg_prover_layout", "lg_prove_batch_queue", "lg_prove_batch_wait",
-    "lg_push_comm_create", "lg_push_comm_bind", "lg_push_comm_last_error", "lg_push_comm_destroy", "lg_prover_set_resident",
+    "lg_push_comm_create", "lg_push_comm_bind", "lg_push_comm_last_error", "lg_push_comm_destroy", "lg_prover_set_resident", "lg_prover_late_columns",
 ]
 
 LG_OK = 0
@@ -160,6 +160,7 @@ def lib():
     L.lg_prover_setup.argtypes = [_vp, _vp, _u32]
     L.lg_prover_layout.argtypes = [_vp, _vp]
     L.lg_prover_set_resident.argtypes = [_vp, ctypes.c_int]
+    L.lg_prover_late_columns.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
     L.lg_push_comm_create.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, _vp]
     L.lg_push_comm_bind.argtypes = [_vp, _vp, ctypes.c_uint32]
     L.lg_push_comm_last_error.argtypes = [_vp]

@@ -21,6 +21,7 @@
 #include <string>
 
 #include <chrono>
+#include <cmath>
 #include <thread>
 
 #include "lg_context.h"
@@ -36,20 +37,29 @@ struct lg_batch_prover_state {
     uint32_t* d_state = nullptr;    // [batch][lg::kSpongeWords]
     uint32_t* d_seeds = nullptr;    // [2][batch][8]: what one sponge launch squeezes
     uint32_t* d_bitmap = nullptr;   // [batch][n / 32]
-    // Staging of what goes home.  The opened columns of sub-proof o (with their indices, sibling digests and paths) leave as soon
-    // as they are gathered, from one of three buffers; the small items (roots, preenc_u_lc, the polynomials and their lengths, the
-    // status word) leave at the end of the batch from one of TWO buffers, so that the next batch -- queued before this one is
-    // waited for -- never stands behind a copy: the buffers mirror the layout's [off_roots, small_bytes) region byte for byte.
-    uint8_t* d_open[3] = {nullptr, nullptr, nullptr};    // [idx | columns | siblings | paths] of sub-proof o, each 64-byte aligned
-    uint64_t open_idx = 0, open_cols = 0, open_sib = 0, open_paths = 0, open_bytes = 0;   // offsets inside d_open[o]
+    // Staging of what goes home, one set PER SLOT (a batch in flight owns its set until it has been waited for, so nothing orders a
+    // later batch's gathers behind an earlier batch's copies).  The opening of sub-proof o leaves as soon as it is gathered:
+    // [idx | refs | siblings | paths | columns], the columns COMPACT -- a column that an earlier sub-proof of the same proof has opened
+    // already is not gathered and not shipped again, its ref says where it lies (open_refs_*_kernel below) -- and only the first
+    // cap[o] column slots travel with the stream-ordered copy: the number of new columns is a sum over the batch of near-independent
+    // hypergeometric counts, cap[o] = mean + six standard deviations; a batch that needs more has the rest fetched by
+    // lg_prove_batch_wait (its staging is intact until then).  The small items (roots, preenc_u_lc, the polynomials and their
+    // lengths, the status word, the three totals) leave at the end of the batch: the buffers mirror the layout's
+    // [off_roots, small_bytes) region byte for byte.
+    uint8_t* d_open[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    uint64_t open_idx = 0, open_ref = 0, open_sib = 0, open_paths = 0, open_cols = 0, open_bytes = 0;   // offsets inside d_open[.][o]
+    uint64_t cap[3] = {0, 0, 0};            // column slots of sub-proof o that the queued copy carries
+    bool compact = true;                    // LG_PROVER_COMPACT=0: every opening ships all of its t columns (refs are the identity)
+    uint32_t* d_owner = nullptr;            // [batch][n]: the ref of a column this proof has opened in this batch, kNoRef otherwise
+    uint32_t* d_slot = nullptr;             // [batch][t]: where the gather puts column (b, i); kNoRef = not gathered
+    uint32_t* d_newcount = nullptr;         // [batch] + [batch + 1] prefix sums
     uint8_t* d_small[2] = {nullptr, nullptr};
     uint64_t small_bytes = 0;
     hipEvent_t ev_gathered[3] = {nullptr, nullptr, nullptr};   // on the encode stream: staging o is complete
-    hipEvent_t ev_copied[3] = {nullptr, nullptr, nullptr};     // on the copy stream: staging o has left for the host
-    bool copied_valid = false;
     // two batches may be in flight (the second queued before the first is waited for): a slot per batch
     struct Slot { const void* out = nullptr; hipEvent_t done = nullptr; hipEvent_t small_copied = nullptr; hipEvent_t chain_done = nullptr; bool busy = false, used = false; } slot[2];
     uint64_t batches = 0;
+    uint64_t late_columns = 0;          // columns lg_prove_batch_wait had to fetch because a batch exceeded cap[o]
     uint32_t ship_blocks = 0;           // workgroups of the ship kernel; 0 = the runtime's copy (default_ship_blocks)
     // The copy stream is the prover's own, created at ANOTHER PRIORITY than the encode stream: the runtime maps streams onto a
     // handful of hardware queues per priority level, and a context that is not the first of its process was seen with its copy
@@ -60,7 +70,7 @@ struct lg_batch_prover_state {
     // RESIDENT mode (lg_prover_set_resident): the opened columns and their paths stay in the device staging; what goes home per
     // sub-proof and proof is a record of four SHA-256 digests (indices, columns, siblings, paths) -- 128 bytes instead of 1.8 MB
     bool resident = false;
-    uint8_t* d_digest[3] = {nullptr, nullptr, nullptr};   // [batch][4][32]
+    uint8_t* d_digest[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // per slot: [batch][4][32]
     uint8_t* d_coldig = nullptr;                            // [2][batch][t][32]: per-column and per-path digests, scratch of the records
 };
 
@@ -71,14 +81,16 @@ static void bp_free(lg_ctx* c) {
     lg_batch_prover_state* b = c->bp;
     if (!b) return;
     if (b->copy) (void)hipStreamDestroy(b->copy);
-    for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_small[0], (void*)b->d_small[1]})
+    for (void* p : {(void*)b->d_ark, (void*)b->d_mds, (void*)b->d_state, (void*)b->d_seeds, (void*)b->d_bitmap, (void*)b->d_small[0], (void*)b->d_small[1],
+                    (void*)b->d_owner, (void*)b->d_slot, (void*)b->d_newcount})
         if (p) (void)hipFree(p);
     if (b->d_coldig) (void)hipFree(b->d_coldig);
     for (int o = 0; o < 3; o++) {
-        if (b->d_digest[o]) (void)hipFree(b->d_digest[o]);
-        if (b->d_open[o]) (void)hipFree(b->d_open[o]);
+        for (int i = 0; i < 2; i++) {
+            if (b->d_digest[i][o]) (void)hipFree(b->d_digest[i][o]);
+            if (b->d_open[i][o]) (void)hipFree(b->d_open[i][o]);
+        }
         if (b->ev_gathered[o]) (void)hipEventDestroy(b->ev_gathered[o]);
-        if (b->ev_copied[o]) (void)hipEventDestroy(b->ev_copied[o]);
     }
     for (auto& sl : b->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -181,6 +193,72 @@ static __global__ void __launch_bounds__(64) digest_records_kernel(const DigestA
     const uint8_t* p = item == 0 ? a.idx + (uint64_t)b * a.t * 4 : item == 1 ? a.coldig + (uint64_t)b * a.t * 32
                      : item == 2 ? a.sib + (uint64_t)b * a.t * 32 : a.coldig + (bt + (uint64_t)b * a.t) * 32;
     sha256_range(p, item == 0 ? (uint64_t)a.t * 4 : (uint64_t)a.t * 32, a.out + (uint64_t)i * 32);
+}
+}  // namespace lg
+
+// ---- which opened columns are new: the three openings of a proof draw t of n leaves each, independently, so a column is often asked
+// for again (Poseidon: t = 156 of n = 1024 -- 15 % of the second opening's columns and 28 % of the third's were opened before).
+// A ref names where the column lies: bits 31..30 the sub-proof whose region holds it, bits 29..0 the column slot in that region.
+namespace lg {
+constexpr uint32_t kNoRef = 0xffffffffu;
+constexpr uint32_t kNewRef = 3u << 30;      // transient: "new, the rank-th new column of its proof" between the count and the finish
+struct RefArgs {
+    const uint32_t* idx;    // [batch][t]: the opened leaves of this sub-proof (distinct per proof)
+    uint32_t* owner;        // [batch][n]
+    uint32_t* ref;          // [batch][t] out
+    uint32_t* slot;         // [batch][t] out: the gather's destination slot; kNoRef = the column is not gathered
+    uint32_t* count;        // [batch]: new columns of the proof
+    uint32_t* base;         // [batch + 1]: their exclusive prefix sums
+    uint32_t* total_out;    // the word of this sub-proof among the small items
+    uint32_t batch, t, n, o, dedup;
+};
+// one wave per proof: the new columns of a proof keep their order (rank = how many new ones precede)
+static __global__ void __launch_bounds__(64) open_refs_count_kernel(const RefArgs a) {
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    uint32_t running = 0;
+    for (uint32_t i0 = 0; i0 < a.t; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t own = kNoRef;
+        if (i < a.t && a.dedup) own = a.owner[(uint64_t)b * a.n + a.idx[(uint64_t)b * a.t + i]];
+        const bool isnew = i < a.t && own == kNoRef;
+        const uint64_t m = __ballot(isnew);
+        if (i < a.t) a.ref[(uint64_t)b * a.t + i] = isnew ? (kNewRef | (running + (uint32_t)__popcll(m & ((1ull << lane) - 1)))) : own;
+        running += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) a.count[b] = running;
+}
+// one workgroup: exclusive prefix sums of the per-proof counts (proof-major slots), the total to the small items
+static __global__ void __launch_bounds__(1024) open_refs_scan_kernel(const RefArgs a) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, per = (a.batch + 1023) / 1024;
+    const uint32_t lo = min(tid * per, a.batch), hi = min(lo + per, a.batch);
+    uint32_t mine = 0;
+    for (uint32_t j = lo; j < hi; j++) mine += a.count[j];
+    part[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - mine;
+    for (uint32_t j = lo; j < hi; j++) { a.base[j] = run; run += a.count[j]; }
+    if (tid == 1023) { a.base[a.batch] = part[1023]; *a.total_out = part[1023]; }
+}
+// one lane per (proof, opened column): the final ref, the gather's slot, and the owner table for the openings still to come
+static __global__ void __launch_bounds__(256) open_refs_finish_kernel(const RefArgs a) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (uint64_t)a.batch * a.t) return;
+    const uint32_t b = (uint32_t)(e / a.t), r = a.ref[e];
+    if ((r >> 30) == 3) {
+        const uint32_t slot = a.base[b] + (r & 0x3fffffffu), ref = (a.o << 30) | slot;
+        a.ref[e] = ref;
+        a.slot[e] = slot;
+        if (a.dedup) a.owner[(uint64_t)b * a.n + a.idx[e]] = ref;
+    } else {
+        a.slot[e] = kNoRef;
+    }
 }
 }  // namespace lg
 
@@ -315,7 +393,7 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_seeds), 2 * B * 32));
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_bitmap), B * (c->n >= 32 ? c->n / 32 : 1) * 4));
         // the flat layout of a batch of proofs in host memory: the small items first (one contiguous region), then per sub-proof
-        // [idx | columns | siblings | paths], the same way its staging buffer is laid out
+        // [idx | refs | siblings | paths | columns], the same way its staging buffer is laid out
         lg_proof_layout& L = b->layout;
         memset(&L, 0, sizeof(L));
         L.batch = c->batch; L.k = c->k; L.rows = c->rows; L.t = t; L.path_len = b->plen;
@@ -328,19 +406,42 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
         L.off_poly_lens = take(2 * B * 4);
         L.off_status = take(64);
         L.off_outputs_ok = take(B * 4);
+        L.off_open_totals = take(64);
         b->small_bytes = off;
+        if ((uint64_t)B * t >= (1ull << 30)) {
+            snprintf(c->err, sizeof(c->err), "lg_prover_setup: batch * t must stay below 2^30 (column refs)");
+            return LG_ERR_UNSUPPORTED;
+        }
+        const uint64_t col_bytes = (uint64_t)c->rows * 32;
         b->open_idx = 0;
-        b->open_cols = align64(B * t * 4);
-        b->open_sib = b->open_cols + align64(B * t * (uint64_t)c->rows * 32);
+        b->open_ref = align64(B * t * 4);
+        b->open_sib = b->open_ref + align64(B * t * 4);
         b->open_paths = b->open_sib + align64(B * t * 32);
-        b->open_bytes = b->open_paths + align64(B * t * (uint64_t)b->plen * 32);
+        b->open_cols = b->open_paths + align64(B * t * (uint64_t)b->plen * 32);
+        b->open_bytes = b->open_cols + align64(B * t * col_bytes);
+        // how many column slots of sub-proof o the queued copy carries: a column of opening o is new with probability
+        // q = (1 - t/n)^o; per proof the count is hypergeometric (variance below t q (1 - q)), the batch's total a sum of `batch` of them
+        { const char* e = getenv("LG_PROVER_COMPACT"); b->compact = !(e && atoi(e) == 0); }
+        const char* margin_env = getenv("LG_PROVER_COMPACT_MARGIN");       // test knob: slots beyond the mean (may be negative)
+        L.shipped_bytes = b->small_bytes;
         for (int o = 0; o < 3; o++) {
+            const uint64_t all = B * t;
+            uint64_t cap = all;
+            if (b->compact && o > 0) {
+                const double q = pow(1.0 - (double)t / (double)c->n, o), mean = (double)all * q, sd = sqrt((double)all * q * (1.0 - q));
+                const double want = mean + (margin_env ? atof(margin_env) : 6.0 * sd + 32.0);
+                cap = want <= 0 ? 0 : (uint64_t)std::min<double>((double)all, ceil(want));
+            }
+            b->cap[o] = cap;
+            L.cap_columns[o] = cap;
             const uint64_t base = off;
             L.off_idx[o] = base + b->open_idx;
-            L.off_columns[o] = base + b->open_cols;
+            L.off_refs[o] = base + b->open_ref;
             L.off_siblings[o] = base + b->open_sib;
             L.off_paths[o] = base + b->open_paths;
+            L.off_columns[o] = base + b->open_cols;
             off += b->open_bytes;
+            L.shipped_bytes += b->open_cols + cap * col_bytes;
         }
         L.total_bytes = off;
         for (int i = 0; i < 2; i++) {
@@ -349,13 +450,15 @@ int lg_prover_setup(lg_ctx* c, const lg_sponge_params* sp, uint32_t t) {
             LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].done, hipEventDisableTiming | hipEventBlockingSync));
             LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].small_copied, hipEventDisableTiming));
             LG_HIP(c, hipEventCreateWithFlags(&b->slot[i].chain_done, hipEventDisableTiming));
+            for (int o = 0; o < 3; o++) {
+                LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_open[i][o]), b->open_bytes));
+                LG_HIP(c, hipMemset(b->d_open[i][o], 0, b->open_bytes));
+            }
         }
-        for (int o = 0; o < 3; o++) {
-            LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_open[o]), b->open_bytes));
-            LG_HIP(c, hipMemset(b->d_open[o], 0, b->open_bytes));
-            LG_HIP(c, hipEventCreateWithFlags(&b->ev_gathered[o], hipEventDisableTiming));
-            LG_HIP(c, hipEventCreateWithFlags(&b->ev_copied[o], hipEventDisableTiming));
-        }
+        for (int o = 0; o < 3; o++) LG_HIP(c, hipEventCreateWithFlags(&b->ev_gathered[o], hipEventDisableTiming));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_owner), B * c->n * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_slot), B * t * 4));
+        LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_newcount), (2 * B + 1) * 4));
         // everything the sub-proof calls would otherwise grow on first use (a buffer that grows under a challenge already written
         // into it would lose it): row-sum partials, the challenge vector, the seeds and the candidate counters
         {
@@ -384,9 +487,17 @@ int lg_prover_set_resident(lg_ctx* c, int on) {
     LG_HIP(c, hipSetDevice(c->device));
     if (on && !b->d_coldig) {
         LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_coldig), (size_t)c->batch * b->t * 64));
-        for (int o = 0; o < 3; o++) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_digest[o]), (size_t)c->batch * 128));
+        for (int i = 0; i < 2; i++)
+            for (int o = 0; o < 3; o++) LG_HIP(c, hipMalloc(reinterpret_cast<void**>(&b->d_digest[i][o]), (size_t)c->batch * 128));
     }
     b->resident = on != 0;
+    return LG_OK;
+}
+
+int lg_prover_late_columns(const lg_ctx* c, uint64_t* out) {
+    if (!c || !out) return LG_ERR_BAD_ARG;
+    if (!c->bp) return LG_ERR_STATE;
+    *out = c->bp->late_columns;
     return LG_OK;
 }
 
@@ -491,30 +602,36 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
     if ((rc = chacha_elements(c, seed0, c->sub.d_r, c->rows)) != LG_OK) return rc;
     if ((rc = interleaved_on_device(c)) != LG_OK) return rc;
     LG_HIP(c, hipMemcpyAsync(small + L.off_lc, c->sub.d_q, (size_t)B * c->k * sizeof(fr), hipMemcpyDeviceToDevice, s));
-    // the three openings share one routine: indices from a seed, the gather into staging, the way home on the copy stream
+    // the three openings share one routine: indices from a seed, which of them are new to the proof, the gather into this slot's
+    // staging, the way home on the copy stream
+    const bool dedup = b->compact && !b->resident;
+    if (dedup) LG_HIP(c, hipMemsetAsync(b->d_owner, 0xff, (size_t)B * c->n * 4, s));
     auto open = [&](int o, const uint32_t* d_seed) -> int {
-        uint8_t* st = b->d_open[o];
+        uint8_t* st = b->d_open[si][o];
         uint32_t* d_idx = reinterpret_cast<uint32_t*>(st + b->open_idx);
-        if (b->copied_valid) LG_HIP(c, hipStreamWaitEvent(s, b->ev_copied[o], 0));   // the previous batch's copy out of this staging
         lg::IndexArgs ia{d_seed, b->d_bitmap, d_idx, B, c->n, t};
         LG_LAUNCH(c, lg::distinct_indices_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ia);
+        lg::RefArgs ra{d_idx, b->d_owner, reinterpret_cast<uint32_t*>(st + b->open_ref), b->d_slot, b->d_newcount, b->d_newcount + B,
+                       reinterpret_cast<uint32_t*>(small + L.off_open_totals) + o, B, t, c->n, (uint32_t)o, dedup ? 1u : 0u};
+        LG_LAUNCH(c, lg::open_refs_count_kernel, dim3(B), dim3(64), 0, s, ra);
+        LG_LAUNCH(c, lg::open_refs_scan_kernel, dim3(1), dim3(1024), 0, s, ra);
+        LG_LAUNCH(c, lg::open_refs_finish_kernel, dim3((uint32_t)(((uint64_t)B * t + 255) / 256)), dim3(256), 0, s, ra);
         { const int rc_ = settle_tree(c); if (rc_ != LG_OK) return rc_; }
-        { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, reinterpret_cast<fr*>(st + b->open_cols), st + b->open_sib, st + b->open_paths); if (rc_ != LG_OK) return rc_; }
+        { const int rc_ = gather_columns_launch(c, 0, B, d_idx, t, reinterpret_cast<fr*>(st + b->open_cols), st + b->open_sib, st + b->open_paths, b->d_slot); if (rc_ != LG_OK) return rc_; }
         if (b->resident) {      // the opening stays here: its four digests per proof go home in its place (the first batch * 128 bytes of the region)
-            lg::DigestArgs da{st + b->open_idx, st + b->open_cols, st + b->open_sib, st + b->open_paths, b->d_coldig, b->d_digest[o], B, t, c->rows, b->plen};
+            lg::DigestArgs da{st + b->open_idx, st + b->open_cols, st + b->open_sib, st + b->open_paths, b->d_coldig, b->d_digest[si][o], B, t, c->rows, b->plen};
             LG_LAUNCH(c, lg::digest_columns_kernel, dim3((uint32_t)(((uint64_t)B * t + 63) / 64), 2), dim3(64), 0, s, da);
             LG_LAUNCH(c, lg::digest_records_kernel, dim3((B * 4 + 63) / 64), dim3(64), 0, s, da);
             LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
             LG_HIP(c, hipStreamWaitEvent(b->copy, b->ev_gathered[o], 0));
-            LG_HIP(c, hipMemcpyAsync(out + L.off_idx[o], b->d_digest[o], (size_t)B * 128, hipMemcpyDeviceToHost, b->copy));
-            LG_HIP(c, hipEventRecord(b->ev_copied[o], b->copy));
+            LG_HIP(c, hipMemcpyAsync(out + L.off_idx[o], b->d_digest[si][o], (size_t)B * 128, hipMemcpyDeviceToHost, b->copy));
             return LG_OK;
         }
         LG_HIP(c, hipEventRecord(b->ev_gathered[o], s));
         LG_HIP(c, hipStreamWaitEvent(b->copy, b->ev_gathered[o], 0));
-        const ShipSeg seg = {st, out + L.off_idx[o], b->open_bytes};   // (staging and the layout's region of sub-proof o are laid out alike)
+        // (staging and the layout's region of sub-proof o are laid out alike; the columns come last and only cap[o] slots of them travel)
+        const ShipSeg seg = {st, out + L.off_idx[o], b->open_cols + b->cap[o] * (uint64_t)c->rows * 32};
         { const int rc_ = ship(c, &seg, 1); if (rc_ != LG_OK) return rc_; }
-        LG_HIP(c, hipEventRecord(b->ev_copied[o], b->copy));
         return LG_OK;
     };
     // 4. absorb(preenc_u_lc); squeeze the opening's seed, then the linear test's (mod.rs:660, 941, 719)
@@ -538,7 +655,6 @@ static int prove_batch_queue_body(lg_ctx* c, const uint64_t* w, const BatchInput
     sa.lens_out = d_lens + B; sa.nsqueeze = 1;
     if ((rc = sponge_launch(c, sa)) != LG_OK) return rc;
     if ((rc = open(2, seed0)) != LG_OK) return rc;
-    b->copied_valid = true;
     // 9. the small items, once everything on the encode stream is done; "done" = the copy stream has shipped them too
     LG_HIP(c, hipMemcpyAsync(small + L.off_status, c->chal.d_short_flag, 4, hipMemcpyDeviceToDevice, s));
     if (in) LG_HIP(c, hipMemcpyAsync(small + L.off_outputs_ok, c->trace.d_ok, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
@@ -588,6 +704,20 @@ int lg_prove_batch_wait(lg_ctx* c, const void* proofs_out) {
                 (void)hipGetLastError();
                 std::this_thread::sleep_for(std::chrono::microseconds(poll_us));
             }
+        }
+    }
+    if (!b->resident) {     // a batch with more new columns than the queued copy carries (cap[o]: six sigma): the rest comes now
+        const lg_proof_layout& L = b->layout;
+        const uint64_t col_bytes = (uint64_t)c->rows * 32;
+        for (int o = 0; o < 3; o++) {
+            uint32_t total = 0;
+            memcpy(&total, static_cast<const uint8_t*>(proofs_out) + L.off_open_totals + 4 * o, 4);
+            if (total <= b->cap[o]) continue;
+            if (total > (uint64_t)c->batch * b->t) { b->slot[si].busy = false; b->slot[si].out = nullptr; snprintf(c->err, sizeof(c->err), "lg_prove_batch_wait: column total out of range"); return LG_ERR_STATE; }
+            const hipError_t q = hipMemcpy(static_cast<uint8_t*>(const_cast<void*>(proofs_out)) + L.off_columns[o] + b->cap[o] * col_bytes,
+                                           b->d_open[si][o] + b->open_cols + b->cap[o] * col_bytes, (total - b->cap[o]) * col_bytes, hipMemcpyDeviceToHost);
+            if (q != hipSuccess) { b->slot[si].busy = false; b->slot[si].out = nullptr; return fail_hip(c, q, "hipMemcpy(columns beyond the queued copy)"); }
+            b->late_columns += total - b->cap[o];
         }
     }
     b->slot[si].busy = false;

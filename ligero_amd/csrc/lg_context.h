@@ -453,7 +453,8 @@ int commit_from_witness(lg_ctx* c, const uint64_t* host_w, uint64_t* host_coeffs
 int commit_resident_matrix(lg_ctx* c);   // commit_pipeline.hip: lg_commit_resident's body
 int trace_on_device(lg_ctx* c, const uint32_t* in_pos, const uint64_t* in_vals, uint64_t nin);   // witness.hip: w of every proof from its inputs
 // openings.hip: the gather of t columns of nproofs proofs from DEVICE indices into DEVICE buffers (queued on the encode stream)
-int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths);
+int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths,
+                          const uint32_t* d_slot = nullptr);
 // subproof.hip: the three polynomials with their challenges already ON THE DEVICE, results left on the device
 //   interleaved: r in sub.d_r [batch][rows]      -> sub.d_q [batch][k]
 //   linear:      seeds in chal.d_seeds           -> sub.aux2k->d_coeffs [batch][2k]

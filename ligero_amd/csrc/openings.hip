@@ -18,6 +18,8 @@ struct GatherArgs {
     uint32_t rows, k, n, logn, t;  // k = plane row length ki
     uint32_t lognp;                // log2 of the number of planes
     uint32_t proof0;               // blockIdx.y = p serves proof proof0 + p: inputs/outputs advance by one proof each
+    const uint32_t* slot;          // null: column c of proof p goes to cols[p][c]; else [proofs][t]: to cols[slot] of ONE region shared by
+                                   // the call's proofs, 0xffffffff = not gathered (the throughput prover's compact openings)
 };
 
 // u.column(i) for the opened indices (src/matrices/mod.rs:169-171) + generate_proof pieces
@@ -30,19 +32,26 @@ __global__ void __launch_bounds__(256) gather_columns_kernel(GatherArgs a) {
         a.nodes += 32 * (uint64_t)(a.proof0 + p) * (a.n - 1);
         a.row_base = (uint64_t)(a.proof0 + p) * a.rows;
         a.idx += (uint64_t)p * a.t;
-        a.cols += (uint64_t)p * ncol_elems;
+        if (a.slot) a.slot += (uint64_t)p * a.t;
+        else a.cols += (uint64_t)p * ncol_elems;
         a.sib += 32 * (uint64_t)p * a.t;
         a.paths += 32 * (uint64_t)p * a.t * plen;
     }
     if (gid < ncol_elems) {
         const uint32_t c = (uint32_t)(gid / a.rows), i = (uint32_t)(gid % a.rows);
+        uint64_t dst = gid;
+        if (a.slot) {
+            const uint32_t sl = a.slot[c];
+            if (sl == 0xffffffffu) return;
+            dst = (uint64_t)sl * a.rows + i;
+        }
         const uint32_t j = a.idx[c];
         const uint32_t s = j & ((1u << a.lognp) - 1), q = j >> a.lognp;
         fr x = fr_load(a.u + (uint64_t)s * a.plane_stride + (a.row_base + i) * a.k + q);
         fr y, z;
         fr_mul_lazy(y, x, a.r2);
         fr_reduce(z, y);
-        fr_store(a.cols + gid, z);
+        fr_store(a.cols + dst, z);
         return;
     }
     const uint64_t h = gid - ncol_elems;
@@ -113,7 +122,8 @@ int lg_read_codeword_rows(lg_ctx* c, uint32_t proof, uint32_t row0, uint32_t nro
 }  // extern "C"
 
 // the gather itself: t columns (+ sibling digests and paths) of nproofs consecutive proofs, indices and outputs on the device
-int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths) {
+int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const uint32_t* d_idx, uint32_t t, fr* d_cols, uint8_t* d_sib, uint8_t* d_paths,
+                          const uint32_t* d_slot) {
     lg::GatherArgs g;
     memset(&g, 0, sizeof(g));
     g.u = c->d_u;
@@ -123,6 +133,7 @@ int gather_columns_launch(lg_ctx* c, uint32_t proof0, uint32_t nproofs, const ui
     g.cols = d_cols;
     g.sib = d_sib;
     g.paths = d_paths;
+    g.slot = d_slot;
     g.r2 = c->tab.r2;
     g.plane_stride = c->total_rows * c->ki;
     g.lognp = (uint32_t)c->lognp;

@@ -134,6 +134,10 @@ int lgp_batch_prover_set_resident(lgp_batch_prover* p, int on) {
     if (!p) return LGP_ERR_BAD_ARG;
     return guarded([&] { p->hip.set_resident(on != 0); return LGP_OK; });
 }
+int lgp_batch_prover_late_columns(const lgp_batch_prover* p, uint64_t* out) {
+    if (!p || !out) return LGP_ERR_BAD_ARG;
+    return guarded([&] { *out = p->hip.late_columns(); return LGP_OK; });
+}
 uint32_t lgp_batch_prover_threads(const lgp_batch_prover* p) { return p ? p->hip.threads() : 0; }
 int lgp_batch_prover_device_trace(const lgp_batch_prover* p) { return p && p->hip.device_trace() ? 1 : 0; }
 int lgp_prover_device_trace(const lgp_prover* p) { return p && p->hip.device_trace() ? 1 : 0; }

@@ -1462,6 +1462,12 @@ public:
         resident_ = on;
     }
     bool resident() const { return resident_; }
+    uint64_t late_columns() const {
+        if (!device_transcript_) throw std::runtime_error("late_columns: created without the device transcript");
+        uint64_t v = 0;
+        check(lg_prover_late_columns(ctx_, &v), "lg_prover_late_columns");
+        return v;
+    }
     // Two batches may be in flight: submit() builds w on the host threads and queues the whole batch on the device, collect()
     // waits for the OLDEST batch queued.  submit(i + 1) before collect(i) keeps the device (and PCIe) busy while the host
     // assembles the next w.
@@ -1590,7 +1596,10 @@ public:
             oc.paths.resize(t_);
             for (size_t c = 0; c < t_; c++) {
                 const size_t e = b * t_ + c;
-                oc.columns[c] = elems(L.off_columns[o], e * rows, rows);
+                uint32_t ref;       // every opened column lies in the arena once: region = the sub-proof that opened it first
+                memcpy(&ref, A + L.off_refs[o] + 4 * e, 4);
+                if ((ref >> 30) > (uint32_t)o || (ref & 0x3fffffffu) >= (uint64_t)batch_ * t_) throw std::runtime_error("the arena holds a column ref out of range");
+                oc.columns[c] = elems(L.off_columns[ref >> 30], (size_t)(ref & 0x3fffffffu) * rows, rows);
                 MerklePath& mp = oc.paths[c];
                 uint32_t li;
                 memcpy(&li, A + L.off_idx[o] + 4 * e, 4);

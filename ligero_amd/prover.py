@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libligero_prover.so")
 SYMBOLS = ["lgp_last_error", "lgp_prover_create", "lgp_prover_destroy", "lgp_prove", "lgp_verify", "lgp_proof_destroy",
            "lgp_proof_info", "lgp_batch_prover_create", "lgp_batch_prover_destroy", "lgp_batch_prover_threads", "lgp_batch_prover_device_trace", "lgp_prover_device_trace",
-           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal", "lgp_proof_field_bytes", "lgp_proof_from_fields", "lgp_batch_prover_set_resident"]
+           "lgp_prove_batch", "lgp_batch_proof", "lgp_batch_prover_create_ex", "lgp_batch_proof_arena", "lgp_prove_batch_submit", "lgp_prove_batch_collect", "lgp_batch_prover_host_stats", "lgp_prove_with_labels", "lgp_sharded_prover_create", "lgp_proof_equal", "lgp_proof_field_bytes", "lgp_proof_from_fields", "lgp_batch_prover_set_resident", "lgp_batch_prover_late_columns"]
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -47,6 +47,7 @@ def lib():
         L.lgp_batch_prover_create_ex.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.lgp_batch_proof_arena.argtypes = [_vp, ctypes.POINTER(_vp), _vp]
         L.lgp_batch_prover_set_resident.argtypes = [_vp, ctypes.c_int]
+        L.lgp_batch_prover_late_columns.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
         L.lgp_prove_batch_submit.argtypes = [_vp, _vp, _vp, ctypes.c_uint64]
         L.lgp_prove_batch_collect.argtypes = [_vp]
         L.lgp_batch_prover_host_stats.argtypes = [_vp, _vp]
@@ -373,7 +374,36 @@ class LigeroBatchProver:
         words = (ctypes.c_uint32 * 6).from_buffer_copy(bytes((ctypes.c_uint64 * 3)(*u64[19:22])))
         lay["batch"], lay["k"], lay["rows"], lay["t"], lay["path_len"] = (int(x) for x in words[:5])
         lay["off_outputs_ok"] = u64[22]
+        lay["off_refs"] = u64[23:26]
+        lay["off_open_totals"] = u64[26]
+        lay["cap_columns"] = u64[27:30]
+        lay["shipped_bytes"] = u64[30]
         return int(base.value), lay
+
+    def arena_columns(self, o: int):
+        """-> bytes of the [batch][t] opened columns of sub-proof o (rows * 32 bytes each), every one looked up through its ref:
+        a column lies in the arena once, in the region of the sub-proof that opened it first (lg_proof_layout.off_refs)"""
+        _, L = self.arena()
+        B, t, cb = L["batch"], L["t"], L["rows"] * 32
+        refs = np.frombuffer(self.arena_read(L["off_refs"][o], B * t * 4), dtype=np.uint32)
+        totals = np.frombuffer(self.arena_read(L["off_open_totals"], 12), dtype=np.uint32)
+        regions = [np.frombuffer(self.arena_read(L["off_columns"][r], int(totals[r]) * cb), dtype=np.uint8).reshape(-1, cb) for r in range(o + 1)]
+        assert int((refs >> 30).max()) <= o
+        out = np.empty((B * t, cb), dtype=np.uint8)
+        for r in range(o + 1):
+            sel = (refs >> 30) == r
+            out[sel] = regions[r][refs[sel] & 0x3FFFFFFF]
+        return out.tobytes()
+
+    def shipped_bytes(self) -> int:
+        """what the queued device-to-host copies of one batch move (lg_proof_layout.shipped_bytes)"""
+        return int(self.arena()[1]["shipped_bytes"])
+
+    def late_columns(self) -> int:
+        """columns that had to be fetched after the queued copies because a batch exceeded cap_columns (lgp_batch_prover_late_columns)"""
+        out = ctypes.c_uint64(0)
+        _check(self._L.lgp_batch_prover_late_columns(self._h, ctypes.byref(out)), "lgp_batch_prover_late_columns")
+        return int(out.value)
 
     def arena_read(self, offset: int, nbytes: int) -> bytes:
         base, _ = self.arena()
@@ -393,7 +423,7 @@ class LigeroBatchProver:
                 recs = [blob[128 * b:128 * (b + 1)] for b in range(B)]
             else:
                 idx = self.arena_read(L["off_idx"][o], B * t * 4)
-                cols = self.arena_read(L["off_columns"][o], B * t * rows * 32)
+                cols = self.arena_columns(o)
                 sib = self.arena_read(L["off_siblings"][o], B * t * 32)
                 paths = self.arena_read(L["off_paths"][o], B * t * plen * 32)
                 for b in range(B):

@@ -186,7 +186,7 @@ def test_resident_mode_delivers_the_digests_of_the_same_proofs(poseidon, oracle,
         _, L = bp.arena()
         assert (L["batch"], L["t"], L["rows"], L["path_len"]) == (B, 156, 344, 9)
         want = bp.opening_digests(from_bytes=True)
-        small_len = L["off_idx"][0]
+        small_len = L["off_open_totals"]                # (the words behind it count the column slots in use: every one in resident mode)
         small_want = bp.arena_read(0, small_len)
         bp.set_resident(True)
         views = bp.prove(idx, allv[sel], copy=False)
@@ -210,6 +210,101 @@ def test_resident_mode_delivers_the_digests_of_the_same_proofs(poseidon, oracle,
         assert bp.opening_digests(from_bytes=True) == first
         gold = proof_fp.golden()["poseidon_batch64"]
         assert proof_fp.same(proof_fp.fingerprint(shipped[B - 1]), gold[sel2[B - 1]])
+
+
+def _batch_inputs(oracle, B, mul=1, add=0):
+    blob = open(os.path.join(GOLDEN, "poseidon_witness_batch64.bin"), "rb").read()
+    ws = [[int.from_bytes(blob[(i * 265 + j) * 32:(i * 265 + j + 1) * 32], "little") for j in range(265)] for i in range(64)]
+    allv = np.stack([oracle.to_mont(oracle.ints_to_limbs(w[1:])) for w in ws])
+    sel = (np.arange(B) * mul + add) % 64
+    return allv[sel], sel
+
+
+def _arena_openings(bp):
+    """-> per sub-proof (idx [B][t], refs [B][t], columns bytes through the refs, siblings, paths) and the totals"""
+    _, L = bp.arena()
+    B, t, plen = L["batch"], L["t"], L["path_len"]
+    out = []
+    for o in range(3):
+        idx = np.frombuffer(bp.arena_read(L["off_idx"][o], B * t * 4), dtype=np.uint32).reshape(B, t)
+        refs = np.frombuffer(bp.arena_read(L["off_refs"][o], B * t * 4), dtype=np.uint32).reshape(B, t)
+        out.append((idx, refs, bp.arena_columns(o), bp.arena_read(L["off_siblings"][o], B * t * 32), bp.arena_read(L["off_paths"][o], B * t * plen * 32)))
+    return out, [int(x) for x in np.frombuffer(bp.arena_read(L["off_open_totals"], 12), dtype=np.uint32)], L
+
+
+@pytest.mark.parametrize("B", [3, 70])
+def test_every_opened_column_travels_once(poseidon, oracle, monkeypatch, B):
+    """lg_proof_layout.off_refs: a column that an earlier sub-proof of the same proof has opened is neither gathered nor shipped again.
+    Against a prover that ships the three sets whole (LG_PROVER_COMPACT=0, refs = the identity): same indices, siblings, paths and --
+    through the refs -- the same column bytes; the refs are what the index sets say (a repeated leaf points at the region and slot of
+    its first opening, new columns fill their region proof-major in index order); the totals are the sizes of the unions; the queued
+    copies carry fewer bytes; and the proofs are the golden ones"""
+    import proof_fp
+    from ligero_amd.prover import LigeroBatchProver
+    inst, prover, idx, vals = poseidon
+    allv, sel = _batch_inputs(oracle, B, mul=5, add=3)
+    monkeypatch.setenv("LG_PROVER_COMPACT", "0")
+    with LigeroBatchProver(inst, B, device_transcript=True) as whole:
+        whole.prove(idx, allv, copy=False)
+        want, wtot, WL = _arena_openings(whole)
+        assert wtot == [B * 156] * 3 and list(WL["cap_columns"]) == [B * 156] * 3
+        for o in range(3):
+            assert (want[o][1] == (np.uint32(o) << 30) + np.arange(B * 156, dtype=np.uint32).reshape(B, 156)).all()
+    monkeypatch.delenv("LG_PROVER_COMPACT")
+    with LigeroBatchProver(inst, B, device_transcript=True) as bp:
+        views = bp.prove(idx, allv, copy=False)
+        got, tot, L = _arena_openings(bp)
+        assert bp.late_columns() == 0
+        assert L["shipped_bytes"] < WL["shipped_bytes"] and L["total_bytes"] == WL["total_bytes"]
+        seen = [dict() for _ in range(B)]            # per proof: leaf -> ref
+        for o in range(3):
+            idx_o, refs, cols, sib, paths = got[o]
+            assert (idx_o == want[o][0]).all() and cols == want[o][2] and sib == want[o][3] and paths == want[o][4], o
+            slot = 0
+            for b in range(B):
+                for c in range(156):
+                    leaf, r = int(idx_o[b, c]), int(refs[b, c])
+                    if leaf in seen[b]:
+                        assert r == seen[b][leaf] and (r >> 30) < o
+                    else:
+                        assert r == (o << 30) | slot
+                        seen[b][leaf] = r
+                        slot += 1
+            assert tot[o] == slot and slot <= L["cap_columns"][o]
+        assert tot[0] == B * 156 and tot[1] < B * 156 and tot[2] < tot[1]
+        gold = proof_fp.golden()["poseidon_batch64"]
+        for b in sorted({0, B // 2, B - 1}):
+            assert proof_fp.same(proof_fp.fingerprint(views[b]), gold[sel[b]]), b
+
+
+def test_a_batch_with_more_new_columns_than_the_queued_copy_carries(poseidon, oracle, monkeypatch):
+    """cap_columns is the mean plus six standard deviations of the batch's number of new columns; a batch beyond it has the rest fetched
+    by lg_prove_batch_wait.  Forced here with a cap BELOW the mean (LG_PROVER_COMPACT_MARGIN=-300 slots): the late fetch happens,
+    also with two batches in flight, and the proofs are the golden ones"""
+    import proof_fp
+    from ligero_amd.prover import LigeroBatchProver
+    inst, prover, idx, vals = poseidon
+    B = 70
+    allv, sel = _batch_inputs(oracle, B, mul=3, add=1)
+    allv2, sel2 = _batch_inputs(oracle, B, mul=7, add=2)
+    monkeypatch.setenv("LG_PROVER_COMPACT_MARGIN", "-300")
+    with LigeroBatchProver(inst, B, device_transcript=True) as bp:
+        views = bp.prove(idx, allv, copy=False)
+        _, tot, L = _arena_openings(bp)
+        assert tot[1] > L["cap_columns"][1] and tot[2] > L["cap_columns"][2]
+        late = bp.late_columns()
+        assert late == (tot[1] - L["cap_columns"][1]) + (tot[2] - L["cap_columns"][2])
+        gold = proof_fp.golden()["poseidon_batch64"]
+        for b in (0, B - 2, B - 1):                      # the last proofs own the slots beyond the cap
+            assert proof_fp.same(proof_fp.fingerprint(views[b]), gold[sel[b]]), b
+            assert prover.verify(views[b])
+        bp.submit(idx, allv2)
+        bp.submit(idx, allv)
+        first = bp.collect()
+        assert proof_fp.same(proof_fp.fingerprint(first[B - 1]), gold[sel2[B - 1]])
+        second = bp.collect()
+        assert proof_fp.same(proof_fp.fingerprint(second[B - 1]), gold[sel[B - 1]])
+        assert bp.late_columns() > 2 * late
 
 
 # ---- the reference's own prove-and-verify tests on BN254 (src/ligero/tests.rs:144-170, 195-243, 245-362), same circuits
