@@ -8,9 +8,10 @@
 #   4. the default bench line (what the driver runs)
 #   5. the large proofs (2^20 / 2^22 constraints: phases, kernels, three provers in flight), the commit from the assignment, the stream
 #      placement A/B and the host's field-arithmetic microbenchmarks
-# Usage: tools/collect_profiles.sh <round tag, e.g. r05> [commit|prover|all]      (copy gpurun_out/profiles/* into profiles/ afterwards;
+# Usage: tools/collect_profiles.sh <round tag, e.g. r05> [commit|prover|throughput|all]      (copy gpurun_out/profiles/* into profiles/ afterwards;
 #        profiles/pmc_traffic.json is rewritten in place by tools/pmc_traffic.py -- set its _source.commit when committing).
-#        The whole collection outlasts one gpurun call (20 min): `commit` = steps 1 and the ISA counts, `prover` = steps 2-5.
+#        The whole collection outlasts one gpurun call (20 min): `commit` = steps 1 and the ISA counts, `prover` = steps 2-5,
+#        `throughput` = step 2 alone.
 set -u
 TAG=${1:-r05}
 PART=${2:-all}
@@ -65,6 +66,7 @@ LIGERO_NO_TORCH_PRELOAD=1 rocprofv3 --kernel-trace --memory-copy-trace --stats -
 cp $(find $D -name '*kernel_stats.csv' | head -1) "$OUT/${TAG}_prover_kernel_stats.csv"
 cp $(find $D -name '*memory_copy_stats.csv' | head -1) "$OUT/${TAG}_prover_memory_copy_stats.csv"
 python3 tools/timeline_summary.py $(find $D -name '*kernel_trace.csv' | head -1) > "$OUT/${TAG}_prover_timeline_summary.log" 2>&1
+python3 tools/copy_gaps.py $D > "$OUT/${TAG}_prover_copy_gaps.log" 2>&1
 # the same child in RESIDENT mode (lg_prover_set_resident: the openings stay on the device, their digests come home): the sponge chain,
 # the gathers and the digest kernels on the critical path; then how batch depth and several contexts change it
 D=/tmp/prof_prover_res; rm -rf $D
@@ -79,6 +81,7 @@ echo "(copies by shader kernels instead of the SDMA engines: they stretch the HB
 LIGERO_NO_TORCH_PRELOAD=1 LG_SHIP_BLOCKS=8 python3 tools/device_transcript_probe.py pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [ship_kernel, 8 workgroups]/' >> "$OUT/${TAG}_device_transcript_probe.log"
 LIGERO_NO_TORCH_PRELOAD=1 LG_COPY_STREAM_PRIORITY=none python3 tools/device_transcript_probe.py pipe:1x1024 pipe:1x1024 --steps=8 2>&1 | grep proofs/s | sed 's/$/   [copy stream at the encode stream'"'"'s priority: the second prover of a process may share its hardware queue, EXPERIMENTS L]/' >> "$OUT/${TAG}_device_transcript_probe.log"
 echo "prover done"
+if [ "$PART" = throughput ]; then ls -la "$OUT"; exit 0; fi
 python3 tools/s20_prove_timing.py 20 6 2>&1 | grep -v amdgpu > "$OUT/${TAG}_s20_prove_timing.log"
 timeout -k 10 600 python3 tools/s20_prove_timing.py 22 3 2>&1 | grep -v amdgpu > "$OUT/${TAG}_s22_prove_timing.log"
 python3 tools/large_proofs_in_flight.py 20 3 6 2>&1 | grep -v amdgpu > "$OUT/${TAG}_large_proofs_in_flight.log"
