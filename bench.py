@@ -230,7 +230,7 @@ def prover_child(argv):
             out["d2h_bytes_per_proof"] = L_["shipped_bytes"] / batch
             out["d2h_bytes_per_proof_as_separate_sets"] = (L_["off_idx"][0] + 3 * (L_["off_columns"][0] - L_["off_idx"][0]) + 3 * batch * L_["t"] * L_["rows"] * 32) / batch
             out["columns_per_proof"] = {"opened": 3 * L_["t"], "shipped_slots": sum(L_["cap_columns"]) / batch,
-                                        "in_use": [int(x) for x in np.frombuffer(bp.arena_read(L_["off_open_totals"], 12), dtype=np.uint32)]}
+                                        "in_use": [int(x) / batch for x in np.frombuffer(bp.arena_read(L_["off_open_totals"], 12), dtype=np.uint32)]}
             if mode == "resident":      # the openings stay on the device: digests come home (lg_prover_set_resident)
                 out["d2h_bytes_per_proof"] = (L_["off_idx"][0] + 3 * batch * 128) / batch
                 bp.set_resident(True)
