@@ -53,7 +53,7 @@ const char* lg_status_string(int status);
 const char* lg_last_error(const lg_ctx* ctx);
 /* ABI version of this header: bumped on any incompatible change. */
 uint32_t lg_abi_version(void);
-#define LG_ABI_VERSION 4u
+#define LG_ABI_VERSION 5u   /* 5: lg_proof_layout grew (off_refs, off_open_totals, cap_columns, shipped_bytes): the columns regions are compact */
 
 /*
  * Context for `batch` independent commitments of identical shape (batch = 1 for
