@@ -154,7 +154,7 @@ def test_device_transcript_batch_prover_equals_the_host_transcript_provers(posei
             assert proofs_equal(single, views[b]), b
             assert prover.verify(views[b]) == (b != 1)
         # two batches in flight: the second is queued before the first is waited for (both arenas, both small-item staging slots,
-        # the three column staging buffers handed from batch to batch); a third submit is refused until one is collected
+        # a staging set per batch in flight); a third submit is refused until one is collected
         bp.submit(idx, allv[sel])
         bp.submit(idx, allv[sel2])
         with pytest.raises(RuntimeError):
