@@ -315,6 +315,7 @@ int lgp_proof_field_bytes(const lgp_proof* proof, int field, int form, uint8_t* 
 
 int lgp_proof_from_fields(lgp_proof** proof_out, const uint8_t* const fields[10], const uint64_t lens[10], int form, uint64_t column_len, uint64_t auth_path_len) {
     if (!proof_out || !fields || !lens || (form != LGP_BYTES_CANONICAL && form != LGP_BYTES_MONTGOMERY)) return LGP_ERR_BAD_ARG;
+    if (auth_path_len > 63 || column_len > (uint64_t{1} << 32)) return LGP_ERR_BAD_ARG;      // (a tree of 2^64 leaves; more rows than an index can name)
     *proof_out = nullptr;
     for (int f = 0; f < LGP_FIELD_COUNT; f++)
         if (lens[f] && !fields[f]) return LGP_ERR_BAD_ARG;
